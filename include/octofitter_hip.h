@@ -1,0 +1,194 @@
+/*
+ * octofitter_hip.h — C ABI of the MI355X (gfx950) hot path for Octofitter.jl.
+ *
+ * One call evaluates, for a batch of W walkers, the epoch-vectorised
+ *   Kepler solve -> sky-plane projection (RA/Dec, sep/PA, RV) -> Gaussian
+ *   log-likelihood reduction over epochs and companions,
+ * and (optionally) its reverse-mode gradient w.r.t. the orbital elements and
+ * the per-observation nuisance parameters.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns an
+ * int32 status (0 = OCTO_OK) and never lets a C++ exception cross the boundary.
+ * It is what a Julia `ccall` / Python `ctypes` binding for this path binds to
+ * (see INTEGRATION.md for the reference-side stub).
+ *
+ * Reference interfaces each symbol stands in for (paths under the reference
+ * tree of sefffal/Octofitter.jl v8.3.0):
+ *
+ *   octo_dataset_create   <- the observation tables captured by make_ln_like:
+ *                            src/likelihoods/system.jl:35-54 (epoch gather),
+ *                            src/likelihoods/relative-astrometry.jl:20-95 (table,
+ *                            sorted by epoch :46-47, optional cor :67-81),
+ *                            OctofitterRadialVelocity/src/rv-absolute.jl:56-113,
+ *                            rv-absolute-margin.jl:60-84, rv-relative.jl:60-101.
+ *   octo_consts_set       <- PlanetOrbits.* physical constants used through
+ *                            src/parameterizations.jl:62-64,215-216 and
+ *                            src/Octofitter.jl:43 (mjup2msol).
+ *   octo_eval / _device   <- make_ln_like's generated body
+ *                            src/likelihoods/system.jl:206-241 applied to W
+ *                            parameter sets at once: orbit constructors (:116-118),
+ *                            _kepsolve_all! (:250-269), then every observation's
+ *                            ln_like (relative-astrometry.jl:166-253,
+ *                            rv-absolute.jl:172-204, rv-absolute-margin.jl:140-185,
+ *                            rv-relative.jl:177-211), i.e. the body of
+ *                            ℓπcallback/∇ℓπcallback below the prior
+ *                            (src/logdensitymodel.jl:134, :169-177).
+ *   per-walker -Inf       <- src/logdensitymodel.jl:120-124, system.jl:214-221.
+ */
+#ifndef OCTOFITTER_HIP_H
+#define OCTOFITTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCTO_VERSION_MAJOR 0
+#define OCTO_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define OCTO_OK      0
+#define OCTO_EINVAL  1   /* bad argument (null pointer, bad size, unsupported combination) */
+#define OCTO_EHIP    2   /* a HIP runtime call failed; see octo_last_error */
+#define OCTO_ENOMEM  3   /* host or device allocation failed */
+#define OCTO_ENODEV  4   /* no usable gfx950 device */
+
+/* ---- observation kinds (one per reference AbstractObs type on the path) -- */
+#define OCTO_ASTROM_RADEC 0  /* PlanetRelAstromObs with (ra, dec, σ_ra, σ_dec[, cor])   */
+#define OCTO_ASTROM_SEPPA 1  /* PlanetRelAstromObs with (pa, sep, σ_pa, σ_sep[, cor])   */
+#define OCTO_RV_ABS       2  /* StarAbsoluteRVObs (no GP, zero trend)                    */
+#define OCTO_RV_ABS_MARG  3  /* MarginalizedStarAbsoluteRVObs (zero trend)               */
+#define OCTO_RV_REL       4  /* PlanetRelativeRVObs (no GP, zero trend)                  */
+#define OCTO_N_KINDS      5
+
+/* ---- orbit parameterisations (PlanetOrbits.jl types) --------------------- */
+#define OCTO_ORBIT_VISUAL_KEP 0  /* Visual{KepOrbit}: a,e,i,ω,Ω,tp,M,plx               */
+#define OCTO_ORBIT_RADVEL     1  /* RadialVelocityOrbit: a,e,ω,tp,M (i,Ω,plx ignored)  */
+
+/* ---- element rows: elems[(planet*OCTO_N_EL + k) * ld + w] ---------------- */
+#define OCTO_EL_A     0   /* semi-major axis [AU]                 */
+#define OCTO_EL_E     1   /* eccentricity, 0 <= e < 1             */
+#define OCTO_EL_I     2   /* inclination [rad]                    */
+#define OCTO_EL_W     3   /* argument of periastron ω [rad]       */
+#define OCTO_EL_O     4   /* longitude of ascending node Ω [rad]  */
+#define OCTO_EL_TP    5   /* epoch of periastron passage [MJD]    */
+#define OCTO_EL_M     6   /* total mass [M_sun]                   */
+#define OCTO_EL_PLX   7   /* parallax [mas]                       */
+#define OCTO_EL_MASS  8   /* companion mass [M_jup]               */
+#define OCTO_N_EL     9
+
+/* ---- nuisance rows: nuis[(obs*OCTO_N_NUIS + k) * ld + w] ----------------- */
+/* astrometry kinds */
+#define OCTO_NU_JITTER     0   /* added in quadrature to both σ (relative-astrometry.jl:234-235) */
+#define OCTO_NU_PLATESCALE 1   /* multiplies the data separation (:202,:211)                    */
+#define OCTO_NU_NORTHANGLE 2   /* rotates the data (:198,:210)                                  */
+/* RV kinds */
+#define OCTO_NU_RV_OFFSET  0   /* rv-absolute.jl:139, rv-relative.jl:130 (ignored by RV_ABS_MARG) */
+#define OCTO_NU_RV_JITTER  1   /* rv-absolute.jl:181,197; rv-absolute-margin.jl:149,174           */
+#define OCTO_N_NUIS        3
+
+/* Physical constants, supplied by the host from PlanetOrbits.* so that parity
+ * is a property of formulas, not of digits baked into a kernel. */
+typedef struct octo_consts {
+    double kepler_year_to_julian_day; /* PlanetOrbits.kepler_year_to_julian_day_conversion_factor */
+    double year2day_julian;           /* PlanetOrbits.year2day_julian  (365.25)                   */
+    double au2m;                      /* PlanetOrbits.au2m                                         */
+    double sec2year_julian;           /* PlanetOrbits.sec2year_julian                              */
+    double pc2au;                     /* PlanetOrbits.pc2au                                        */
+    double rad2as;                    /* PlanetOrbits.rad2as                                       */
+    double mjup2msol;                 /* Octofitter.mjup2msol = PlanetOrbits.mjup2msol_IAU         */
+} octo_consts;
+
+/* One observation table, post-constructor (sorted by epoch), host pointers.
+ * The library copies the columns; the caller keeps ownership. */
+typedef struct octo_obs_desc {
+    int32_t kind;          /* OCTO_ASTROM_* / OCTO_RV_*                                     */
+    int32_t planet;        /* 0-based planet the table is attached to; -1 for system tables */
+    int64_t n_epochs;      /* rows; may be 0                                                */
+    const double* epoch;   /* [n_epochs] MJD                                                */
+    const double* y1;      /* ra | pa | rv                                                  */
+    const double* y2;      /* dec | sep | NULL                                              */
+    const double* s1;      /* σ_ra | σ_pa | σ_rv                                            */
+    const double* s2;      /* σ_dec | σ_sep | NULL                                          */
+    const double* cor;     /* correlation column or NULL (astrometry only)                  */
+} octo_obs_desc;
+
+typedef struct octo_planet_desc {
+    int32_t orbit_kind;    /* OCTO_ORBIT_*                                                  */
+    int32_t has_mass;      /* planet declares a `mass` variable (relative-astrometry.jl:122) */
+} octo_planet_desc;
+
+typedef struct octo_ctx octo_ctx;
+typedef struct octo_dataset octo_dataset;
+
+/* Defaults: the PlanetOrbits.jl / Octofitter.jl constant values this build assumes
+ * when the host does not call octo_consts_set. */
+int32_t octo_consts_default(octo_consts* out);
+
+int32_t octo_version(int32_t* major, int32_t* minor);
+
+/* Context = one HIP device + one stream + scratch. Not thread-safe: one ctx
+ * per host thread (datasets may be shared read-only between contexts on the
+ * same device). */
+int32_t octo_ctx_create(octo_ctx** out, int32_t device_id);
+int32_t octo_ctx_destroy(octo_ctx* ctx);
+int32_t octo_consts_set(octo_ctx* ctx, const octo_consts* c);
+const char* octo_last_error(const octo_ctx* ctx);
+
+/* Upload the observation tables (one-time). Observation likelihoods are summed
+ * in the order given. */
+int32_t octo_dataset_create(octo_ctx* ctx,
+                            const octo_obs_desc* obs, int32_t n_obs,
+                            const octo_planet_desc* planets, int32_t n_planets,
+                            octo_dataset** out);
+int32_t octo_dataset_destroy(octo_dataset* ds);
+int64_t octo_dataset_n_rows(const octo_dataset* ds);   /* Σ n_epochs over tables */
+
+/* Batched evaluation, HOST buffers (blocking).
+ *   elems   [n_planets*OCTO_N_EL][ld]  walker index fastest (SoA)
+ *   nuis    [n_obs*OCTO_N_NUIS][ld] or NULL (defaults: jitter 0, platescale 1,
+ *           northangle 0, offset 0)
+ *   ll_out  [W]
+ *   g_elems [n_planets*OCTO_N_EL][ld] or NULL  -> forward only
+ *   g_nuis  [n_obs*OCTO_N_NUIS][ld]  or NULL
+ * Per-walker numerical invalidity is data, not an error: ll = -Inf and zero
+ * gradients for NaN/Inf inputs, e outside [0,1), a <= 0, M <= 0. */
+int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds,
+                  const double* elems, const double* nuis, int64_t ld, int64_t W,
+                  double* ll_out, double* g_elems, double* g_nuis);
+
+/* Same, DEVICE buffers already resident in HBM, enqueued on `hip_stream`
+ * (NULL = the context's own stream). Asynchronous: pair with octo_sync (or
+ * synchronise the stream yourself) before reading outputs. */
+int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* ds,
+                         const double* d_elems, const double* d_nuis, int64_t ld, int64_t W,
+                         double* d_ll_out, double* d_g_elems, double* d_g_nuis,
+                         void* hip_stream);
+int32_t octo_sync(octo_ctx* ctx);
+
+/* Measurement hook used by bench.py: average duration in milliseconds of the
+ * dominant (epoch-loop) kernel over the launches since the last reset, from
+ * hipEvents recorded on the launch stream. Enabled by octo_timing_enable. */
+int32_t octo_timing_enable(octo_ctx* ctx, int32_t on);
+int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int32_t reset);
+
+/* Parallel-tempering swap step on device-resident log-likelihoods gathered from
+ * all replicas (the one collective of the path; the gather itself is RCCL's
+ * all_gather issued by the host). Deterministic even/odd neighbour swaps driven
+ * by a counter-based RNG (seed, step) shared by all ranks:
+ *   log A = (β_i − β_{i+1}) (ℓ_{i+1} − ℓ_i)     on log-likelihoods,
+ * swapping the β-index of the two replicas, never their states.
+ *   d_ll       [n_chains][n_temps]  log-likelihood of the replica currently holding chain c, slot t
+ *   d_beta     [n_temps]            inverse-temperature ladder (slot order)
+ *   d_slot2rep [n_chains][n_temps]  in/out permutation: which replica sits at ladder slot t
+ * `parity` 0 swaps pairs (0,1),(2,3)…; 1 swaps (1,2),(3,4)…  */
+int32_t octo_pt_swap_device(octo_ctx* ctx, const double* d_ll_by_replica, const double* d_beta,
+                            int32_t* d_slot2rep, int32_t n_temps, int64_t n_chains,
+                            int32_t parity, uint64_t seed, uint64_t step,
+                            int32_t* d_accepted, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTOFITTER_HIP_H */

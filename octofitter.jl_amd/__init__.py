@@ -1,0 +1,15 @@
+"""
+octofitter.jl_amd — MI355X-native epoch-loop likelihood path for Octofitter.jl.
+
+The directory name carries a dot (it is the reference's name), so it is loaded by path:
+`from __graft_entry__ import load_package; pkg = load_package()` registers it as the module
+`octofitter_jl_amd`. Contents: csrc/ (HIP kernels + C ABI), host/ (Python mirror of the
+reference's observation / system / ln_like surface over ctypes), julia/ (the ccall shim a
+maintainer would drop into Octofitter.jl).
+"""
+from .host import capi  # noqa: F401
+from .host.observations import (  # noqa: F401
+    PlanetRelAstromObs, PlanetRelAstromLikelihood, StarAbsoluteRVObs, StarAbsoluteRVLikelihood,
+    MarginalizedStarAbsoluteRVObs, PlanetRelativeRVObs, PlanetRelativeRVLikelihood,
+)
+from .host.system import Planet, System, make_ln_like, BatchedLnLike  # noqa: F401

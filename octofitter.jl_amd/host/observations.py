@@ -1,0 +1,169 @@
+"""
+Host-side mirror of the reference's observation types on the hot path.
+
+Same names, column conventions and constructor error behaviour as the reference, so that the
+parity tests read like the reference's own tests:
+
+  PlanetRelAstromObs              src/likelihoods/relative-astrometry.jl:20-95
+  StarAbsoluteRVObs               OctofitterRadialVelocity/src/rv-absolute.jl:56-113
+  MarginalizedStarAbsoluteRVObs   OctofitterRadialVelocity/src/rv-absolute-margin.jl:60-84
+  PlanetRelativeRVObs             OctofitterRadialVelocity/src/rv-relative.jl:60-101
+
+A "table" is anything column-like: a dict of equal-length sequences, or a list of row dicts.
+Priors / Derived variable blocks are host-side model specification and stay in the reference
+(SURVEY.md §2 rows 4, 9): here an observation only carries the NAMES of its nuisance
+variables so that `make_ln_like` can look them up in θ_obs.
+"""
+from __future__ import annotations
+
+import re
+import unicodedata
+import warnings
+
+import numpy as np
+
+from . import capi
+
+astrom_cols1 = ("epoch", "ra", "dec", "σ_ra", "σ_dec")      # relative-astrometry.jl:3
+astrom_cols3 = ("epoch", "pa", "sep", "σ_pa", "σ_sep")      # relative-astrometry.jl:4
+rv_cols = ("epoch", "rv", "σ_rv")
+
+_ASCII = {"σ_ra": "sigma_ra", "σ_dec": "sigma_dec", "σ_pa": "sigma_pa", "σ_sep": "sigma_sep", "σ_rv": "sigma_rv"}
+_MJD_1950, _MJD_2050 = 33282.0, 69807.0   # mjd("1950"), mjd("2050")
+
+
+def normalizename(name: str) -> str:
+    """src/variables.jl:1068-1073."""
+    uname = unicodedata.normalize("NFC", name).strip()
+    ident = uname if uname.isidentifier() else "".join(ch if (ch.isalnum() or ch == "_") else "_" for ch in uname)
+    if not ident or not (ident[0].isalpha() or ident[0] == "_"):
+        ident = "_" + ident
+    return re.sub(r"(_)\1+", "_", ident)
+
+
+def _as_table(observations) -> dict:
+    if isinstance(observations, dict):
+        tab = {k: np.atleast_1d(np.asarray(v)) for k, v in observations.items()}
+    else:
+        rows = list(observations)
+        if not rows:
+            raise ValueError("empty observation table")
+        keys = list(rows[0].keys())
+        tab = {k: np.asarray([r[k] for r in rows]) for k in keys}
+    for ascii_name_of, uni in ((v, k) for k, v in _ASCII.items()):
+        if ascii_name_of in tab and uni not in tab:
+            tab[uni] = tab.pop(ascii_name_of)
+    return tab
+
+
+def _equal_length_cols(tab) -> bool:
+    return len({len(v) for v in tab.values()}) <= 1
+
+
+def _warn_epoch_range(epoch):
+    if np.any(epoch >= _MJD_2050) or np.any(epoch <= _MJD_1950):
+        warnings.warn("The data you entered fell outside the range year 1950 to year 2050. The expected input "
+                      "format is MJD (modified julian date). We suggest you double check your input data!")
+
+
+class AbstractObs:
+    kind = None
+    nuisance_names: tuple = ()
+
+    def likelihoodname(self):
+        return self.name
+
+    def _c_table(self, planet_index):
+        raise NotImplementedError
+
+
+class PlanetRelAstromObs(AbstractObs):
+    """Relative astrometry between a host star and a secondary body (mas / radians)."""
+    nuisance_names = ("jitter", "platescale", "northangle")
+
+    def __init__(self, observations, *, name, variables=None):
+        table = _as_table(observations)
+        if not _equal_length_cols(table):
+            raise ValueError("The columns in the input data do not all have the same length")
+        has1 = set(astrom_cols1) <= set(table)
+        has3 = set(astrom_cols3) <= set(table)
+        if not has1 and not has3:
+            raise ValueError(f"Expected columns {astrom_cols1} or {astrom_cols3}")
+        table = {k: np.asarray(v, dtype=np.float64) for k, v in table.items()}
+        _warn_epoch_range(table["epoch"])
+        ii = np.argsort(table["epoch"], kind="stable")          # relative-astrometry.jl:46-47
+        table = {k: v[ii] for k, v in table.items()}
+        self.is_seppa = "pa" in table and "sep" in table         # :53 — pa/sep takes precedence
+        if self.is_seppa:
+            if np.any(table["pa"] >= 2 * np.pi) or np.any(table["pa"] <= -2 * np.pi):
+                warnings.warn("The data you entered fell outside the range [-2pi, +2pi]. The expected input format "
+                              "is radians (you can use `deg2rad` to convert). We suggest you double check your input data!")
+        if "cor" in table and np.any(np.abs(table["cor"]) > 1 - 1e-5):   # :70-72
+            raise ValueError(f"Correlation values may not be well-specified: {table['cor']}")
+        self.table = table
+        self.name = name
+        self.variables = variables
+        self.kind = capi.ASTROM_SEPPA if self.is_seppa else capi.ASTROM_RADEC
+
+    def __len__(self):
+        return len(self.table["epoch"])
+
+    def _c_table(self, planet_index):
+        t = self.table
+        if self.is_seppa:
+            y1, y2, s1, s2 = t["pa"], t["sep"], t["σ_pa"], t["σ_sep"]
+        else:
+            y1, y2, s1, s2 = t["ra"], t["dec"], t["σ_ra"], t["σ_dec"]
+        return dict(kind=self.kind, planet=planet_index, epoch=t["epoch"], y1=y1, y2=y2, s1=s1, s2=s2, cor=t.get("cor"))
+
+
+PlanetRelAstromLikelihood = PlanetRelAstromObs   # backwards-compat alias, relative-astrometry.jl:98
+
+
+class _RVBase(AbstractObs):
+    nuisance_names = ("offset", "jitter")
+
+    def __init__(self, observations, *, name, variables=None, trend_function=None, gaussian_process=None):
+        if trend_function is not None or gaussian_process is not None:
+            # Those branches (rv-absolute.jl:205-315, user trend closures) are host-side Julia code and
+            # out of scope for the kernel; the Julia shim falls back to the reference closure for them.
+            raise NotImplementedError("trend_function / gaussian_process observations are not on the HIP path")
+        table = _as_table(observations)
+        if not _equal_length_cols(table):
+            raise ValueError("The columns in the input data do not all have the same length")
+        if not set(rv_cols) <= set(table):
+            raise ValueError(f"Expected columns {rv_cols}")
+        if "inst_idx" in table and len(np.unique(table["inst_idx"])) > 1:
+            raise ValueError("Deprecated: data from separate RV instruments should now be placed into different "
+                             "StarAbsoluteRVLikelihood likelihood objects, rather than specified by an inst_idx parameter.")
+        table = {k: np.asarray(v, dtype=np.float64) for k, v in table.items() if k in rv_cols}
+        ii = np.argsort(table["epoch"], kind="stable")
+        table = {k: v[ii] for k, v in table.items()}
+        _warn_epoch_range(table["epoch"])
+        self.table = table
+        self.name = name
+        self.variables = variables
+
+    def __len__(self):
+        return len(self.table["epoch"])
+
+    def _c_table(self, planet_index):
+        t = self.table
+        return dict(kind=self.kind, planet=planet_index, epoch=t["epoch"], y1=t["rv"], y2=None, s1=t["σ_rv"], s2=None, cor=None)
+
+
+class StarAbsoluteRVObs(_RVBase):
+    kind = capi.RV_ABS
+
+
+class MarginalizedStarAbsoluteRVObs(_RVBase):
+    kind = capi.RV_ABS_MARG
+    nuisance_names = ("jitter",)
+
+
+class PlanetRelativeRVObs(_RVBase):
+    kind = capi.RV_REL
+
+
+StarAbsoluteRVLikelihood = StarAbsoluteRVObs
+PlanetRelativeRVLikelihood = PlanetRelativeRVObs

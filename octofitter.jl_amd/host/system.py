@@ -1,0 +1,280 @@
+"""
+Host-side mirror of the reference's model containers and of `make_ln_like`, batched.
+
+  Planet, System           src/variables.jl:461-508, 536-594 (containers only; priors/derived stay in Julia)
+  make_ln_like             src/likelihoods/system.jl:21-242
+  BatchedLnLike.__call__   the generated closure of system.jl:206-241 applied to W parameter sets,
+                           i.e. what ℓπcallback adds at src/logdensitymodel.jl:134
+  BatchedLnLike.ln_like_and_grad
+                           the likelihood part of ∇ℓπcallback (src/logdensitymodel.jl:169-177):
+                           value + gradient w.r.t. the resolved orbital elements and nuisances.
+
+θ for a batch of W walkers is the reference's nested NamedTuple with every leaf a length-W
+array (or a scalar, broadcast):
+
+    θ = dict(M=..., plx=..., observations={obsname: dict(offset=..., jitter=...)},
+             planets={"b": dict(a=..., e=..., i=..., ω=..., Ω=..., tp=..., mass=...,
+                                observations={obsname: dict(jitter=..., platescale=..., northangle=...)})})
+
+All compute goes through the C ABI (include/octofitter_hip.h). There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .observations import AbstractObs, normalizename
+
+_EL_KEYS = (("a",), ("e",), ("i",), ("ω", "w", "omega"), ("Ω", "O", "Omega"), ("tp",), ("M",), ("plx",), ("mass",))
+_BASIS = {"Visual{KepOrbit}": capi.ORBIT_VISUAL_KEP, "RadialVelocityOrbit": capi.ORBIT_RADVEL}
+
+
+class Planet:
+    def __init__(self, *, name, basis="Visual{KepOrbit}", observations=(), variables=None):
+        if basis not in _BASIS:
+            raise NotImplementedError(f"basis {basis!r} is not on the HIP path (supported: {sorted(_BASIS)})")
+        self.name = str(name)
+        self.basis = basis
+        self.observations = tuple(observations)
+        self.variables = variables
+        for o in self.observations:
+            if not isinstance(o, AbstractObs):
+                raise TypeError(f"planet observation {o!r} is not an AbstractObs")
+
+
+class System:
+    def __init__(self, *, name, companions=(), observations=(), variables=None):
+        self.name = str(name)
+        self.planets = tuple(companions)
+        self.observations = tuple(observations)
+        self.variables = variables
+        names = [p.name for p in self.planets]
+        if len(set(names)) != len(names):
+            raise ValueError("planet names must be unique")
+
+
+def _lookup(d, keys):
+    for k in keys:
+        if k in d:
+            return d[k]
+    return None
+
+
+class BatchedLnLike:
+    """Callable returned by make_ln_like. Holds one HIP context and the uploaded dataset."""
+
+    def __init__(self, system: System, θ_example: dict, device: int = 0, consts: capi.OctoConsts | None = None):
+        self.system = system
+        self.lib = capi.load_library()
+        # ---- epoch gather in the reference's standardised order (system.jl:35-54) ----------------
+        self.all_epochs = []
+        self.epoch_start_index_mapping = {}
+        j = 1
+        for obs in system.observations:
+            self.epoch_start_index_mapping[id(obs)] = j
+            j += len(obs)
+            self.all_epochs.extend(obs.table["epoch"].tolist())
+        for pl in system.planets:
+            for obs in pl.observations:
+                self.epoch_start_index_mapping[id(obs)] = j
+                j += len(obs)
+                self.all_epochs.extend(obs.table["epoch"].tolist())
+        # ---- evaluation order: planet observations planet by planet, then system (system.jl:229-235)
+        self.obs_entries = []   # (obs, planet_index or -1, planet_name or None, θ_obs key)
+        for ip, pl in enumerate(system.planets):
+            for obs in pl.observations:
+                if obs.kind in (capi.RV_ABS, capi.RV_ABS_MARG):
+                    raise ValueError(f"{type(obs).__name__} is a system-level observation")
+                self.obs_entries.append((obs, ip, pl.name, normalizename(obs.likelihoodname())))
+        for obs in system.observations:
+            if obs.kind not in (capi.RV_ABS, capi.RV_ABS_MARG):
+                raise ValueError(f"{type(obs).__name__} must be attached to a planet")
+            self.obs_entries.append((obs, -1, None, normalizename(obs.likelihoodname())))
+        self.n_planets = len(system.planets)
+        if self.n_planets < 1:
+            raise ValueError("the HIP path needs at least one planet")
+        planets_ex = θ_example.get("planets", {})
+        self.planet_desc = []
+        for pl in system.planets:
+            θp = planets_ex.get(pl.name, {})
+            self.planet_desc.append(dict(orbit_kind=_BASIS[pl.basis], has_mass="mass" in θp))
+        # every planet contributes to absolute RV and requires a mass (rv-absolute.jl:146-155)
+        if any(e[0].kind in (capi.RV_ABS, capi.RV_ABS_MARG) for e in self.obs_entries):
+            for pl, d in zip(system.planets, self.planet_desc):
+                if not d["has_mass"]:
+                    raise KeyError(f"planet {pl.name} has no `mass` variable but the system has absolute RV data")
+        self.obs_tables = [e[0]._c_table(e[1]) for e in self.obs_entries]
+        # ---- C side ------------------------------------------------------------------------------
+        self._ctx = C.c_void_p()
+        self._check(self.lib.octo_ctx_create(C.byref(self._ctx), int(device)), "octo_ctx_create")
+        if consts is not None:
+            self._check(self.lib.octo_consts_set(self._ctx, C.byref(consts)), "octo_consts_set")
+        obs_arr, keep = capi.pack_obs(self.obs_tables)
+        pl_arr = capi.pack_planets(self.planet_desc)
+        self._ds = C.c_void_p()
+        self._check(self.lib.octo_dataset_create(self._ctx, obs_arr, len(self.obs_tables), pl_arr, self.n_planets,
+                                                 C.byref(self._ds)), "octo_dataset_create")
+        del keep
+        self.n_obs = len(self.obs_tables)
+        self.n_rows = int(self.lib.octo_dataset_n_rows(self._ds))
+
+    # -- lifecycle ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ds", None):
+            self.lib.octo_dataset_destroy(self._ds)
+            self._ds = None
+        if getattr(self, "_ctx", None):
+            self.lib.octo_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status, what):
+        if status != capi.OCTO_OK:
+            msg = self.lib.octo_last_error(self._ctx) if self._ctx else b""
+            raise capi.OctoError(status, f"{what}: {(msg or b'').decode()}")
+
+    # -- θ <-> SoA ---------------------------------------------------------------------------------
+    def _batch_size(self, θ):
+        W = 1
+        def visit(d):
+            nonlocal W
+            for v in d.values():
+                if isinstance(v, dict):
+                    visit(v)
+                else:
+                    n = np.size(v)
+                    if n != 1:
+                        if W != 1 and n != W:
+                            raise ValueError("inconsistent batch sizes in θ")
+                        W = n
+        visit(θ)
+        return W
+
+    def pack(self, θ):
+        """merge(θ_system, θ_planet) per planet (system.jl:117) -> elems [P*9, W]; θ_obs -> nuis [n_obs*3, W]."""
+        W = self._batch_size(θ)
+        elems = np.zeros((self.n_planets * capi.N_EL, W))
+        for ip, pl in enumerate(self.system.planets):
+            θp = θ.get("planets", {}).get(pl.name, {})
+            for k, keys in enumerate(_EL_KEYS):
+                v = _lookup(θp, keys)
+                if v is None:
+                    v = _lookup(θ, keys)      # planet-level wins, as in merge(θ_system, θ_planet)
+                if v is None:
+                    radvel_unused = self.planet_desc[ip]["orbit_kind"] == capi.ORBIT_RADVEL and k in (capi.EL_I, capi.EL_O, capi.EL_PLX)
+                    if k == capi.EL_MASS or radvel_unused:
+                        v = 0.0
+                    else:
+                        raise KeyError(f"planet {pl.name}: missing orbital element {keys[0]}")
+                elems[ip * capi.N_EL + k, :] = v
+        nuis = None
+        any_nuis = False
+        buf = np.zeros((self.n_obs * capi.N_NUIS, W))
+        for io, (obs, ip, plname, key) in enumerate(self.obs_entries):
+            if ip >= 0:
+                θobs = θ.get("planets", {}).get(plname, {}).get("observations", {}).get(key, {})
+            else:
+                θobs = θ.get("observations", {}).get(key, {})
+            if obs.kind in (capi.ASTROM_RADEC, capi.ASTROM_SEPPA):
+                defaults = (("jitter", 0.0), ("platescale", 1.0), ("northangle", 0.0))   # relative-astrometry.jl:170-172
+            else:
+                defaults = (("offset", 0.0), ("jitter", 0.0))
+                if obs.kind == capi.RV_ABS_MARG and "jitter" not in θobs:
+                    raise KeyError("MarginalizedStarAbsoluteRVObs requires θ_obs.jitter (rv-absolute-margin.jl:149)")
+            for k, (nm, dv) in enumerate(defaults):
+                if nm in θobs:
+                    any_nuis = True
+                    buf[io * capi.N_NUIS + k, :] = θobs[nm]
+                else:
+                    buf[io * capi.N_NUIS + k, :] = dv
+        if any_nuis:
+            nuis = buf
+        return elems, nuis
+
+    def unpack_grad(self, g_elems, g_nuis):
+        out = dict(planets={}, observations={})
+        for ip, pl in enumerate(self.system.planets):
+            out["planets"][pl.name] = {keys[0]: g_elems[ip * capi.N_EL + k] for k, keys in enumerate(_EL_KEYS)}
+            out["planets"][pl.name]["observations"] = {}
+        if g_nuis is not None:
+            for io, (obs, ip, plname, key) in enumerate(self.obs_entries):
+                names = ("jitter", "platescale", "northangle") if obs.kind in (capi.ASTROM_RADEC, capi.ASTROM_SEPPA) else ("offset", "jitter")
+                d = {nm: g_nuis[io * capi.N_NUIS + k] for k, nm in enumerate(names)}
+                if ip >= 0:
+                    out["planets"][plname]["observations"][key] = d
+                else:
+                    out["observations"][key] = d
+        return out
+
+    # -- evaluation: host arrays ---------------------------------------------------------------------
+    def ln_like_arrays(self, elems, nuis=None, grad=False):
+        elems = np.ascontiguousarray(elems, dtype=np.float64)
+        if elems.ndim != 2 or elems.shape[0] != self.n_planets * capi.N_EL:
+            raise ValueError(f"elems must be [{self.n_planets * capi.N_EL}, W]")
+        W = elems.shape[1]
+        nu = None
+        if nuis is not None:
+            nu = np.ascontiguousarray(nuis, dtype=np.float64)
+            if nu.shape != (self.n_obs * capi.N_NUIS, W):
+                raise ValueError(f"nuis must be [{self.n_obs * capi.N_NUIS}, {W}]")
+        ll = np.empty(W)
+        g_el = np.empty_like(elems) if grad else None
+        g_nu = np.empty_like(nu) if (grad and nu is not None) else None
+        self._check(self.lib.octo_eval(self._ctx, self._ds, capi._dptr(elems), capi._dptr(nu), W, W,
+                                       capi._dptr(ll), capi._dptr(g_el), capi._dptr(g_nu)), "octo_eval")
+        return (ll, g_el, g_nu) if grad else ll
+
+    def __call__(self, θ):
+        elems, nuis = self.pack(θ)
+        return self.ln_like_arrays(elems, nuis)
+
+    def ln_like_and_grad(self, θ):
+        elems, nuis = self.pack(θ)
+        ll, g_el, g_nu = self.ln_like_arrays(elems, nuis, grad=True)
+        return ll, self.unpack_grad(g_el, g_nu)
+
+    # -- evaluation: device-resident torch tensors (plumbing for bench / sharded drivers) -------------
+    def ln_like_device(self, elems_t, nuis_t=None, grad=False, out=None, stream=None):
+        """elems_t: torch float64 CUDA tensor [P*9, W] (contiguous). Enqueues on torch's current stream
+        unless `stream` (a raw hipStream_t integer) is given. Returns torch tensors; asynchronous."""
+        import torch
+        assert elems_t.is_cuda and elems_t.dtype == torch.float64 and elems_t.is_contiguous()
+        W = elems_t.shape[1]
+        if out is None:
+            ll = torch.empty(W, dtype=torch.float64, device=elems_t.device)
+            g_el = torch.empty_like(elems_t) if grad else None
+            g_nu = torch.empty_like(nuis_t) if (grad and nuis_t is not None) else None
+        else:
+            ll, g_el, g_nu = out
+        if stream is None:
+            stream = torch.cuda.current_stream(elems_t.device).cuda_stream
+        self._check(self.lib.octo_eval_device(
+            self._ctx, self._ds, elems_t.data_ptr(), nuis_t.data_ptr() if nuis_t is not None else None, W, W,
+            ll.data_ptr(), g_el.data_ptr() if g_el is not None else None, g_nu.data_ptr() if g_nu is not None else None,
+            C.c_void_p(stream)), "octo_eval_device")
+        return (ll, g_el, g_nu) if grad else ll
+
+    def sync(self):
+        self._check(self.lib.octo_sync(self._ctx), "octo_sync")
+
+    def timing_enable(self, on=True):
+        self._check(self.lib.octo_timing_enable(self._ctx, int(on)), "octo_timing_enable")
+
+    def timing_read(self, reset=True):
+        ms = C.c_double()
+        n = C.c_int64()
+        self._check(self.lib.octo_timing_read(self._ctx, C.byref(ms), C.byref(n), int(reset)), "octo_timing_read")
+        return ms.value, n.value
+
+
+def make_ln_like(system: System, θ_system: dict, device: int = 0, consts=None) -> BatchedLnLike:
+    """Mirror of `make_ln_like(system::System, θ_system)` (src/likelihoods/system.jl:21): θ_system is an
+    example parameter set used, as in the reference, only to discover which variables exist."""
+    return BatchedLnLike(system, θ_system, device=device, consts=consts)

@@ -1,0 +1,198 @@
+"""
+mp_oracle.py — independent 50-digit oracle for the epoch-loop likelihood path.
+
+TEST INFRASTRUCTURE (only tests/ and oracle/make_golden.py import this). PARITY UNPINNED:
+see the header of oracle/octo_oracle.c — the reference is Julia-only, cannot run here and
+ships no golden value for this path, so this file pins the *mathematics* instead:
+
+  * Kepler's equation is solved by Newton iteration at 50 digits (no Markley formula);
+  * the sky-plane position uses the textbook rotation of the orbital-plane vector
+    (r cos ν, r sin ν) by ω, i, Ω with the axis conventions the reference documents in
+    docs/src/faq.md:106-143 (+x East/RA, +y North/Dec, +z away; Ω from North through East),
+    i.e. neither the reference-order `2atan(ν_fact tan(E/2))` path of oracle/octo_oracle.c nor
+    the Thiele-Innes path of the HIP kernels;
+  * the likelihood terms are the closed-form Gaussian densities the reference evaluates through
+    Distributions.jl (src/likelihoods/relative-astrometry.jl:166-253,
+    OctofitterRadialVelocity/src/rv-absolute.jl:172-204, rv-absolute-margin.jl:140-185,
+    rv-relative.jl:177-211);
+  * gradients are central differences at 60 digits (error ~1e-40), so they test the
+    analytic adjoints rather than restate them.
+
+Inputs use the C-ABI layout of include/octofitter_hip.h.
+"""
+from __future__ import annotations
+
+import mpmath as mp
+
+mp.mp.dps = 60
+
+KINDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4}
+ORBIT_VISUAL_KEP, ORBIT_RADVEL = 0, 1
+EL = ["a", "e", "i", "w", "O", "tp", "M", "plx", "mass"]
+N_EL, N_NUIS = 9, 3
+
+DEFAULT_CONSTS = dict(
+    kepler_year_to_julian_day=365.2568983840419,
+    year2day_julian=365.25,
+    au2m=1.495978707e11,
+    sec2year_julian=3.168808781402895e-8,
+    pc2au=206265.0,
+    rad2as=206265.0,
+    mjup2msol=0.0009545942339693249,
+)
+
+
+def kepler_newton(MA, e):
+    """Eccentric anomaly in [-π, π] congruent to the root of E - e sin E = MA."""
+    twopi = 2 * mp.pi
+    M = MA - twopi * mp.nint(MA / twopi)
+    E = M if e < mp.mpf("0.8") else mp.pi * mp.sign(M) if M != 0 else mp.mpf(0)
+    for _ in range(200):
+        f = E - e * mp.sin(E) - M
+        fp = 1 - e * mp.cos(E)
+        dE = f / fp
+        E -= dE
+        if abs(dE) < mp.mpf(10) ** (-(mp.mp.dps - 5)):
+            break
+    return E
+
+
+def _orbit(c, kind, el):
+    a, e, inc, w, O, tp, M, plx, _mass = el
+    P_d = mp.mpf(c["kepler_year_to_julian_day"]) * mp.sqrt(a ** 3 / M)
+    P_yr = P_d / mp.mpf(c["year2day_julian"])
+    o = dict(a=a, e=e, w=w, tp=tp, M=M, P_d=P_d)
+    if kind == ORBIT_VISUAL_KEP:
+        o.update(i=inc, O=O, mas_per_au=plx * mp.mpf(c["rad2as"]) / mp.mpf(c["pc2au"]),
+                 K=2 * mp.pi * a * mp.sin(inc) / (P_yr * mp.sqrt(1 - e * e)) * mp.mpf(c["au2m"]) * mp.mpf(c["sec2year_julian"]))
+    else:
+        o.update(i=mp.pi / 2, O=mp.mpf(0), mas_per_au=mp.mpf(0),
+                 K=2 * mp.pi * a / (P_yr * mp.sqrt(1 - e * e)) * mp.mpf(c["au2m"]) * mp.mpf(c["sec2year_julian"]))
+    return o
+
+
+def solve(o, t):
+    """-> dict(E, nu, r, ra, dec, rv) for the companion relative to the primary."""
+    MA = 2 * mp.pi * (mp.mpf(t) - o["tp"]) / o["P_d"]
+    E = kepler_newton(MA, o["e"])
+    e = o["e"]
+    Xo = o["a"] * (mp.cos(E) - e)                       # orbital-plane coordinates, periapsis on +X
+    Yo = o["a"] * mp.sqrt(1 - e * e) * mp.sin(E)
+    r = mp.sqrt(Xo * Xo + Yo * Yo)
+    nu = mp.atan2(Yo, Xo)
+    u = nu + o["w"]
+    # rotate by ω (in-plane), tilt by i about the line of nodes, rotate node to PA Ω (from North through East)
+    north = r * (mp.cos(u) * mp.cos(o["O"]) - mp.sin(u) * mp.cos(o["i"]) * mp.sin(o["O"]))
+    east = r * (mp.cos(u) * mp.sin(o["O"]) + mp.sin(u) * mp.cos(o["i"]) * mp.cos(o["O"]))
+    rv = o["K"] * (mp.cos(u) + e * mp.cos(o["w"]))
+    return dict(E=E, nu=nu, r=r, ra=east * o["mas_per_au"], dec=north * o["mas_per_au"], rv=rv)
+
+
+def ln_like(c, planets, obs, elems, nuis):
+    """One walker. elems: [n_planets][9] mpf; nuis: [n_obs][3] mpf or None."""
+    n_pl = len(planets)
+    orbs = [_orbit(c, planets[p]["orbit_kind"], elems[p]) for p in range(n_pl)]
+    m_sol = [elems[p][8] * mp.mpf(c["mjup2msol"]) if planets[p]["has_mass"] else mp.mpf(0) for p in range(n_pl)]
+    log2pi = mp.log(2 * mp.pi)
+    total = mp.mpf(0)
+    for io, ob in enumerate(obs):
+        kind = KINDS[ob["kind"]] if isinstance(ob["kind"], str) else ob["kind"]
+        nz = nuis[io] if nuis is not None else None
+        ip = ob["planet"]
+        ll = mp.mpf(0)
+        if kind in (0, 1):
+            jitter = nz[0] if nz is not None else mp.mpf(0)
+            plate = nz[1] if nz is not None else mp.mpf(1)
+            north = nz[2] if nz is not None else mp.mpf(0)
+            for j, t in enumerate(ob["epoch"]):
+                sols = [solve(o, t) for o in orbs]
+                ra = sols[ip]["ra"]
+                dec = sols[ip]["dec"]
+                for p in range(n_pl):
+                    if p != ip and orbs[p]["a"] < orbs[ip]["a"] and planets[p]["has_mass"]:
+                        f = m_sol[p] / orbs[p]["M"]          # star about the inner barycentre: -(−m/M · offset)
+                        ra += f * sols[p]["ra"]
+                        dec += f * sols[p]["dec"]
+                if kind == 1:
+                    rho = mp.sqrt(ra * ra + dec * dec)
+                    pa = mp.atan2(ra, dec)
+                    d = (mp.mpf(ob["y1"][j]) + north) - pa
+                    d = d - 2 * mp.pi * mp.nint(d / (2 * mp.pi))     # wrapped to [-π, π]
+                    r1 = d
+                    r2 = mp.mpf(ob["y2"][j]) * plate - rho
+                else:
+                    x, y = mp.mpf(ob["y1"][j]), mp.mpf(ob["y2"][j])
+                    cn, sn = mp.cos(north), mp.sin(north)
+                    # data rotated by −northangle (angle measured East through North), scaled by platescale
+                    r1 = plate * (x * cn + y * sn) - ra
+                    r2 = plate * (y * cn - x * sn) - dec
+                v1 = mp.mpf(ob["s1"][j]) ** 2 + jitter ** 2
+                v2 = mp.mpf(ob["s2"][j]) ** 2 + jitter ** 2
+                rho_c = mp.mpf(ob["cor"][j]) if ob.get("cor") is not None else mp.mpf(0)
+                det = v1 * v2 * (1 - rho_c ** 2)
+                quad = (r1 * r1 / v1 - 2 * rho_c * r1 * r2 / mp.sqrt(v1 * v2) + r2 * r2 / v2) / (1 - rho_c ** 2)
+                ll += -log2pi - mp.log(det) / 2 - quad / 2
+        else:
+            offset = nz[0] if (nz is not None and kind != 3) else mp.mpf(0)
+            jitter = nz[1] if nz is not None else mp.mpf(0)
+            A = B = C = mp.mpf(0)
+            for j, t in enumerate(ob["epoch"]):
+                sols = [solve(o, t) for o in orbs]
+                model = offset
+                if kind == 4:
+                    model += sols[ip]["rv"]
+                    for p in range(n_pl):
+                        if p != ip and orbs[p]["a"] < orbs[ip]["a"] and planets[p]["has_mass"]:
+                            model += -m_sol[p] / orbs[p]["M"] * sols[p]["rv"]
+                else:
+                    for p in range(n_pl):
+                        model += -m_sol[p] / orbs[p]["M"] * sols[p]["rv"]
+                resid = mp.mpf(ob["y1"][j]) - model
+                var = mp.mpf(ob["s1"][j]) ** 2 + jitter ** 2
+                if kind == 3:
+                    A += 1 / var
+                    B -= 2 * resid / var
+                    C += resid ** 2 / var
+                    ll -= mp.log(2 * mp.pi * var)
+                else:
+                    ll += -(log2pi + mp.log(var)) / 2 - resid ** 2 / var / 2
+            if kind == 3:
+                ll -= -B ** 2 / (4 * A) + C + mp.log(A)
+        total += ll
+    return total
+
+
+def ln_like_and_grad(c, planets, obs, elems, nuis, h_rel=mp.mpf(10) ** -25):
+    """Central-difference gradient at working precision 60 digits. Returns (ll, g_elems, g_nuis)."""
+    elems = [[mp.mpf(x) for x in row] for row in elems]
+    nuis_m = [[mp.mpf(x) for x in row] for row in nuis] if nuis is not None else None
+    f0 = ln_like(c, planets, obs, elems, nuis_m)
+    g_el = [[mp.mpf(0)] * N_EL for _ in elems]
+    for p in range(len(elems)):
+        for k in range(N_EL):
+            if planets[p]["orbit_kind"] == ORBIT_RADVEL and k in (2, 4, 7):
+                continue
+            if k == 8 and not planets[p]["has_mass"]:
+                continue
+            x = elems[p][k]
+            h = h_rel * max(abs(x), mp.mpf(1))
+            elems[p][k] = x + h
+            fp = ln_like(c, planets, obs, elems, nuis_m)
+            elems[p][k] = x - h
+            fm = ln_like(c, planets, obs, elems, nuis_m)
+            elems[p][k] = x
+            g_el[p][k] = (fp - fm) / (2 * h)
+    g_nu = None
+    if nuis_m is not None:
+        g_nu = [[mp.mpf(0)] * N_NUIS for _ in nuis_m]
+        for io in range(len(nuis_m)):
+            for k in range(N_NUIS):
+                x = nuis_m[io][k]
+                h = h_rel * max(abs(x), mp.mpf(1))
+                nuis_m[io][k] = x + h
+                fp = ln_like(c, planets, obs, elems, nuis_m)
+                nuis_m[io][k] = x - h
+                fm = ln_like(c, planets, obs, elems, nuis_m)
+                nuis_m[io][k] = x
+                g_nu[io][k] = (fp - fm) / (2 * h)
+    return f0, g_el, g_nu

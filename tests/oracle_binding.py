@@ -1,0 +1,85 @@
+"""ctypes binding of oracle/liboctooracle.so — the CHECKER. Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+capi = pkg.capi
+
+ORACLE_DIR = ROOT / "oracle"
+ORACLE_LIB = ORACLE_DIR / "liboctooracle.so"
+_lib = None
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", str(ORACLE_DIR)], check=True)
+
+
+def load_oracle():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not ORACLE_LIB.exists():
+        build_oracle()
+    lib = C.CDLL(str(ORACLE_LIB))
+    dp = capi.c_double_p
+    lib.octo_oracle_eval.restype = C.c_int32
+    lib.octo_oracle_eval.argtypes = [C.POINTER(capi.OctoConsts), C.POINTER(capi.OctoObsDesc), C.c_int32,
+                                     C.POINTER(capi.OctoPlanetDesc), C.c_int32, dp, dp, C.c_int64, C.c_int64,
+                                     dp, dp, dp, C.POINTER(C.c_uint8), C.c_int32]
+    lib.octo_oracle_kepler_markley.restype = C.c_double
+    lib.octo_oracle_kepler_markley.argtypes = [C.c_double, C.c_double]
+    lib.octo_oracle_orbitsolve.restype = C.c_int32
+    lib.octo_oracle_orbitsolve.argtypes = [C.POINTER(capi.OctoConsts), C.c_int32, dp, C.c_double, dp]
+    lib.octo_oracle_consts_default.restype = C.c_int32
+    lib.octo_oracle_consts_default.argtypes = [C.POINTER(capi.OctoConsts)]
+    _lib = lib
+    return lib
+
+
+def oracle_consts():
+    c = capi.OctoConsts()
+    assert load_oracle().octo_oracle_consts_default(C.byref(c)) == 0
+    return c
+
+
+def oracle_eval(obs_tables, planets, elems, nuis=None, grad=True, active=None, consts=None, n_threads=1):
+    """elems: [n_planets*9, W] float64; nuis: [n_obs*3, W] or None.
+    Returns ll[W], g_elems (or None), g_nuis (or None)."""
+    lib = load_oracle()
+    consts = consts or oracle_consts()
+    elems = np.ascontiguousarray(elems, dtype=np.float64)
+    W = elems.shape[1]
+    obs_arr, keep = capi.pack_obs(obs_tables)
+    pl_arr = capi.pack_planets(planets)
+    ll = np.empty(W)
+    g_el = np.zeros_like(elems) if grad else None
+    nu = None if nuis is None else np.ascontiguousarray(nuis, dtype=np.float64)
+    g_nu = np.zeros_like(nu) if (grad and nu is not None) else None
+    mask = None
+    if active is not None:
+        mask = np.ascontiguousarray(active, dtype=np.uint8)
+    st = lib.octo_oracle_eval(C.byref(consts), obs_arr, len(obs_tables), pl_arr, len(planets),
+                              capi._dptr(elems), capi._dptr(nu), W, W, capi._dptr(ll), capi._dptr(g_el), capi._dptr(g_nu),
+                              mask.ctypes.data_as(C.POINTER(C.c_uint8)) if mask is not None else None, n_threads)
+    assert st == 0, st
+    del keep
+    return ll, g_el, g_nu
+
+
+def oracle_orbitsolve(el9, t, orbit_kind=0, consts=None):
+    lib = load_oracle()
+    consts = consts or oracle_consts()
+    el9 = np.ascontiguousarray(el9, dtype=np.float64)
+    out = np.empty(10)
+    assert lib.octo_oracle_orbitsolve(C.byref(consts), orbit_kind, capi._dptr(el9), float(t), capi._dptr(out)) == 0
+    return dict(zip(["MA", "EA", "nu", "r", "raoff", "decoff", "radvel", "n", "K", "cart2angle"], out))

@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""
+bench.py — throughput of the epoch-loop likelihood hot path on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the hot path (k_setup -> k_main -> k_finish through octo_eval_device) over one
+batch of synthetic input that is already resident in HBM: BASELINE.json config 3 — 1 planet, 1e4 RA/Dec
+epochs x 1e4 prior-drawn walkers, forward log-likelihood + reverse gradient w.r.t. the orbital elements.
+Metric: epoch-likelihood evaluations per second = walkers x rows x steps / wall time, whole job.
+Multi-GPU: walkers are independent -> each rank owns its own 1e4 walkers (weak scaling), the dataset is
+replicated, and there is NO collective on the data path (the only collective of the path is the
+parallel-tempering swap step, exercised with --workload pt).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      HBM bound as contracted by north_star: achieved = algorithmic bytes per launch
+                (40 B per RA/Dec row per walker + 136 B per walker) / average duration of the
+                dominant kernel k_main measured with HIP events on its launch stream.
+  cpu_baseline  the CPU restatement (oracle/, kind "port") timed on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_PER_ROW = 40.0          # epoch, ra, dec, σ_ra, σ_dec  
+BYTES_PER_WALKER = 64.0 + 72.0  # read 8 elements, write ll + 8 adjoints
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--epochs", type=int, default=10_000)
+    ap.add_argument("--walkers", type=int, default=10_000, help="walkers per GPU")
+    ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt"], default="grad")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, obs_tables, planets, seconds):
+    """Oracle (reference-order restatement, forward-mode duals = ForwardDiff chunk) on all host cores."""
+    import oracle_binding as ob
+    import synth
+    cores = os.cpu_count() or 1
+    E = cfg["n_epochs"]
+    mask = synth.active_mask(1, 1, mass=False, nuis=False)
+    probe = min(cfg["n_walkers"], 2 * cores)
+    t0 = time.perf_counter()
+    ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :probe], None, grad=True, active=mask, n_threads=0)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    rate = probe * E / dt
+    n = int(min(cfg["n_walkers"], max(cores, rate * seconds / E)))
+    n = max(cores, n // cores * cores)
+    t0 = time.perf_counter()
+    ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :n], None, grad=True, active=mask, n_threads=0)
+    dt = time.perf_counter() - t0
+    return {"value": n * E / dt, "unit": "epoch-likelihood evals/s (fwd+grad)", "cores": cores, "kind": "port",
+            "sample": f"{n} walkers x {E} epochs of the same workload, oracle/liboctooracle.so (gcc -O3, OpenMP over walkers, "
+                      f"8 forward-mode partials), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from __graft_entry__ import load_package
+    import synth
+    pkg = load_package()
+    capi = pkg.capi
+
+    grad = args.workload in ("grad", "two_planet", "pt") and args.workload != "fwd"
+    if args.workload == "two_planet":
+        c4 = synth.config_two_planet()
+        astrom = pkg.PlanetRelAstromObs(c4["astrom"], name="astrom")
+        rv = pkg.StarAbsoluteRVObs(c4["rv"], name="rv")
+        b = pkg.Planet(name="b", observations=[])
+        c = pkg.Planet(name="c", observations=[astrom])
+        system = pkg.System(name="cfg4", companions=[b, c], observations=[rv])
+        θex = dict(M=1.2, plx=50.0, planets=dict(b=dict(a=3, e=0.1, i=1, ω=1, Ω=2, tp=5e4, mass=5), c=dict(a=15, e=0.3, i=1, ω=.5, Ω=2, tp=5e4, mass=10)))
+        fn = pkg.make_ln_like(system, θex, device=local_rank)
+        # nuisance rows follow the evaluation order: planet observations first, then system observations
+        elems_h, nuis_h = c4["elems"], c4["nuis"]
+        n_rows, W = c4["n_rows"], c4["n_walkers"]
+        workload = "config4: 2 planets, 2500 RA/Dec + 2500 abs-RV epochs x 4096 walkers, fwd+grad"
+        bytes_per_launch = W * (2500 * 40.0 + 2500 * 24.0) + W * 8.0 * (18 + 6 + 1 + 18 + 6)
+        cfg = None
+    else:
+        cfg = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2,
+                                  seed=None if world == 1 else 20260929 + 3 + 1000 * rank)
+        obs, planet = synth.to_mirror(pkg, cfg)
+        system = pkg.System(name="bench", companions=[planet], observations=[])
+        fn = pkg.make_ln_like(system, cfg["theta_example"], device=local_rank)
+        elems_h, nuis_h = cfg["elems"], None
+        n_rows, W = cfg["n_epochs"], cfg["n_walkers"]
+        workload = f"config{'3' if grad else '2'}: 1 planet, {n_rows} RA/Dec epochs x {W} walkers/GPU, {'fwd+reverse-grad' if grad else 'fwd only'}"
+        bytes_per_launch = W * n_rows * BYTES_PER_ROW + W * (BYTES_PER_WALKER if grad else 72.0)
+
+    elems = torch.tensor(elems_h, device=dev)
+    nuis = torch.tensor(nuis_h, device=dev) if nuis_h is not None else None
+    out = (torch.empty(W, dtype=torch.float64, device=dev),
+           torch.empty_like(elems) if grad else None,
+           torch.empty_like(nuis) if (grad and nuis is not None) else None)
+
+    pt = None
+    if args.workload == "pt":
+        # config 5: temperatures sharded over ranks; every step = fwd+grad-free explorer evaluation, RCCL
+        # all_gather of the per-replica log-likelihoods, deterministic neighbour swap of β labels.
+        from octofitter_jl_amd.host.tempering import TemperedSwap
+        n_temps_total = 8 * world
+        chains = W // 8
+        pt = TemperedSwap(fn, n_temps_total=n_temps_total, n_chains=chains, rank=rank, world=world, device=dev, seed=20260929)
+        grad = False
+        out = (out[0], None, None)
+        workload = f"config5: {n_temps_total} temperatures x {chains} walkers x {n_rows} epochs, sharded by temperature, RCCL all_gather swap"
+
+    def run_step(i):
+        if grad:
+            fn.ln_like_device(elems, nuis, grad=True, out=out)
+        else:
+            fn.ln_like_device(elems, nuis, grad=False, out=(out[0], None, None))
+        if pt is not None:
+            pt.swap_step(out[0], i)
+
+    for i in range(args.warmup):
+        run_step(i)
+    torch.cuda.synchronize()
+    fn.timing_enable(True)
+    fn.timing_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_n = fn.timing_read(reset=True)
+    fn.timing_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    evals = float(W) * n_rows * args.steps * world
+    value = evals / dt
+    res = {
+        "metric": "epoch-likelihood evals/sec (fwd+grad), 1e4 epochs x 1e4 walkers" if args.workload == "grad" else f"epoch-likelihood evals/sec ({args.workload})",
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "walkers_per_gpu": W, "rows": n_rows, "parallelism": f"walkers sharded x{world}, dataset replicated, no data-path collective"},
+    }
+    if rank == 0:
+        ach = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc.exists() and args.workload == "grad":
+            try:
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": (ach / HBM_PEAK_GBPS) if ach else None, "traffic": traffic,
+                           "kernel": "k_main", "kernel_avg_ms": kern_ms, "kernel_launches": kern_n,
+                           "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "note": "path is FP64-VALU bound (compulsory HBM traffic ~0.02 B/eval); see DESIGN.md"}
+        if not args.no_cpu_baseline and cfg is not None and world == 1 and args.workload in ("grad",):
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, fn.obs_tables, fn.planet_desc, args.cpu_seconds)
+            except Exception as ex:  # the checker is optional for the measurement itself
+                res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex}"}
+        print(json.dumps(res), flush=True)
+    fn.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,3 +13,5 @@ from .host.observations import (  # noqa: F401
     MarginalizedStarAbsoluteRVObs, PlanetRelativeRVObs, PlanetRelativeRVLikelihood,
 )
 from .host.system import Planet, System, make_ln_like, BatchedLnLike  # noqa: F401
+from .host.sharding import shard_range, ShardedLnLike  # noqa: F401,E402
+from .host.tempering import TemperedSwap  # noqa: F401,E402

@@ -1,0 +1,529 @@
+// octo_api.hip — C ABI of include/octofitter_hip.h over the HIP runtime (gfx950 only).
+// Host logic only: uploads, task tables, scratch, kernel dispatch, timing. No CPU compute path:
+// every entry point that evaluates fails with OCTO_ENODEV / OCTO_EHIP when no device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "octo_kernels.h"
+#include "octofitter_hip.h"
+
+using namespace octo;
+
+namespace {
+
+struct TaskTable {
+    int chunk = 0;
+    int n_tasks = 0;
+    Task* d_tasks = nullptr;
+    double* d_const_pre = nullptr;   // per-task constants for the no-nuisance path
+    double* d_const_raw = nullptr;   // per-task constants for the nuisance path
+    std::vector<Task> h_tasks;
+};
+
+}  // namespace
+
+struct octo_dataset {
+    int device = 0;
+    int n_obs = 0, n_planets = 0;
+    int kind_mask = 0;
+    int64_t n_rows = 0;
+    std::vector<DevObs> h_obs;
+    std::vector<std::vector<double>> h_rowconst_pre, h_rowconst_raw;   // per obs, per row
+    DevObs* d_obs = nullptr;
+    std::vector<double*> d_bufs;
+    octo_planet_desc planets[MAXP];
+    std::vector<TaskTable> tables;
+};
+
+struct octo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    octo_consts consts;
+    std::string err;
+    // scratch (device)
+    int64_t cap_w = 0, cap_part = 0, cap_io = 0, cap_marg = 0;
+    double* d_wc = nullptr;
+    int32_t* d_valid = nullptr;
+    double* d_partials = nullptr;
+    double* d_marg = nullptr;
+    double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
+    int64_t cap_in = 0, cap_out = 0;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double t_ms = 0.0;
+    int64_t t_n = 0;
+};
+
+namespace {
+
+int fail(octo_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? OCTO_ENOMEM : OCTO_EHIP,                  \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+DevConsts dev_consts(const octo_consts& c) {
+    DevConsts d;
+    d.k_yr = c.kepler_year_to_julian_day; d.yd = c.year2day_julian; d.au2m = c.au2m; d.sec2yr = c.sec2year_julian;
+    // cart2angle = rad2as·1e3 / (1000/plx · pc2au)  =  plx · rad2as/pc2au   (parameterizations.jl:215-216)
+    d.mas_per_au_per_plx = c.rad2as / c.pc2au;
+    d.mjup2msol = c.mjup2msol;
+    return d;
+}
+
+template <typename T>
+int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
+    if (need <= cap) return OCTO_OK;
+    if (p) { HIPCHK(ctx, hipFree(p)); p = nullptr; cap = 0; }
+    const int64_t n = need + need / 8;
+    HIPCHK(ctx, hipMalloc((void**)&p, sizeof(T) * (size_t)n));
+    cap = n;
+    return OCTO_OK;
+}
+
+// Build (or fetch) the task table for a row-chunk size. Tasks never straddle tables and tables keep
+// their order, so k_finish can sum each observation's partials contiguously and in a fixed order.
+int get_tasks(octo_ctx* ctx, octo_dataset* ds, int chunk, TaskTable** out) {
+    for (auto& t : ds->tables)
+        if (t.chunk == chunk) { *out = &t; return OCTO_OK; }
+    TaskTable tt;
+    tt.chunk = chunk;
+    std::vector<double> cpre, craw;
+    for (int o = 0; o < ds->n_obs; ++o) {
+        const int64_t n = ds->h_obs[o].n;
+        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+            Task t;
+            t.obs = o; t.row0 = (int32_t)r0; t.nrows = (int32_t)std::min<int64_t>(chunk, n - r0); t.pad = 0;
+            tt.h_tasks.push_back(t);
+            double a = 0.0, b = 0.0;
+            for (int64_t r = r0; r < r0 + t.nrows; ++r) { a += ds->h_rowconst_pre[o][r]; b += ds->h_rowconst_raw[o][r]; }
+            cpre.push_back(a); craw.push_back(b);
+        }
+    }
+    tt.n_tasks = (int)tt.h_tasks.size();
+    if (tt.n_tasks > 0) {
+        HIPCHK(ctx, hipMalloc((void**)&tt.d_tasks, sizeof(Task) * tt.n_tasks));
+        HIPCHK(ctx, hipMalloc((void**)&tt.d_const_pre, sizeof(double) * tt.n_tasks));
+        HIPCHK(ctx, hipMalloc((void**)&tt.d_const_raw, sizeof(double) * tt.n_tasks));
+        HIPCHK(ctx, hipMemcpy(tt.d_tasks, tt.h_tasks.data(), sizeof(Task) * tt.n_tasks, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(tt.d_const_pre, cpre.data(), sizeof(double) * tt.n_tasks, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(tt.d_const_raw, craw.data(), sizeof(double) * tt.n_tasks, hipMemcpyHostToDevice));
+    }
+    ds->tables.push_back(std::move(tt));
+    *out = &ds->tables.back();
+    return OCTO_OK;
+}
+
+int pick_chunk(const octo_dataset* ds, int64_t W) {
+    // enough waves to fill 256 CUs × 4 SIMDs several times over, small enough tasks for an even tail
+    const int64_t cols = (W + WAVE - 1) / WAVE;
+    const int64_t target_waves = 24576;
+    int64_t want_tasks = std::max<int64_t>(1, (target_waves + cols - 1) / cols);
+    int64_t chunk = (ds->n_rows + want_tasks - 1) / want_tasks;
+    chunk = std::max<int64_t>(chunk, 32);
+    chunk = std::min<int64_t>(chunk, 4096);
+    // quantise so that repeated calls with similar W reuse a table
+    int64_t q = 32;
+    while (q < chunk) q += (q < 256 ? 32 : 128);
+    return (int)q;
+}
+
+template <int P, bool GRAD, bool NUIS, int KM>
+int launch_all(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t st) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    const int64_t cols = (a.W + WAVE - 1) / WAVE;
+    const int64_t need = (int64_t)a.n_tasks * L::NACC * a.ldw;
+    int rc = grow(ctx, ctx->d_partials, ctx->cap_part, need);
+    if (rc) return rc;
+    a.partials = ctx->d_partials;
+    const dim3 gsetup((unsigned)((a.W + 255) / 256));
+    hipLaunchKernelGGL(k_setup, gsetup, dim3(256), 0, st, a);
+    if (a.n_tasks > 0) {
+        if (GRAD && L::HAS_MARG) {
+            // marginalised RV: forward pre-pass for μ̂ and A, then the gradient pass
+            using L0 = Layout<P, false, NUIS, KM>;
+            static_assert(L0::NACC <= L::NACC, "forward partials fit in the gradient buffer");
+            rc = grow(ctx, ctx->d_marg, ctx->cap_marg, (int64_t)a.n_obs * 2 * a.ldw);
+            if (rc) return rc;
+            a.marg = nullptr; a.marg_out = ctx->d_marg;
+            hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE), 0, st, a);
+            hipLaunchKernelGGL((k_marg<P, NUIS, KM>), gsetup, dim3(256), 0, st, a);
+            a.marg = ctx->d_marg;
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->timing) {
+            if (ctx->ev_used == ctx->ev_pool.size()) {
+                hipEvent_t x, y;
+                HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
+                ctx->ev_pool.emplace_back(x, y);
+            }
+            e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
+            HIPCHK(ctx, hipEventRecord(e0, st));
+        }
+        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE), 0, st, a);
+        if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, st));
+    }
+    hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), gsetup, dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return OCTO_OK;
+}
+
+template <int P, int KM>
+int dispatch2(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
+    if (grad) return nuis ? launch_all<P, true, true, KM>(ctx, ds, a, st) : launch_all<P, true, false, KM>(ctx, ds, a, st);
+    return nuis ? launch_all<P, false, true, KM>(ctx, ds, a, st) : launch_all<P, false, false, KM>(ctx, ds, a, st);
+}
+
+template <int P>
+int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
+    const int km = ds->kind_mask;
+    if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_SEPPA)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA>(ctx, ds, a, grad, nuis, st);
+    return dispatch2<P, KM_ALL>(ctx, ds, a, grad, nuis, st);
+}
+
+int drain_timing(octo_ctx* ctx) {
+    for (size_t k = 0; k < ctx->ev_used; ++k) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev_pool[k].second));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[k].first, ctx->ev_pool[k].second));
+        ctx->t_ms += ms;
+        ctx->t_n += 1;
+    }
+    ctx->ev_used = 0;
+    return OCTO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t octo_consts_default(octo_consts* out) {
+    if (!out) return OCTO_EINVAL;
+    // PlanetOrbits.jl / Octofitter.jl values this build assumes unless the host overrides them.
+    out->kepler_year_to_julian_day = 365.2568983840419;   // 2π√(au³/GM☉)/86400
+    out->year2day_julian = 365.25;
+    out->au2m = 1.495978707e11;
+    out->sec2year_julian = 3.168808781402895e-8;
+    out->pc2au = 206265.0;
+    out->rad2as = 206265.0;
+    out->mjup2msol = 0.0009545942339693249;
+    return OCTO_OK;
+}
+
+int32_t octo_version(int32_t* major, int32_t* minor) {
+    if (major) *major = OCTO_VERSION_MAJOR;
+    if (minor) *minor = OCTO_VERSION_MINOR;
+    return OCTO_OK;
+}
+
+int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
+    if (!out) return OCTO_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return OCTO_ENODEV;
+    octo_ctx* ctx = new (std::nothrow) octo_ctx();
+    if (!ctx) return OCTO_ENOMEM;
+    ctx->device = device_id;
+    octo_consts_default(&ctx->consts);
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return OCTO_EHIP;
+    }
+    *out = ctx;
+    return OCTO_OK;
+}
+
+int32_t octo_ctx_destroy(octo_ctx* ctx) {
+    if (!ctx) return OCTO_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg);
+    (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out);
+    delete ctx;
+    return OCTO_OK;
+}
+
+int32_t octo_consts_set(octo_ctx* ctx, const octo_consts* c) {
+    if (!ctx || !c) return OCTO_EINVAL;
+    const double* v = (const double*)c;
+    for (int k = 0; k < 7; ++k)
+        if (!(v[k] > 0.0) || !std::isfinite(v[k])) return fail(ctx, OCTO_EINVAL, "octo_consts_set: constants must be finite and positive");
+    ctx->consts = *c;
+    return OCTO_OK;
+}
+
+const char* octo_last_error(const octo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_obs,
+                            const octo_planet_desc* planets, int32_t n_planets, octo_dataset** out) {
+    if (!ctx || !out || n_obs < 0 || (n_obs > 0 && !obs) || !planets) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: null argument");
+    *out = nullptr;
+    if (n_planets < 1 || n_planets > MAXP) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: 1..4 planets supported");
+    for (int p = 0; p < n_planets; ++p)
+        if (planets[p].orbit_kind != OCTO_ORBIT_VISUAL_KEP && planets[p].orbit_kind != OCTO_ORBIT_RADVEL)
+            return fail(ctx, OCTO_EINVAL, "octo_dataset_create: unknown orbit kind");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    octo_dataset* ds = new (std::nothrow) octo_dataset();
+    if (!ds) return fail(ctx, OCTO_ENOMEM, "octo_dataset_create: host allocation failed");
+    ds->device = ctx->device; ds->n_obs = n_obs; ds->n_planets = n_planets;
+    for (int p = 0; p < n_planets; ++p) ds->planets[p] = planets[p];
+    auto bail = [&](int code, const std::string& msg) { octo_dataset_destroy(ds); return fail(ctx, code, msg); };
+    ds->h_obs.resize(n_obs); ds->h_rowconst_pre.resize(n_obs); ds->h_rowconst_raw.resize(n_obs);
+    for (int o = 0; o < n_obs; ++o) {
+        const octo_obs_desc& d = obs[o];
+        if (d.kind < 0 || d.kind >= OCTO_N_KINDS) return bail(OCTO_EINVAL, "octo_dataset_create: unknown observation kind");
+        if (d.n_epochs < 0 || d.n_epochs > 0x7fffffff) return bail(OCTO_EINVAL, "octo_dataset_create: bad n_epochs");
+        const bool astrom = d.kind == OCTO_ASTROM_RADEC || d.kind == OCTO_ASTROM_SEPPA;
+        const bool planet_obs = astrom || d.kind == OCTO_RV_REL;
+        if (planet_obs && (d.planet < 0 || d.planet >= n_planets)) return bail(OCTO_EINVAL, "octo_dataset_create: planet index out of range");
+        if (d.n_epochs > 0 && (!d.epoch || !d.y1 || !d.s1 || (astrom && (!d.y2 || !d.s2))))
+            return bail(OCTO_EINVAL, "octo_dataset_create: missing column");
+        if (astrom && planets[d.planet].orbit_kind != OCTO_ORBIT_VISUAL_KEP)
+            return bail(OCTO_EINVAL, "octo_dataset_create: astrometry needs a Visual{KepOrbit} planet");
+        if (!planet_obs)   // every planet contributes to absolute RV and requires a mass (rv-absolute.jl:146-155)
+            for (int p = 0; p < n_planets; ++p)
+                if (!planets[p].has_mass) return bail(OCTO_EINVAL, "octo_dataset_create: absolute RV needs a mass on every planet");
+        ds->kind_mask |= 1 << d.kind;
+        const int64_t n = d.n_epochs;
+        std::vector<double> raw((size_t)n * ROW_STRIDE, 0.0), pre((size_t)n * ROW_STRIDE, 0.0);
+        ds->h_rowconst_pre[o].resize(n); ds->h_rowconst_raw[o].resize(n);
+        for (int64_t r = 0; r < n; ++r) {
+            double* a = &raw[(size_t)r * ROW_STRIDE];
+            double* b = &pre[(size_t)r * ROW_STRIDE];
+            a[0] = b[0] = d.epoch[r]; a[1] = b[1] = d.y1[r];
+            if (astrom) {
+                const double s1 = d.s1[r], s2 = d.s2[r], c = d.cor ? d.cor[r] : 0.0;
+                if (d.cor && !(std::fabs(c) <= 1.0 - 1e-5))   // relative-astrometry.jl:70-72
+                    return bail(OCTO_EINVAL, "octo_dataset_create: correlation values may not be well-specified");
+                a[2] = b[2] = d.y2[r]; a[3] = s1; a[4] = s2; a[5] = c;
+                const double omc = 1.0 - c * c;
+                b[3] = 1.0 / (s1 * s1 * omc); b[4] = 1.0 / (s2 * s2 * omc); b[5] = -c / (s1 * s2 * omc);
+                ds->h_rowconst_pre[o][r] = -LOG2PI - 0.5 * std::log(s1 * s1 * s2 * s2 * omc);
+                ds->h_rowconst_raw[o][r] = -LOG2PI;
+            } else {
+                const double s = d.s1[r];
+                a[2] = s; b[2] = 1.0 / (s * s);
+                if (d.kind == OCTO_RV_ABS_MARG) {
+                    ds->h_rowconst_pre[o][r] = -std::log(TWO_PI * s * s);   // −log(2π var), rv-absolute-margin.jl:179
+                    ds->h_rowconst_raw[o][r] = 0.0;
+                } else {
+                    ds->h_rowconst_pre[o][r] = -0.5 * (LOG2PI + std::log(s * s));
+                    ds->h_rowconst_raw[o][r] = -0.5 * LOG2PI;
+                }
+            }
+        }
+        DevObs& h = ds->h_obs[o];
+        h.kind = d.kind; h.planet = planet_obs ? d.planet : -1; h.has_cor = d.cor ? 1 : 0; h.pad = 0; h.n = n;
+        h.raw = h.pre = nullptr;
+        if (n > 0) {
+            double *dr = nullptr, *dp = nullptr;
+            const size_t bytes = sizeof(double) * (size_t)n * ROW_STRIDE;
+            if (hipMalloc((void**)&dr, bytes) != hipSuccess) return bail(OCTO_ENOMEM, "octo_dataset_create: hipMalloc failed");
+            ds->d_bufs.push_back(dr);
+            if (hipMalloc((void**)&dp, bytes) != hipSuccess) return bail(OCTO_ENOMEM, "octo_dataset_create: hipMalloc failed");
+            ds->d_bufs.push_back(dp);
+            if (hipMemcpy(dr, raw.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dp, pre.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
+                return bail(OCTO_EHIP, "octo_dataset_create: upload failed");
+            h.raw = dr; h.pre = dp;
+        }
+        ds->n_rows += n;
+    }
+    if (n_obs > 0) {
+        if (hipMalloc((void**)&ds->d_obs, sizeof(DevObs) * n_obs) != hipSuccess) return bail(OCTO_ENOMEM, "octo_dataset_create: hipMalloc failed");
+        if (hipMemcpy(ds->d_obs, ds->h_obs.data(), sizeof(DevObs) * n_obs, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(OCTO_EHIP, "octo_dataset_create: upload failed");
+    }
+    *out = ds;
+    return OCTO_OK;
+}
+
+int32_t octo_dataset_destroy(octo_dataset* ds) {
+    if (!ds) return OCTO_OK;
+    (void)hipSetDevice(ds->device);
+    for (double* p : ds->d_bufs) (void)hipFree(p);
+    for (auto& t : ds->tables) { (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw); }
+    (void)hipFree(ds->d_obs);
+    delete ds;
+    return OCTO_OK;
+}
+
+int64_t octo_dataset_n_rows(const octo_dataset* ds) { return ds ? ds->n_rows : -1; }
+
+int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d_elems, const double* d_nuis,
+                         int64_t ld, int64_t W, double* d_ll, double* d_g_elems, double* d_g_nuis, void* hip_stream) {
+    if (!ctx || !cds || !d_elems || !d_ll) return fail(ctx, OCTO_EINVAL, "octo_eval_device: null argument");
+    if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_eval_device: need 0 <= W <= ld");
+    if (d_g_nuis && (!d_g_elems || !d_nuis)) return fail(ctx, OCTO_EINVAL, "octo_eval_device: g_nuis needs g_elems and nuis");
+    if (d_g_elems && d_nuis && !d_g_nuis) return fail(ctx, OCTO_EINVAL, "octo_eval_device: nuis given with g_elems but no g_nuis");
+    if (cds->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_eval_device: dataset lives on another device");
+    if (W == 0) return OCTO_OK;
+    octo_dataset* ds = const_cast<octo_dataset*>(cds);   // task-table cache only
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    if (ctx->timing && ctx->ev_used >= 4096) { int rc = drain_timing(ctx); if (rc) return rc; }
+    TaskTable* tt = nullptr;
+    int rc = get_tasks(ctx, ds, pick_chunk(ds, W), &tt);
+    if (rc) return rc;
+    const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
+    if (ldw > ctx->cap_w) {
+        int64_t c1 = ctx->cap_w, c2 = ctx->cap_w;
+        int64_t need = ldw;
+        // both buffers share the walker capacity
+        if (ctx->d_wc) { HIPCHK(ctx, hipFree(ctx->d_wc)); ctx->d_wc = nullptr; }
+        if (ctx->d_valid) { HIPCHK(ctx, hipFree(ctx->d_valid)); ctx->d_valid = nullptr; }
+        (void)c1; (void)c2;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_wc, sizeof(double) * (size_t)need * NWC * MAXP));
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_valid, sizeof(int32_t) * (size_t)need));
+        ctx->cap_w = need;
+    }
+    EvalArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.obs = ds->d_obs; a.tasks = tt->d_tasks; a.task_const = d_nuis ? tt->d_const_raw : tt->d_const_pre;
+    a.n_obs = ds->n_obs; a.n_tasks = tt->n_tasks; a.n_planets = ds->n_planets;
+    for (int p = 0; p < ds->n_planets; ++p) { a.orbit_kind[p] = ds->planets[p].orbit_kind; a.has_mass[p] = ds->planets[p].has_mass; }
+    a.elems = d_elems; a.nuis = d_nuis; a.ld = ld; a.W = W;
+    a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w;
+    a.ll_out = d_ll; a.g_elems = d_g_elems; a.g_nuis = d_g_nuis;
+    a.c = dev_consts(ctx->consts);
+    const bool grad = d_g_elems != nullptr, nuis = d_nuis != nullptr;
+    switch (ds->n_planets) {
+        case 1: return dispatch1<1>(ctx, ds, a, grad, nuis, st);
+        case 2: return dispatch1<2>(ctx, ds, a, grad, nuis, st);
+        case 3: return dispatch1<3>(ctx, ds, a, grad, nuis, st);
+        default: return dispatch1<4>(ctx, ds, a, grad, nuis, st);
+    }
+}
+
+int32_t octo_sync(octo_ctx* ctx) {
+    if (!ctx) return OCTO_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return OCTO_OK;
+}
+
+int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, const double* nuis, int64_t ld, int64_t W,
+                  double* ll_out, double* g_elems, double* g_nuis) {
+    if (!ctx || !ds || !elems || !ll_out) return fail(ctx, OCTO_EINVAL, "octo_eval: null argument");
+    if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_eval: need 0 <= W <= ld");
+    if (W == 0) return OCTO_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n_el = ds->n_planets * OCTO_N_EL, n_nu = ds->n_obs * OCTO_N_NUIS;
+    const int64_t ldd = (W + 63) / 64 * 64;
+    const int64_t n_in = (int64_t)(n_el + (nuis ? n_nu : 0)) * ldd;
+    const int64_t n_out = (int64_t)(1 + (g_elems ? n_el : 0) + (g_nuis ? n_nu : 0)) * ldd;
+    int rc = grow(ctx, ctx->d_in, ctx->cap_in, n_in);
+    if (rc) return rc;
+    rc = grow(ctx, ctx->d_out, ctx->cap_out, n_out);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, elems, sizeof(double) * ld, sizeof(double) * W, n_el,
+                                 hipMemcpyHostToDevice, st));
+    double* d_nuis = nullptr;
+    if (nuis) {
+        d_nuis = ctx->d_in + (int64_t)n_el * ldd;
+        HIPCHK(ctx, hipMemcpy2DAsync(d_nuis, sizeof(double) * ldd, nuis, sizeof(double) * ld, sizeof(double) * W, n_nu,
+                                     hipMemcpyHostToDevice, st));
+    }
+    double* d_ll = ctx->d_out;
+    double* d_ge = g_elems ? ctx->d_out + ldd : nullptr;
+    double* d_gn = g_nuis ? ctx->d_out + (int64_t)(1 + (g_elems ? n_el : 0)) * ldd : nullptr;
+    rc = octo_eval_device(ctx, ds, ctx->d_in, d_nuis, ldd, W, d_ll, d_ge, d_gn, st);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ll_out, d_ll, sizeof(double) * W, hipMemcpyDeviceToHost, st));
+    if (g_elems)
+        HIPCHK(ctx, hipMemcpy2DAsync(g_elems, sizeof(double) * ld, d_ge, sizeof(double) * ldd, sizeof(double) * W, n_el,
+                                     hipMemcpyDeviceToHost, st));
+    if (g_nuis)
+        HIPCHK(ctx, hipMemcpy2DAsync(g_nuis, sizeof(double) * ld, d_gn, sizeof(double) * ldd, sizeof(double) * W, n_nu,
+                                     hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return OCTO_OK;
+}
+
+int32_t octo_timing_enable(octo_ctx* ctx, int32_t on) {
+    if (!ctx) return OCTO_EINVAL;
+    ctx->timing = on != 0;
+    return OCTO_OK;
+}
+
+int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int32_t reset) {
+    if (!ctx) return OCTO_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = drain_timing(ctx);
+    if (rc) return rc;
+    if (avg_ms) *avg_ms = ctx->t_n > 0 ? ctx->t_ms / (double)ctx->t_n : 0.0;
+    if (n_launches) *n_launches = ctx->t_n;
+    if (reset) { ctx->t_ms = 0.0; ctx->t_n = 0; }
+    return OCTO_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------- parallel tempering swap
+namespace {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {   // splitmix64 finaliser
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_pt_swap(const double* __restrict__ ll, const double* __restrict__ beta,
+                                                 int32_t* slot2rep, int n_temps, int64_t n_chains, int parity,
+                                                 uint64_t seed, uint64_t step, int32_t* accepted) {
+    const int n_pairs = (n_temps - parity) / 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_chains * n_pairs) return;
+    const int64_t c = idx / n_pairs;
+    const int t = parity + 2 * (int)(idx % n_pairs);
+    int32_t* s2r = slot2rep + c * n_temps;
+    const int ri = s2r[t], rj = s2r[t + 1];
+    const double li = ll[c * n_temps + ri], lj = ll[c * n_temps + rj];
+    const double logA = (beta[t] - beta[t + 1]) * (lj - li);
+    // counter-based uniform in (0,1]: identical on every rank for the same (seed, step, chain, slot)
+    const uint64_t h = mix64(mix64(mix64(seed ^ 0x6f63746f50545357ull) + step) + (uint64_t)c * 0x100000001b3ull + (uint64_t)t);
+    const double u = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+    const bool acc = isfinite(li) && isfinite(lj) ? (log(u) < logA) : (isfinite(lj) && !isfinite(li) && beta[t] > beta[t + 1]);
+    if (acc) {
+        s2r[t] = rj; s2r[t + 1] = ri;
+        if (accepted) atomicAdd(&accepted[t], 1);
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t octo_pt_swap_device(octo_ctx* ctx, const double* d_ll_by_replica, const double* d_beta,
+                                       int32_t* d_slot2rep, int32_t n_temps, int64_t n_chains, int32_t parity,
+                                       uint64_t seed, uint64_t step, int32_t* d_accepted, void* hip_stream) {
+    if (!ctx || !d_ll_by_replica || !d_beta || !d_slot2rep) return fail(ctx, OCTO_EINVAL, "octo_pt_swap_device: null argument");
+    if (n_temps < 2 || n_chains < 1 || (parity != 0 && parity != 1)) return fail(ctx, OCTO_EINVAL, "octo_pt_swap_device: bad sizes");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    const int n_pairs = (n_temps - parity) / 2;
+    if (n_pairs == 0) return OCTO_OK;
+    const int64_t n = n_chains * n_pairs;
+    hipLaunchKernelGGL(k_pt_swap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_ll_by_replica, d_beta, d_slot2rep,
+                       n_temps, n_chains, parity, seed, step, d_accepted);
+    HIPCHK(ctx, hipGetLastError());
+    return OCTO_OK;
+}

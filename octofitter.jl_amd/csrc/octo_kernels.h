@@ -1,0 +1,483 @@
+// octo_kernels.h — the three kernels of one batched evaluation (gfx950):
+//
+//   k_setup   per (walker, planet): orbit-constructor constants (PlanetOrbits KepOrbit / Visual /
+//             RadialVelocityOrbit ctor; witnesses src/parameterizations.jl:62-64, 215-216) and the
+//             per-walker validity flag (src/logdensitymodel.jl:120-124, src/likelihoods/system.jl:214-221).
+//   k_main    THE hot kernel. grid = (walker tiles of 64) × (row tasks); lane = walker. Fuses
+//             _kepsolve_all! (system.jl:250-269), simulate! + ln_like of every observation kind
+//             (relative-astrometry.jl:104-142,166-253; rv-absolute.jl:135-204; rv-absolute-margin.jl:106-185;
+//             rv-relative.jl:121-211) and the reverse sweep into ~8-10 running sums per planet.
+//   k_finish  per walker: fixed-order sum of the task partials (deterministic), closed-form terms,
+//             and the map from the running sums to ∂ll/∂(a,e,i,ω,Ω,tp,M,plx,mass) and nuisances.
+#pragma once
+#include "octo_device.h"
+#include "octofitter_hip.h"
+
+namespace octo {
+
+constexpr int MAXP = 4;
+constexpr int ROW_STRIDE = 8;   // doubles per observation row record (64 B = one s_load_dwordx16)
+
+// kind mask bits
+constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16;
+constexpr int KM_RV = KM_RVABS | KM_MARG | KM_RVREL;
+constexpr int KM_ALL = 31;
+
+struct DevObs {
+    int32_t kind, planet, has_cor, pad;
+    int64_t n;
+    const double* raw;   // [n][8]: astrom {t,y1,y2,s1,s2,cor,0,0}; rv {t,rv,σ,0...}
+    const double* pre;   // [n][8]: astrom {t,y1,y2,p11,p22,p12,0,0} (Σ⁻¹ entries); rv {t,rv,1/σ²,0...}
+};
+
+struct Task {
+    int32_t obs, row0, nrows, pad;
+};
+
+struct DevConsts {
+    double k_yr, yd, au2m, sec2yr, mas_per_au_per_plx /* rad2as/pc2au */, mjup2msol;
+};
+
+struct EvalArgs {
+    const DevObs* obs;
+    const Task* tasks;
+    const double* task_const;     // [n_tasks] walker-independent additive constant of the task's rows
+    int32_t n_obs, n_tasks, n_planets, pad;
+    int32_t orbit_kind[MAXP];
+    int32_t has_mass[MAXP];
+    const double* elems;          // [P*9][ld]
+    const double* nuis;           // [n_obs*3][ld] or null
+    int64_t ld, W;
+    double* wc;                   // [P*NWC][ldw]
+    int32_t* valid;               // [ldw]
+    double* partials;             // [n_tasks*NACC][ldw]
+    const double* marg;           // [n_obs*2][ldw]: μ̂ and A of each marginalised-RV table (grad pass) or null
+    double* marg_out;
+    int64_t ldw;
+    double* ll_out; double* g_elems; double* g_nuis;
+    DevConsts c;
+};
+
+template <int P, bool GRAD, bool NUIS, int KM>
+struct Layout {
+    static constexpr bool HAS_RV = (KM & KM_RV) != 0;
+    static constexpr bool HAS_MARG = (KM & KM_MARG) != 0;
+    static constexpr bool HAS_ASTROM = (KM & (KM_RADEC | KM_SEPPA)) != 0;
+    static constexpr int OFF_S = 0;
+    static constexpr int OFF_NU = 1;
+    static constexpr int N_NU = (GRAD && NUIS) ? 3 : 0;
+    static constexpr int OFF_MARG = OFF_NU + N_NU;
+    static constexpr int N_MARG = HAS_MARG ? 3 : 0;
+    static constexpr int OFF_PL = OFF_MARG + N_MARG;
+    // per planet: GB GG GA GF GE GM GT [GC] [GK GW]
+    static constexpr int PL_N = !GRAD ? 0 : (HAS_RV ? 10 : (P > 1 ? 8 : 7));
+    static constexpr int NACC = OFF_PL + P * PL_N;
+    enum { GB = 0, GG, GA, GF, GE, GM, GT, GC, GK, GW };
+};
+
+// ------------------------------------------------------------------------------------ k_setup
+__global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.W) return;
+    bool ok = true;
+    for (int p = 0; p < a.n_planets; ++p) {
+        const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + w;
+        const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
+        const double sma = el[OCTO_EL_A * a.ld], e = el[OCTO_EL_E * a.ld], om = el[OCTO_EL_W * a.ld];
+        const double tp = el[OCTO_EL_TP * a.ld], Mt = el[OCTO_EL_M * a.ld];
+        double inc = radvel ? 0.0 : el[OCTO_EL_I * a.ld];
+        double Om = radvel ? 0.0 : el[OCTO_EL_O * a.ld];
+        const double plx = radvel ? 1.0 : el[OCTO_EL_PLX * a.ld];
+        const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
+        ok = ok && isfinite(sma) && isfinite(e) && isfinite(inc) && isfinite(om) && isfinite(Om) && isfinite(tp) &&
+             isfinite(Mt) && isfinite(plx) && isfinite(mass);
+        ok = ok && (e >= 0.0) && (e < 1.0) && (sma > 0.0) && (Mt > 0.0) && (plx > 0.0);
+        // PlanetOrbits KepOrbit ctor invariants: i = rem(i, π, RoundDown), Ω = rem2pi(Ω, RoundDown)
+        inc = inc - PI * floor(inc / PI);
+        Om = Om - TWO_PI * floor(Om / TWO_PI);
+        const double P_d = a.c.k_yr * sqrt(sma * sma * sma / Mt);       // parameterizations.jl:62
+        const double ome2 = 1.0 - e * e;
+        const double beta = sqrt(ome2);
+        double si, ci, sw, cw, sO, cO;
+        sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO);
+        if (radvel) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
+        // Thiele-Innes constants (parameterizations.jl:34-37) scaled to mas: T = a · cart2angle
+        const double T = radvel ? 0.0 : sma * plx * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
+        const double A = cO * cw - sO * sw * ci, B = sO * cw + cO * sw * ci;
+        const double F = -cO * sw - sO * cw * ci, G = -sO * sw + cO * cw * ci;
+        // K = ((2π a)/P_yr)/√(1−e²) · au2m · sec2year · sin i
+        const double K = (TWO_PI * sma / (P_d / a.c.yd)) / beta * a.c.au2m * a.c.sec2yr * si;
+        double* o = a.wc + (int64_t)p * NWC * a.ldw + w;
+        o[WC_INVP * a.ldw] = 1.0 / P_d; o[WC_TP * a.ldw] = tp; o[WC_E * a.ldw] = e; o[WC_BETA * a.ldw] = beta;
+        o[WC_K1 * a.ldw] = MK_K1N / (1.0 + e);
+        o[WC_CB * a.ldw] = T * B; o[WC_CG * a.ldw] = T * G; o[WC_CA * a.ldw] = T * A; o[WC_CF * a.ldw] = T * F;
+        o[WC_K * a.ldw] = K; o[WC_COSW * a.ldw] = cw; o[WC_SINW * a.ldw] = sw;
+        o[WC_MU * a.ldw] = mass * a.c.mjup2msol / Mt; o[WC_A * a.ldw] = sma;
+    }
+    if (a.nuis) {
+        for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok = ok && isfinite(a.nuis[(int64_t)k * a.ld + w]);
+    }
+    a.valid[w] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------ k_main
+template <int P, bool GRAD, bool NUIS, int KM>
+__global__ __launch_bounds__(64) void k_main(EvalArgs a) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    const int64_t w = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    const int64_t wl = w < a.W ? w : a.W - 1;          // tail lanes recompute the last walker; results discarded
+    const Task tk = a.tasks[blockIdx.y];                // wave-uniform: scalar loads
+    const DevObs ob = a.obs[tk.obs];
+
+    PC pc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) load_pc(pc[p], a.wc, a.ldw, p, wl);
+
+    double acc[L::NACC];
+#pragma unroll
+    for (int k = 0; k < L::NACC; ++k) acc[k] = 0.0;
+
+    const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA;
+
+    if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
+        // coefficient of each planet's sky offset in the model (relative-astrometry.jl:117-138):
+        // 1 for the planet the table is attached to, +m/M for strictly-inner companions with a mass.
+        double f[P];
+        if constexpr (P == 1) {
+            f[0] = 1.0;
+        } else {
+            double a_this = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) a_this = (p == ob.planet) ? pc[p].a : a_this;
+#pragma unroll
+            for (int p = 0; p < P; ++p) f[p] = (p == ob.planet) ? 1.0 : ((pc[p].a < a_this) ? pc[p].mu : 0.0);
+        }
+        double jit = 0.0, j2 = 0.0, ps = 1.0, na = 0.0, sn = 0.0, cn = 1.0;
+        if constexpr (NUIS) {
+            const double* nu = a.nuis + (int64_t)tk.obs * OCTO_N_NUIS * a.ld + wl;
+            jit = nu[OCTO_NU_JITTER * a.ld]; ps = nu[OCTO_NU_PLATESCALE * a.ld];
+            na = nu[OCTO_NU_NORTHANGLE * a.ld];
+            sincos(na, &sn, &cn);
+            j2 = jit * jit;
+        }
+        const bool seppa = (KM & KM_SEPPA) && ob.kind == OCTO_ASTROM_SEPPA;
+        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)tk.row0 * ROW_STRIDE;
+        for (int j = 0; j < tk.nrows; ++j) {
+            const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
+            const double t = rw[0], y1 = rw[1], y2 = rw[2], c3 = rw[3], c4 = rw[4], c5 = rw[5];
+            KSol s[P];
+            double ra_m = 0.0, dec_m = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                s[p] = kepler_solve(t, pc[p]);
+                ra_m = fma(f[p], fma(pc[p].cB, s[p].X, pc[p].cG * s[p].Y), ra_m);
+                dec_m = fma(f[p], fma(pc[p].cA, s[p].X, pc[p].cF * s[p].Y), dec_m);
+            }
+            // residuals
+            double r1, r2, rho = 1.0, irho = 1.0, u1 = 0.0, u2 = 0.0;
+            if (seppa) {
+                // relative-astrometry.jl:192-202
+                const double rho2 = fma(ra_m, ra_m, dec_m * dec_m);
+                rho = sqrt(rho2);
+                irho = 1.0 / rho;
+                const double pa = atan2(ra_m, dec_m);
+                double dpa = (y1 + na) - pa + PI;
+                dpa = fmod(dpa, TWO_PI) - PI;                  // Julia `%`: truncated remainder
+                dpa = dpa < -PI ? dpa + TWO_PI : dpa;
+                r1 = dpa;
+                r2 = fma(y2, ps, -rho);
+            } else {
+                // relative-astrometry.jl:210-215: the data are rotated by −northangle and scaled
+                u1 = fma(y1, cn, y2 * sn);
+                u2 = fma(y2, cn, -(y1 * sn));
+                r1 = fma(ps, u1, -ra_m);
+                r2 = fma(ps, u2, -dec_m);
+            }
+            // density; g1, g2 = ∂ll/∂r1, ∂ll/∂r2
+            double g1, g2;
+            if constexpr (!NUIS) {
+                // precomputed Σ⁻¹ (the jitter == 0 branch, relative-astrometry.jl:218-219)
+                const double a1 = fma(c3, r1, c5 * r2), a2 = fma(c5, r1, c4 * r2);
+                acc[L::OFF_S] = fma(r1, a1, fma(r2, a2, acc[L::OFF_S]));   // Σ rᵀΣ⁻¹r ; ll = const − ½Σ
+                g1 = -a1; g2 = -a2;
+            } else {
+                const double v1 = fma(c3, c3, j2), v2 = fma(c4, c4, j2);   // hypot(σ, jitter)², :234-235
+                const double cor = ob.has_cor ? c5 : 0.0;
+                const double omc = 1.0 - cor * cor;
+                const double ic = 1.0 / omc;
+                const double i1 = rsqrt(v1), i2 = rsqrt(v2);
+                const double z1 = r1 * i1, z2 = r2 * i2;
+                const double h1 = (z1 - cor * z2) * ic, h2 = (z2 - cor * z1) * ic;
+                const double qf = z1 * h1 + z2 * h2;
+                acc[L::OFF_S] += log(v1 * v2 * omc) + qf;                  // ll = −n·log2π − ½Σ(...)
+                g1 = -h1 * i1; g2 = -h2 * i2;
+                if constexpr (GRAD) {
+                    acc[L::OFF_NU + OCTO_NU_JITTER] += jit * ((z1 * h1 - 1.0) * i1 * i1 + (z2 * h2 - 1.0) * i2 * i2);
+                    if (seppa) {
+                        acc[L::OFF_NU + OCTO_NU_PLATESCALE] = fma(g2, y2, acc[L::OFF_NU + OCTO_NU_PLATESCALE]);
+                        acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += g1;
+                    } else {
+                        acc[L::OFF_NU + OCTO_NU_PLATESCALE] += g1 * u1 + g2 * u2;
+                        acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += ps * (g1 * u2 - g2 * u1);
+                    }
+                }
+            }
+            if constexpr (GRAD) {
+                // adjoint of the model position
+                double rab, deb;
+                if (seppa) {
+                    const double pab = -g1, rhob = -g2;
+                    rab = (rhob * ra_m + pab * dec_m * irho) * irho;
+                    deb = (rhob * dec_m - pab * ra_m * irho) * irho;
+                } else {
+                    rab = -g1; deb = -g2;
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double* g = &acc[L::OFF_PL + p * L::PL_N];
+                    const double ra_f = f[p] * rab, de_f = f[p] * deb;
+                    g[L::GB] = fma(s[p].X, ra_f, g[L::GB]);
+                    g[L::GG] = fma(s[p].Y, ra_f, g[L::GG]);
+                    g[L::GA] = fma(s[p].X, de_f, g[L::GA]);
+                    g[L::GF] = fma(s[p].Y, de_f, g[L::GF]);
+                    if constexpr (P > 1) {
+                        const double rp = fma(pc[p].cB, s[p].X, pc[p].cG * s[p].Y), dp = fma(pc[p].cA, s[p].X, pc[p].cF * s[p].Y);
+                        g[L::GC] += (p == ob.planet) ? 0.0 : ((f[p] != 0.0) ? fma(rab, rp, deb * dp) : 0.0);
+                    }
+                    const double Xb = fma(pc[p].cB, ra_f, pc[p].cA * de_f);
+                    const double Yb = fma(pc[p].cG, ra_f, pc[p].cF * de_f);
+                    kepler_adjoint(s[p], pc[p], t, Xb, Yb, 0.0, 0.0, g[L::GE], g[L::GM], g[L::GT]);
+                }
+            }
+        }
+    }
+    if (L::HAS_RV && !is_astrom) {
+        // coefficient of K_p·V_p in the RV model: RV_REL: +1 for this planet (rv-relative.jl:143), −m/M for
+        // strictly-inner massive companions (:148-156); absolute RV: −m/M for every planet (rv-absolute.jl:146-155).
+        double gc[P];
+        const bool rel = ob.kind == OCTO_RV_REL;
+        {
+            double a_this = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) a_this = (p == ob.planet) ? pc[p].a : a_this;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                gc[p] = rel ? ((p == ob.planet) ? 1.0 : ((pc[p].a < a_this) ? -pc[p].mu : 0.0)) : -pc[p].mu;
+        }
+        const bool marg = (KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG;
+        double off = 0.0, jit = 0.0, j2 = 0.0;
+        if constexpr (NUIS) {
+            const double* nu = a.nuis + (int64_t)tk.obs * OCTO_N_NUIS * a.ld + wl;
+            off = marg ? 0.0 : nu[OCTO_NU_RV_OFFSET * a.ld];
+            jit = nu[OCTO_NU_RV_JITTER * a.ld];
+            j2 = jit * jit;
+        }
+        double mu_hat = 0.0, iA = 0.0;
+        if (GRAD && marg && a.marg) {
+            mu_hat = a.marg[((int64_t)tk.obs * 2 + 0) * a.ldw + wl];
+            iA = 1.0 / a.marg[((int64_t)tk.obs * 2 + 1) * a.ldw + wl];
+        }
+        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)tk.row0 * ROW_STRIDE;
+        for (int j = 0; j < tk.nrows; ++j) {
+            const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
+            const double t = rw[0], rv = rw[1], c2 = rw[2];
+            KSol s[P];
+            double V[P], cnu[P], snu[P];
+            double model = off;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                s[p] = kepler_solve(t, pc[p]);
+                cnu[p] = s[p].X * s[p].invD; snu[p] = s[p].Y * s[p].invD;
+                V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
+                model = fma(gc[p] * pc[p].K, V[p], model);
+            }
+            const double resid = rv - model;
+            double iv, var = 1.0;
+            if constexpr (NUIS) { var = fma(c2, c2, j2); iv = 1.0 / var; } else { iv = c2; }
+            double rvb;   // ∂ll/∂model
+            if (marg) {
+                // rv-absolute-margin.jl:171-180
+                acc[L::OFF_MARG + 0] += iv;
+                acc[L::OFF_MARG + 1] = fma(-2.0 * resid, iv, acc[L::OFF_MARG + 1]);
+                acc[L::OFF_MARG + 2] = fma(resid * resid, iv, acc[L::OFF_MARG + 2]);
+                if constexpr (NUIS) acc[L::OFF_S] += log(TWO_PI * var);
+                const double dm = resid - mu_hat;
+                rvb = 2.0 * dm * iv;
+                if constexpr (GRAD && NUIS)
+                    acc[L::OFF_NU + OCTO_NU_RV_JITTER] += 2.0 * jit * iv * (dm * dm * iv - 1.0 + iv * iA);
+            } else {
+                if constexpr (NUIS) acc[L::OFF_S] += log(var) + resid * resid * iv;
+                else acc[L::OFF_S] = fma(resid * resid, iv, acc[L::OFF_S]);
+                rvb = resid * iv;
+                if constexpr (GRAD && NUIS) {
+                    acc[L::OFF_NU + OCTO_NU_RV_OFFSET] += rvb;
+                    acc[L::OFF_NU + OCTO_NU_RV_JITTER] += jit * iv * (resid * resid * iv - 1.0);
+                }
+            }
+            if constexpr (GRAD) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double* g = &acc[L::OFF_PL + p * L::PL_N];
+                    g[L::GK] = fma(gc[p] * V[p], rvb, g[L::GK]);
+                    const bool via_mu = rel ? (p != ob.planet && gc[p] != 0.0) : true;
+                    g[L::GC] += via_mu ? -(pc[p].K * V[p] * rvb) : 0.0;
+                    const double Vb = gc[p] * pc[p].K * rvb;
+                    g[L::GW] = fma(Vb, -fma(cnu[p] + pc[p].e, pc[p].sw, snu[p] * pc[p].cw), g[L::GW]);
+                    const double cb = Vb * pc[p].cw, sb = -Vb * pc[p].sw;
+                    const double Xb = cb * s[p].invD, Yb = sb * s[p].invD;
+                    const double Db = -fma(cb, cnu[p], sb * snu[p]) * s[p].invD;
+                    kepler_adjoint(s[p], pc[p], t, Xb, Yb, Db, cb, g[L::GE], g[L::GM], g[L::GT]);
+                }
+            }
+        }
+    }
+    if (w < a.W) {
+        double* out = a.partials + (int64_t)blockIdx.y * L::NACC * a.ldw + w;
+#pragma unroll
+        for (int k = 0; k < L::NACC; ++k) out[(int64_t)k * a.ldw] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------ k_marg
+// Pre-pass for marginalised-RV tables when a gradient is requested: μ̂ = −B/(2A) and A per walker.
+template <int P, bool NUIS, int KM>
+__global__ __launch_bounds__(256) void k_marg(EvalArgs a) {
+    using L = Layout<P, false, NUIS, KM>;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.W) return;
+    if constexpr (L::HAS_MARG) {
+        for (int o = 0; o < a.n_obs; ++o) {
+            if (a.obs[o].kind != OCTO_RV_ABS_MARG) continue;
+            double A = 0.0, B = 0.0;
+            for (int t = 0; t < a.n_tasks; ++t) {
+                if (a.tasks[t].obs != o) continue;
+                const double* pt = a.partials + (int64_t)t * L::NACC * a.ldw + w;
+                A += pt[(int64_t)(L::OFF_MARG + 0) * a.ldw];
+                B += pt[(int64_t)(L::OFF_MARG + 1) * a.ldw];
+            }
+            a.marg_out[((int64_t)o * 2 + 0) * a.ldw + w] = -B / (2.0 * A);
+            a.marg_out[((int64_t)o * 2 + 1) * a.ldw + w] = A;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ k_finish
+template <int P, bool GRAD, bool NUIS, int KM>
+__global__ __launch_bounds__(256) void k_finish(EvalArgs a) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.W) return;
+    double ll = 0.0;
+    double gp[P > 0 ? P * (L::PL_N > 0 ? L::PL_N : 1) : 1];
+#pragma unroll
+    for (int k = 0; k < P * L::PL_N; ++k) gp[k] = 0.0;
+    // observations are summed in the order given (system.jl:93,186); tasks of one table are contiguous
+    int t = 0;
+    for (int o = 0; o < a.n_obs; ++o) {
+        const int kind = a.obs[o].kind;
+        double S = 0.0, cst = 0.0, mA = 0.0, mB = 0.0, mC = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0;
+        for (; t < a.n_tasks && a.tasks[t].obs == o; ++t) {
+            const double* pt = a.partials + (int64_t)t * L::NACC * a.ldw + w;
+            S += pt[(int64_t)L::OFF_S * a.ldw];
+            cst += a.task_const[t];
+            if constexpr (L::HAS_MARG) {
+                mA += pt[(int64_t)(L::OFF_MARG + 0) * a.ldw];
+                mB += pt[(int64_t)(L::OFF_MARG + 1) * a.ldw];
+                mC += pt[(int64_t)(L::OFF_MARG + 2) * a.ldw];
+            }
+            if constexpr (L::N_NU > 0) {
+                nu0 += pt[(int64_t)(L::OFF_NU + 0) * a.ldw];
+                nu1 += pt[(int64_t)(L::OFF_NU + 1) * a.ldw];
+                nu2 += pt[(int64_t)(L::OFF_NU + 2) * a.ldw];
+            }
+#pragma unroll
+            for (int k = 0; k < P * L::PL_N; ++k) gp[k] += pt[(int64_t)(L::OFF_PL + k) * a.ldw];
+        }
+        double llo;
+        if (L::HAS_MARG && kind == OCTO_RV_ABS_MARG) {
+            // ll = −Σ log(2π var) − (−B²/(4A) + C + log A)      rv-absolute-margin.jl:179-181
+            const double slog = NUIS ? S : -cst;
+            llo = (a.obs[o].n > 0) ? -slog - (-mB * mB / (4.0 * mA) + mC + log(mA)) : 0.0;
+        } else {
+            // NUIS: S = Σ(log|Σ| + q) [astrom] or Σ(log var + r²/var) [rv]; cst = −n·log2π·(1 or ½)
+            // !NUIS: S = Σ q, cst = Σ(−log2π·k − ½ log|Σ|)
+            llo = cst - 0.5 * S;
+        }
+        ll += llo;
+        if constexpr (L::N_NU > 0) {
+            double* gn = a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w;
+            const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA;
+            gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : nu0;
+            gn[(int64_t)a.ld] = nu1;
+            gn[(int64_t)2 * a.ld] = astrom ? nu2 : 0.0;
+        }
+    }
+    const bool ok = a.valid[w] != 0 && isfinite(ll);
+    a.ll_out[w] = ok ? ll : -INFINITY;
+    if constexpr (GRAD) {
+        if (!ok && L::N_NU > 0) {
+            for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + w] = 0.0;
+        }
+        bool gfinite = true;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + w;
+            double* ge = a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w;
+            const double* g = &gp[p * L::PL_N];
+            const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
+            const double sma = el[OCTO_EL_A * a.ld], e = el[OCTO_EL_E * a.ld], om = el[OCTO_EL_W * a.ld];
+            const double Mt = el[OCTO_EL_M * a.ld];
+            double inc = radvel ? 0.0 : el[OCTO_EL_I * a.ld], Om = radvel ? 0.0 : el[OCTO_EL_O * a.ld];
+            const double plx = radvel ? 1.0 : el[OCTO_EL_PLX * a.ld];
+            const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
+            inc = inc - PI * floor(inc / PI);
+            Om = Om - TWO_PI * floor(Om / TWO_PI);
+            const double P_d = a.c.k_yr * sqrt(sma * sma * sma / Mt);
+            const double beta = sqrt(1.0 - e * e);
+            double si, ci, sw, cw, sO, cO;
+            sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO);
+            const double kappa = a.c.mas_per_au_per_plx;
+            const double sm = plx * kappa, T = sma * sm;
+            const double A = cO * cw - sO * sw * ci, B = sO * cw + cO * sw * ci;
+            const double F = -cO * sw - sO * cw * ci, G = -sO * sw + cO * cw * ci;
+            double ab = 0, eb = g[L::GE], ib = 0, wb = 0, Ob = 0, tpb, Mb = 0, plxb = 0, massb = 0, Pb = 0;
+            if (!radvel) {
+                const double Bb = T * g[L::GB], Gb = T * g[L::GG], Ab = T * g[L::GA], Fb = T * g[L::GF];
+                const double Tb = B * g[L::GB] + G * g[L::GG] + A * g[L::GA] + F * g[L::GF];
+                ab += Tb * sm; plxb += Tb * sma * kappa;
+                ib = Ab * (sO * sw * si) + Bb * (-cO * sw * si) + Fb * (sO * cw * si) + Gb * (-cO * cw * si);
+                wb = Ab * (-cO * sw - sO * cw * ci) + Bb * (-sO * sw + cO * cw * ci) + Fb * (-cO * cw + sO * sw * ci) + Gb * (-sO * cw - cO * sw * ci);
+                Ob = Ab * (-sO * cw - cO * sw * ci) + Bb * (cO * cw - sO * sw * ci) + Fb * (sO * sw - cO * cw * ci) + Gb * (-cO * sw - sO * cw * ci);
+            }
+            if constexpr (L::HAS_RV) {
+                const double sieff = radvel ? 1.0 : si;
+                const double Kc = TWO_PI * a.c.yd * a.c.au2m * a.c.sec2yr;      // K = Kc·a·sin i /(P_d·β)
+                const double K = Kc * sma * sieff / (P_d * beta);
+                const double Kb = g[L::GK];
+                ab += Kb * K / sma;
+                if (!radvel) ib += Kb * Kc * sma * ci / (P_d * beta);
+                Pb += -Kb * K / P_d;
+                eb += Kb * K * e / (beta * beta);
+                wb += g[L::GW];
+            }
+            // M = 2π (t − tp)/P_d
+            tpb = -(TWO_PI / P_d) * g[L::GM];
+            Pb += -(TWO_PI / (P_d * P_d)) * g[L::GT];
+            // P_d = k · a^{3/2} · M_tot^{−1/2}
+            ab += Pb * 1.5 * P_d / sma;
+            Mb += -0.5 * Pb * P_d / Mt;
+            if constexpr (L::PL_N > L::GC) {
+                const double mu = mass * a.c.mjup2msol / Mt;
+                if (a.has_mass[p]) { massb = g[L::GC] * a.c.mjup2msol / Mt; Mb += -g[L::GC] * mu / Mt; }
+            }
+            const double out[OCTO_N_EL] = {ab, eb, radvel ? 0.0 : ib, wb, radvel ? 0.0 : Ob, tpb, Mb, radvel ? 0.0 : plxb, massb};
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) gfinite = gfinite && isfinite(out[k]);
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) ge[(int64_t)k * a.ld] = ok ? out[k] : 0.0;
+        }
+        (void)gfinite;
+    }
+}
+
+}  // namespace octo

@@ -1,0 +1,69 @@
+"""
+Parallel-tempering swap step over RCCL — the one collective of the path (BASELINE config 5).
+
+Reference: Pigeons.jl's communication step, reached through ext/OctofitterPigeonsExt/OctofitterPigeonsExt.jl:76-128
+(target = model, reference chain = prior-only model :61-67). Replicas keep their states; neighbouring
+temperatures exchange their β LABELS with probability min(1, exp((β_i − β_{i+1})(ℓ_{i+1} − ℓ_i))) on the
+log-LIKELIHOOD (the reference chain is the prior), so one all_gather of ℓ per step is the whole exchange.
+
+Sharding: temperatures (replicas) are split contiguously over ranks; every rank holds all `n_chains`
+independent PT chains for its replicas: local walker index = r_local * n_chains + c.
+Every rank runs the same deterministic swap (counter-based RNG keyed by (seed, step, chain, slot)) on the
+gathered ℓ, so the permutation never has to be communicated.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from .sharding import shard_range
+
+
+class TemperedSwap:
+    def __init__(self, fn, n_temps_total, n_chains, rank=0, world=1, device=None, seed=0, betas=None, group=None, swap_impl=None):
+        import torch
+        self.torch = torch
+        self.fn, self.rank, self.world, self.group = fn, rank, world, group
+        self.n_temps, self.n_chains, self.seed = int(n_temps_total), int(n_chains), int(seed)
+        if self.n_temps % world:
+            raise ValueError("temperatures must divide evenly over ranks")
+        self.lo, self.hi = shard_range(self.n_temps, rank, world)
+        self.device = device
+        if betas is None:
+            betas = torch.linspace(1.0, 0.0, self.n_temps, dtype=torch.float64) ** 3     # geometric-ish ladder, β_0 = 1 (target)
+        self.beta = torch.as_tensor(betas, dtype=torch.float64).to(device)
+        self.slot2rep = torch.arange(self.n_temps, dtype=torch.int32).repeat(self.n_chains, 1).contiguous().to(device)
+        self.accepted = torch.zeros(self.n_temps, dtype=torch.int32, device=device)
+        self._ll_all = torch.empty(self.n_temps * self.n_chains, dtype=torch.float64, device=device)
+        self._swap_impl = swap_impl       # tests inject a CPU stand-in; the product path is the HIP kernel below
+
+    def local_betas(self):
+        """β of every local walker under the current label assignment, [n_local_temps * n_chains]."""
+        torch = self.torch
+        rep2slot = torch.empty_like(self.slot2rep)
+        ar = torch.arange(self.n_temps, dtype=torch.int32, device=self.slot2rep.device).repeat(self.n_chains, 1)
+        rep2slot.scatter_(1, self.slot2rep.long(), ar)
+        b = self.beta[rep2slot[:, self.lo:self.hi].long()]        # [n_chains, n_local]
+        return b.t().contiguous().reshape(-1)
+
+    def swap_step(self, ll_local, step):
+        """ll_local: [n_local_temps * n_chains] log-likelihoods of this rank's replicas. Returns slot2rep."""
+        torch = self.torch
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.all_gather_into_tensor(self._ll_all, ll_local.contiguous(), group=self.group)
+            ll_all = self._ll_all
+        else:
+            ll_all = ll_local
+        ll_cr = ll_all.view(self.n_temps, self.n_chains).t().contiguous()     # [n_chains][n_temps(replica)]
+        parity = int(step) % 2
+        if self._swap_impl is not None:
+            self._swap_impl(ll_cr, self.beta, self.slot2rep, parity, self.seed, int(step), self.accepted)
+            return self.slot2rep
+        if not ll_cr.is_cuda:
+            raise RuntimeError("TemperedSwap needs device tensors: the swap step runs as a HIP kernel (no CPU fallback)")
+        stream = torch.cuda.current_stream(ll_cr.device).cuda_stream
+        self.fn._check(self.fn.lib.octo_pt_swap_device(
+            self.fn._ctx, ll_cr.data_ptr(), self.beta.data_ptr(), self.slot2rep.data_ptr(), self.n_temps, self.n_chains,
+            parity, C.c_uint64(self.seed), C.c_uint64(int(step)), self.accepted.data_ptr(), C.c_void_p(stream)), "octo_pt_swap_device")
+        self._keep = ll_cr     # keep the transposed buffer alive until the stream has consumed it
+        return self.slot2rep

@@ -1,0 +1,196 @@
+"""
+make_golden.py — writes tests/golden/fixtures.json from the independent 50-digit oracle
+(oracle/mp_oracle.py). Run in the build container:  python oracle/make_golden.py
+
+TEST INFRASTRUCTURE. The tables below that come from the reference's own tests are DATA the
+reference ships (cited per case); expected values are computed here, because the reference holds
+no golden log-likelihood for this path and cannot be run (no Julia).
+"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import mpmath as mp
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import mp_oracle as mpo  # noqa: E402
+
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "tests" / "golden" / "fixtures.json"
+C = mpo.DEFAULT_CONSTS
+VIS = dict(orbit_kind=0, has_mass=False)
+VISM = dict(orbit_kind=0, has_mass=True)
+RVO = dict(orbit_kind=1, has_mass=True)
+
+
+def fl(x):
+    return float(x)
+
+
+def run_case(name, planets, obs, elems, nuis, note):
+    """elems: [P*9][W] array; nuis: [n_obs*3][W] or None."""
+    elems = np.asarray(elems, dtype=np.float64)
+    W = elems.shape[1]
+    P = len(planets)
+    ll, ge, gn, se, sn = [], [], [], [], []
+    for w in range(W):
+        el = [[mp.mpf(float(elems[p * 9 + k, w])) for k in range(9)] for p in range(P)]
+        nu = None
+        if nuis is not None:
+            nu = [[mp.mpf(float(nuis[o * 3 + k][w])) for k in range(3)] for o in range(len(obs))]
+        f0, g_el, g_nu, s_el, s_nu = mpo.ln_like_and_grad(C, planets, obs, el, nu, with_scale=True)
+        ll.append(fl(f0))
+        ge.append([fl(g_el[p][k]) for p in range(P) for k in range(9)])
+        se.append([fl(s_el[p][k]) for p in range(P) for k in range(9)])
+        gn.append([fl(g_nu[o][k]) for o in range(len(obs)) for k in range(3)] if g_nu is not None else None)
+        sn.append([fl(s_nu[o][k]) for o in range(len(obs)) for k in range(3)] if s_nu is not None else None)
+    case = dict(name=name, note=note, planets=planets,
+                obs=[{k: (None if v is None else (v if not isinstance(v, (list, np.ndarray)) else [float(x) for x in v])) for k, v in ob.items()} for ob in obs],
+                elems=elems.tolist(), nuis=None if nuis is None else np.asarray(nuis, dtype=np.float64).tolist(),
+                ll=ll, g_elems=np.asarray(ge).T.tolist(), s_elems=np.asarray(se).T.tolist(),
+                g_nuis=None if nuis is None else np.asarray(gn).T.tolist(),
+                s_nuis=None if nuis is None else np.asarray(sn).T.tolist())
+    print(f"  {name}: W={W} rows={sum(len(o['epoch']) for o in obs)} ll[0]={ll[0]:.12g}", flush=True)
+    return case
+
+
+def astrom(planet, epoch, y1, y2, s1, s2, cor=None, seppa=False):
+    return dict(kind="ASTROM_SEPPA" if seppa else "ASTROM_RADEC", planet=planet, epoch=list(map(float, epoch)),
+                y1=list(map(float, y1)), y2=list(map(float, y2)), s1=list(map(float, s1)), s2=list(map(float, s2)),
+                cor=None if cor is None else list(map(float, cor)))
+
+
+def rvtab(kind, planet, epoch, rv, s):
+    return dict(kind=kind, planet=planet, epoch=list(map(float, epoch)), y1=list(map(float, rv)), y2=None,
+                s1=list(map(float, s)), s2=None, cor=None)
+
+
+def col(*rows):
+    return np.array(rows, dtype=np.float64)
+
+
+def main():
+    rng = np.random.default_rng(20260929)
+    cases = []
+
+    # ---- F1: northangle sign regression orbit, /root/reference/test/unit/likelihoods.jl:38-58 -------------
+    ep = [50000.0, 50300.0, 50600.0, 50900.0, 51200.0]
+    el1 = [15.0, 0.2, 0.6, 0.3, 1.1, 50000.0, 1.2, 50.0, 0.0]
+    orb = mpo._orbit(C, 0, [mp.mpf(x) for x in el1])
+    sols = [mpo.solve(orb, t) for t in ep]
+    ra_m = [s["ra"] for s in sols]
+    dec_m = [s["dec"] for s in sols]
+    pa_m = [mp.atan2(r, d) for r, d in zip(ra_m, dec_m)]
+    sep_m = [mp.sqrt(r * r + d * d) for r, d in zip(ra_m, dec_m)]
+    eps = mp.mpf("0.05")
+    pa_d = [p + eps for p in pa_m]
+    ra_d = [fl(s * mp.sin(p)) for s, p in zip(sep_m, pa_d)]
+    dec_d = [fl(s * mp.cos(p)) for s, p in zip(sep_m, pa_d)]
+    nu1 = col([0.0, 0.0, 0.0, 0.7], [1.0, 1.0, 1.0, 1.01], [0.0, 0.05, -0.05, -0.03])   # jitter, platescale, northangle
+    cases.append(run_case("F1_northangle_seppa", [VIS], [astrom(0, ep, [fl(p) for p in pa_d], [fl(s) for s in sep_m], [0.001] * 5, [1.0] * 5, seppa=True)],
+                          np.tile(np.array(el1)[:, None], (1, 4)), nu1, "test/unit/likelihoods.jl:38-58 (sep/PA table)"))
+    cases.append(run_case("F1_northangle_radec", [VIS], [astrom(0, ep, ra_d, dec_d, [1.0] * 5, [1.0] * 5)],
+                          np.tile(np.array(el1)[:, None], (1, 4)), nu1, "test/unit/likelihoods.jl:38-58 (RA/Dec table)"))
+
+    # ---- F2: tutorial 8-epoch RA/Dec table, /root/reference/test/integration-tests.jl:8-15 -----------------
+    ep2 = [50000, 50120, 50240, 50360, 50480, 50600, 50720, 50840]
+    ra2 = [-505.7637580573554, -502.570356287689, -498.2089148883798, -492.67768482682357, -485.9770335870402,
+           -478.1095526888573, -469.0801731788123, -458.89628893460525]
+    dec2 = [-66.92982418533026, -37.47217527025044, -7.927548139010479, 21.63557115669823, 51.147204404903704,
+            80.53589069730698, 109.72870493064629, 138.65128697876773]
+    W = 16
+    a = rng.uniform(8, 20, W); e = rng.uniform(0.0, 0.6, W); inc = np.arccos(rng.uniform(-1, 1, W))
+    w_ = rng.uniform(0, 2 * np.pi, W); O = rng.uniform(0, 2 * np.pi, W); M = rng.normal(1.2, 0.1, W); plx = rng.normal(50, 0.02, W)
+    tp = 50000 - rng.uniform(0, 1, W) * 365.2568983840419 * np.sqrt(a ** 3 / M)
+    el2 = np.stack([a, e, inc, w_, O, tp, M, plx, np.zeros(W)])
+    el2[:, 0] = [12.0, 0.11, np.deg2rad(41), np.deg2rad(38), np.deg2rad(16), 41479.14852101943, 1.2000965847634995, 50.0, 0.0]
+    cases.append(run_case("F2_tutorial_radec", [VIS], [astrom(0, ep2, ra2, dec2, [10.0] * 8, [10.0] * 8, cor=[0.0] * 8)], el2, None,
+                          "test/integration-tests.jl:8-15; walker 0 = the orbit that reproduces the table to 1e-12 mas"))
+
+    # ---- F3: correlated table, /root/reference/test/unit-tests.jl:700-707 ---------------------------------
+    ra3 = [-494.4, -495.0, -493.7, -490.4, -485.2, -478.1, -469.1, -458.3]
+    dec3 = [-76.7, -44.9, -12.9, 19.1, 51.0, 82.8, 114.3, 145.3]
+    s3 = [12.6, 10.4, 9.9, 8.7, 8.0, 6.9, 5.8, 4.2]
+    cor3 = [0.2, 0.5, 0.1, -0.8, 0.3, -0.0, 0.1, -0.2]
+    nu3 = col([0.0, 0.0, 3.5, 3.5, 0.0, 12.0, 0.5, 0.0], [1.0, 1.0, 1.0, 0.99, 1.02, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.01, -0.02, 0.0, 0.0, 0.0])
+    cases.append(run_case("F3_cor_radec", [VIS], [astrom(0, ep2, ra3, dec3, s3, s3, cor=cor3)], el2[:, :8], nu3,
+                          "test/unit-tests.jl:700-707 (cor column) with and without jitter/platescale/northangle"))
+    cases.append(run_case("F3_cor_radec_nonuis", [VIS], [astrom(0, ep2, ra3, dec3, s3, s3, cor=cor3)], el2[:, :8], None,
+                          "same table, no nuisance block (precomputed-Σ branch, relative-astrometry.jl:218-219)"))
+    # the same sky positions as a sep/PA table with a correlation column
+    pa3 = [fl(mp.atan2(mp.mpf(r), mp.mpf(d))) for r, d in zip(ra3, dec3)]
+    sep3 = [fl(mp.sqrt(mp.mpf(r) ** 2 + mp.mpf(d) ** 2)) for r, d in zip(ra3, dec3)]
+    cases.append(run_case("F3_cor_seppa", [VIS], [astrom(0, ep2, pa3, sep3, [0.02] * 8, s3, cor=cor3, seppa=True)], el2[:, :8], nu3,
+                          "sep/PA form of the F3 table"))
+
+    # ---- F4: jitter sensitivity model, /root/reference/test/unit/distributions.jl:103-131 -------------------
+    ep4 = [58000.0, 58200.0, 58400.0]
+    el4 = np.tile(col(10.0, 0.2, 0.5, 0.3, 0.4, 58000.0, 1.0, 50.0, 0.0)[:, None], (1, 2))
+    nu4 = col([0.001, 300.0], [1.0, 1.0], [0.0, 0.0])
+    cases.append(run_case("F4_jitter", [VIS], [astrom(0, ep4, [100.0, 110.0, 120.0], [100.0, 95.0, 90.0], [5.0] * 3, [5.0] * 3)], el4, nu4,
+                          "test/unit/distributions.jl:103-131, jitter in {0.001, 300}"))
+
+    # ---- F5: RV, orbit of OctofitterRadialVelocity/test/runtests.jl:173-184 -------------------------------
+    ep5 = np.linspace(50000.0, 50200.0, 20)
+    a5 = float(np.cbrt(80.0 ** 2 * 1.0))
+    W5 = 6
+    el5 = np.stack([np.full(W5, a5) * rng.uniform(0.9, 1.1, W5), rng.uniform(0, 0.5, W5), np.zeros(W5), rng.uniform(0, 6.28, W5), np.zeros(W5),
+                    50000.0 + rng.uniform(-50, 50, W5), rng.normal(1.0, 0.05, W5), np.zeros(W5), rng.uniform(1, 30, W5)])
+    el5[:, 0] = [a5, 0.0, 0.0, 0.0, 0.0, 50000.0, 1.0, 0.0, 5.0]      # the reference's circular orbit (e = 0 early-return path)
+    rv5 = 50.0 + 0.1 * rng.normal(0, 1, 20) * 10 + 30 * np.sin(2 * np.pi * (ep5 - 50000) / 1234.5)
+    nu5 = col(rng.normal(50, 10, W5), np.exp(rng.uniform(np.log(0.01), np.log(50), W5)), np.zeros(W5))
+    cases.append(run_case("F5_rv_relative", [RVO], [rvtab("RV_REL", 0, ep5, rv5, [1.0] * 20)], el5, nu5,
+                          "PlanetRelativeRVObs on a RadialVelocityOrbit, runtests.jl:173-184"))
+    cases.append(run_case("F5_rv_absolute", [RVO], [rvtab("RV_ABS", -1, ep5, rv5 * 0.01, [0.3] * 20)], el5, nu5 * np.array([[0.01], [0.02], [1.0]]),
+                          "StarAbsoluteRVObs, same orbit, reflex of the primary"))
+    cases.append(run_case("F5_rv_marginalized", [RVO], [rvtab("RV_ABS_MARG", -1, ep5, rv5 * 0.01, [0.3 + 0.01 * k for k in range(20)])], el5,
+                          nu5 * np.array([[0.0], [0.02], [1.0]]), "MarginalizedStarAbsoluteRVObs (rv-absolute-margin.jl:168-181)"))
+    elv = el5.copy(); elv[2] = rng.uniform(0.2, 2.9, W5); elv[4] = rng.uniform(0, 6.28, W5); elv[7] = 40.0
+    cases.append(run_case("F5_rv_absolute_visual_nonuis", [VISM], [rvtab("RV_ABS", -1, ep5, rv5 * 0.01, [0.3] * 20)], elv, None,
+                          "absolute RV on a Visual{KepOrbit} (K carries sin i), no nuisance block"))
+
+    # ---- F6: two planets, inner-barycentre term (relative-astrometry.jl:117-133, rv-relative.jl:145-160) ----
+    W6 = 6
+    e_in = np.stack([rng.uniform(2.5, 3.5, W6), rng.uniform(0, 0.4, W6), np.arccos(rng.uniform(-1, 1, W6)), rng.uniform(0, 6.28, W6), rng.uniform(0, 6.28, W6),
+                     50000 + rng.uniform(0, 1500, W6), np.full(W6, 1.2), np.full(W6, 50.0), np.full(W6, 5.0) * rng.uniform(0.5, 2, W6)])
+    e_out = np.stack([rng.uniform(12, 18, W6), rng.uniform(0, 0.5, W6), np.arccos(rng.uniform(-1, 1, W6)), rng.uniform(0, 6.28, W6), rng.uniform(0, 6.28, W6),
+                      50000 + rng.uniform(0, 15000, W6), np.full(W6, 1.2), np.full(W6, 50.0), np.full(W6, 10.0) * rng.uniform(0.5, 2, W6)])
+    e_out[0, 5] = 2.0      # one walker where the "outer" planet is actually inside: the term must switch off
+    el6 = np.concatenate([e_in, e_out])
+    ep6 = 50000.0 + 137.0 * np.arange(7)
+    ra6 = rng.normal(0, 300, 7); dec6 = rng.normal(0, 300, 7)
+    epr = 50010.0 + 91.0 * np.arange(9)
+    rv6 = rng.normal(0, 40, 9)
+    nu6 = np.concatenate([col(rng.uniform(0, 5, W6), rng.normal(1, 0.01, W6), rng.normal(0, 0.02, W6)),
+                          col(rng.normal(0, 20, W6), rng.uniform(0.5, 5, W6), np.zeros(W6)),
+                          col(rng.normal(0, 20, W6), rng.uniform(0.5, 5, W6), np.zeros(W6))])
+    obs6 = [astrom(1, ep6, ra6, dec6, [8.0] * 7, [9.0] * 7), rvtab("RV_REL", 1, epr, rv6 * 50, [30.0] * 9), rvtab("RV_ABS", -1, epr, rv6, [5.0] * 9)]
+    cases.append(run_case("F6_two_planet", [VISM, VISM], obs6, el6, nu6,
+                          "astrometry + relative RV on the outer planet, absolute RV on the star; masses ~5 & ~10 Mjup"))
+    cases.append(run_case("F6_two_planet_nonuis", [VISM, VISM], obs6, el6, None, "same, no nuisance block"))
+    obs6b = [astrom(0, ep6, ra6 * 0.2, dec6 * 0.2, [8.0] * 7, [9.0] * 7), astrom(1, ep6, ra6, dec6, [8.0] * 7, [9.0] * 7, cor=[0.3] * 7),
+             rvtab("RV_ABS_MARG", -1, epr, rv6, [5.0] * 9)]
+    nu6b = np.concatenate([nu6[:3], nu6[:3] * 0.5 + 0.5, col(np.zeros(W6), rng.uniform(0.5, 5, W6), np.zeros(W6))])
+    cases.append(run_case("F6_two_planet_marg", [VISM, VISM], obs6b, el6, nu6b, "astrometry on both planets + marginalised RV"))
+
+    # ---- F7: Kepler edge grid: e in {0,1e-12,.5,.9,.99,.999999} x M in {0,±1e-9,±(π−1e-9),±π,40} -----------
+    es = [0.0, 1e-12, 0.5, 0.9, 0.99, 0.999999]
+    Ms = [0.0, 1e-9, -1e-9, np.pi - 1e-9, -(np.pi - 1e-9), np.pi, -np.pi, 40.0]
+    tp7, a7, M7 = 50000.0, 5.0, 1.0
+    P7 = 365.2568983840419 * np.sqrt(a7 ** 3 / M7)
+    ep7 = sorted(tp7 + m / (2 * np.pi) * P7 for m in Ms)
+    el7 = np.stack([np.full(6, a7), np.array(es), np.full(6, 1.0), np.full(6, 0.5), np.full(6, 2.0), np.full(6, tp7), np.full(6, M7), np.full(6, 50.0), np.zeros(6)])
+    ra7 = rng.normal(0, 100, len(ep7)); dec7 = rng.normal(0, 100, len(ep7))
+    cases.append(run_case("F7_kepler_edges", [VIS], [astrom(0, ep7, ra7, dec7, [10.0] * len(ep7), [10.0] * len(ep7))], el7, None,
+                          "eccentricity / mean-anomaly edge grid incl. t == tp"))
+
+    OUT.parent.mkdir(parents=True, exist_ok=True)
+    OUT.write_text(json.dumps(dict(consts=C, cases=cases, generator="oracle/make_golden.py (mpmath %s, dps=%d)" % (mp.__version__, mp.mp.dps)), indent=0))
+    print("wrote", OUT, OUT.stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    main()

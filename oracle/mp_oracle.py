@@ -89,12 +89,18 @@ def solve(o, t):
 
 
 def ln_like(c, planets, obs, elems, nuis):
-    """One walker. elems: [n_planets][9] mpf; nuis: [n_obs][3] mpf or None."""
+    """One walker: total log-likelihood."""
+    return mp.fsum(ln_like_terms(c, planets, obs, elems, nuis))
+
+
+def ln_like_terms(c, planets, obs, elems, nuis):
+    """One walker. elems: [n_planets][9] mpf; nuis: [n_obs][3] mpf or None.
+    Returns the additive terms of the log-likelihood: one per table row, one per marginalised-RV table."""
     n_pl = len(planets)
     orbs = [_orbit(c, planets[p]["orbit_kind"], elems[p]) for p in range(n_pl)]
     m_sol = [elems[p][8] * mp.mpf(c["mjup2msol"]) if planets[p]["has_mass"] else mp.mpf(0) for p in range(n_pl)]
     log2pi = mp.log(2 * mp.pi)
-    total = mp.mpf(0)
+    terms = []
     for io, ob in enumerate(obs):
         kind = KINDS[ob["kind"]] if isinstance(ob["kind"], str) else ob["kind"]
         nz = nuis[io] if nuis is not None else None
@@ -131,7 +137,7 @@ def ln_like(c, planets, obs, elems, nuis):
                 rho_c = mp.mpf(ob["cor"][j]) if ob.get("cor") is not None else mp.mpf(0)
                 det = v1 * v2 * (1 - rho_c ** 2)
                 quad = (r1 * r1 / v1 - 2 * rho_c * r1 * r2 / mp.sqrt(v1 * v2) + r2 * r2 / v2) / (1 - rho_c ** 2)
-                ll += -log2pi - mp.log(det) / 2 - quad / 2
+                terms.append(-log2pi - mp.log(det) / 2 - quad / 2)
         else:
             offset = nz[0] if (nz is not None and kind != 3) else mp.mpf(0)
             jitter = nz[1] if nz is not None else mp.mpf(0)
@@ -155,19 +161,22 @@ def ln_like(c, planets, obs, elems, nuis):
                     C += resid ** 2 / var
                     ll -= mp.log(2 * mp.pi * var)
                 else:
-                    ll += -(log2pi + mp.log(var)) / 2 - resid ** 2 / var / 2
+                    terms.append(-(log2pi + mp.log(var)) / 2 - resid ** 2 / var / 2)
             if kind == 3:
                 ll -= -B ** 2 / (4 * A) + C + mp.log(A)
-        total += ll
-    return total
+                terms.append(ll)
+    return terms
 
 
-def ln_like_and_grad(c, planets, obs, elems, nuis, h_rel=mp.mpf(10) ** -25):
-    """Central-difference gradient at working precision 60 digits. Returns (ll, g_elems, g_nuis)."""
+def ln_like_and_grad(c, planets, obs, elems, nuis, h_rel=mp.mpf(10) ** -25, with_scale=False):
+    """Central-difference gradient at working precision 60 digits. Returns (ll, g_elems, g_nuis) and, with
+    with_scale, also (s_elems, s_nuis) = Σ_terms |∂term/∂θ|: the size of what a gradient component sums over,
+    i.e. the scale its rounding error is measured against when the terms cancel."""
     elems = [[mp.mpf(x) for x in row] for row in elems]
     nuis_m = [[mp.mpf(x) for x in row] for row in nuis] if nuis is not None else None
     f0 = ln_like(c, planets, obs, elems, nuis_m)
     g_el = [[mp.mpf(0)] * N_EL for _ in elems]
+    s_el = [[mp.mpf(0)] * N_EL for _ in elems]
     for p in range(len(elems)):
         for k in range(N_EL):
             if planets[p]["orbit_kind"] == ORBIT_RADVEL and k in (2, 4, 7):
@@ -177,22 +186,29 @@ def ln_like_and_grad(c, planets, obs, elems, nuis, h_rel=mp.mpf(10) ** -25):
             x = elems[p][k]
             h = h_rel * max(abs(x), mp.mpf(1))
             elems[p][k] = x + h
-            fp = ln_like(c, planets, obs, elems, nuis_m)
+            fp = ln_like_terms(c, planets, obs, elems, nuis_m)
             elems[p][k] = x - h
-            fm = ln_like(c, planets, obs, elems, nuis_m)
+            fm = ln_like_terms(c, planets, obs, elems, nuis_m)
             elems[p][k] = x
-            g_el[p][k] = (fp - fm) / (2 * h)
-    g_nu = None
+            d = [(a - b) / (2 * h) for a, b in zip(fp, fm)]
+            g_el[p][k] = mp.fsum(d)
+            s_el[p][k] = mp.fsum(abs(v) for v in d)
+    g_nu = s_nu = None
     if nuis_m is not None:
         g_nu = [[mp.mpf(0)] * N_NUIS for _ in nuis_m]
+        s_nu = [[mp.mpf(0)] * N_NUIS for _ in nuis_m]
         for io in range(len(nuis_m)):
             for k in range(N_NUIS):
                 x = nuis_m[io][k]
                 h = h_rel * max(abs(x), mp.mpf(1))
                 nuis_m[io][k] = x + h
-                fp = ln_like(c, planets, obs, elems, nuis_m)
+                fp = ln_like_terms(c, planets, obs, elems, nuis_m)
                 nuis_m[io][k] = x - h
-                fm = ln_like(c, planets, obs, elems, nuis_m)
+                fm = ln_like_terms(c, planets, obs, elems, nuis_m)
                 nuis_m[io][k] = x
-                g_nu[io][k] = (fp - fm) / (2 * h)
+                d = [(a - b) / (2 * h) for a, b in zip(fp, fm)]
+                g_nu[io][k] = mp.fsum(d)
+                s_nu[io][k] = mp.fsum(abs(v) for v in d)
+    if with_scale:
+        return f0, g_el, g_nu, s_el, s_nu
     return f0, g_el, g_nu

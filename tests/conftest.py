@@ -1,0 +1,56 @@
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_binding as ob
+    ob.load_oracle()
+    return ob
+
+
+KIND_IDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4}
+
+
+def case_tables(case):
+    """golden JSON case -> (obs_tables for capi.pack_obs, planets, elems, nuis)."""
+    obs = []
+    for ob in case["obs"]:
+        obs.append(dict(kind=KIND_IDS[ob["kind"]], planet=ob["planet"],
+                        **{k: (None if ob[k] is None else np.asarray(ob[k], dtype=np.float64)) for k in ("epoch", "y1", "y2", "s1", "s2", "cor")}))
+    elems = np.asarray(case["elems"], dtype=np.float64)
+    nuis = None if case["nuis"] is None else np.asarray(case["nuis"], dtype=np.float64)
+    return obs, case["planets"], elems, nuis
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(ROOT / "tests" / "golden" / "fixtures.json") as f:
+        return json.load(f)
+
+
+def rel_err(x, ref, scale=None):
+    """Per-component error relative to max(|ref|, scale)."""
+    x = np.asarray(x, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    den = np.maximum(np.abs(ref), 0.0 if scale is None else scale)
+    den = np.where(den == 0, 1.0, den)
+    return np.abs(x - ref) / den

@@ -1,0 +1,59 @@
+"""Thin test helper over the C ABI (ctypes): one context + dataset per call set. Used by -m gpu tests."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from __graft_entry__ import load_package
+
+pkg = load_package()
+capi = pkg.capi
+
+
+class GpuPath:
+    def __init__(self, obs_tables, planets, device=0, consts=None):
+        self.lib = capi.load_library()
+        self.ctx = C.c_void_p()
+        st = self.lib.octo_ctx_create(C.byref(self.ctx), device)
+        if st != 0:
+            raise capi.OctoError(st, "octo_ctx_create")
+        if consts is not None:
+            self._chk(self.lib.octo_consts_set(self.ctx, C.byref(consts)))
+        obs_arr, keep = capi.pack_obs(obs_tables)
+        pl_arr = capi.pack_planets(planets)
+        self.ds = C.c_void_p()
+        self._chk(self.lib.octo_dataset_create(self.ctx, obs_arr, len(obs_tables), pl_arr, len(planets), C.byref(self.ds)))
+        self.n_obs, self.n_planets = len(obs_tables), len(planets)
+
+    def _chk(self, st):
+        if st != 0:
+            raise capi.OctoError(st, (self.lib.octo_last_error(self.ctx) or b"").decode())
+
+    def eval(self, elems, nuis=None, grad=True):
+        elems = np.ascontiguousarray(elems, dtype=np.float64)
+        W = elems.shape[1]
+        nu = None if nuis is None else np.ascontiguousarray(nuis, dtype=np.float64)
+        ll = np.full(W, np.nan)
+        g_el = np.full_like(elems, np.nan) if grad else None
+        g_nu = np.full_like(nu, np.nan) if (grad and nu is not None) else None
+        self._chk(self.lib.octo_eval(self.ctx, self.ds, capi._dptr(elems), capi._dptr(nu), W, W,
+                                     capi._dptr(ll), capi._dptr(g_el), capi._dptr(g_nu)))
+        return ll, g_el, g_nu
+
+    def close(self):
+        if self.ds:
+            self.lib.octo_dataset_destroy(self.ds); self.ds = None
+        if self.ctx:
+            self.lib.octo_ctx_destroy(self.ctx); self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def gpu_eval(obs_tables, planets, elems, nuis=None, grad=True, consts=None):
+    with GpuPath(obs_tables, planets, consts=consts) as g:
+        return g.eval(elems, nuis, grad)

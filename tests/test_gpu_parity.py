@@ -1,0 +1,278 @@
+"""
+GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  * the committed golden vectors (50-digit oracle),
+  * the CPU oracle (reference-order restatement) on the same seeded inputs,
+  * size-independent properties at BASELINE.json's full sizes,
+  * the reference tests' self-consistency properties, through the host mirror.
+
+Tolerances (north_star: log-likelihood and gradient within 1e-8 relative):
+  ll      |Δ| <= 1e-10 · max(|ll|, 1)
+  grad    |Δ| <= 1e-8 · |g| + 1e-12 · (S + max_w S),  S = Σ_rows |∂ll_row/∂θ|  (the cancellation floor; for
+          oracle comparisons S is replaced by the row maximum of |g| over the batch)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import case_tables, rel_err
+from test_oracle import grad_ok, northangle_scan, _northangle_tables
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-10
+G_RTOL = 1e-8
+G_CANCEL = 1e-12
+
+
+def _gpu():
+    import gpu_binding
+    return gpu_binding
+
+
+def _cmp_oracle(name, ll, g_el, g_nu, ll_o, g_o, gn_o, ll_rtol=LL_RTOL, g_rtol=G_RTOL):
+    ok_o = np.isfinite(ll_o)
+    assert np.array_equal(np.isfinite(ll), ok_o), name
+    assert np.all(np.isneginf(ll[~ok_o])), name
+    err = rel_err(ll[ok_o], ll_o[ok_o], 1.0)
+    assert np.all(err < ll_rtol), (name, "ll", err.max())
+    if g_el is not None:
+        assert np.all(g_el[:, ~ok_o] == 0.0), name
+        scale = np.abs(g_o[:, ok_o]).max(axis=1, keepdims=True) * np.ones_like(g_o[:, ok_o]) * 1e3
+        ok, worst = grad_ok(g_el[:, ok_o], g_o[:, ok_o], scale, rtol=g_rtol, cancel=G_CANCEL)
+        assert ok, (name, "g_elems", worst)
+    if g_nu is not None:
+        scale = np.abs(gn_o[:, ok_o]).max(axis=1, keepdims=True) * np.ones_like(gn_o[:, ok_o]) * 1e3
+        ok, worst = grad_ok(g_nu[:, ok_o], gn_o[:, ok_o], scale, rtol=g_rtol, cancel=G_CANCEL)
+        assert ok, (name, "g_nuis", worst)
+
+
+def test_golden_vectors_through_c_abi(golden):
+    gb = _gpu()
+    for case in golden["cases"]:
+        obs, planets, elems, nuis = case_tables(case)
+        ll, g_el, g_nu = gb.gpu_eval(obs, planets, elems, nuis, grad=True)
+        ll_f, _, _ = gb.gpu_eval(obs, planets, elems, nuis, grad=False)
+        assert np.array_equal(ll, ll_f), (case["name"], "forward-only and gradient launches disagree")
+        ref_ll = np.asarray(case["ll"])
+        has_marg = any(ob["kind"] == "RV_ABS_MARG" for ob in case["obs"])
+        err = rel_err(ll, ref_ll, 1.0)
+        assert np.all(err < (1e-9 if has_marg else LL_RTOL)), (case["name"], "ll", err.max())
+        cancel = 1e-10 if has_marg else G_CANCEL
+        rtol = G_RTOL
+        if case["name"] == "F7_kepler_edges":
+            rtol = 1e-7      # e = 0.999999: cond ~ 1/(1-e)^2 on d/de; still far inside the reference's own error there
+        ok, worst = grad_ok(g_el, case["g_elems"], case["s_elems"], rtol=rtol, cancel=cancel)
+        assert ok, (case["name"], "g_elems", worst)
+        if nuis is not None:
+            ok, worst = grad_ok(g_nu, case["g_nuis"], case["s_nuis"], rtol=rtol, cancel=cancel)
+            assert ok, (case["name"], "g_nuis", worst)
+
+
+@pytest.mark.parametrize("n_epochs,n_walkers", [(1, 1), (7, 63), (96, 257), (513, 1000), (2048, 130)])
+def test_astrometry_vs_oracle(oracle, n_epochs, n_walkers):
+    gb = _gpu()
+    cfg = synth.config_astrom(n_epochs=n_epochs, n_walkers=n_walkers, seed=100 + n_epochs)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    ll, g_el, _ = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=True)
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, cfg["elems"], None, grad=True, active=synth.active_mask(1, 1, mass=False, nuis=False))
+    _cmp_oracle(f"astrom {n_epochs}x{n_walkers}", ll, g_el, None, ll_o, g_o, None)
+
+
+def test_all_kinds_two_planets_vs_oracle(oracle):
+    gb = _gpu()
+    cfg = synth.config_two_planet(n_astrom=300, n_rv=280, n_walkers=333, seed=5)
+    a, r = cfg["astrom"], cfg["rv"]
+    rng = np.random.default_rng(9)
+    n = len(a["epoch"])
+    pa = np.arctan2(a["ra"], a["dec"]); sep = np.hypot(a["ra"], a["dec"])
+    obs = [
+        dict(kind=0, planet=1, epoch=a["epoch"], y1=a["ra"], y2=a["dec"], s1=a["σ_ra"], s2=a["σ_dec"], cor=rng.uniform(-0.7, 0.7, n)),
+        dict(kind=1, planet=1, epoch=a["epoch"] + 0.5, y1=pa, y2=sep, s1=np.full(n, 0.02), s2=a["σ_ra"], cor=None),
+        dict(kind=0, planet=0, epoch=a["epoch"][:50], y1=a["ra"][:50] * 0.2, y2=a["dec"][:50] * 0.2, s1=a["σ_ra"][:50], s2=a["σ_dec"][:50], cor=None),
+        dict(kind=4, planet=1, epoch=r["epoch"], y1=r["rv"] * 30, y2=None, s1=r["σ_rv"] * 10, s2=None, cor=None),
+        dict(kind=2, planet=-1, epoch=r["epoch"], y1=r["rv"], y2=None, s1=r["σ_rv"], s2=None, cor=None),
+        dict(kind=3, planet=-1, epoch=r["epoch"][::2], y1=r["rv"][::2] + 3.0, y2=None, s1=r["σ_rv"][::2] * 1.5, s2=None, cor=None),
+    ]
+    planets = [dict(orbit_kind=0, has_mass=True), dict(orbit_kind=0, has_mass=True)]
+    W = cfg["n_walkers"]
+    nuis = np.zeros((len(obs) * 3, W))
+    for o in range(3):
+        nuis[o * 3 + 0] = rng.uniform(0, 5, W); nuis[o * 3 + 1] = rng.normal(1, 0.01, W); nuis[o * 3 + 2] = rng.normal(0, 0.01, W)
+    nuis[0, :40] = 0.0                      # jitter == 0 branch inside a nuisance batch
+    for o in range(3, 6):
+        nuis[o * 3 + 0] = rng.normal(10, 3, W); nuis[o * 3 + 1] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+    elems = cfg["elems"].copy()
+    elems[9 + 0, :20] = elems[0, :20] * 0.5  # some walkers: "outer" planet inside the "inner" one
+    for nz in (nuis, None):
+        ll, g_el, g_nu = gb.gpu_eval(obs, planets, elems, nz, grad=True)
+        ll_f, _, _ = gb.gpu_eval(obs, planets, elems, nz, grad=False)
+        assert np.array_equal(ll, ll_f)
+        ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, elems, nz, grad=True)
+        _cmp_oracle("all kinds", ll, g_el, g_nu, ll_o, g_o, gn_o, ll_rtol=1e-9)
+
+
+def test_radvel_orbit_and_empty_table(oracle):
+    gb = _gpu()
+    rng = np.random.default_rng(3)
+    W = 70
+    ep = np.linspace(50000.0, 50200.0, 20)
+    obs = [dict(kind=4, planet=0, epoch=ep, y1=rng.normal(0, 30, 20), y2=None, s1=np.full(20, 2.0), s2=None, cor=None),
+           dict(kind=2, planet=-1, epoch=np.zeros(0), y1=np.zeros(0), y2=None, s1=np.zeros(0), s2=None, cor=None)]
+    planets = [dict(orbit_kind=1, has_mass=True)]
+    elems = np.stack([rng.uniform(0.5, 3, W), rng.uniform(0, 0.8, W), np.full(W, np.nan), rng.uniform(0, 6.28, W), np.full(W, np.nan),
+                      50000 + rng.uniform(-100, 100, W), rng.normal(1, 0.05, W), np.full(W, np.nan), rng.uniform(0, 10, W)])
+    nuis = np.stack([rng.normal(0, 5, W), rng.uniform(0.1, 3, W), np.zeros(W), rng.normal(0, 5, W), rng.uniform(0.1, 3, W), np.zeros(W)])
+    ll, g_el, g_nu = gb.gpu_eval(obs, planets, elems, nuis, grad=True)
+    ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, elems, nuis, grad=True)
+    assert np.all(np.isfinite(ll_o))
+    _cmp_oracle("radvel", ll, g_el, g_nu, ll_o, g_o, gn_o)
+    assert np.all(g_el[[2, 4, 7]] == 0.0)   # rows a RadialVelocityOrbit ignores carry no gradient (NaN inputs tolerated)
+
+
+def test_invalid_walkers(oracle):
+    gb = _gpu()
+    cfg = synth.config_astrom(n_epochs=40, n_walkers=130, seed=11)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    el = cfg["elems"].copy()
+    el[1, 3] = 1.0; el[1, 4] = -1e-3; el[0, 5] = 0.0; el[6, 6] = -1.0; el[7, 7] = 0.0; el[3, 8] = np.nan; el[5, 9] = np.inf; el[1, 64] = 1.5
+    bad = [3, 4, 5, 6, 7, 8, 9, 64]
+    ll, g_el, _ = gb.gpu_eval(obs, planets, el, None, grad=True)
+    assert np.all(np.isneginf(ll[bad])) and np.all(g_el[:, bad] == 0.0)
+    good = np.setdiff1d(np.arange(130), bad)
+    assert np.all(np.isfinite(ll[good]))
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el, None, grad=True, active=synth.active_mask(1, 1, mass=False, nuis=False))
+    _cmp_oracle("invalid", ll, g_el, None, ll_o, g_o, None)
+
+
+def test_full_size_properties(oracle):
+    """BASELINE configs 2/3 (1 planet, 1e4 RA/Dec epochs × 1e4 walkers): determinism, additivity over a split of the
+    table, and direct parity with the oracle for a seeded sample of walkers at the full epoch count."""
+    gb = _gpu()
+    cfg = synth.config_astrom()       # 1e4 × 1e4, rng 20260929+2
+    t = cfg["table"]
+    mk = lambda sl: dict(kind=0, planet=0, epoch=t["epoch"][sl], y1=t["ra"][sl], y2=t["dec"][sl], s1=t["σ_ra"][sl], s2=t["σ_dec"][sl], cor=None)
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    full = gb.GpuPath([mk(slice(None))], planets)
+    ll, g, _ = full.eval(cfg["elems"], None, grad=True)
+    ll2, g2, _ = full.eval(cfg["elems"], None, grad=True)
+    assert np.array_equal(ll, ll2) and np.array_equal(g, g2), "not deterministic"
+    llf, _, _ = full.eval(cfg["elems"], None, grad=False)
+    assert np.array_equal(ll, llf)
+    full.close()
+    assert np.all(np.isfinite(ll))
+    # additivity: ln_like over the table == ln_like over two tables that split it (system.jl:93 sums observations)
+    split = gb.GpuPath([mk(slice(0, 3777)), mk(slice(3777, None))], planets)
+    ll_s, g_s, _ = split.eval(cfg["elems"], None, grad=True)
+    split.close()
+    assert np.all(rel_err(ll_s, ll, 1.0) < 1e-12)
+    assert np.all(np.abs(g_s - g) <= 1e-11 * np.abs(g).max(axis=1, keepdims=True))
+    # oracle parity for a seeded sample of walkers at full E
+    idx = np.random.default_rng(0).choice(cfg["n_walkers"], 24, replace=False)
+    ll_o, g_o, _ = oracle.oracle_eval([mk(slice(None))], planets, cfg["elems"][:, idx], None, grad=True,
+                                      active=synth.active_mask(1, 1, mass=False, nuis=False), n_threads=0)
+    _cmp_oracle("full size sample", ll[idx], g[:, idx], None, ll_o, g_o, None)
+
+
+def test_mirror_reference_properties(pkg, oracle):
+    """test/unit/likelihoods.jl:32-95 and test/unit/distributions.jl:102-152 through the host mirror's
+    PlanetRelAstromObs / Planet / System / make_ln_like surface, on the HIP path."""
+    el, eps, seppa, radec = _northangle_tables(oracle)
+    grid = np.linspace(-0.1, 0.1, 2001)
+    best = {}
+    for name, tab in (("seppa", dict(epoch=seppa["epoch"], sep=seppa["y2"], pa=seppa["y1"], σ_sep=seppa["s2"], σ_pa=seppa["s1"])),
+                      ("radec", dict(epoch=radec["epoch"], ra=radec["y1"], dec=radec["y2"], σ_ra=radec["s1"], σ_dec=radec["s2"]))):
+        obs = pkg.PlanetRelAstromObs(tab, name="inst")
+        pl = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[obs])
+        sys_ = pkg.System(name="northangle_test", companions=[pl], observations=[])
+        θ = dict(plx=50.0, planets=dict(b=dict(M=1.2, a=15.0, e=0.2, i=0.6, ω=0.3, Ω=1.1, tp=50000.0, observations=dict(inst=dict(northangle=grid)))))
+        ln_like = pkg.make_ln_like(sys_, θ)
+        ll = ln_like(θ)
+        best[name] = grid[np.argmax(ll)]
+        θ0 = dict(θ); θ0["planets"] = dict(b=dict(θ["planets"]["b"], observations=dict(inst=dict(northangle=np.array([0.0, -0.0])))))
+        z = ln_like(θ0)
+        assert z[0] == z[1]
+        ln_like.close()
+    assert abs(best["seppa"] + eps) < 1e-3 and abs(best["radec"] + eps) < 1e-3
+    # jitter sensitivity
+    tbl = dict(epoch=[58000.0, 58200.0, 58400.0], ra=[100.0, 110.0, 120.0], dec=[100.0, 95.0, 90.0], σ_ra=[5.0] * 3, σ_dec=[5.0] * 3)
+    obs = pkg.PlanetRelAstromLikelihood(tbl, name="d_radec")
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=(obs,))
+    sys_ = pkg.System(name="jitter_prop_test", companions=(b,))
+    θ = dict(M=1.0, plx=50.0, planets=dict(b=dict(a=10.0, e=0.2, i=0.5, ω=0.3, Ω=0.4, tp=58000.0, observations=dict(d_radec=dict(jitter=np.array([0.001, 300.0]))))))
+    fn = pkg.make_ln_like(sys_, θ)
+    ll, grads = fn.ln_like_and_grad(θ)
+    assert ll[1] - ll[0] > 1
+    assert grads["planets"]["b"]["observations"]["d_radec"]["jitter"].shape == (2,)
+    fn.close()
+
+
+def test_device_resident_api_matches_host_api(pkg):
+    import torch
+    cfg = synth.config_astrom(n_epochs=200, n_walkers=500, seed=21)
+    obs, planet = synth.to_mirror(pkg, cfg)
+    fn = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
+    ll_h, g_h, _ = fn.ln_like_arrays(cfg["elems"], None, grad=True)
+    el_t = torch.tensor(cfg["elems"], device="cuda:0")
+    ll_t, g_t, _ = fn.ln_like_device(el_t, None, grad=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(ll_t.cpu().numpy(), ll_h) and np.array_equal(g_t.cpu().numpy(), g_h)
+    fn.close()
+
+
+def _pt_swap_reference(ll, beta, slot2rep, parity, seed, step):
+    """NumPy restatement of k_pt_swap (octo_api.hip) for the test."""
+    M64 = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9e3779b97f4a7c15) & M64
+        z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & M64
+        z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & M64
+        return z ^ (z >> 31)
+    n_chains, n_temps = ll.shape
+    out = slot2rep.copy()
+    acc = np.zeros(n_temps, dtype=np.int32)
+    for c in range(n_chains):
+        for t in range(parity, n_temps - 1, 2):
+            ri, rj = out[c, t], out[c, t + 1]
+            li, lj = ll[c, ri], ll[c, rj]
+            logA = (beta[t] - beta[t + 1]) * (lj - li)
+            h = mix((mix((mix(seed ^ 0x6f63746f50545357) + step) & M64) + c * 0x100000001b3 + t) & M64)
+            u = ((h >> 11) + 1.0) * (1.0 / 9007199254740992.0)
+            if np.log(u) < logA:
+                out[c, t], out[c, t + 1] = rj, ri
+                acc[t] += 1
+    return out, acc
+
+
+def test_pt_swap_kernel(pkg):
+    import torch
+    lib = pkg.capi.load_library()
+    ctx = C.c_void_p()
+    assert lib.octo_ctx_create(C.byref(ctx), 0) == 0
+    rng = np.random.default_rng(2)
+    n_chains, n_temps = 37, 16
+    ll = rng.normal(-100, 5, (n_chains, n_temps))
+    beta = np.linspace(1.0, 0.0, n_temps) ** 2
+    s2r = np.stack([rng.permutation(n_temps) for _ in range(n_chains)]).astype(np.int32)
+    d_ll = torch.tensor(ll, device="cuda:0"); d_beta = torch.tensor(beta, device="cuda:0")
+    d_s2r = torch.tensor(s2r, device="cuda:0"); d_acc = torch.zeros(n_temps, dtype=torch.int32, device="cuda:0")
+    ref = s2r
+    acc_ref = np.zeros(n_temps, dtype=np.int32)
+    for step in range(6):
+        st = lib.octo_pt_swap_device(ctx, d_ll.data_ptr(), d_beta.data_ptr(), d_s2r.data_ptr(), n_temps, n_chains, step % 2,
+                                     1234, step, d_acc.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert st == 0
+        ref, a = _pt_swap_reference(ll, beta, ref, step % 2, 1234, step)
+        acc_ref += a
+    torch.cuda.synchronize()
+    assert np.array_equal(d_s2r.cpu().numpy(), ref)
+    assert np.array_equal(d_acc.cpu().numpy(), acc_ref)
+    assert np.all(np.sort(ref, axis=1) == np.arange(n_temps))
+    assert acc_ref.sum() > 0
+    lib.octo_ctx_destroy(ctx)

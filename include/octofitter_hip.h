@@ -167,6 +167,12 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* ds,
                          void* hip_stream);
 int32_t octo_sync(octo_ctx* ctx);
 
+/* Batched eccentric-anomaly solve, HOST buffers (blocking): E = kepler_solver(MA, e) for 0 <= e < 1, the
+ * call the reference makes at src/parameterizations.jl:340 (PlanetOrbits.kepler_solver, Markley). Runs the same
+ * device routine the likelihood kernel uses. sinE_out / cosE_out may be NULL. Invalid inputs give NaN. */
+int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n,
+                          double* E_out, double* sinE_out, double* cosE_out);
+
 /* Measurement hook used by bench.py: average duration in milliseconds of the
  * dominant (epoch-loop) kernel over the launches since the last reset, from
  * hipEvents recorded on the launch stream. Enabled by octo_timing_enable. */

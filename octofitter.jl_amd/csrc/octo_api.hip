@@ -459,6 +459,28 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
     return OCTO_OK;
 }
 
+int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n, double* E_out, double* sinE_out,
+                          double* cosE_out) {
+    if (!ctx || !MA || !e || !E_out || n < 0) return fail(ctx, OCTO_EINVAL, "octo_kepler_solve: null argument");
+    if (n == 0) return OCTO_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = grow(ctx, ctx->d_in, ctx->cap_in, 2 * n);
+    if (rc) return rc;
+    rc = grow(ctx, ctx->d_out, ctx->cap_out, 3 * n);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, MA, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_in + n, e, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_kepler, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx->d_in, ctx->d_in + n, n, ctx->d_out,
+                       ctx->d_out + n, ctx->d_out + 2 * n);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(E_out, ctx->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    if (sinE_out) HIPCHK(ctx, hipMemcpyAsync(sinE_out, ctx->d_out + n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    if (cosE_out) HIPCHK(ctx, hipMemcpyAsync(cosE_out, ctx->d_out + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return OCTO_OK;
+}
+
 int32_t octo_timing_enable(octo_ctx* ctx, int32_t on) {
     if (!ctx) return OCTO_EINVAL;
     ctx->timing = on != 0;

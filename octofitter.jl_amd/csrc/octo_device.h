@@ -4,13 +4,25 @@
 // loop; everything that depends only on the observation row is wave-uniform and arrives through
 // scalar loads (SGPRs), so a row costs no vector-memory traffic at all.
 //
-// The Kepler solve follows the reference's solver (PlanetOrbits.jl `kepler_solver(MA, e, Markley())`,
-// call site src/parameterizations.jl:340; provenance docs/src/kepler.md:15-19): Markley's cubic
-// starter + one fifth-order correction — non-iterative, hence divergence-free across the 64 lanes.
-// The projection uses the Thiele-Innes form the reference itself uses in ofti_linear_solve
+// Kepler solve. The reference's solver is PlanetOrbits.jl `kepler_solver(MA, e, Markley())` (call site
+// src/parameterizations.jl:340; provenance docs/src/kepler.md:15-19): Markley's cubic starter E1 followed by
+// ONE fifth-order correction δ5 — non-iterative, hence divergence-free across the 64 lanes. The root of
+// Kepler's equation is unique, so any E1 inside the correction's basin gives the same E to rounding. That is
+// what makes a CDNA4-shaped implementation legal:
+//   * the starter is evaluated in FP32 (2x the FP64 issue rate, single-instruction v_sqrt/v_rcp/v_log/v_exp):
+//     its own error (~4e-4 by construction) dwarfs FP32 rounding;
+//   * sin/cos(E1) come from one half-angle polynomial pair on |E1|/2 <= 1.59 (no range reduction, no
+//     quadrant selects, no Payne-Hanek slow path: |E1| <= π by construction);
+//   * the three divisions of the correction use v_rcp_f64 (2^-23) with 0/1/1 Newton steps — the sensitivity
+//     of E to δ3, δ4 is O(δ²);
+//   * sin/cos(E) follow from (sin E1, cos E1) by a rotation through δ5 (|δ5| < 5e-4: Taylor to δ^6).
+// tools/kepler_proto.py measures this scheme against an 80-bit Newton solve over 2e6 (M, e) pairs incl.
+// e -> 1 − 1e-9 and |M| -> 0, π: residual-weighted error 5.1e-16 max vs 7.1e-16 for the all-FP64 reference
+// algorithm. tests/test_gpu_parity.py::test_kepler_* check the device code itself.
+//
+// Projection: the Thiele-Innes form the reference itself uses in ofti_linear_solve
 // (src/parameterizations.jl:343-353): X = cos E − e, Y = √(1−e²) sin E, ra = cB X + cG Y,
-// dec = cA X + cF Y — algebraically identical to orbitsolve's 2·atan(ν_fact·tan(E/2)) route
-// (no tan/atan/second sincos), parity-checked against oracle/ to ≤1e-12.
+// dec = cA X + cF Y — algebraically identical to orbitsolve's 2·atan(ν_fact·tan(E/2)) route.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,82 +43,145 @@ enum : int {
     WC_TP,        // epoch of periastron   [MJD]
     WC_E,         // eccentricity
     WC_BETA,      // √(1−e²)
-    WC_K1,        // MK_K1N / (1+e)
+    WC_EOB,       // e / √(1−e²)
     WC_CB, WC_CG, WC_CA, WC_CF,   // mas per unit (X, Y):  ra = CB·X + CG·Y,  dec = CA·X + CF·Y
     WC_K,         // RV semi-amplitude     [m/s]
     WC_COSW, WC_SINW,
     WC_MU,        // m_planet / M_tot  (0 when the planet declares no mass)
     WC_A,         // semi-major axis       [AU]
+    WC_F32A,      // packed {float e, float 1−e}   (starter constants, FP32)
+    WC_F32B,      // packed {float k1 = MK_K1N/(1+e), float 0}
     NWC
 };
 
 struct PC {   // one planet's constants for one walker, in registers
-    double invP, tp, e, beta, k1, cB, cG, cA, cF, K, cw, sw, mu, a;
+    double invP, tp, e, beta, eob, cB, cG, cA, cF, K, cw, sw, mu, a;
+    float ef, omef, k1f;
 };
 
-struct KSol { double X, Y, sE, cE, invD; };
+struct KSol { double X, Y, sE, cE, invD, dt, E; };
 
 __device__ __forceinline__ void load_pc(PC& pc, const double* __restrict__ wc, int64_t ldw, int p, int64_t w) {
     const double* b = wc + (int64_t)p * NWC * ldw + w;
     pc.invP = b[WC_INVP * ldw]; pc.tp = b[WC_TP * ldw]; pc.e = b[WC_E * ldw]; pc.beta = b[WC_BETA * ldw];
-    pc.k1 = b[WC_K1 * ldw]; pc.cB = b[WC_CB * ldw]; pc.cG = b[WC_CG * ldw]; pc.cA = b[WC_CA * ldw];
+    pc.eob = b[WC_EOB * ldw]; pc.cB = b[WC_CB * ldw]; pc.cG = b[WC_CG * ldw]; pc.cA = b[WC_CA * ldw];
     pc.cF = b[WC_CF * ldw]; pc.K = b[WC_K * ldw]; pc.cw = b[WC_COSW * ldw]; pc.sw = b[WC_SINW * ldw];
     pc.mu = b[WC_MU * ldw]; pc.a = b[WC_A * ldw];
+    const float2 fa = *reinterpret_cast<const float2*>(&b[WC_F32A * ldw]);
+    const float2 fb = *reinterpret_cast<const float2*>(&b[WC_F32B * ldw]);
+    pc.ef = fa.x; pc.omef = fa.y; pc.k1f = fb.x;
 }
 
-// Eccentric anomaly and the quantities every projection needs.
+__device__ __forceinline__ double pack_f32x2(float x, float y) {
+    float2 v = make_float2(x, y);
+    return *reinterpret_cast<double*>(&v);
+}
+
+// sin and cos of x for |x| <= 3.18 via the half angle: h = x/2, polynomials in u = h² (Chebyshev fits on
+// |h| <= 1.59, tools/gen_sincos_poly.py: approximation error 1.5e-17 / 8.7e-18), then sin x = 2 s c,
+// cos x = 1 − 2 s². 24 FP64 instructions, branch-free.
+__device__ __forceinline__ void sincos_halfangle(double x, double& s, double& c) {
+    const double h = 0.5 * x;
+    const double u = h * h;
+    double ps = 2.7193985903359714e-15;                 // sin(h)/h = 1 + u·Q(u), Q of degree 7
+    ps = fma(ps, u, -7.642822688610201e-13);
+    ps = fma(ps, u, 1.6058933154149512e-10);
+    ps = fma(ps, u, -2.5052106738943426e-08);
+    ps = fma(ps, u, 2.7557319209590407e-06);
+    ps = fma(ps, u, -0.0001984126984119912);
+    ps = fma(ps, u, 0.00833333333333316);
+    ps = fma(ps, u, -0.16666666666666666);
+    double pc = -1.51077353714095e-16;                  // cos(h) = 1 + u·Qc(u), Qc of degree 8
+    pc = fma(pc, u, 4.776743872294959e-14);
+    pc = fma(pc, u, -1.1470664505957302e-11);
+    pc = fma(pc, u, 2.0876755532557785e-09);
+    pc = fma(pc, u, -2.7557319207812853e-07);
+    pc = fma(pc, u, 2.480158730147785e-05);
+    pc = fma(pc, u, -0.0013888888888888464);
+    pc = fma(pc, u, 0.04166666666666666);
+    pc = fma(pc, u, -0.5);
+    const double sh = fma(h * u, ps, h);
+    const double ch = fma(u, pc, 1.0);
+    const double t = sh + sh;
+    s = t * ch;
+    c = fma(-t, sh, 1.0);
+}
+
+// v_rcp_f64 (≈2^-23) + NR Newton steps (each doubles the correct bits): NR = 1 -> 2^-46, NR = 2 -> full.
+template <int NR>
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// Eccentric anomaly and the quantities every projection needs. INV_NR: Newton steps on 1/(1 − e cos E)
+// (1 when it only feeds adjoints, 2 when it feeds a model value).
+template <int INV_NR>
 __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc) {
-    // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
-    const double u = (t - pc.tp) * pc.invP;
-    const double M = (u - rint(u)) * TWO_PI;
-    const double e = pc.e;
-    const double ome = 1.0 - e;
-    // ---- Markley (1995) starter, eqs (20),(5),(9),(10),(14),(15)
-    const double alpha = fma(pc.k1, PI - fabs(M), MK_K0);
-    const double d = fma(alpha, e, 3.0 * ome);
-    const double ad = alpha * d;
-    const double M2 = M * M;
-    const double q = fma(2.0 * ad, ome, -M2);
-    const double r = M * fma(3.0 * ad, d - ome, M2);
-    const double q2 = q * q;
-    const double x = fabs(r) + sqrt(fma(q2, q, r * r));
-    const double w = cbrt(x * x);
-    const double E1 = (2.0 * r * w / fma(w, w + q, q2) + M) / d;
-    // ---- one fifth-order correction, eqs (21)-(29)
-    double s1, c1;
-    sincos(E1, &s1, &c1);
-    const double f2 = e * s1, f3 = e * c1;
-    const double f0 = E1 - f2 - M;
-    const double f1 = 1.0 - f3;
-    const double d3 = -f0 / (f1 - f0 * f2 / (2.0 * f1));
-    const double d4 = -f0 / (f1 + f2 * d3 * 0.5 + d3 * d3 * f3 * (1.0 / 6.0));
-    const double d42 = d4 * d4;
-    double d5 = -f0 / (f1 + d4 * f2 * 0.5 + d42 * f3 * (1.0 / 6.0) - d42 * d4 * f2 * (1.0 / 24.0));
-    // M == 0 or e == 0: the reference returns M itself (early exit); the formulas above give the
-    // same value up to rounding, the select keeps the exact reference result.
-    const bool trivial = (M == 0.0) | (e == 0.0);
-    const double E = trivial ? M : E1 + d5;
     KSol s;
-    sincos(E, &s.sE, &s.cE);
+    // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
+    s.dt = t - pc.tp;
+    const double u = s.dt * pc.invP;
+    const double M = (u - rint(u)) * TWO_PI;
+    // ---- Markley (1995) starter, eqs (20),(5),(9),(10),(14),(15), in FP32
+    const float Mf = (float)M;
+    const float ef = pc.ef, omef = pc.omef;
+    const float alpha = fmaf(pc.k1f, (float)PI - fabsf(Mf), (float)MK_K0);
+    const float d = fmaf(alpha, ef, 3.0f * omef);
+    const float ad = alpha * d;
+    const float M2 = Mf * Mf;
+    const float q = fmaf(2.0f * ad, omef, -M2);
+    const float r = Mf * fmaf(3.0f * ad, d - omef, M2);
+    const float q2 = q * q;
+    const float disc = fmaxf(fmaf(q2, q, r * r), 0.0f);
+    const float x = fabsf(r) + __builtin_amdgcn_sqrtf(disc);
+    const float w = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (2.0f / 3.0f));   // cbrt(x²)
+    const float den = fmaf(w, w + q, q2);
+    const float E1f = fmaf(2.0f * r * w, __builtin_amdgcn_rcpf(den), Mf) * __builtin_amdgcn_rcpf(d);
+    const double E1 = (double)E1f;
+    // ---- one fifth-order correction, eqs (21)-(29), FP64
+    double s1, c1;
+    sincos_halfangle(E1, s1, c1);
+    const double e = pc.e;
+    const double f2 = e * s1, f3 = e * c1;
+    const double f0 = (E1 - M) - f2;
+    const double f1 = 1.0 - f3;
+    const double hf2 = 0.5 * f2, sf3 = f3 * (1.0 / 6.0);
+    const double d3 = -f0 * __builtin_amdgcn_rcp(fma(-f0 * hf2, __builtin_amdgcn_rcp(f1), f1));
+    const double d4 = -f0 * rcp_nr<1>(fma(d3, fma(d3, sf3, hf2), f1));
+    const double d5 = -f0 * rcp_nr<1>(fma(d4, fma(d4, fma(-d4, f2 * (1.0 / 24.0), sf3), hf2), f1));
+    s.E = E1 + d5;                                                   // eq. (29); dead code unless a caller reads it
+    // ---- sin/cos(E1 + δ5) by rotation; |δ5| < 5e-4
+    const double dd = d5 * d5;
+    const double sd = d5 * fma(dd, fma(dd, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+    const double cm1 = dd * fma(dd, fma(dd, -1.0 / 720.0, 1.0 / 24.0), -0.5);
+    s.sE = s1 + fma(s1, cm1, c1 * sd);
+    s.cE = c1 + fma(c1, cm1, -(s1 * sd));
+    // M == 0: E1f = 0 exactly and f0 = 0, so E = 0 like the reference's early return; e == 0: f2 = f3 = 0,
+    // d5 = −(E1 − M) exactly, E = M to rounding, like the reference's early return.
     s.X = s.cE - e;
     s.Y = pc.beta * s.sE;
-    s.invD = 1.0 / (1.0 - e * s.cE);
+    s.invD = rcp_nr<INV_NR>(fma(-e, s.cE, 1.0));
     return s;
 }
 
 // Reverse sweep through X = cE − e, Y = β sE, D = 1 − e cE and the Kepler root E(M, e).
 // Inputs: adjoints of X, Y, D and the direct e-adjoint accumulated so far.
 // Adds into ge (Σ ē), gm (Σ M̄), gt (Σ M̄·(t−tp)).
-__device__ __forceinline__ void kepler_adjoint(const KSol& s, const PC& pc, double t, double Xb, double Yb, double Db,
+template <bool HAS_D>
+__device__ __forceinline__ void kepler_adjoint(const KSol& s, const PC& pc, double Xb, double Yb, double Db,
                                                double eb_direct, double& ge, double& gm, double& gt) {
-    const double cEb = Xb - pc.e * Db;
-    const double sEb = pc.beta * Yb;
-    const double Eb = sEb * s.cE - cEb * s.sE;
+    const double cEb = HAS_D ? fma(-pc.e, Db, Xb) : Xb;
+    const double Eb = fma(pc.beta * Yb, s.cE, -(cEb * s.sE));
     const double Mb = Eb * s.invD;                                  // ∂E/∂M = 1/(1 − e cos E)
-    const double eb = eb_direct - Xb - s.cE * Db - (pc.e / pc.beta) * s.sE * Yb + Mb * s.sE;   // ∂E/∂e = sin E/(1 − e cos E)
+    double eb = fma(Mb, s.sE, -Xb);                                 // ∂E/∂e = sin E/(1 − e cos E)
+    eb = fma(-(pc.eob * s.sE), Yb, eb);
+    if (HAS_D) eb = fma(-s.cE, Db, eb + eb_direct);
     ge += eb;
     gm += Mb;
-    gt = fma(Mb, t - pc.tp, gt);
+    gt = fma(Mb, s.dt, gt);
 }
 
 }  // namespace octo

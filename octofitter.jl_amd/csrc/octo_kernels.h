@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
         const double K = (TWO_PI * sma / (P_d / a.c.yd)) / beta * a.c.au2m * a.c.sec2yr * si;
         double* o = a.wc + (int64_t)p * NWC * a.ldw + w;
         o[WC_INVP * a.ldw] = 1.0 / P_d; o[WC_TP * a.ldw] = tp; o[WC_E * a.ldw] = e; o[WC_BETA * a.ldw] = beta;
-        o[WC_K1 * a.ldw] = MK_K1N / (1.0 + e);
+        o[WC_EOB * a.ldw] = e / beta;
+        o[WC_F32A * a.ldw] = pack_f32x2((float)e, (float)(1.0 - e));
+        o[WC_F32B * a.ldw] = pack_f32x2((float)(MK_K1N / (1.0 + e)), 0.0f);
         o[WC_CB * a.ldw] = T * B; o[WC_CG * a.ldw] = T * G; o[WC_CA * a.ldw] = T * A; o[WC_CF * a.ldw] = T * F;
         o[WC_K * a.ldw] = K; o[WC_COSW * a.ldw] = cw; o[WC_SINW * a.ldw] = sw;
         o[WC_MU * a.ldw] = mass * a.c.mjup2msol / Mt; o[WC_A * a.ldw] = sma;
@@ -118,6 +120,24 @@ __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
         for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok = ok && isfinite(a.nuis[(int64_t)k * a.ld + w]);
     }
     a.valid[w] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------ k_kepler
+// Batched PlanetOrbits.kepler_solver(MA, e) (call site src/parameterizations.jl:340) through the same device
+// routine k_main uses; exported as octo_kepler_solve so tests can check the solver itself.
+__global__ __launch_bounds__(256) void k_kepler(const double* __restrict__ MA, const double* __restrict__ ecc, int64_t n,
+                                                 double* E, double* sE, double* cE) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PC pc = {};
+    const double e = ecc[i];
+    pc.invP = 1.0 / TWO_PI; pc.tp = 0.0; pc.e = e; pc.beta = sqrt(1.0 - e * e); pc.eob = e / pc.beta;
+    pc.ef = (float)e; pc.omef = (float)(1.0 - e); pc.k1f = (float)(MK_K1N / (1.0 + e));
+    const KSol s = kepler_solve<2>(MA[i], pc);
+    const bool ok = (e >= 0.0) && (e < 1.0) && isfinite(MA[i]);
+    E[i] = ok ? s.E : NAN;
+    if (sE) sE[i] = ok ? s.sE : NAN;
+    if (cE) cE[i] = ok ? s.cE : NAN;
 }
 
 // ------------------------------------------------------------------------------------ k_main
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
             double ra_m = 0.0, dec_m = 0.0;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                s[p] = kepler_solve(t, pc[p]);
+                s[p] = kepler_solve<1>(t, pc[p]);
                 ra_m = fma(f[p], fma(pc[p].cB, s[p].X, pc[p].cG * s[p].Y), ra_m);
                 dec_m = fma(f[p], fma(pc[p].cA, s[p].X, pc[p].cF * s[p].Y), dec_m);
             }
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
                     }
                     const double Xb = fma(pc[p].cB, ra_f, pc[p].cA * de_f);
                     const double Yb = fma(pc[p].cG, ra_f, pc[p].cF * de_f);
-                    kepler_adjoint(s[p], pc[p], t, Xb, Yb, 0.0, 0.0, g[L::GE], g[L::GM], g[L::GT]);
+                    kepler_adjoint<false>(s[p], pc[p], Xb, Yb, 0.0, 0.0, g[L::GE], g[L::GM], g[L::GT]);
                 }
             }
         }
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
             double model = off;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                s[p] = kepler_solve(t, pc[p]);
+                s[p] = kepler_solve<2>(t, pc[p]);
                 cnu[p] = s[p].X * s[p].invD; snu[p] = s[p].Y * s[p].invD;
                 V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
                 model = fma(gc[p] * pc[p].K, V[p], model);
@@ -326,7 +346,7 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
                     const double cb = Vb * pc[p].cw, sb = -Vb * pc[p].sw;
                     const double Xb = cb * s[p].invD, Yb = sb * s[p].invD;
                     const double Db = -fma(cb, cnu[p], sb * snu[p]) * s[p].invD;
-                    kepler_adjoint(s[p], pc[p], t, Xb, Yb, Db, cb, g[L::GE], g[L::GM], g[L::GT]);
+                    kepler_adjoint<true>(s[p], pc[p], Xb, Yb, Db, cb, g[L::GE], g[L::GM], g[L::GT]);
                 }
             }
         }

@@ -276,3 +276,57 @@ def test_pt_swap_kernel(pkg):
     assert np.all(np.sort(ref, axis=1) == np.arange(n_temps))
     assert acc_ref.sum() > 0
     lib.octo_ctx_destroy(ctx)
+
+
+def _kepler_device(pkg, MA, e):
+    lib = pkg.capi.load_library()
+    ctx = C.c_void_p()
+    assert lib.octo_ctx_create(C.byref(ctx), 0) == 0
+    MA = np.ascontiguousarray(MA, dtype=np.float64); e = np.ascontiguousarray(e, dtype=np.float64)
+    E = np.empty_like(MA); sE = np.empty_like(MA); cE = np.empty_like(MA)
+    dp = pkg.capi._dptr
+    assert lib.octo_kepler_solve(ctx, dp(MA), dp(e), MA.size, dp(E), dp(sE), dp(cE)) == 0
+    lib.octo_ctx_destroy(ctx)
+    return E, sE, cE
+
+
+def test_kepler_device_solver(pkg, oracle):
+    """The device Kepler routine (FP32 Markley starter + FP64 fifth-order correction) against Kepler's equation,
+    an 80-bit Newton solve, and the reference algorithm in the oracle — over the whole elliptic domain, including
+    e -> 1 − 1e-9, |M| -> 0 and |M| -> π. Error is weighted by 1 − e cos E (the conditioning of the root)."""
+    rng = np.random.default_rng(5)
+    n = 400_000
+    e = np.concatenate([rng.uniform(0, 1, n // 2), 1 - 10 ** rng.uniform(-9, -1, n // 2)])
+    e[:8] = [0.0, 1e-12, 0.5, 0.9, 0.99, 0.999999, 0.0, 0.3]
+    M = np.concatenate([rng.uniform(-np.pi, np.pi, n // 4), 10 ** rng.uniform(-17, 0.4, n // 4) * rng.choice([-1, 1], n // 4),
+                        (np.pi - 10 ** rng.uniform(-16, 0, n // 4)) * rng.choice([-1, 1], n // 4), rng.uniform(-np.pi, np.pi, n - 3 * (n // 4))])
+    M = np.clip(M, -np.pi, np.pi)
+    rng.shuffle(M)
+    M[:8] = [1.0, 1e-9, -1e-9, np.pi, -np.pi, 0.0, 0.0, 0.0]
+    E, sE, cE = _kepler_device(pkg, M, e)
+    assert np.all(np.isfinite(E))
+    # 80-bit Newton truth
+    Ml = M.astype(np.longdouble); el = e.astype(np.longdouble)
+    Et = np.where(el < 0.8, Ml, np.sign(Ml) * np.longdouble(np.pi)); Et = np.where(Ml == 0, 0, Et)
+    for _ in range(80):
+        Et = Et - (Et - el * np.sin(Et) - Ml) / (1 - el * np.cos(Et))
+    cond = (1 - el * np.cos(Et)).astype(np.float64)
+    err = np.abs((E - Et).astype(np.float64)) * cond
+    assert err.max() < 1.5e-15, err.max()
+    assert np.abs(sE - np.sin(Et).astype(np.float64)).max() * 1.0 < 1e-11     # unweighted, dominated by e -> 1 conditioning
+    assert (np.abs(sE - np.sin(Et).astype(np.float64)) * cond).max() < 2e-15
+    assert (np.abs(cE - np.cos(Et).astype(np.float64)) * cond).max() < 2e-15
+    assert E[5] == 0.0 and E[6] == 0.0 and abs(E[7]) == 0.0                    # M == 0 -> E == 0 exactly (early return)
+    # reference algorithm (oracle) on a subsample: same root
+    lib = oracle.load_oracle()
+    idx = rng.choice(n, 5000, replace=False)
+    Eo = np.array([lib.octo_oracle_kepler_markley(float(M[i]), float(e[i])) for i in idx])
+    assert (np.abs(E[idx] - Eo) * cond[idx]).max() < 2e-15
+    # large mean anomalies are reduced like rem2pi(·, RoundNearest)
+    big = np.array([40.0, -1234.5, 6.0e3, 2 * np.pi * 7 + 0.25])
+    Eb, _, _ = _kepler_device(pkg, big, np.full(4, 0.4))
+    Eo = np.array([lib.octo_oracle_kepler_markley(float(m), 0.4) for m in big])
+    assert np.abs(Eb - Eo).max() < 1e-12
+    # invalid inputs
+    En, _, _ = _kepler_device(pkg, np.array([1.0, 1.0, np.nan]), np.array([1.0, -0.1, 0.3]))
+    assert np.all(np.isnan(En))

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -107,9 +108,10 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int chunk, TaskTable** out) {
     std::vector<double> cpre, craw;
     for (int o = 0; o < ds->n_obs; ++o) {
         const int64_t n = ds->h_obs[o].n;
-        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t span = (int64_t)chunk * WPB;    // one block = WPB waves x chunk rows
+        for (int64_t r0 = 0; r0 < n; r0 += span) {
             Task t;
-            t.obs = o; t.row0 = (int32_t)r0; t.nrows = (int32_t)std::min<int64_t>(chunk, n - r0); t.pad = 0;
+            t.obs = o; t.row0 = (int32_t)r0; t.nrows = (int32_t)std::min<int64_t>(span, n - r0); t.pad = 0;
             tt.h_tasks.push_back(t);
             double a = 0.0, b = 0.0;
             for (int64_t r = r0; r < r0 + t.nrows; ++r) { a += ds->h_rowconst_pre[o][r]; b += ds->h_rowconst_raw[o][r]; }
@@ -131,9 +133,13 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int chunk, TaskTable** out) {
 }
 
 int pick_chunk(const octo_dataset* ds, int64_t W) {
+    if (const char* ev = std::getenv("OCTO_CHUNK")) {   // tuning knob for experiments
+        const int v = std::atoi(ev);
+        if (v > 0) return v;
+    }
     // enough waves to fill 256 CUs × 4 SIMDs several times over, small enough tasks for an even tail
     const int64_t cols = (W + WAVE - 1) / WAVE;
-    const int64_t target_waves = 24576;
+    const int64_t target_waves = 16384;
     int64_t want_tasks = std::max<int64_t>(1, (target_waves + cols - 1) / cols);
     int64_t chunk = (ds->n_rows + want_tasks - 1) / want_tasks;
     chunk = std::max<int64_t>(chunk, 32);
@@ -162,7 +168,8 @@ int launch_all(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t s
             rc = grow(ctx, ctx->d_marg, ctx->cap_marg, (int64_t)a.n_obs * 2 * a.ldw);
             if (rc) return rc;
             a.marg = nullptr; a.marg_out = ctx->d_marg;
-            hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE), 0, st, a);
+            hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                               sizeof(double) * L0::NACC * WAVE, st, a);
             hipLaunchKernelGGL((k_marg<P, NUIS, KM>), gsetup, dim3(256), 0, st, a);
             a.marg = ctx->d_marg;
         }
@@ -176,10 +183,12 @@ int launch_all(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t s
             e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
             HIPCHK(ctx, hipEventRecord(e0, st));
         }
-        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                           sizeof(double) * L::NACC * WAVE, st, a);
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, st));
     }
-    hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), gsetup, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * FIN_G),
+                       sizeof(double) * 12 * FIN_G * WAVE, st, a);
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;
 }
@@ -194,7 +203,8 @@ template <int P>
 int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
     const int km = ds->kind_mask;
     if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_SEPPA)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA>(ctx, ds, a, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR>(ctx, ds, a, grad, nuis, st);
     return dispatch2<P, KM_ALL>(ctx, ds, a, grad, nuis, st);
 }
 
@@ -302,6 +312,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
             for (int p = 0; p < n_planets; ++p)
                 if (!planets[p].has_mass) return bail(OCTO_EINVAL, "octo_dataset_create: absolute RV needs a mass on every planet");
         ds->kind_mask |= 1 << d.kind;
+        if (astrom && d.cor) ds->kind_mask |= KM_COR;
         const int64_t n = d.n_epochs;
         std::vector<double> raw((size_t)n * ROW_STRIDE, 0.0), pre((size_t)n * ROW_STRIDE, 0.0);
         ds->h_rowconst_pre[o].resize(n); ds->h_rowconst_raw[o].resize(n);
@@ -398,7 +409,7 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     EvalArgs a;
     std::memset(&a, 0, sizeof(a));
     a.obs = ds->d_obs; a.tasks = tt->d_tasks; a.task_const = d_nuis ? tt->d_const_raw : tt->d_const_pre;
-    a.n_obs = ds->n_obs; a.n_tasks = tt->n_tasks; a.n_planets = ds->n_planets;
+    a.n_obs = ds->n_obs; a.n_tasks = tt->n_tasks; a.n_planets = ds->n_planets; a.chunk = tt->chunk;
     for (int p = 0; p < ds->n_planets; ++p) { a.orbit_kind[p] = ds->planets[p].orbit_kind; a.has_mass[p] = ds->planets[p].has_mass; }
     a.elems = d_elems; a.nuis = d_nuis; a.ld = ld; a.W = W;
     a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w;

@@ -51,15 +51,18 @@ enum : int {
     WC_A,         // semi-major axis       [AU]
     WC_F32A,      // packed {float e, float 1−e}   (starter constants, FP32)
     WC_F32B,      // packed {float k1 = MK_K1N/(1+e), float 0}
+    WC_CGB, WC_CFB,   // CG·β, CF·β          ra = CB·cosE + CGB·sinE − CBE,  dec = CA·cosE + CFB·sinE − CAE
+    WC_CBE, WC_CAE,   // CB·e, CA·e
     NWC
 };
 
 struct PC {   // one planet's constants for one walker, in registers
     double invP, tp, e, beta, eob, cB, cG, cA, cF, K, cw, sw, mu, a;
+    double cGb, cFb, cBe, cAe;
     float ef, omef, k1f;
 };
 
-struct KSol { double X, Y, sE, cE, invD, dt, E; };
+struct KSol { double sE, cE, invD, dt, E; };
 
 __device__ __forceinline__ void load_pc(PC& pc, const double* __restrict__ wc, int64_t ldw, int p, int64_t w) {
     const double* b = wc + (int64_t)p * NWC * ldw + w;
@@ -67,6 +70,7 @@ __device__ __forceinline__ void load_pc(PC& pc, const double* __restrict__ wc, i
     pc.eob = b[WC_EOB * ldw]; pc.cB = b[WC_CB * ldw]; pc.cG = b[WC_CG * ldw]; pc.cA = b[WC_CA * ldw];
     pc.cF = b[WC_CF * ldw]; pc.K = b[WC_K * ldw]; pc.cw = b[WC_COSW * ldw]; pc.sw = b[WC_SINW * ldw];
     pc.mu = b[WC_MU * ldw]; pc.a = b[WC_A * ldw];
+    pc.cGb = b[WC_CGB * ldw]; pc.cFb = b[WC_CFB * ldw]; pc.cBe = b[WC_CBE * ldw]; pc.cAe = b[WC_CAE * ldw];
     const float2 fa = *reinterpret_cast<const float2*>(&b[WC_F32A * ldw]);
     const float2 fb = *reinterpret_cast<const float2*>(&b[WC_F32B * ldw]);
     pc.ef = fa.x; pc.omef = fa.y; pc.k1f = fb.x;
@@ -77,29 +81,42 @@ __device__ __forceinline__ double pack_f32x2(float x, float y) {
     return *reinterpret_cast<double*>(&v);
 }
 
-// sin and cos of x for |x| <= 3.18 via the half angle: h = x/2, polynomials in u = h² (Chebyshev fits on
-// |h| <= 1.59, tools/gen_sincos_poly.py: approximation error 1.5e-17 / 8.7e-18), then sin x = 2 s c,
-// cos x = 1 − 2 s². 24 FP64 instructions, branch-free.
+// Polynomial / Taylor coefficients live in constant memory on purpose: a wave-uniform load puts them in SGPRs
+// once per wave, and every Horner step becomes one VOP3 `v_fma_f64 v, v, v, s[k]`. As literals hipcc keeps
+// copies in VGPRs and re-materialises the addend with a v_mov_b64 in front of a VOP2 v_fmac per step
+// (+15 VALU instructions per row, measured in the r1 ISA dump).
+__constant__ double OCTO_KT[24] = {
+    // sin(h)/h = 1 + u·Q(u), Q degree 7 (Chebyshev fit on |h| <= 1.59, tools/gen_sincos_poly.py; error 1.5e-17)
+    2.7193985903359714e-15, -7.642822688610201e-13, 1.6058933154149512e-10, -2.5052106738943426e-08,
+    2.7557319209590407e-06, -0.0001984126984119912, 0.00833333333333316, -0.16666666666666666,
+    // cos(h) = 1 + u·Qc(u), Qc degree 8 (error 8.7e-18)
+    -1.51077353714095e-16, 4.776743872294959e-14, -1.1470664505957302e-11, 2.0876755532557785e-09,
+    -2.7557319207812853e-07, 2.480158730147785e-05, -0.0013888888888888464, 0.04166666666666666, -0.5,
+    // Taylor: sin δ = δ(1 + δ²(−1/6 + δ²/120)), cos δ − 1 = δ²(−1/2 + δ²(1/24 − δ²/720))
+    1.0 / 120.0, -1.0 / 6.0, -1.0 / 720.0, 1.0 / 24.0,
+    0.0, 0.0, 0.0};
+
+// sin and cos of x for |x| <= 3.18 via the half angle: h = x/2, polynomials in u = h², then
+// sin x = 2 s c, cos x = 1 − 2 s². 24 FP64 instructions, branch-free, no range reduction.
 __device__ __forceinline__ void sincos_halfangle(double x, double& s, double& c) {
+    const double* __restrict__ K = OCTO_KT;
     const double h = 0.5 * x;
     const double u = h * h;
-    double ps = 2.7193985903359714e-15;                 // sin(h)/h = 1 + u·Q(u), Q of degree 7
-    ps = fma(ps, u, -7.642822688610201e-13);
-    ps = fma(ps, u, 1.6058933154149512e-10);
-    ps = fma(ps, u, -2.5052106738943426e-08);
-    ps = fma(ps, u, 2.7557319209590407e-06);
-    ps = fma(ps, u, -0.0001984126984119912);
-    ps = fma(ps, u, 0.00833333333333316);
-    ps = fma(ps, u, -0.16666666666666666);
-    double pc = -1.51077353714095e-16;                  // cos(h) = 1 + u·Qc(u), Qc of degree 8
-    pc = fma(pc, u, 4.776743872294959e-14);
-    pc = fma(pc, u, -1.1470664505957302e-11);
-    pc = fma(pc, u, 2.0876755532557785e-09);
-    pc = fma(pc, u, -2.7557319207812853e-07);
-    pc = fma(pc, u, 2.480158730147785e-05);
-    pc = fma(pc, u, -0.0013888888888888464);
-    pc = fma(pc, u, 0.04166666666666666);
-    pc = fma(pc, u, -0.5);
+    double ps = fma(K[0], u, K[1]);
+    ps = fma(ps, u, K[2]);
+    ps = fma(ps, u, K[3]);
+    ps = fma(ps, u, K[4]);
+    ps = fma(ps, u, K[5]);
+    ps = fma(ps, u, K[6]);
+    ps = fma(ps, u, K[7]);
+    double pc = fma(K[8], u, K[9]);
+    pc = fma(pc, u, K[10]);
+    pc = fma(pc, u, K[11]);
+    pc = fma(pc, u, K[12]);
+    pc = fma(pc, u, K[13]);
+    pc = fma(pc, u, K[14]);
+    pc = fma(pc, u, K[15]);
+    pc = fma(pc, u, K[16]);
     const double sh = fma(h * u, ps, h);
     const double ch = fma(u, pc, 1.0);
     const double t = sh + sh;
@@ -145,43 +162,25 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc) {
     double s1, c1;
     sincos_halfangle(E1, s1, c1);
     const double e = pc.e;
-    const double f2 = e * s1, f3 = e * c1;
+    const double f2 = e * s1;
+    const double hf2 = 0.5 * f2, q24 = f2 * (1.0 / 24.0);
+    const double sf3 = (e * (1.0 / 6.0)) * c1;
+    const double f1 = fma(-e, c1, 1.0);
     const double f0 = (E1 - M) - f2;
-    const double f1 = 1.0 - f3;
-    const double hf2 = 0.5 * f2, sf3 = f3 * (1.0 / 6.0);
-    const double d3 = -f0 * __builtin_amdgcn_rcp(fma(-f0 * hf2, __builtin_amdgcn_rcp(f1), f1));
+    const double d3 = -(f0 * f1) * __builtin_amdgcn_rcp(fma(f1, f1, -(f0 * hf2)));   // Halley, one raw reciprocal
     const double d4 = -f0 * rcp_nr<1>(fma(d3, fma(d3, sf3, hf2), f1));
-    const double d5 = -f0 * rcp_nr<1>(fma(d4, fma(d4, fma(-d4, f2 * (1.0 / 24.0), sf3), hf2), f1));
+    const double d5 = -f0 * rcp_nr<1>(fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1));
     s.E = E1 + d5;                                                   // eq. (29); dead code unless a caller reads it
-    // ---- sin/cos(E1 + δ5) by rotation; |δ5| < 5e-4
+    // ---- sin/cos(E1 + δ5) by rotation; |δ5| < 5e-4: sin δ = δ(1 − δ²/6) (+1e-19), cos δ − 1 = δ²(−1/2 + δ²/24) (+1e-23)
     const double dd = d5 * d5;
-    const double sd = d5 * fma(dd, fma(dd, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-    const double cm1 = dd * fma(dd, fma(dd, -1.0 / 720.0, 1.0 / 24.0), -0.5);
+    const double sd = d5 * fma(dd, OCTO_KT[18], 1.0);
+    const double cm1 = dd * fma(dd, OCTO_KT[20], -0.5);
     s.sE = s1 + fma(s1, cm1, c1 * sd);
     s.cE = c1 + fma(c1, cm1, -(s1 * sd));
     // M == 0: E1f = 0 exactly and f0 = 0, so E = 0 like the reference's early return; e == 0: f2 = f3 = 0,
     // d5 = −(E1 − M) exactly, E = M to rounding, like the reference's early return.
-    s.X = s.cE - e;
-    s.Y = pc.beta * s.sE;
     s.invD = rcp_nr<INV_NR>(fma(-e, s.cE, 1.0));
     return s;
-}
-
-// Reverse sweep through X = cE − e, Y = β sE, D = 1 − e cE and the Kepler root E(M, e).
-// Inputs: adjoints of X, Y, D and the direct e-adjoint accumulated so far.
-// Adds into ge (Σ ē), gm (Σ M̄), gt (Σ M̄·(t−tp)).
-template <bool HAS_D>
-__device__ __forceinline__ void kepler_adjoint(const KSol& s, const PC& pc, double Xb, double Yb, double Db,
-                                               double eb_direct, double& ge, double& gm, double& gt) {
-    const double cEb = HAS_D ? fma(-pc.e, Db, Xb) : Xb;
-    const double Eb = fma(pc.beta * Yb, s.cE, -(cEb * s.sE));
-    const double Mb = Eb * s.invD;                                  // ∂E/∂M = 1/(1 − e cos E)
-    double eb = fma(Mb, s.sE, -Xb);                                 // ∂E/∂e = sin E/(1 − e cos E)
-    eb = fma(-(pc.eob * s.sE), Yb, eb);
-    if (HAS_D) eb = fma(-s.cE, Db, eb + eb_direct);
-    ge += eb;
-    gm += Mb;
-    gt = fma(Mb, s.dt, gt);
 }
 
 }  // namespace octo

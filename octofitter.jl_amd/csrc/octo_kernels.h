@@ -1,12 +1,14 @@
-// octo_kernels.h — the three kernels of one batched evaluation (gfx950):
+// octo_kernels.h — the kernels of one batched evaluation (gfx950):
 //
 //   k_setup   per (walker, planet): orbit-constructor constants (PlanetOrbits KepOrbit / Visual /
 //             RadialVelocityOrbit ctor; witnesses src/parameterizations.jl:62-64, 215-216) and the
 //             per-walker validity flag (src/logdensitymodel.jl:120-124, src/likelihoods/system.jl:214-221).
-//   k_main    THE hot kernel. grid = (walker tiles of 64) × (row tasks); lane = walker. Fuses
-//             _kepsolve_all! (system.jl:250-269), simulate! + ln_like of every observation kind
+//   k_main    THE hot kernel. grid = (walker tiles of 64) × (row tasks); block = 4 waves that share a
+//             walker tile and split the task's rows; lane = walker. Fuses _kepsolve_all!
+//             (system.jl:250-269), simulate! + ln_like of every observation kind
 //             (relative-astrometry.jl:104-142,166-253; rv-absolute.jl:135-204; rv-absolute-margin.jl:106-185;
-//             rv-relative.jl:121-211) and the reverse sweep into ~8-10 running sums per planet.
+//             rv-relative.jl:121-211) and the reverse sweep into ~9-12 running sums per planet; the four
+//             waves' sums are combined through LDS in a fixed order, one partial per (tile, task).
 //   k_finish  per walker: fixed-order sum of the task partials (deterministic), closed-form terms,
 //             and the map from the running sums to ∂ll/∂(a,e,i,ω,Ω,tp,M,plx,mass) and nuisances.
 #pragma once
@@ -17,11 +19,13 @@ namespace octo {
 
 constexpr int MAXP = 4;
 constexpr int ROW_STRIDE = 8;   // doubles per observation row record (64 B = one s_load_dwordx16)
+constexpr int WPB = 4;          // waves per k_main block (row split + LDS combine)
+constexpr int FIN_G = 4;        // task groups per walker in k_finish
 
 // kind mask bits
-constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16;
+constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16, KM_COR = 32;
 constexpr int KM_RV = KM_RVABS | KM_MARG | KM_RVREL;
-constexpr int KM_ALL = 31;
+constexpr int KM_ALL = 63;
 
 struct DevObs {
     int32_t kind, planet, has_cor, pad;
@@ -42,7 +46,7 @@ struct EvalArgs {
     const DevObs* obs;
     const Task* tasks;
     const double* task_const;     // [n_tasks] walker-independent additive constant of the task's rows
-    int32_t n_obs, n_tasks, n_planets, pad;
+    int32_t n_obs, n_tasks, n_planets, chunk;   // chunk = rows per wave inside a task
     int32_t orbit_kind[MAXP];
     int32_t has_mass[MAXP];
     const double* elems;          // [P*9][ld]
@@ -63,16 +67,19 @@ struct Layout {
     static constexpr bool HAS_RV = (KM & KM_RV) != 0;
     static constexpr bool HAS_MARG = (KM & KM_MARG) != 0;
     static constexpr bool HAS_ASTROM = (KM & (KM_RADEC | KM_SEPPA)) != 0;
+    static constexpr bool HAS_COR = (KM & KM_COR) != 0;
     static constexpr int OFF_S = 0;
     static constexpr int OFF_NU = 1;
     static constexpr int N_NU = (GRAD && NUIS) ? 3 : 0;
     static constexpr int OFF_MARG = OFF_NU + N_NU;
     static constexpr int N_MARG = HAS_MARG ? 3 : 0;
     static constexpr int OFF_PL = OFF_MARG + N_MARG;
-    // per planet: GB GG GA GF GE GM GT [GC] [GK GW]
-    static constexpr int PL_N = !GRAD ? 0 : (HAS_RV ? 10 : (P > 1 ? 8 : 7));
+    // per planet, all weighted by the planet's coefficient in the model:
+    //   U1 Σ cosE·r̄a  U2 Σ sinE·r̄a  U3 Σ cosE·d̄ec  U4 Σ sinE·d̄ec  U5 Σ r̄a  U6 Σ d̄ec
+    //   GE Σ M̄·sinE (+ direct RV terms)  GM Σ M̄  GT Σ M̄·(t−tp)  [GC ∂/∂(m/M)]  [GK ∂/∂K  GW ∂/∂ω direct]
+    enum { U1 = 0, U2, U3, U4, U5, U6, GE, GM, GT, GC, GK, GW };
+    static constexpr int PL_N = !GRAD ? 0 : (HAS_RV ? 12 : (P > 1 ? 10 : 9));
     static constexpr int NACC = OFF_PL + P * PL_N;
-    enum { GB = 0, GG, GA, GF, GE, GM, GT, GC, GK, GW };
 };
 
 // ------------------------------------------------------------------------------------ k_setup
@@ -113,6 +120,8 @@ __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
         o[WC_F32A * a.ldw] = pack_f32x2((float)e, (float)(1.0 - e));
         o[WC_F32B * a.ldw] = pack_f32x2((float)(MK_K1N / (1.0 + e)), 0.0f);
         o[WC_CB * a.ldw] = T * B; o[WC_CG * a.ldw] = T * G; o[WC_CA * a.ldw] = T * A; o[WC_CF * a.ldw] = T * F;
+        o[WC_CGB * a.ldw] = T * G * beta; o[WC_CFB * a.ldw] = T * F * beta;
+        o[WC_CBE * a.ldw] = T * B * e; o[WC_CAE * a.ldw] = T * A * e;
         o[WC_K * a.ldw] = K; o[WC_COSW * a.ldw] = cw; o[WC_SINW * a.ldw] = sw;
         o[WC_MU * a.ldw] = mass * a.c.mjup2msol / Mt; o[WC_A * a.ldw] = sma;
     }
@@ -142,12 +151,19 @@ __global__ __launch_bounds__(256) void k_kepler(const double* __restrict__ MA, c
 
 // ------------------------------------------------------------------------------------ k_main
 template <int P, bool GRAD, bool NUIS, int KM>
-__global__ __launch_bounds__(64) void k_main(EvalArgs a) {
+__global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
-    const int64_t w = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x >> 6;                    // wave-uniform
+    const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;          // tail lanes recompute the last walker; results discarded
     const Task tk = a.tasks[blockIdx.y];                // wave-uniform: scalar loads
     const DevObs ob = a.obs[tk.obs];
+    // this wave's slice of the task's rows
+    const int r_lo = min(wv * a.chunk, tk.nrows);
+    const int r_hi = min(r_lo + a.chunk, tk.nrows);
+    const int row_first = tk.row0 + r_lo, n_rows = r_hi - r_lo;
 
     PC pc[P];
 #pragma unroll
@@ -181,24 +197,32 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
             j2 = jit * jit;
         }
         const bool seppa = (KM & KM_SEPPA) && ob.kind == OCTO_ASTROM_SEPPA;
-        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)tk.row0 * ROW_STRIDE;
-        for (int j = 0; j < tk.nrows; ++j) {
+        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE;
+        for (int j = 0; j < n_rows; ++j) {
             const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
             const double t = rw[0], y1 = rw[1], y2 = rw[2], c3 = rw[3], c4 = rw[4], c5 = rw[5];
             KSol s[P];
-            double ra_m = 0.0, dec_m = 0.0;
+            double rap[P], dep[P];      // each planet's own sky offset [mas]
+            double ra_m, dec_m;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 s[p] = kepler_solve<1>(t, pc[p]);
-                ra_m = fma(f[p], fma(pc[p].cB, s[p].X, pc[p].cG * s[p].Y), ra_m);
-                dec_m = fma(f[p], fma(pc[p].cA, s[p].X, pc[p].cF * s[p].Y), dec_m);
+                rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
+                dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
+            }
+            if constexpr (P == 1) {
+                ra_m = rap[0]; dec_m = dep[0];
+            } else {
+                ra_m = 0.0; dec_m = 0.0;
+#pragma unroll
+                for (int p = 0; p < P; ++p) { ra_m = fma(f[p], rap[p], ra_m); dec_m = fma(f[p], dep[p], dec_m); }
             }
             // residuals
-            double r1, r2, rho = 1.0, irho = 1.0, u1 = 0.0, u2 = 0.0;
+            double r1, r2, irho = 1.0, u1 = 0.0, u2 = 0.0;
             if (seppa) {
                 // relative-astrometry.jl:192-202
                 const double rho2 = fma(ra_m, ra_m, dec_m * dec_m);
-                rho = sqrt(rho2);
+                const double rho = sqrt(rho2);
                 irho = 1.0 / rho;
                 const double pa = atan2(ra_m, dec_m);
                 double dpa = (y1 + na) - pa + PI;
@@ -208,21 +232,28 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
                 r2 = fma(y2, ps, -rho);
             } else {
                 // relative-astrometry.jl:210-215: the data are rotated by −northangle and scaled
-                u1 = fma(y1, cn, y2 * sn);
-                u2 = fma(y2, cn, -(y1 * sn));
-                r1 = fma(ps, u1, -ra_m);
-                r2 = fma(ps, u2, -dec_m);
+                if constexpr (NUIS) {
+                    u1 = fma(y1, cn, y2 * sn);
+                    u2 = fma(y2, cn, -(y1 * sn));
+                    r1 = fma(ps, u1, -ra_m);
+                    r2 = fma(ps, u2, -dec_m);
+                } else {
+                    r1 = y1 - ra_m;
+                    r2 = y2 - dec_m;
+                }
             }
             // density; g1, g2 = ∂ll/∂r1, ∂ll/∂r2
             double g1, g2;
             if constexpr (!NUIS) {
                 // precomputed Σ⁻¹ (the jitter == 0 branch, relative-astrometry.jl:218-219)
-                const double a1 = fma(c3, r1, c5 * r2), a2 = fma(c5, r1, c4 * r2);
+                double a1, a2;
+                if constexpr (L::HAS_COR) { a1 = fma(c3, r1, c5 * r2); a2 = fma(c5, r1, c4 * r2); }
+                else { a1 = c3 * r1; a2 = c4 * r2; }
                 acc[L::OFF_S] = fma(r1, a1, fma(r2, a2, acc[L::OFF_S]));   // Σ rᵀΣ⁻¹r ; ll = const − ½Σ
                 g1 = -a1; g2 = -a2;
             } else {
                 const double v1 = fma(c3, c3, j2), v2 = fma(c4, c4, j2);   // hypot(σ, jitter)², :234-235
-                const double cor = ob.has_cor ? c5 : 0.0;
+                const double cor = (L::HAS_COR && ob.has_cor) ? c5 : 0.0;
                 const double omc = 1.0 - cor * cor;
                 const double ic = 1.0 / omc;
                 const double i1 = rsqrt(v1), i2 = rsqrt(v2);
@@ -255,18 +286,22 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     double* g = &acc[L::OFF_PL + p * L::PL_N];
-                    const double ra_f = f[p] * rab, de_f = f[p] * deb;
-                    g[L::GB] = fma(s[p].X, ra_f, g[L::GB]);
-                    g[L::GG] = fma(s[p].Y, ra_f, g[L::GG]);
-                    g[L::GA] = fma(s[p].X, de_f, g[L::GA]);
-                    g[L::GF] = fma(s[p].Y, de_f, g[L::GF]);
-                    if constexpr (P > 1) {
-                        const double rp = fma(pc[p].cB, s[p].X, pc[p].cG * s[p].Y), dp = fma(pc[p].cA, s[p].X, pc[p].cF * s[p].Y);
-                        g[L::GC] += (p == ob.planet) ? 0.0 : ((f[p] != 0.0) ? fma(rab, rp, deb * dp) : 0.0);
-                    }
-                    const double Xb = fma(pc[p].cB, ra_f, pc[p].cA * de_f);
-                    const double Yb = fma(pc[p].cG, ra_f, pc[p].cF * de_f);
-                    kepler_adjoint<false>(s[p], pc[p], Xb, Yb, 0.0, 0.0, g[L::GE], g[L::GM], g[L::GT]);
+                    const double ra_f = (P == 1) ? rab : f[p] * rab, de_f = (P == 1) ? deb : f[p] * deb;
+                    g[L::U1] = fma(s[p].cE, ra_f, g[L::U1]);
+                    g[L::U2] = fma(s[p].sE, ra_f, g[L::U2]);
+                    g[L::U3] = fma(s[p].cE, de_f, g[L::U3]);
+                    g[L::U4] = fma(s[p].sE, de_f, g[L::U4]);
+                    g[L::U5] += ra_f;
+                    g[L::U6] += de_f;
+                    if constexpr (P > 1)
+                        g[L::GC] += (p == ob.planet) ? 0.0 : ((f[p] != 0.0) ? fma(rab, rap[p], deb * dep[p]) : 0.0);
+                    // Ē = r̄a·∂ra/∂E + d̄ec·∂dec/∂E ;  M̄ = Ē/(1 − e cos E)
+                    const double dra = fma(pc[p].cGb, s[p].cE, -(pc[p].cB * s[p].sE));
+                    const double dde = fma(pc[p].cFb, s[p].cE, -(pc[p].cA * s[p].sE));
+                    const double Mb = fma(ra_f, dra, de_f * dde) * s[p].invD;
+                    g[L::GE] = fma(Mb, s[p].sE, g[L::GE]);          // ∂E/∂e = sin E/(1 − e cos E); the rest of ē in k_finish
+                    g[L::GM] += Mb;
+                    g[L::GT] = fma(Mb, s[p].dt, g[L::GT]);
                 }
             }
         }
@@ -297,8 +332,8 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
             mu_hat = a.marg[((int64_t)tk.obs * 2 + 0) * a.ldw + wl];
             iA = 1.0 / a.marg[((int64_t)tk.obs * 2 + 1) * a.ldw + wl];
         }
-        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)tk.row0 * ROW_STRIDE;
-        for (int j = 0; j < tk.nrows; ++j) {
+        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE;
+        for (int j = 0; j < n_rows; ++j) {
             const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
             const double t = rw[0], rv = rw[1], c2 = rw[2];
             KSol s[P];
@@ -307,7 +342,8 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 s[p] = kepler_solve<2>(t, pc[p]);
-                cnu[p] = s[p].X * s[p].invD; snu[p] = s[p].Y * s[p].invD;
+                cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
+                snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
                 V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
                 model = fma(gc[p] * pc[p].K, V[p], model);
             }
@@ -343,15 +379,39 @@ __global__ __launch_bounds__(64) void k_main(EvalArgs a) {
                     g[L::GC] += via_mu ? -(pc[p].K * V[p] * rvb) : 0.0;
                     const double Vb = gc[p] * pc[p].K * rvb;
                     g[L::GW] = fma(Vb, -fma(cnu[p] + pc[p].e, pc[p].sw, snu[p] * pc[p].cw), g[L::GW]);
+                    // V(cos ν, sin ν, e) with cos ν = X/D, sin ν = Y/D, X = cE − e, Y = β sE, D = 1 − e cE
                     const double cb = Vb * pc[p].cw, sb = -Vb * pc[p].sw;
                     const double Xb = cb * s[p].invD, Yb = sb * s[p].invD;
                     const double Db = -fma(cb, cnu[p], sb * snu[p]) * s[p].invD;
-                    kepler_adjoint<true>(s[p], pc[p], Xb, Yb, Db, cb, g[L::GE], g[L::GM], g[L::GT]);
+                    const double cEb = fma(-pc[p].e, Db, Xb);
+                    const double Eb = fma(pc[p].beta * Yb, s[p].cE, -(cEb * s[p].sE));
+                    const double Mb = Eb * s[p].invD;
+                    double eb = fma(Mb, s[p].sE, cb - Xb);
+                    eb = fma(-(pc[p].eob * s[p].sE), Yb, eb);
+                    eb = fma(-s[p].cE, Db, eb);
+                    g[L::GE] += eb;
+                    g[L::GM] += Mb;
+                    g[L::GT] = fma(Mb, s[p].dt, g[L::GT]);
                 }
             }
         }
     }
-    if (w < a.W) {
+    // ---- combine the block's waves through LDS in a fixed order (deterministic), one partial per (tile, task).
+    // Waves take turns through one NACC×64 buffer, so the footprint stays <= 28 KB for the widest layout.
+#pragma unroll 1
+    for (int q = 1; q < WPB; ++q) {
+        if (wv == q) {
+#pragma unroll
+            for (int k = 0; k < L::NACC; ++k) lds[k * WAVE + lane] = acc[k];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int k = 0; k < L::NACC; ++k) acc[k] += lds[k * WAVE + lane];
+        }
+        __syncthreads();
+    }
+    if (wv == 0 && w < a.W) {
         double* out = a.partials + (int64_t)blockIdx.y * L::NACC * a.ldw + w;
 #pragma unroll
         for (int k = 0; k < L::NACC; ++k) out[(int64_t)k * a.ldw] = acc[k];
@@ -382,24 +442,33 @@ __global__ __launch_bounds__(256) void k_marg(EvalArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ k_finish
+// block = 64 walkers × FIN_G task groups: group g sums tasks g, g+FIN_G, … of each observation (more loads in
+// flight than one thread per walker), groups are combined through LDS in a fixed order, group 0 finishes.
 template <int P, bool GRAD, bool NUIS, int KM>
-__global__ __launch_bounds__(256) void k_finish(EvalArgs a) {
+__global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= a.W) return;
-    double ll = 0.0;
-    double gp[P > 0 ? P * (L::PL_N > 0 ? L::PL_N : 1) : 1];
+    constexpr int NPL = P * L::PL_N;
+    constexpr int NOBS_ACC = 7;              // S, 3 marg, 3 nuis per observation
+    constexpr int LDS_ROWS = NOBS_ACC > L::PL_N ? NOBS_ACC : L::PL_N;
+    static_assert(LDS_ROWS <= 12, "k_finish LDS scratch is sized for 12 rows");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int grp = threadIdx.x >> 6;
+    const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
+    const int64_t wl = w < a.W ? w : a.W - 1;
+    double gp[NPL > 0 ? NPL : 1];
 #pragma unroll
-    for (int k = 0; k < P * L::PL_N; ++k) gp[k] = 0.0;
-    // observations are summed in the order given (system.jl:93,186); tasks of one table are contiguous
+    for (int k = 0; k < NPL; ++k) gp[k] = 0.0;
+    // LDS scratch: [max(NOBS_ACC, PL_N)][FIN_G][64], reused per observation and per planet (two barriers each)
+    double ll = 0.0;
     int t = 0;
     for (int o = 0; o < a.n_obs; ++o) {
-        const int kind = a.obs[o].kind;
-        double S = 0.0, cst = 0.0, mA = 0.0, mB = 0.0, mC = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0;
-        for (; t < a.n_tasks && a.tasks[t].obs == o; ++t) {
-            const double* pt = a.partials + (int64_t)t * L::NACC * a.ldw + w;
+        double S = 0.0, mA = 0.0, mB = 0.0, mC = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0, cst = 0.0;
+        int t_end = t;
+        while (t_end < a.n_tasks && a.tasks[t_end].obs == o) { cst += a.task_const[t_end]; ++t_end; }
+        for (int tt = t + grp; tt < t_end; tt += FIN_G) {
+            const double* pt = a.partials + (int64_t)tt * L::NACC * a.ldw + wl;
             S += pt[(int64_t)L::OFF_S * a.ldw];
-            cst += a.task_const[t];
             if constexpr (L::HAS_MARG) {
                 mA += pt[(int64_t)(L::OFF_MARG + 0) * a.ldw];
                 mB += pt[(int64_t)(L::OFF_MARG + 1) * a.ldw];
@@ -411,34 +480,71 @@ __global__ __launch_bounds__(256) void k_finish(EvalArgs a) {
                 nu2 += pt[(int64_t)(L::OFF_NU + 2) * a.ldw];
             }
 #pragma unroll
-            for (int k = 0; k < P * L::PL_N; ++k) gp[k] += pt[(int64_t)(L::OFF_PL + k) * a.ldw];
+            for (int k = 0; k < NPL; ++k) gp[k] += pt[(int64_t)(L::OFF_PL + k) * a.ldw];
         }
-        double llo;
-        if (L::HAS_MARG && kind == OCTO_RV_ABS_MARG) {
-            // ll = −Σ log(2π var) − (−B²/(4A) + C + log A)      rv-absolute-margin.jl:179-181
-            const double slog = NUIS ? S : -cst;
-            llo = (a.obs[o].n > 0) ? -slog - (-mB * mB / (4.0 * mA) + mC + log(mA)) : 0.0;
-        } else {
-            // NUIS: S = Σ(log|Σ| + q) [astrom] or Σ(log var + r²/var) [rv]; cst = −n·log2π·(1 or ½)
-            // !NUIS: S = Σ q, cst = Σ(−log2π·k − ½ log|Σ|)
-            llo = cst - 0.5 * S;
+        t = t_end;
+        double* lo = lds + grp * WAVE + lane;
+        lo[0 * FIN_G * WAVE] = S; lo[1 * FIN_G * WAVE] = mA; lo[2 * FIN_G * WAVE] = mB; lo[3 * FIN_G * WAVE] = mC;
+        lo[4 * FIN_G * WAVE] = nu0; lo[5 * FIN_G * WAVE] = nu1; lo[6 * FIN_G * WAVE] = nu2;
+        __syncthreads();
+        if (grp == 0) {
+            const int kind = a.obs[o].kind;
+            double v[NOBS_ACC];
+#pragma unroll
+            for (int k = 0; k < NOBS_ACC; ++k) {
+                double x = 0.0;
+#pragma unroll
+                for (int g = 0; g < FIN_G; ++g) x += lds[(k * FIN_G + g) * WAVE + lane];
+                v[k] = x;
+            }
+            double llo;
+            if (L::HAS_MARG && kind == OCTO_RV_ABS_MARG) {
+                // ll = −Σ log(2π var) − (−B²/(4A) + C + log A)      rv-absolute-margin.jl:179-181
+                const double slog = NUIS ? v[0] : -cst;
+                llo = (a.obs[o].n > 0) ? -slog - (-v[2] * v[2] / (4.0 * v[1]) + v[3] + log(v[1])) : 0.0;
+            } else {
+                // NUIS: S = Σ(log|Σ| + q) [astrom] or Σ(log var + r²/var) [rv]; cst = −n·log2π·(1 or ½)
+                // !NUIS: S = Σ q, cst = Σ(−log2π·k − ½ log|Σ|)
+                llo = cst - 0.5 * v[0];
+            }
+            ll += llo;                   // observations are summed in the order given (system.jl:93,186)
+            if constexpr (L::N_NU > 0) {
+                if (w < a.W) {
+                    double* gn = a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w;
+                    const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA;
+                    gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : v[4];
+                    gn[(int64_t)a.ld] = v[5];
+                    gn[(int64_t)2 * a.ld] = astrom ? v[6] : 0.0;
+                }
+            }
         }
-        ll += llo;
-        if constexpr (L::N_NU > 0) {
-            double* gn = a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w;
-            const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA;
-            gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : nu0;
-            gn[(int64_t)a.ld] = nu1;
-            gn[(int64_t)2 * a.ld] = astrom ? nu2 : 0.0;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if constexpr (L::PL_N > 0) {
+#pragma unroll
+            for (int k = 0; k < L::PL_N; ++k) lds[(k * FIN_G + grp) * WAVE + lane] = gp[p * L::PL_N + k];
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int k = 0; k < L::PL_N; ++k) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int g = 0; g < FIN_G; ++g) v += lds[(k * FIN_G + g) * WAVE + lane];
+                    gp[p * L::PL_N + k] = v;
+                }
+            }
+            __syncthreads();
         }
     }
+    if (grp != 0 || w >= a.W) return;
     const bool ok = a.valid[w] != 0 && isfinite(ll);
     a.ll_out[w] = ok ? ll : -INFINITY;
     if constexpr (GRAD) {
         if (!ok && L::N_NU > 0) {
             for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + w] = 0.0;
         }
-        bool gfinite = true;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + w;
@@ -462,8 +568,14 @@ __global__ __launch_bounds__(256) void k_finish(EvalArgs a) {
             const double F = -cO * sw - sO * cw * ci, G = -sO * sw + cO * cw * ci;
             double ab = 0, eb = g[L::GE], ib = 0, wb = 0, Ob = 0, tpb, Mb = 0, plxb = 0, massb = 0, Pb = 0;
             if (!radvel) {
-                const double Bb = T * g[L::GB], Gb = T * g[L::GG], Ab = T * g[L::GA], Fb = T * g[L::GF];
-                const double Tb = B * g[L::GB] + G * g[L::GG] + A * g[L::GA] + F * g[L::GF];
+                // adjoints of cB, cG, cA, cF (mas per unit X = cosE − e, Y = β sinE) from the running sums
+                const double gB = g[L::U1] - e * g[L::U5], gG = beta * g[L::U2];
+                const double gA = g[L::U3] - e * g[L::U6], gF = beta * g[L::U4];
+                // ē: −Σ X̄ − (e/β) Σ sinE·Ȳ, with X̄ = cB r̄a + cA d̄ec, Ȳ = cG r̄a + cF d̄ec
+                eb -= T * (B * g[L::U5] + A * g[L::U6]);
+                eb -= (e / beta) * T * (G * g[L::U2] + F * g[L::U4]);
+                const double Bb = T * gB, Gb = T * gG, Ab = T * gA, Fb = T * gF;
+                const double Tb = B * gB + G * gG + A * gA + F * gF;
                 ab += Tb * sm; plxb += Tb * sma * kappa;
                 ib = Ab * (sO * sw * si) + Bb * (-cO * sw * si) + Fb * (sO * cw * si) + Gb * (-cO * cw * si);
                 wb = Ab * (-cO * sw - sO * cw * ci) + Bb * (-sO * sw + cO * cw * ci) + Fb * (-cO * cw + sO * sw * ci) + Gb * (-sO * cw - cO * sw * ci);
@@ -492,11 +604,8 @@ __global__ __launch_bounds__(256) void k_finish(EvalArgs a) {
             }
             const double out[OCTO_N_EL] = {ab, eb, radvel ? 0.0 : ib, wb, radvel ? 0.0 : Ob, tpb, Mb, radvel ? 0.0 : plxb, massb};
 #pragma unroll
-            for (int k = 0; k < OCTO_N_EL; ++k) gfinite = gfinite && isfinite(out[k]);
-#pragma unroll
             for (int k = 0; k < OCTO_N_EL; ++k) ge[(int64_t)k * a.ld] = ok ? out[k] : 0.0;
         }
-        (void)gfinite;
     }
 }
 

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = threadIdx.x >> 6;                    // wave-uniform
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction; make it an SGPR
+                                                                          // so the row pointer stays scalar (s_load, not global_load)
     const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;          // tail lanes recompute the last walker; results discarded
     const Task tk = a.tasks[blockIdx.y];                // wave-uniform: scalar loads
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     static_assert(LDS_ROWS <= 12, "k_finish LDS scratch is sized for 12 rows");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
-    const int grp = threadIdx.x >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;
     double gp[NPL > 0 ? NPL : 1];

@@ -1,0 +1,103 @@
+"""
+CPU tests (-m "not gpu") of the host logic: the mirror of the reference's observation / system containers,
+the θ <-> SoA packing, and the C-ABI library (loads and exports every symbol include/octofitter_hip.h declares;
+no compute calls here — those need a GPU and live in test_gpu_parity.py).
+"""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = (ROOT / "include" / "octofitter_hip.h").read_text()
+    declared = set(re.findall(r"\b(octo_[a-z_0-9]+)\s*\(", header))
+    declared -= {"octo_ctx", "octo_dataset", "octo_consts", "octo_obs_desc", "octo_planet_desc"}
+    assert len(declared) >= 15
+    lib = pkg.capi.load_library()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
+    assert declared == set(pkg.capi.EXPORTED_SYMBOLS), declared ^ set(pkg.capi.EXPORTED_SYMBOLS)
+    maj, mnr = C.c_int32(), C.c_int32()
+    assert lib.octo_version(C.byref(maj), C.byref(mnr)) == 0 and (maj.value, mnr.value) == (0, 1)
+    c = pkg.capi.default_consts(lib)
+    assert c.year2day_julian == 365.25 and abs(c.kepler_year_to_julian_day - 365.2568983840419) < 1e-12
+    assert abs(c.sec2year_julian * 365.25 * 86400 - 1) < 1e-15 and c.pc2au == c.rad2as
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    """The product path has no CPU fallback: without a device, context creation reports OCTO_ENODEV."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = pkg.capi.load_library()
+    ctx = C.c_void_p()
+    assert lib.octo_ctx_create(C.byref(ctx), 0) == pkg.capi.OCTO_ENODEV
+    obs = pkg.PlanetRelAstromObs(dict(epoch=[50000.0], ra=[1.0], dec=[1.0], σ_ra=[1.0], σ_dec=[1.0]), name="a")
+    sys_ = pkg.System(name="s", companions=[pkg.Planet(name="b", observations=[obs])])
+    with pytest.raises(pkg.capi.OctoError):
+        pkg.make_ln_like(sys_, dict(planets=dict(b=dict())))
+
+
+def test_oracle_defaults_equal_library_defaults(pkg, oracle):
+    a = pkg.capi.default_consts()
+    b = oracle.oracle_consts()
+    assert a.as_dict() == b.as_dict()
+
+
+def test_rel_astrom_constructor(pkg):
+    """src/likelihoods/relative-astrometry.jl:26-94 and test/unit/likelihoods.jl:2-30."""
+    radec = pkg.PlanetRelAstromLikelihood(dict(epoch=[5100.0, 5000.0], ra=[110.0, 100.0], dec=[55.0, 50.0], σ_ra=[1.0, 1.0], σ_dec=[1.0, 1.0]),
+                                          name="test_radec")
+    assert len(radec) == 2 and "ra" in radec.table and not radec.is_seppa
+    assert list(radec.table["epoch"]) == [5000.0, 5100.0] and list(radec.table["ra"]) == [100.0, 110.0]   # sorted by epoch
+    seppa = pkg.PlanetRelAstromLikelihood([dict(epoch=5000.0, sep=100.0, pa=1.0, σ_sep=1.0, σ_pa=0.1),
+                                           dict(epoch=5100.0, sep=110.0, pa=1.1, σ_sep=1.0, σ_pa=0.1)], name="test_seppa")
+    assert len(seppa) == 2 and seppa.is_seppa and seppa.kind == pkg.capi.ASTROM_SEPPA
+    with pytest.raises(ValueError):      # invalid column combination
+        pkg.PlanetRelAstromLikelihood(dict(epoch=[5000.0], ra=[100.0], pa=[1.0], σ_ra=[1.0], σ_pa=[0.1]), name="test_invalid")
+    with pytest.raises(ValueError):      # ragged columns
+        pkg.PlanetRelAstromObs(dict(epoch=[1.0, 2.0], ra=[1.0], dec=[1.0, 2.0], σ_ra=[1.0, 1.0], σ_dec=[1.0, 1.0]), name="x")
+    with pytest.raises(ValueError):      # |cor| > 1 - 1e-5
+        pkg.PlanetRelAstromObs(dict(epoch=[50000.0], ra=[1.0], dec=[1.0], σ_ra=[1.0], σ_dec=[1.0], cor=[0.999999]), name="x")
+    with pytest.warns(UserWarning):      # epochs outside 1950-2050 MJD
+        pkg.PlanetRelAstromObs(dict(epoch=[5000.0], ra=[1.0], dec=[1.0], σ_ra=[1.0], σ_dec=[1.0]), name="x")
+    t = seppa._c_table(0)
+    assert t["kind"] == 1 and np.array_equal(t["y1"], [1.0, 1.1]) and np.array_equal(t["y2"], [100.0, 110.0])
+
+
+def test_rv_constructors(pkg):
+    rows = [dict(epoch=50010.0, rv=3.0, σ_rv=1.0), dict(epoch=50000.0, rv=1.0, σ_rv=2.0)]
+    for cls, kind in ((pkg.StarAbsoluteRVObs, 2), (pkg.MarginalizedStarAbsoluteRVObs, 3), (pkg.PlanetRelativeRVObs, 4)):
+        o = cls(rows, name="HIRES 2020")
+        assert o.kind == kind and list(o.table["epoch"]) == [50000.0, 50010.0] and list(o.table["rv"]) == [1.0, 3.0]
+    with pytest.raises(ValueError):
+        pkg.StarAbsoluteRVObs(dict(epoch=[50000.0], rv=[1.0]), name="x")
+    with pytest.raises(NotImplementedError):   # GP / trend branches stay on the reference's Julia path
+        pkg.StarAbsoluteRVObs(rows, name="x", trend_function=lambda θ, t: 0.0)
+    with pytest.raises(ValueError):
+        pkg.StarAbsoluteRVObs(dict(epoch=[1.0, 2.0], rv=[1.0, 2.0], σ_rv=[1.0, 1.0], inst_idx=[1, 2]), name="x")
+
+
+def test_normalizename(pkg):
+    from octofitter_jl_amd.host.observations import normalizename
+    assert normalizename("HIRES 2020") == "HIRES_2020"
+    assert normalizename("d_radec") == "d_radec"
+    assert normalizename("2mass") == "_2mass"
+    assert normalizename("a--b  c") == "a_b_c"
+    assert normalizename(" GRAVITY ") == "GRAVITY"
+
+
+def test_shard_range(pkg):
+    for n, world in ((10, 3), (10000, 8), (5, 8), (64, 8), (0, 2)):
+        parts = [pkg.shard_range(n, r, world) for r in range(world)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        pkg.shard_range(4, 4, 4)

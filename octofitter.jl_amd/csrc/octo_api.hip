@@ -151,7 +151,7 @@ int pick_chunk(const octo_dataset* ds, int64_t W) {
 }
 
 template <int P, bool GRAD, bool NUIS, int KM>
-int launch_all(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t st) {
+int launch_all(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Task* tt_tasks, hipStream_t st) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
     const int64_t need = (int64_t)a.n_tasks * L::NACC * a.ldw;
@@ -161,15 +161,25 @@ int launch_all(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t s
     const dim3 gsetup((unsigned)((a.W + 255) / 256));
     hipLaunchKernelGGL(k_setup, gsetup, dim3(256), 0, st, a);
     if (a.n_tasks > 0) {
-        if (GRAD && L::HAS_MARG) {
-            // marginalised RV: forward pre-pass for μ̂ and A, then the gradient pass
+        if (GRAD && L::HAS_MARG && (ds->kind_mask & KM_MARG)) {
+            // marginalised RV: forward pre-pass over those tables' tasks for μ̂ and A, then the gradient pass
             using L0 = Layout<P, false, NUIS, KM>;
             static_assert(L0::NACC <= L::NACC, "forward partials fit in the gradient buffer");
             rc = grow(ctx, ctx->d_marg, ctx->cap_marg, (int64_t)a.n_obs * 2 * a.ldw);
             if (rc) return rc;
             a.marg = nullptr; a.marg_out = ctx->d_marg;
-            hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
-                               sizeof(double) * L0::NACC * WAVE, st, a);
+            for (int t0 = 0; t0 < a.n_tasks;) {
+                const int o = tt_tasks[t0].obs;
+                int t1 = t0;
+                while (t1 < a.n_tasks && tt_tasks[t1].obs == o) ++t1;
+                if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) {
+                    a.task0 = t0;
+                    hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)(t1 - t0)), dim3(WAVE * WPB),
+                                       sizeof(double) * L0::NACC * WAVE, st, a);
+                }
+                t0 = t1;
+            }
+            a.task0 = 0;
             hipLaunchKernelGGL((k_marg<P, NUIS, KM>), gsetup, dim3(256), 0, st, a);
             a.marg = ctx->d_marg;
         }
@@ -194,18 +204,19 @@ int launch_all(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t s
 }
 
 template <int P, int KM>
-int dispatch2(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
-    if (grad) return nuis ? launch_all<P, true, true, KM>(ctx, ds, a, st) : launch_all<P, true, false, KM>(ctx, ds, a, st);
-    return nuis ? launch_all<P, false, true, KM>(ctx, ds, a, st) : launch_all<P, false, false, KM>(ctx, ds, a, st);
+int dispatch2(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Task* tk, bool grad, bool nuis, hipStream_t st) {
+    if (grad) return nuis ? launch_all<P, true, true, KM>(ctx, ds, a, tk, st) : launch_all<P, true, false, KM>(ctx, ds, a, tk, st);
+    return nuis ? launch_all<P, false, true, KM>(ctx, ds, a, tk, st) : launch_all<P, false, false, KM>(ctx, ds, a, tk, st);
 }
 
 template <int P>
-int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
+int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Task* tk, bool grad, bool nuis, hipStream_t st) {
     const int km = ds->kind_mask;
-    if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR>(ctx, ds, a, grad, nuis, st);
-    return dispatch2<P, KM_ALL>(ctx, ds, a, grad, nuis, st);
+    if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, tk, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, tk, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR>(ctx, ds, a, tk, grad, nuis, st);
+    if ((km & KM_MARG) == 0) return dispatch2<P, KM_ALL & ~KM_MARG>(ctx, ds, a, tk, grad, nuis, st);
+    return dispatch2<P, KM_ALL>(ctx, ds, a, tk, grad, nuis, st);
 }
 
 int drain_timing(octo_ctx* ctx) {
@@ -417,10 +428,10 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     a.c = dev_consts(ctx->consts);
     const bool grad = d_g_elems != nullptr, nuis = d_nuis != nullptr;
     switch (ds->n_planets) {
-        case 1: return dispatch1<1>(ctx, ds, a, grad, nuis, st);
-        case 2: return dispatch1<2>(ctx, ds, a, grad, nuis, st);
-        case 3: return dispatch1<3>(ctx, ds, a, grad, nuis, st);
-        default: return dispatch1<4>(ctx, ds, a, grad, nuis, st);
+        case 1: return dispatch1<1>(ctx, ds, a, tt->h_tasks.data(), grad, nuis, st);
+        case 2: return dispatch1<2>(ctx, ds, a, tt->h_tasks.data(), grad, nuis, st);
+        case 3: return dispatch1<3>(ctx, ds, a, tt->h_tasks.data(), grad, nuis, st);
+        default: return dispatch1<4>(ctx, ds, a, tt->h_tasks.data(), grad, nuis, st);
     }
 }
 

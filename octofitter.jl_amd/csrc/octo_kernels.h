@@ -47,6 +47,7 @@ struct EvalArgs {
     const Task* tasks;
     const double* task_const;     // [n_tasks] walker-independent additive constant of the task's rows
     int32_t n_obs, n_tasks, n_planets, chunk;   // chunk = rows per wave inside a task
+    int32_t task0, pad0;                        // first task of this launch (k_main grid.y is relative to it)
     int32_t orbit_kind[MAXP];
     int32_t has_mass[MAXP];
     const double* elems;          // [P*9][ld]
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
                                                                           // so the row pointer stays scalar (s_load, not global_load)
     const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;          // tail lanes recompute the last walker; results discarded
-    const Task tk = a.tasks[blockIdx.y];                // wave-uniform: scalar loads
+    const int task = a.task0 + (int)blockIdx.y;
+    const Task tk = a.tasks[task];                      // wave-uniform: scalar loads
     const DevObs ob = a.obs[tk.obs];
     // this wave's slice of the task's rows
     const int r_lo = min(wv * a.chunk, tk.nrows);
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         __syncthreads();
     }
     if (wv == 0 && w < a.W) {
-        double* out = a.partials + (int64_t)blockIdx.y * L::NACC * a.ldw + w;
+        double* out = a.partials + (int64_t)task * L::NACC * a.ldw + w;
 #pragma unroll
         for (int k = 0; k < L::NACC; ++k) out[(int64_t)k * a.ldw] = acc[k];
     }

@@ -99,7 +99,7 @@ def main():
     pkg = load_package()
     capi = pkg.capi
 
-    grad = args.workload in ("grad", "two_planet", "pt") and args.workload != "fwd"
+    grad = args.workload in ("grad", "two_planet")
     if args.workload == "two_planet":
         c4 = synth.config_two_planet()
         astrom = pkg.PlanetRelAstromObs(c4["astrom"], name="astrom")
@@ -185,18 +185,26 @@ def main():
     }
     if rank == 0:
         ach = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-        traffic = None
+        traffic, flops_per_eval = None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists() and args.workload == "grad":
-            try:
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        if pmc.exists() and args.workload == "grad" and (n_rows, W) == (10_000, 10_000):
+            try:      # PMC figures are per launch of exactly this workload; measured off-line (separate --pmc passes)
+                j = json.loads(pmc.read_text())
+                traffic, flops_per_eval = j.get("hbm_bytes_per_launch"), j.get("fp64_flops_per_eval")
             except Exception:
                 traffic = None
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": (ach / HBM_PEAK_GBPS) if ach else None, "traffic": traffic,
                            "kernel": "k_main", "kernel_avg_ms": kern_ms, "kernel_launches": kern_n,
                            "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "note": "path is FP64-VALU bound (compulsory HBM traffic ~0.02 B/eval); see DESIGN.md"}
+                           "note": "algorithmic bytes (SURVEY 8d) over the live k_main duration, as north_star contracts; rows are "
+                                   "reused across 64 lanes from the scalar cache, so real HBM traffic is `traffic` bytes per launch "
+                                   "and frac may exceed 1. The kernel's true bound is FP64 VALU issue (see `valu`, DESIGN.md)"}
+        if flops_per_eval and kern_ms > 0:
+            tf = flops_per_eval * float(W) * n_rows / (kern_ms * 1e-3) / 1e12
+            res["roofline"]["valu"] = {"bound": "fp64_vector", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                                       "fp64_flops_per_eval": flops_per_eval,
+                                       "note": "FP64 flops only (FMA = 2); VALU issue slots are ~100 % busy at the sustained ~2.0 GHz clock"}
         if not args.no_cpu_baseline and cfg is not None and world == 1 and args.workload in ("grad",):
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg, fn.obs_tables, fn.planet_desc, args.cpu_seconds)

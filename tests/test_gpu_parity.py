@@ -5,10 +5,11 @@ GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
   * size-independent properties at BASELINE.json's full sizes,
   * the reference tests' self-consistency properties, through the host mirror.
 
-Tolerances (north_star: log-likelihood and gradient within 1e-8 relative):
-  ll      |Δ| <= 1e-10 · max(|ll|, 1)
-  grad    |Δ| <= 1e-8 · |g| + 1e-12 · (S + max_w S),  S = Σ_rows |∂ll_row/∂θ|  (the cancellation floor; for
-          oracle comparisons S is replaced by the row maximum of |g| over the batch)
+Tolerances. The north_star bar is "log-likelihood and gradient within 1e-8 relative"; the tests hold the HIP path
+to 1000x tighter, close to what tools/parity_report.py measures on the GPU (ll ~5e-15, gradients ~5e-15 of scale):
+  ll      |Δ| <= 1e-12 · max(|ll|, 1)          (1e-9 where the reference's marginalised-RV formula cancels)
+  grad    |Δ| <= 1e-9 · |g| + 1e-13 · (S + max_w S),  S = Σ_rows |∂ll_row/∂θ|  (the rounding floor of a sum whose
+          terms cancel; for oracle comparisons S is replaced by 10x the row maximum of |g| over the batch)
 """
 import ctypes as C
 
@@ -21,9 +22,9 @@ from test_oracle import grad_ok, northangle_scan, _northangle_tables
 
 pytestmark = pytest.mark.gpu
 
-LL_RTOL = 1e-10
-G_RTOL = 1e-8
-G_CANCEL = 1e-12
+LL_RTOL = 1e-12
+G_RTOL = 1e-9
+G_CANCEL = 1e-13
 
 
 def _gpu():
@@ -39,11 +40,11 @@ def _cmp_oracle(name, ll, g_el, g_nu, ll_o, g_o, gn_o, ll_rtol=LL_RTOL, g_rtol=G
     assert np.all(err < ll_rtol), (name, "ll", err.max())
     if g_el is not None:
         assert np.all(g_el[:, ~ok_o] == 0.0), name
-        scale = np.abs(g_o[:, ok_o]).max(axis=1, keepdims=True) * np.ones_like(g_o[:, ok_o]) * 1e3
+        scale = np.abs(g_o[:, ok_o]).max(axis=1, keepdims=True) * np.ones_like(g_o[:, ok_o]) * 10
         ok, worst = grad_ok(g_el[:, ok_o], g_o[:, ok_o], scale, rtol=g_rtol, cancel=G_CANCEL)
         assert ok, (name, "g_elems", worst)
     if g_nu is not None:
-        scale = np.abs(gn_o[:, ok_o]).max(axis=1, keepdims=True) * np.ones_like(gn_o[:, ok_o]) * 1e3
+        scale = np.abs(gn_o[:, ok_o]).max(axis=1, keepdims=True) * np.ones_like(gn_o[:, ok_o]) * 10
         ok, worst = grad_ok(g_nu[:, ok_o], gn_o[:, ok_o], scale, rtol=g_rtol, cancel=G_CANCEL)
         assert ok, (name, "g_nuis", worst)
 
@@ -62,7 +63,8 @@ def test_golden_vectors_through_c_abi(golden):
         cancel = 1e-10 if has_marg else G_CANCEL
         rtol = G_RTOL
         if case["name"] == "F7_kepler_edges":
-            rtol = 1e-7      # e = 0.999999: cond ~ 1/(1-e)^2 on d/de; still far inside the reference's own error there
+            rtol = 1e-9      # e = 0.999999: cond ~ 1/(1-e)^2 on d/de (the reference-order oracle is off by 2e-6 there,
+            cancel = 1e-10   # the Thiele-Innes form of the kernel by 2e-11)
         ok, worst = grad_ok(g_el, case["g_elems"], case["s_elems"], rtol=rtol, cancel=cancel)
         assert ok, (case["name"], "g_elems", worst)
         if nuis is not None:
@@ -112,7 +114,7 @@ def test_all_kinds_two_planets_vs_oracle(oracle):
         ll_f, _, _ = gb.gpu_eval(obs, planets, elems, nz, grad=False)
         assert np.array_equal(ll, ll_f)
         ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, elems, nz, grad=True)
-        _cmp_oracle("all kinds", ll, g_el, g_nu, ll_o, g_o, gn_o, ll_rtol=1e-9)
+        _cmp_oracle("all kinds", ll, g_el, g_nu, ll_o, g_o, gn_o, ll_rtol=1e-9, g_rtol=1e-8)   # marginalised-RV cancellation
 
 
 def test_radvel_orbit_and_empty_table(oracle):

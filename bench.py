@@ -47,9 +47,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--epochs", type=int, default=10_000)
     ap.add_argument("--walkers", type=int, default=10_000, help="walkers per GPU")
-    ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt"], default="grad")
+    ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti"], default="grad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for single-GPU dry runs")
+    ap.add_argument("--device", type=int, default=None, help="force the HIP device index (dry runs of the N>1 path on one GPU)")
     return ap.parse_args()
 
 
@@ -88,11 +90,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from __graft_entry__ import load_package
     import synth
@@ -100,6 +106,28 @@ def main():
     capi = pkg.capi
 
     grad = args.workload in ("grad", "two_planet")
+    if args.workload == "ofti":
+        # batched ofti_linear_solve (src/parameterizations.jl:318-405), forward marginal likelihood
+        cfg0 = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=6)
+        t = cfg0["table"]
+        solver = pkg.OftiLinearSolver(t["epoch"], t["ra"], t["dec"], t["σ_ra"], t["σ_dec"], None, 1000.0, device=dev_index)
+        el = cfg0["elems"]
+        nl = torch.tensor(np.stack([el[1], el[0], el[5], el[6], el[7]]), device=dev)
+        for _ in range(args.warmup):
+            solver.eval_device(nl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            solver.eval_device(nl)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"metric": "OFTI marginal-likelihood epoch evals/sec (fwd)", "value": args.epochs * args.walkers * args.steps / dt,
+                              "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": f"ofti_linear_solve: {args.epochs} RA/Dec epochs x {args.walkers} walkers, forward"}}))
+        solver.close()
+        return
     if args.workload == "two_planet":
         c4 = synth.config_two_planet()
         astrom = pkg.PlanetRelAstromObs(c4["astrom"], name="astrom")
@@ -108,7 +136,7 @@ def main():
         c = pkg.Planet(name="c", observations=[astrom])
         system = pkg.System(name="cfg4", companions=[b, c], observations=[rv])
         θex = dict(M=1.2, plx=50.0, planets=dict(b=dict(a=3, e=0.1, i=1, ω=1, Ω=2, tp=5e4, mass=5), c=dict(a=15, e=0.3, i=1, ω=.5, Ω=2, tp=5e4, mass=10)))
-        fn = pkg.make_ln_like(system, θex, device=local_rank)
+        fn = pkg.make_ln_like(system, θex, device=dev_index)
         # nuisance rows follow the evaluation order: planet observations first, then system observations
         elems_h, nuis_h = c4["elems"], c4["nuis"]
         n_rows, W = c4["n_rows"], c4["n_walkers"]
@@ -120,7 +148,7 @@ def main():
                                   seed=None if world == 1 else 20260929 + 3 + 1000 * rank)
         obs, planet = synth.to_mirror(pkg, cfg)
         system = pkg.System(name="bench", companions=[planet], observations=[])
-        fn = pkg.make_ln_like(system, cfg["theta_example"], device=local_rank)
+        fn = pkg.make_ln_like(system, cfg["theta_example"], device=dev_index)
         elems_h, nuis_h = cfg["elems"], None
         n_rows, W = cfg["n_epochs"], cfg["n_walkers"]
         workload = f"config{'3' if grad else '2'}: 1 planet, {n_rows} RA/Dec epochs x {W} walkers/GPU, {'fwd+reverse-grad' if grad else 'fwd only'}"

@@ -173,6 +173,21 @@ int32_t octo_sync(octo_ctx* ctx);
 int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n,
                           double* E_out, double* sinE_out, double* cosE_out);
 
+/* OFTI marginal likelihood: batched `ofti_linear_solve(epochs, ra, dec, σ_ra, σ_dec, cor, σ_ABFG,
+ * e, a, tp, M, plx)` — src/parameterizations.jl:318-405. The handle holds one RA/Dec table (cor may be NULL = 0) and
+ * σ_ABFG; an evaluation takes the nonlinear parameters nl[(k)*ld + w], k ∈ {e, a, tp, M, plx}, and returns the
+ * posterior-mean Thiele-Innes constants abfg[(k)*ld + w], k ∈ {A, B, F, G} (may be NULL) and log_marginal_likelihood[w].
+ * Invalid walkers (non-finite input, e ∉ [0,1), a <= 0, M <= 0): log-likelihood -Inf, constants NaN. */
+typedef struct octo_ofti octo_ofti;
+int32_t octo_ofti_create(octo_ctx* ctx, const double* epochs, const double* ra, const double* dec,
+                         const double* sigma_ra, const double* sigma_dec, const double* cor, int64_t n_epochs,
+                         double sigma_abfg, octo_ofti** out);
+int32_t octo_ofti_destroy(octo_ofti* h);
+int32_t octo_ofti_eval(octo_ctx* ctx, const octo_ofti* h, const double* nl, int64_t ld, int64_t W,
+                       double* abfg_out, double* logml_out);
+int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d_nl, int64_t ld, int64_t W,
+                              double* d_abfg_out, double* d_logml_out, void* hip_stream);
+
 /* Measurement hook used by bench.py: average duration in milliseconds of the
  * dominant (epoch-loop) kernel over the launches since the last reset, from
  * hipEvents recorded on the launch stream. Enabled by octo_timing_enable. */

@@ -43,6 +43,13 @@ struct octo_dataset {
     std::vector<TaskTable> tables;
 };
 
+struct octo_ofti {
+    int device = 0;
+    int64_t n = 0;
+    double* d_rows = nullptr;
+    double lambda = 0, data_quad = 0, log_det_data_cov = 0, log_det_prior_inv = 0, n_log2pi = 0;
+};
+
 struct octo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -517,6 +524,107 @@ int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int
     if (avg_ms) *avg_ms = ctx->t_n > 0 ? ctx->t_ms / (double)ctx->t_n : 0.0;
     if (n_launches) *n_launches = ctx->t_n;
     if (reset) { ctx->t_ms = 0.0; ctx->t_n = 0; }
+    return OCTO_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------- OFTI marginal likelihood
+extern "C" {
+
+int32_t octo_ofti_create(octo_ctx* ctx, const double* epochs, const double* ra, const double* dec, const double* s_ra,
+                         const double* s_dec, const double* cor, int64_t n, double sigma_abfg, octo_ofti** out) {
+    if (!ctx || !out || n < 0 || (n > 0 && (!epochs || !ra || !dec || !s_ra || !s_dec))) return fail(ctx, OCTO_EINVAL, "octo_ofti_create: null argument");
+    if (!(sigma_abfg > 0.0) || n > 0x7fffffff) return fail(ctx, OCTO_EINVAL, "octo_ofti_create: bad sigma_ABFG or size");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    octo_ofti* h = new (std::nothrow) octo_ofti();
+    if (!h) return fail(ctx, OCTO_ENOMEM, "octo_ofti_create: host allocation failed");
+    h->device = ctx->device; h->n = n;
+    std::vector<double> rows((size_t)n * ROW_STRIDE, 0.0);
+    for (int64_t j = 0; j < n; ++j) {
+        // inverse covariance of one epoch, parameterizations.jl:359-366
+        const double sr = s_ra[j], sd = s_dec[j], rho = cor ? cor[j] : 0.0;
+        const double det = sr * sr * sd * sd * (1.0 - rho * rho);
+        const double wrr = sd * sd / det, wdd = sr * sr / det, wrd = -rho * sr * sd / det;
+        double* r = &rows[(size_t)j * ROW_STRIDE];
+        r[0] = epochs[j]; r[1] = wrr; r[2] = wdd; r[3] = wrd;
+        r[4] = wrr * ra[j] + wrd * dec[j]; r[5] = wdd * dec[j] + wrd * ra[j];
+        h->data_quad += ra[j] * r[4] + dec[j] * r[5];              // dot(d, W, d), :387
+        h->log_det_data_cov += std::log(det);                      // :394-400
+    }
+    h->lambda = 1.0 / (sigma_abfg * sigma_abfg);
+    h->log_det_prior_inv = 4.0 * std::log(h->lambda);              // :391
+    h->n_log2pi = (double)n * std::log(TWO_PI);
+    if (n > 0) {
+        if (hipMalloc((void**)&h->d_rows, sizeof(double) * rows.size()) != hipSuccess) { delete h; return fail(ctx, OCTO_ENOMEM, "octo_ofti_create: hipMalloc failed"); }
+        if (hipMemcpy(h->d_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(h->d_rows); delete h; return fail(ctx, OCTO_EHIP, "octo_ofti_create: upload failed");
+        }
+    }
+    *out = h;
+    return OCTO_OK;
+}
+
+int32_t octo_ofti_destroy(octo_ofti* h) {
+    if (!h) return OCTO_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_rows);
+    delete h;
+    return OCTO_OK;
+}
+
+int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d_nl, int64_t ld, int64_t W, double* d_abfg,
+                              double* d_logml, void* hip_stream) {
+    if (!ctx || !h || !d_nl || !d_logml) return fail(ctx, OCTO_EINVAL, "octo_ofti_eval_device: null argument");
+    if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_ofti_eval_device: need 0 <= W <= ld");
+    if (h->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_ofti_eval_device: handle lives on another device");
+    if (W == 0) return OCTO_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    OftiArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const int64_t cols = (W + WAVE - 1) / WAVE;
+    int chunk = 32;
+    {   // same sizing rule as the likelihood kernel
+        const int64_t want_tasks = std::max<int64_t>(1, (16384 + cols - 1) / cols);
+        int64_t c = (h->n + want_tasks - 1) / std::max<int64_t>(want_tasks, 1);
+        c = std::min<int64_t>(std::max<int64_t>(c, 32), 4096);
+        chunk = (int)((c + 31) / 32 * 32);
+    }
+    a.rows = h->d_rows; a.n_rows = (int32_t)h->n; a.chunk = chunk;
+    a.n_tasks = (int32_t)((h->n + (int64_t)chunk * WPB - 1) / ((int64_t)chunk * WPB));
+    a.nl = d_nl; a.ld = ld; a.W = W; a.ldw = cols * WAVE;
+    int rc = grow(ctx, ctx->d_partials, ctx->cap_part, (int64_t)std::max(a.n_tasks, 1) * OFTI_NACC * a.ldw);
+    if (rc) return rc;
+    a.partials = ctx->d_partials; a.abfg = d_abfg; a.logml = d_logml;
+    a.k_yr = ctx->consts.kepler_year_to_julian_day; a.lambda = h->lambda; a.data_quad = h->data_quad;
+    a.log_det_data_cov = h->log_det_data_cov; a.log_det_prior_inv = h->log_det_prior_inv; a.n_log2pi = h->n_log2pi;
+    if (a.n_tasks > 0)
+        hipLaunchKernelGGL(k_ofti_main, dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB), sizeof(double) * OFTI_NACC * WAVE, st, a);
+    hipLaunchKernelGGL(k_ofti_finish, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return OCTO_OK;
+}
+
+int32_t octo_ofti_eval(octo_ctx* ctx, const octo_ofti* h, const double* nl, int64_t ld, int64_t W, double* abfg_out, double* logml_out) {
+    if (!ctx || !h || !nl || !logml_out) return fail(ctx, OCTO_EINVAL, "octo_ofti_eval: null argument");
+    if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_ofti_eval: need 0 <= W <= ld");
+    if (W == 0) return OCTO_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t ldd = (W + 63) / 64 * 64;
+    int rc = grow(ctx, ctx->d_in, ctx->cap_in, 5 * ldd);
+    if (rc) return rc;
+    rc = grow(ctx, ctx->d_out, ctx->cap_out, 5 * ldd);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, nl, sizeof(double) * ld, sizeof(double) * W, 5, hipMemcpyHostToDevice, st));
+    rc = octo_ofti_eval_device(ctx, h, ctx->d_in, ldd, W, abfg_out ? ctx->d_out + ldd : nullptr, ctx->d_out, st);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(logml_out, ctx->d_out, sizeof(double) * W, hipMemcpyDeviceToHost, st));
+    if (abfg_out)
+        HIPCHK(ctx, hipMemcpy2DAsync(abfg_out, sizeof(double) * ld, ctx->d_out + ldd, sizeof(double) * ldd, sizeof(double) * W, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
     return OCTO_OK;
 }
 

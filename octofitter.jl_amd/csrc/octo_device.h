@@ -134,7 +134,7 @@ __device__ __forceinline__ double rcp_nr(double x) {
 }
 
 // Eccentric anomaly and the quantities every projection needs. INV_NR: Newton steps on 1/(1 − e cos E)
-// (1 when it only feeds adjoints, 2 when it feeds a model value).
+// (1 when it only feeds adjoints, 2 when it feeds a model value, -1 when nobody needs it).
 template <int INV_NR>
 __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc) {
     KSol s;
@@ -179,7 +179,7 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc) {
     s.cE = c1 + fma(c1, cm1, -(s1 * sd));
     // M == 0: E1f = 0 exactly and f0 = 0, so E = 0 like the reference's early return; e == 0: f2 = f3 = 0,
     // d5 = −(E1 − M) exactly, E = M to rounding, like the reference's early return.
-    s.invD = rcp_nr<INV_NR>(fma(-e, s.cE, 1.0));
+    if constexpr (INV_NR >= 0) s.invD = rcp_nr<(INV_NR >= 0 ? INV_NR : 0)>(fma(-e, s.cE, 1.0));
     return s;
 }
 

@@ -612,4 +612,136 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     }
 }
 
+// ==================================================================================== OFTI
+// ofti_linear_solve(epochs, ra, dec, σ_ra, σ_dec, cor, σ_ABFG, e, a, tp, M, plx) — src/parameterizations.jl:318-405:
+// for fixed (e, a, tp, M) the sky position is linear in the Thiele-Innes constants (A, B, F, G); they are
+// marginalised analytically under an isotropic Gaussian prior. Per walker: the same Kepler solve per epoch
+// (:337-345), the 4x4 normal equations D'WD (13 running sums), a Cholesky solve, the marginal log-likelihood (:402).
+constexpr int OFTI_NACC = 13;   // Sxx,Sxy,Syy for weights {rr, dd, rd}; Σxq, Σyq, Σxp, Σyp
+
+struct OftiArgs {
+    const double* rows;       // [n][8] {t, w_rr, w_dd, w_rd, p = w_rr·ra + w_rd·dec, q = w_dd·dec + w_rd·ra, 0, 0}
+    int32_t n_rows, n_tasks, chunk, pad;
+    const double* nl;         // [5][ld]: e, a, tp, M, plx
+    int64_t ld, W, ldw;
+    double* partials;         // [n_tasks*13][ldw]
+    double* abfg; double* logml;
+    double k_yr, lambda /* 1/σ_ABFG² */, data_quad, log_det_data_cov, log_det_prior_inv, n_log2pi;
+};
+
+__global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
+    const int64_t wl = w < a.W ? w : a.W - 1;
+    const int task_rows = a.chunk * WPB;
+    const int row0 = (int)blockIdx.y * task_rows;
+    const int nrows = min(task_rows, a.n_rows - row0);
+    const int r_lo = min(wv * a.chunk, nrows), r_hi = min(r_lo + a.chunk, nrows);
+    PC pc = {};
+    {
+        const double e = a.nl[0 * a.ld + wl], sma = a.nl[1 * a.ld + wl], tp = a.nl[2 * a.ld + wl], Mt = a.nl[3 * a.ld + wl];
+        const double P_d = a.k_yr * sqrt(sma * sma * sma / Mt);      // parameterizations.jl:322
+        pc.invP = 1.0 / P_d; pc.tp = tp; pc.e = e; pc.beta = sqrt(1.0 - e * e);   // sqrt1me2, :325
+        pc.ef = (float)e; pc.omef = (float)(1.0 - e); pc.k1f = (float)(MK_K1N / (1.0 + e));
+    }
+    double acc[OFTI_NACC];
+#pragma unroll
+    for (int k = 0; k < OFTI_NACC; ++k) acc[k] = 0.0;
+    const double* __restrict__ rows = a.rows + (int64_t)(row0 + r_lo) * ROW_STRIDE;
+    for (int j = 0; j < r_hi - r_lo; ++j) {
+        const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
+        const double t = rw[0], wrr = rw[1], wdd = rw[2], wrd = rw[3], pp = rw[4], qq = rw[5];
+        const KSol s = kepler_solve<-1>(t, pc);
+        const double x = s.cE - pc.e, y = s.sE * pc.beta;            // :343-345
+        const double xx = x * x, xy = x * y, yy = y * y;
+        acc[0] = fma(wrr, xx, acc[0]); acc[1] = fma(wrr, xy, acc[1]); acc[2] = fma(wrr, yy, acc[2]);
+        acc[3] = fma(wdd, xx, acc[3]); acc[4] = fma(wdd, xy, acc[4]); acc[5] = fma(wdd, yy, acc[5]);
+        acc[6] = fma(wrd, xx, acc[6]); acc[7] = fma(wrd, xy, acc[7]); acc[8] = fma(wrd, yy, acc[8]);
+        acc[9] = fma(x, qq, acc[9]); acc[10] = fma(y, qq, acc[10]);
+        acc[11] = fma(x, pp, acc[11]); acc[12] = fma(y, pp, acc[12]);
+    }
+#pragma unroll 1
+    for (int q = 1; q < WPB; ++q) {
+        if (wv == q) {
+#pragma unroll
+            for (int k = 0; k < OFTI_NACC; ++k) lds[k * WAVE + lane] = acc[k];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int k = 0; k < OFTI_NACC; ++k) acc[k] += lds[k * WAVE + lane];
+        }
+        __syncthreads();
+    }
+    if (wv == 0 && w < a.W) {
+        double* out = a.partials + (int64_t)blockIdx.y * OFTI_NACC * a.ldw + w;
+#pragma unroll
+        for (int k = 0; k < OFTI_NACC; ++k) out[(int64_t)k * a.ldw] = acc[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ofti_finish(OftiArgs a) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.W) return;
+    double v[OFTI_NACC];
+#pragma unroll
+    for (int k = 0; k < OFTI_NACC; ++k) v[k] = 0.0;
+    for (int t = 0; t < a.n_tasks; ++t) {
+        const double* pt = a.partials + (int64_t)t * OFTI_NACC * a.ldw + w;
+#pragma unroll
+        for (int k = 0; k < OFTI_NACC; ++k) v[k] += pt[(int64_t)k * a.ldw];
+    }
+    const double e = a.nl[0 * a.ld + w], sma = a.nl[1 * a.ld + w], tp = a.nl[2 * a.ld + w], Mt = a.nl[3 * a.ld + w], plx = a.nl[4 * a.ld + w];
+    const bool ok = isfinite(e) && isfinite(sma) && isfinite(tp) && isfinite(Mt) && isfinite(plx) && e >= 0.0 && e < 1.0 && sma > 0.0 && Mt > 0.0;
+    // Σ_post⁻¹ = D'WD + Λ  (order A, B, F, G)                       parameterizations.jl:370-374
+    const double lam = a.lambda;
+    double S[4][4];
+    S[0][0] = v[3] + lam; S[0][1] = v[6]; S[0][2] = v[4]; S[0][3] = v[7];
+    S[1][1] = v[0] + lam; S[1][2] = v[7]; S[1][3] = v[1];
+    S[2][2] = v[5] + lam; S[2][3] = v[8];
+    S[3][3] = v[2] + lam;
+    const double b[4] = {v[9], v[11], v[10], v[12]};
+    // Cholesky S = L L'
+    double L[4][4];
+    bool pd = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double sum = S[j][i];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sum -= L[i][k] * L[j][k];
+            if (i == j) { pd = pd && (sum > 0.0); L[i][i] = sqrt(sum); }
+            else L[i][j] = sum / L[j][j];
+        }
+    }
+    double z[4], mu[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double sum = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sum -= L[i][k] * z[k];
+        z[i] = sum / L[i][i];
+    }
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        double sum = z[i];
+#pragma unroll
+        for (int k = i + 1; k < 4; ++k) sum -= L[k][i] * mu[k];
+        mu[i] = sum / L[i][i];
+    }
+    const double post_quad = z[0] * z[0] + z[1] * z[1] + z[2] * z[2] + z[3] * z[3];   // μ'Σ⁻¹μ = |L⁻¹b|²
+    const double log_det_post_inv = 2.0 * (log(L[0][0]) + log(L[1][1]) + log(L[2][2]) + log(L[3][3]));
+    // :402
+    const double lm = -0.5 * (a.data_quad - post_quad + log_det_post_inv - a.log_det_prior_inv + a.log_det_data_cov) - a.n_log2pi;
+    const bool fin = ok && pd && isfinite(lm);
+    a.logml[w] = fin ? lm : -INFINITY;
+    if (a.abfg) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.abfg[(int64_t)k * a.ld + w] = fin ? mu[k] : NAN;
+    }
+}
+
 }  // namespace octo

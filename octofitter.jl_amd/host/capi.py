@@ -117,6 +117,11 @@ _SIGS = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "octo_sync": (C.c_int32, [C.c_void_p]),
     "octo_kepler_solve": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "octo_ofti_create": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64,
+                                     C.c_double, C.POINTER(C.c_void_p)]),
+    "octo_ofti_destroy": (C.c_int32, [C.c_void_p]),
+    "octo_ofti_eval": (C.c_int32, [C.c_void_p, C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),
+    "octo_ofti_eval_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "octo_timing_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "octo_timing_read": (C.c_int32, [C.c_void_p, c_double_p, C.POINTER(C.c_int64), C.c_int32]),
     "octo_pt_swap_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,

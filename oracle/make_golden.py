@@ -192,5 +192,39 @@ def main():
     print("wrote", OUT, OUT.stat().st_size, "bytes")
 
 
+def ofti_cases():
+    """tests/golden/ofti.json — OFTI marginal likelihood (src/parameterizations.jl:318-405) on the setup of
+    examples/ofti_rejection_sampling.jl:26-49,67-82: truth orbit a=10, e=0.3, i=1, ω=0.5, Ω=2, tp=50000, M=1.2, plx=50;
+    8 epochs 50000..50840, σ=10 mas, σ_ABFG=1000; walkers drawn from that example's priors."""
+    import synth_free as sf
+    rng = np.random.default_rng(20260929 + 33)
+    out = []
+    for name, n_ep, with_cor, sig in (("ofti_example", 8, False, 1000.0), ("ofti_cor_37", 37, True, 300.0)):
+        ep = np.linspace(50000.0, 50840.0, n_ep)
+        ra, dec = sf.truth_radec(ep)
+        ra = ra + 10.0 * rng.normal(size=n_ep); dec = dec + 10.0 * rng.normal(size=n_ep)
+        s_ra = np.full(n_ep, 10.0) if not with_cor else rng.uniform(5, 15, n_ep)
+        s_dec = np.full(n_ep, 10.0) if not with_cor else rng.uniform(5, 15, n_ep)
+        cor = None if not with_cor else rng.uniform(-0.8, 0.8, n_ep)
+        W = 12
+        M = np.abs(rng.normal(1.2, 0.1, W)) + 0.1; plx = rng.normal(50.0, 0.5, W)
+        e = rng.uniform(0, 0.99, W); a = np.exp(rng.uniform(0, np.log(100.0), W)); tau = rng.uniform(0, 1, W)
+        e[0], a[0], M[0], plx[0], tau[0] = 0.3, 10.0, 1.2, 50.0, 0.0          # the truth
+        e[1] = 0.0                                                            # circular: early-return branch of the solver
+        tp = ep[0] + tau * np.sqrt(a ** 3 / M) * C["kepler_year_to_julian_day"]
+        nl = np.stack([e, a, tp, M, plx])
+        res = [mpo.ofti_linear_solve(C, list(ep), list(ra), list(dec), list(s_ra), list(s_dec), None if cor is None else list(cor), sig, *nl[:, w]) for w in range(W)]
+        out.append(dict(name=name, epochs=ep.tolist(), ra=ra.tolist(), dec=dec.tolist(), s_ra=s_ra.tolist(), s_dec=s_dec.tolist(),
+                        cor=None if cor is None else cor.tolist(), sigma_abfg=sig, nl=nl.tolist(),
+                        abfg=[[fl(r[k]) for r in res] for k in range(4)], logml=[fl(r[4]) for r in res]))
+        print(f"  {name}: W={W} logml[0]={out[-1]['logml'][0]:.12g}", flush=True)
+    p = ROOT / "tests" / "golden" / "ofti.json"
+    p.write_text(json.dumps(dict(consts=C, cases=out, generator="oracle/make_golden.py ofti_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    sys.path.insert(0, str(ROOT / "oracle"))
+    if "--ofti-only" not in sys.argv:
+        main()
+    ofti_cases()

@@ -212,3 +212,36 @@ def ln_like_and_grad(c, planets, obs, elems, nuis, h_rel=mp.mpf(10) ** -25, with
     if with_scale:
         return f0, g_el, g_nu, s_el, s_nu
     return f0, g_el, g_nu
+
+
+def ofti_linear_solve(c, epochs, ra, dec, s_ra, s_dec, cor, sigma_abfg, e, a, tp, M, plx):
+    """Independent 60-digit evaluation of the OFTI marginal likelihood (src/parameterizations.jl:288-316 docstring):
+    Gaussian integral over (A, B, F, G) ~ N(0, σ²I) of the astrometry likelihood, by completing the square with
+    mpmath matrices; Kepler by Newton. Returns (A, B, F, G, log_marginal)."""
+    e, a, tp, M = mp.mpf(e), mp.mpf(a), mp.mpf(tp), mp.mpf(M)
+    P_d = mp.mpf(c["kepler_year_to_julian_day"]) * mp.sqrt(a ** 3 / M)
+    N = len(epochs)
+    S = mp.matrix(4, 4)
+    b = mp.matrix(4, 1)
+    dq = mp.mpf(0); ldc = mp.mpf(0)
+    for j in range(N):
+        E = kepler_newton(2 * mp.pi * (mp.mpf(epochs[j]) - tp) / P_d, e)
+        x = mp.cos(E) - e
+        y = mp.sqrt(1 - e * e) * mp.sin(E)
+        sr, sd = mp.mpf(s_ra[j]), mp.mpf(s_dec[j])
+        rho = mp.mpf(cor[j]) if cor is not None else mp.mpf(0)
+        Sig = mp.matrix([[sr * sr, rho * sr * sd], [rho * sr * sd, sd * sd]])
+        Wj = Sig ** -1
+        Dj = mp.matrix([[0, x, 0, y], [x, 0, y, 0]])
+        dj = mp.matrix([mp.mpf(ra[j]), mp.mpf(dec[j])])
+        S += Dj.T * Wj * Dj
+        b += Dj.T * Wj * dj
+        dq += (dj.T * Wj * dj)[0]
+        ldc += mp.log(mp.det(Sig))
+    lam = 1 / mp.mpf(sigma_abfg) ** 2
+    for i in range(4):
+        S[i, i] += lam
+    mu = mp.lu_solve(S, b)
+    pq = (mu.T * b)[0]
+    lm = -(dq - pq + mp.log(mp.det(S)) - 4 * mp.log(lam) + ldc) / 2 - N * mp.log(2 * mp.pi)
+    return mu[0], mu[1], mu[2], mu[3], lm

@@ -15,8 +15,8 @@
  * (SURVEY.md §4, §8c). This file therefore restates (a) the reference's own code where it is in
  * the tree, citing file:line, and (b) the published algorithms of those packages, and it is
  * pinned against an INDEPENDENT 50-digit mpmath oracle (oracle/mp_oracle.py ->
- * tests/golden/*.json), against the reference tests' self-consistency properties
- * (tests/test_reference_properties.py), and against the tutorial astrometry table that the
+ * the fixtures under tests/golden/), against the reference tests' self-consistency properties
+ * (tests/test_oracle.py), and against the tutorial astrometry table that the
  * reference ships in test/integration-tests.jl:8-15 — not against outputs of the reference.
  *
  * Build: oracle/Makefile  ->  oracle/liboctooracle.so   (gcc -O3 -march=native -fopenmp, no fast-math)
@@ -167,6 +167,109 @@ int32_t octo_oracle_orbitsolve(const octo_consts* c, int32_t orbit_kind, const d
     out10[1] = s.EA.v; out10[2] = s.nu.v; out10[3] = s.r.v;
     out10[4] = raoff_np0(&s, &o).v; out10[5] = decoff_np0(&s, &o).v; out10[6] = radvel_np0(&s, &o).v;
     out10[7] = o.n.v; out10[8] = o.K.v; out10[9] = o.cart2angle.v;
+    return OCTO_OK;
+}
+
+/* ofti_linear_solve — restated from /root/reference/src/parameterizations.jl:318-405 (the function is IN the tree;
+ * only kepler_solver is third-party): dense D (2N×4), block-diagonal W (2N×2N), DtW = D'W, Σ_post⁻¹ = DtW·D + Λ,
+ * Σ_post = inv(·) and logdet(·) by LU with partial pivoting (what Julia's `inv`/`logdet` do), μ = (Σ_post·DtW)·d.
+ * nl = {e, a, tp, M, plx}; out5 = {A, B, F, G, log_marginal_likelihood}. */
+static int lu4(double A[4][4], int piv[4], double* sign) {
+    *sign = 1.0;
+    for (int k = 0; k < 4; ++k) {
+        int p = k; double mx = fabs(A[k][k]);
+        for (int i = k + 1; i < 4; ++i) if (fabs(A[i][k]) > mx) { mx = fabs(A[i][k]); p = i; }
+        piv[k] = p;
+        if (mx == 0.0) return -1;
+        if (p != k) { for (int j = 0; j < 4; ++j) { double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; } *sign = -*sign; }
+        for (int i = k + 1; i < 4; ++i) {
+            A[i][k] /= A[k][k];
+            for (int j = k + 1; j < 4; ++j) A[i][j] -= A[i][k] * A[k][j];
+        }
+    }
+    return 0;
+}
+
+int32_t octo_oracle_ofti(const octo_consts* c, const double* epochs, const double* ra, const double* dec, const double* s_ra,
+                         const double* s_dec, const double* cor, int64_t N, double sigma_abfg, const double* nl, double* out5) {
+    if (!c || !nl || !out5 || N < 0) return OCTO_EINVAL;
+    const double e = nl[0], a = nl[1], tp = nl[2], M = nl[3], plx = nl[4];
+    for (int k = 0; k < 5; ++k) out5[k] = NAN;
+    out5[4] = -INFINITY;
+    if (!(isfinite(e) && isfinite(a) && isfinite(tp) && isfinite(M) && isfinite(plx)) || !(e >= 0.0 && e < 1.0) || !(a > 0.0) || !(M > 0.0)) return OCTO_OK;
+    const double period_days = sqrt(a * a * a / M) * c->kepler_year_to_julian_day;       /* :322 */
+    const double n = 2.0 * M_PI / (period_days / c->year2day_julian);                     /* :323 */
+    const double sqrt1me2 = sqrt(1.0 - e * e);                                            /* :325 */
+    const int64_t R = 2 * N;
+    double* D = (double*)calloc((size_t)(R > 0 ? R : 1) * 4, sizeof(double));
+    double* d = (double*)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
+    double* Wm = (double*)calloc((size_t)(R > 0 ? R : 1) * 3, sizeof(double));    /* per epoch: W_rr, W_dd, W_rd */
+    for (int64_t j = 0; j < N; ++j) {
+        const double MA = n / c->year2day_julian * (epochs[j] - tp);                      /* :337 */
+        const double EA = octo_oracle_kepler_markley(MA, e);                              /* :340 */
+        const double sea = sin(EA), cea = cos(EA);
+        const double x = cea - e, y = sea * sqrt1me2;                                     /* :344-345 */
+        D[(2 * j) * 4 + 1] = x; D[(2 * j) * 4 + 3] = y;        /* ra row: B, G   :350-351 */
+        D[(2 * j + 1) * 4 + 0] = x; D[(2 * j + 1) * 4 + 2] = y; /* dec row: A, F  :352-353 */
+        d[2 * j] = ra[j]; d[2 * j + 1] = dec[j];
+        const double sr = s_ra[j], sd = s_dec[j], rho = cor ? cor[j] : 0.0;
+        const double det = sr * sr * sd * sd * (1.0 - rho * rho);                         /* :362 */
+        Wm[3 * j + 0] = sd * sd / det; Wm[3 * j + 1] = sr * sr / det; Wm[3 * j + 2] = -rho * sr * sd / det;
+    }
+    /* DtW = D' * W  (4 × 2N) */
+    double* DtW = (double*)calloc((size_t)(R > 0 ? R : 1) * 4, sizeof(double));
+    for (int64_t j = 0; j < N; ++j)
+        for (int k = 0; k < 4; ++k) {
+            const double dr = D[(2 * j) * 4 + k], dd = D[(2 * j + 1) * 4 + k];
+            DtW[k * R + 2 * j] = dr * Wm[3 * j + 0] + dd * Wm[3 * j + 2];
+            DtW[k * R + 2 * j + 1] = dr * Wm[3 * j + 2] + dd * Wm[3 * j + 1];
+        }
+    const double lam = 1.0 / (sigma_abfg * sigma_abfg);
+    double S[4][4], LU[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 4; ++k) {
+            double acc = 0.0;
+            for (int64_t r = 0; r < R; ++r) acc += DtW[i * R + r] * D[r * 4 + k];
+            S[i][k] = acc + (i == k ? lam : 0.0);                                          /* :374 */
+            LU[i][k] = S[i][k];
+        }
+    int piv[4]; double sign;
+    if (lu4(LU, piv, &sign) != 0) { free(D); free(d); free(Wm); free(DtW); return OCTO_OK; }
+    /* inv via LU: solve for each unit vector */
+    double Sinv[4][4];
+    for (int col = 0; col < 4; ++col) {
+        double bb[4] = {0, 0, 0, 0}; bb[col] = 1.0;
+        for (int k = 0; k < 4; ++k) { const double t = bb[k]; bb[k] = bb[piv[k]]; bb[piv[k]] = t; }
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < i; ++k) bb[i] -= LU[i][k] * bb[k];
+        for (int i = 3; i >= 0; --i) { for (int k = i + 1; k < 4; ++k) bb[i] -= LU[i][k] * bb[k]; bb[i] /= LU[i][i]; }
+        for (int i = 0; i < 4; ++i) Sinv[i][col] = bb[i];
+    }
+    /* μ_post = (Σ_post * DtW) * d     :378 */
+    double mu[4];
+    for (int i = 0; i < 4; ++i) {
+        double acc = 0.0;
+        for (int64_t r = 0; r < R; ++r) {
+            double t = 0.0;
+            for (int k = 0; k < 4; ++k) t += Sinv[i][k] * DtW[k * R + r];
+            acc += t * d[r];
+        }
+        mu[i] = acc;
+    }
+    double data_quad = 0.0, ldc = 0.0;
+    for (int64_t j = 0; j < N; ++j) {                                                     /* :387, :394-400 */
+        data_quad += d[2 * j] * (Wm[3 * j + 0] * d[2 * j] + Wm[3 * j + 2] * d[2 * j + 1]) + d[2 * j + 1] * (Wm[3 * j + 2] * d[2 * j] + Wm[3 * j + 1] * d[2 * j + 1]);
+        ldc += log(s_ra[j] * s_ra[j] * s_dec[j] * s_dec[j] * (1.0 - (cor ? cor[j] * cor[j] : 0.0)));
+    }
+    double post_quad = 0.0;
+    for (int i = 0; i < 4; ++i) { double t = 0.0; for (int k = 0; k < 4; ++k) t += S[i][k] * mu[k]; post_quad += mu[i] * t; }   /* :388 */
+    double logdet = 0.0;
+    for (int i = 0; i < 4; ++i) { logdet += log(fabs(LU[i][i])); if (LU[i][i] < 0) sign = -sign; }                            /* :390 */
+    if (sign < 0) logdet = NAN;
+    const double ldp = 4.0 * log(1.0 / (sigma_abfg * sigma_abfg));                        /* :391 */
+    out5[0] = mu[0]; out5[1] = mu[1]; out5[2] = mu[2]; out5[3] = mu[3];
+    out5[4] = -0.5 * (data_quad - post_quad + logdet - ldp + ldc) - (double)N * log(2.0 * M_PI);   /* :402 */
+    if (!isfinite(out5[4])) { out5[4] = -INFINITY; for (int k = 0; k < 4; ++k) out5[k] = NAN; }
+    free(D); free(d); free(Wm); free(DtW);
     return OCTO_OK;
 }
 

@@ -18,6 +18,8 @@ int32_t octo_oracle_eval(const octo_consts* c,
 double octo_oracle_kepler_markley(double MA, double e);
 int32_t octo_oracle_orbitsolve(const octo_consts* c, int32_t orbit_kind, const double* el9, double t, double* out10);
 int32_t octo_oracle_consts_default(octo_consts* out);
+int32_t octo_oracle_ofti(const octo_consts* c, const double* epochs, const double* ra, const double* dec, const double* s_ra,
+                         const double* s_dec, const double* cor, int64_t N, double sigma_abfg, const double* nl5, double* out5);
 int32_t octo_oracle_max_partials(void);
 #ifdef __cplusplus
 }

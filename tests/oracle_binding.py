@@ -42,6 +42,8 @@ def load_oracle():
     lib.octo_oracle_orbitsolve.argtypes = [C.POINTER(capi.OctoConsts), C.c_int32, dp, C.c_double, dp]
     lib.octo_oracle_consts_default.restype = C.c_int32
     lib.octo_oracle_consts_default.argtypes = [C.POINTER(capi.OctoConsts)]
+    lib.octo_oracle_ofti.restype = C.c_int32
+    lib.octo_oracle_ofti.argtypes = [C.POINTER(capi.OctoConsts), dp, dp, dp, dp, dp, dp, C.c_int64, C.c_double, dp, dp]
     _lib = lib
     return lib
 
@@ -83,3 +85,21 @@ def oracle_orbitsolve(el9, t, orbit_kind=0, consts=None):
     out = np.empty(10)
     assert lib.octo_oracle_orbitsolve(C.byref(consts), orbit_kind, capi._dptr(el9), float(t), capi._dptr(out)) == 0
     return dict(zip(["MA", "EA", "nu", "r", "raoff", "decoff", "radvel", "n", "K", "cart2angle"], out))
+
+
+def oracle_ofti(epochs, ra, dec, s_ra, s_dec, cor, sigma_abfg, nl, consts=None):
+    """nl: [5, W] = e, a, tp, M, plx. Returns abfg [4, W], logml [W] (reference-order restatement, one walker at a time)."""
+    lib = load_oracle()
+    consts = consts or oracle_consts()
+    cols = [np.ascontiguousarray(v, dtype=np.float64) for v in (epochs, ra, dec, s_ra, s_dec)]
+    cc = None if cor is None else np.ascontiguousarray(cor, dtype=np.float64)
+    nl = np.ascontiguousarray(nl, dtype=np.float64)
+    W = nl.shape[1]
+    abfg = np.empty((4, W)); lm = np.empty(W)
+    out = np.empty(5)
+    for w in range(W):
+        x = np.ascontiguousarray(nl[:, w])
+        assert lib.octo_oracle_ofti(C.byref(consts), *[capi._dptr(v) for v in cols], capi._dptr(cc), len(cols[0]), float(sigma_abfg),
+                                    capi._dptr(x), capi._dptr(out)) == 0
+        abfg[:, w] = out[:4]; lm[w] = out[4]
+    return abfg, lm

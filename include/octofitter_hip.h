@@ -188,6 +188,48 @@ int32_t octo_ofti_eval(octo_ctx* ctx, const octo_ofti* h, const double* nl, int6
 int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d_nl, int64_t ld, int64_t W,
                               double* d_abfg_out, double* d_logml_out, void* hip_stream);
 
+/* ---- Standard parameterisation on the device ------------------------------------------------
+ * The whole log-posterior callback ℓπcallback / ∇ℓπcallback (src/logdensitymodel.jl:110-146, 169-177) for models
+ * whose variables are the reference's standard building blocks, so that θ_t never leaves HBM:
+ *   invlink of each prior (Bijectors: src/variables.jl:1449-1493), logpdf_with_trans of each prior in declaration
+ *   order (src/variables.jl:1205-1369), UniformCircular angles and their UnitLengthPrior terms (:279-323),
+ *   tp = θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω) (src/parameterizations.jl:6-69), then the likelihood above.
+ * A model is: D priors (one per θ_t entry, in the reference's flattening order) and, for every kernel input (element
+ * row of each planet, nuisance row of each observation), a SOURCE saying how it is built from the natural θ. */
+#define OCTO_PRIOR_UNIFORM     0   /* Uniform(p0, p1)                                                   */
+#define OCTO_PRIOR_LOGUNIFORM  1   /* LogUniform(p0, p1)                                                */
+#define OCTO_PRIOR_NORMAL      2   /* Normal(p0 = μ, p1 = σ)                                            */
+#define OCTO_PRIOR_TRUNCNORMAL 3   /* truncated(Normal(p0, p1), lower = lo, upper = hi); ±INFINITY = open */
+#define OCTO_PRIOR_SINE        4   /* Octofitter.Sine()  (src/distributions.jl:14-39)                   */
+typedef struct octo_prior {
+    int32_t kind, pad;
+    double p0, p1, lo, hi;
+} octo_prior;
+
+#define OCTO_SRC_CONST    0   /* value                                                                       */
+#define OCTO_SRC_THETA    1   /* θ[i0] (natural domain)                                                      */
+#define OCTO_SRC_CIRCULAR 2   /* atan(θ[i1], θ[i0]) / 2π · value      — UniformCircular(value), + UnitLengthPrior */
+#define OCTO_SRC_TPERI    3   /* θ_at_epoch_to_tperi(atan(θ[i1], θ[i0]), value; M, e, a, i, ω, Ω) of this planet  */
+#define OCTO_SRC_FLAG_UNITLEN 1   /* this use of the (i0, i1) pair also contributes its UnitLengthPrior term (set it on exactly
+                                     one source per UniformCircular variable; variables.jl:309-323) */
+typedef struct octo_source {
+    int32_t kind, i0, i1, flags;
+    double value;
+} octo_source;
+
+typedef struct octo_model octo_model;
+int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prior* priors, int32_t D,
+                          const octo_source* elem_src /* [n_planets*OCTO_N_EL] */,
+                          const octo_source* nuis_src /* [n_obs*OCTO_N_NUIS] or NULL = defaults */,
+                          octo_model** out);
+int32_t octo_model_destroy(octo_model* m);
+/* theta_t[(d)*ld + w], d < D: unconstrained parameters. lp_out[W]; grad_out[(d)*ld + w] or NULL. HOST buffers. */
+int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, int64_t ld, int64_t W,
+                           double* lp_out, double* grad_out);
+/* DEVICE buffers, asynchronous on hip_stream (NULL = the context's stream). */
+int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_theta_t, int64_t ld, int64_t W,
+                                  double* d_lp_out, double* d_grad_out, void* hip_stream);
+
 /* Measurement hook used by bench.py: average duration in milliseconds of the
  * dominant (epoch-loop) kernel over the launches since the last reset, from
  * hipEvents recorded on the launch stream. Enabled by octo_timing_enable. */

@@ -16,3 +16,6 @@ from .host.system import Planet, System, make_ln_like, BatchedLnLike  # noqa: F4
 from .host.sharding import shard_range, ShardedLnLike  # noqa: F401,E402
 from .host.tempering import TemperedSwap  # noqa: F401,E402
 from .host.ofti import OftiLinearSolver, ofti_linear_solve  # noqa: F401,E402
+from .host.priors import (Uniform, LogUniform, Normal, TruncatedNormal, truncated, Sine, UniformCircular,  # noqa: F401,E402
+                          θ_at_epoch_to_tperi, variables)
+from .host.model import LogDensityModel  # noqa: F401,E402

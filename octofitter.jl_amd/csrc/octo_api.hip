@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "octo_kernels.h"
+#include "octo_model.h"
 #include "octofitter_hip.h"
 
 using namespace octo;
@@ -524,6 +525,145 @@ int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int
     if (avg_ms) *avg_ms = ctx->t_n > 0 ? ctx->t_ms / (double)ctx->t_n : 0.0;
     if (n_launches) *n_launches = ctx->t_n;
     if (reset) { ctx->t_ms = 0.0; ctx->t_n = 0; }
+    return OCTO_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------- standard parameterisation
+struct octo_model {
+    int device = 0;
+    const octo_dataset* ds = nullptr;
+    int D = 0, n_el = 0, n_nu = 0;
+    bool has_nuis = false;
+    octo_prior* d_priors = nullptr;
+    octo_source* d_esrc = nullptr;
+    octo_source* d_nsrc = nullptr;
+    double* d_buf = nullptr;   // elems | nuis | J | lpp | glp | ll | g_el | g_nu, all [rows][ldw]
+    int64_t cap_w = 0;
+    double *d_th = nullptr, *d_res = nullptr;   // staging for host buffers
+    int64_t cap_th = 0, cap_res = 0;
+};
+
+extern "C" {
+
+int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prior* priors, int32_t D, const octo_source* elem_src,
+                          const octo_source* nuis_src, octo_model** out) {
+    if (!ctx || !ds || !priors || !elem_src || !out) return fail(ctx, OCTO_EINVAL, "octo_model_create: null argument");
+    if (D < 1 || D > 32) return fail(ctx, OCTO_EINVAL, "octo_model_create: 1 <= D <= 32 supported");
+    if (ds->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_model_create: dataset lives on another device");
+    *out = nullptr;
+    const int n_el = ds->n_planets * OCTO_N_EL, n_nu = ds->n_obs * OCTO_N_NUIS;
+    auto check_src = [&](const octo_source& s, bool elem) {
+        if (s.kind < OCTO_SRC_CONST || s.kind > OCTO_SRC_TPERI) return false;
+        if (s.kind == OCTO_SRC_THETA && (s.i0 < 0 || s.i0 >= D)) return false;
+        if ((s.kind == OCTO_SRC_CIRCULAR || s.kind == OCTO_SRC_TPERI) && (s.i0 < 0 || s.i0 >= D || s.i1 < 0 || s.i1 >= D)) return false;
+        if (s.kind == OCTO_SRC_TPERI && !elem) return false;
+        return true;
+    };
+    for (int k = 0; k < D; ++k)
+        if (priors[k].kind < OCTO_PRIOR_UNIFORM || priors[k].kind > OCTO_PRIOR_SINE) return fail(ctx, OCTO_EINVAL, "octo_model_create: unknown prior kind");
+    for (int k = 0; k < n_el; ++k) if (!check_src(elem_src[k], true)) return fail(ctx, OCTO_EINVAL, "octo_model_create: bad element source");
+    bool has_nuis = false;
+    if (nuis_src)
+        for (int k = 0; k < n_nu; ++k) {
+            if (!check_src(nuis_src[k], false)) return fail(ctx, OCTO_EINVAL, "octo_model_create: bad nuisance source");
+            const int r = k % OCTO_N_NUIS; const int kind = ds->h_obs[k / OCTO_N_NUIS].kind;
+            const double dflt = (kind <= OCTO_ASTROM_SEPPA && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+            if (nuis_src[k].kind != OCTO_SRC_CONST || nuis_src[k].value != dflt) has_nuis = true;
+        }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    octo_model* m = new (std::nothrow) octo_model();
+    if (!m) return fail(ctx, OCTO_ENOMEM, "octo_model_create: host allocation failed");
+    m->device = ctx->device; m->ds = ds; m->D = D; m->n_el = n_el; m->n_nu = n_nu; m->has_nuis = has_nuis;
+    auto bail = [&](int code, const char* msg) { octo_model_destroy(m); return fail(ctx, code, msg); };
+    if (hipMalloc((void**)&m->d_priors, sizeof(octo_prior) * D) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
+    if (hipMalloc((void**)&m->d_esrc, sizeof(octo_source) * n_el) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
+    if (hipMemcpy(m->d_priors, priors, sizeof(octo_prior) * D, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_esrc, elem_src, sizeof(octo_source) * n_el, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(OCTO_EHIP, "octo_model_create: upload failed");
+    if (nuis_src && n_nu > 0) {
+        if (hipMalloc((void**)&m->d_nsrc, sizeof(octo_source) * n_nu) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
+        if (hipMemcpy(m->d_nsrc, nuis_src, sizeof(octo_source) * n_nu, hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
+    }
+    *out = m;
+    return OCTO_OK;
+}
+
+int32_t octo_model_destroy(octo_model* m) {
+    if (!m) return OCTO_OK;
+    (void)hipSetDevice(m->device);
+    (void)hipFree(m->d_priors); (void)hipFree(m->d_esrc); (void)hipFree(m->d_nsrc); (void)hipFree(m->d_buf);
+    (void)hipFree(m->d_th); (void)hipFree(m->d_res);
+    delete m;
+    return OCTO_OK;
+}
+
+int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_theta_t, int64_t ld, int64_t W, double* d_lp,
+                                  double* d_grad, void* hip_stream) {
+    if (!ctx || !m || !d_theta_t || !d_lp) return fail(ctx, OCTO_EINVAL, "octo_model_logpost_device: null argument");
+    if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_model_logpost_device: need 0 <= W <= ld");
+    if (m->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_model_logpost_device: model lives on another device");
+    if (W == 0) return OCTO_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
+    const int n_in = m->n_el + m->n_nu;
+    const int64_t rows = (int64_t)n_in + (int64_t)n_in * m->D + 1 + m->D + 1 + n_in;
+    if (ldw > m->cap_w) {
+        if (m->d_buf) { HIPCHK(ctx, hipFree(m->d_buf)); m->d_buf = nullptr; m->cap_w = 0; }
+        HIPCHK(ctx, hipMalloc((void**)&m->d_buf, sizeof(double) * (size_t)(rows * ldw)));
+        m->cap_w = ldw;
+    }
+    const int64_t L = m->cap_w;
+    ModelArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.priors = m->d_priors; a.esrc = m->d_esrc; a.nsrc = m->d_nsrc; a.obs = m->ds->d_obs;
+    a.D = m->D; a.n_el = m->n_el; a.n_nu = m->n_nu; a.n_planets = m->ds->n_planets;
+    a.theta_t = d_theta_t; a.ld = ld; a.W = W; a.ldw = L;
+    double* p = m->d_buf;
+    a.elems = p; p += (int64_t)m->n_el * L;
+    a.nuis = p; p += (int64_t)m->n_nu * L;
+    a.J = p; p += (int64_t)n_in * m->D * L;
+    a.lpp = p; p += L;
+    a.glp = p; p += (int64_t)m->D * L;
+    double* d_ll = p; p += L;
+    double* d_gel = p; p += (int64_t)m->n_el * L;
+    double* d_gnu = p;
+    a.ll = d_ll; a.g_el = d_gel; a.g_nu = m->has_nuis ? d_gnu : nullptr;
+    a.lp_out = d_lp; a.grad_out = d_grad;
+    a.k_yr = ctx->consts.kepler_year_to_julian_day; a.yd = ctx->consts.year2day_julian;
+    const dim3 g64((unsigned)((W + 63) / 64));
+    if (m->D <= 16) hipLaunchKernelGGL(k_model_fwd<16>, g64, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_model_fwd<32>, g64, dim3(64), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    const bool grad = d_grad != nullptr;
+    int rc = octo_eval_device(ctx, m->ds, a.elems, m->has_nuis ? a.nuis : nullptr, L, W, d_ll, grad ? d_gel : nullptr,
+                              (grad && m->has_nuis) ? d_gnu : nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_model_bwd, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return OCTO_OK;
+}
+
+int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, int64_t ld, int64_t W, double* lp_out, double* grad_out) {
+    if (!ctx || !m || !theta_t || !lp_out) return fail(ctx, OCTO_EINVAL, "octo_model_logpost: null argument");
+    if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_model_logpost: need 0 <= W <= ld");
+    if (W == 0) return OCTO_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t ldd = (W + 63) / 64 * 64;
+    int rc = grow(ctx, m->d_th, m->cap_th, (int64_t)m->D * ldd);
+    if (rc) return rc;
+    rc = grow(ctx, m->d_res, m->cap_res, (int64_t)(m->D + 1) * ldd);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpy2DAsync(m->d_th, sizeof(double) * ldd, theta_t, sizeof(double) * ld, sizeof(double) * W, m->D, hipMemcpyHostToDevice, st));
+    rc = octo_model_logpost_device(ctx, m, m->d_th, ldd, W, m->d_res, grad_out ? m->d_res + ldd : nullptr, st);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(lp_out, m->d_res, sizeof(double) * W, hipMemcpyDeviceToHost, st));
+    if (grad_out)
+        HIPCHK(ctx, hipMemcpy2DAsync(grad_out, sizeof(double) * ld, m->d_res + ldd, sizeof(double) * ldd, sizeof(double) * W, m->D, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
     return OCTO_OK;
 }
 

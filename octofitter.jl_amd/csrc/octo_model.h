@@ -1,0 +1,206 @@
+// octo_model.h — standard parameterisation on the device: θ_t -> natural θ (Bijectors invlink,
+// src/variables.jl:1449-1493), log-prior with Jacobian in declaration order (:1205-1369), UniformCircular angles and
+// their UnitLengthPrior terms (:279-323), tp = θ_at_epoch_to_tperi (src/parameterizations.jl:6-69) -> the kernel's
+// inputs, their Jacobian w.r.t. θ_t by forward-mode duals (exactly what ForwardDiff does on the host in the reference,
+// src/logdensitymodel.jl:169-177 — this part has no epoch loop, it is O(W·D²)), then after the likelihood kernels
+// ∇θ_t = Jᵀ ḡ + ∇(prior). One thread per walker; cost is negligible next to k_main.
+#pragma once
+#include "octo_kernels.h"
+
+namespace octo {
+
+template <int N>
+struct Dual {
+    double v;
+    double d[N];
+};
+
+#define DFOR _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_)
+template <int N> __device__ __forceinline__ Dual<N> dconst(double x) { Dual<N> r; r.v = x; DFOR r.d[k_] = 0.0; return r; }
+template <int N> __device__ __forceinline__ Dual<N> dvar(double x, int slot) { Dual<N> r = dconst<N>(x); DFOR r.d[k_] = (k_ == slot) ? 1.0 : 0.0; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v; DFOR r.d[k_] = a.d[k_] + b.d[k_]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v; DFOR r.d[k_] = a.d[k_] - b.d[k_]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a) { Dual<N> r; r.v = -a.v; DFOR r.d[k_] = -a.d[k_]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v; DFOR r.d[k_] = a.d[k_] * b.v + a.v * b.d[k_]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r; r.v = a.v / b.v; const double ib = 1.0 / b.v; DFOR r.d[k_] = (a.d[k_] - r.v * b.d[k_]) * ib; return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, double s) { Dual<N> r; r.v = a.v * s; DFOR r.d[k_] = a.d[k_] * s; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, double s) { Dual<N> r = a; r.v = a.v + s; return r; }
+template <int N> __device__ __forceinline__ Dual<N> chain(const Dual<N>& a, double fv, double df) { Dual<N> r; r.v = fv; DFOR r.d[k_] = a.d[k_] * df; return r; }
+template <int N> __device__ __forceinline__ Dual<N> dsqrt(const Dual<N>& a) { const double s = sqrt(a.v); return chain(a, s, 0.5 / s); }
+template <int N> __device__ __forceinline__ Dual<N> dlog(const Dual<N>& a) { return chain(a, log(a.v), 1.0 / a.v); }
+template <int N> __device__ __forceinline__ Dual<N> dsin(const Dual<N>& a) { return chain(a, sin(a.v), cos(a.v)); }
+template <int N> __device__ __forceinline__ Dual<N> dcos(const Dual<N>& a) { return chain(a, cos(a.v), -sin(a.v)); }
+template <int N> __device__ __forceinline__ Dual<N> datan2(const Dual<N>& y, const Dual<N>& x) {
+    Dual<N> r; r.v = atan2(y.v, x.v); const double ih = 1.0 / (x.v * x.v + y.v * y.v);
+    DFOR r.d[k_] = (x.v * y.d[k_] - y.v * x.d[k_]) * ih; return r;
+}
+
+struct ModelArgs {
+    const octo_prior* priors;       // [D]
+    const octo_source* esrc;        // [n_el]
+    const octo_source* nsrc;        // [n_nu] or null
+    const DevObs* obs;
+    int32_t D, n_el, n_nu, n_planets;
+    const double* theta_t; int64_t ld, W, ldw;
+    double* elems; double* nuis;    // [n_el][ldw], [n_nu][ldw]   (kernel inputs)
+    double* J;                      // [(n_el+n_nu)*D][ldw]
+    double* lpp; double* glp;       // [ldw], [D][ldw]            (prior + UnitLength terms and their θ_t-gradient)
+    const double* ll; const double* g_el; const double* g_nu;     // from the likelihood kernels
+    double* lp_out; double* grad_out;
+    double k_yr, yd;
+};
+
+// Bijectors.invlink + logpdf_with_trans (TruncatedBijector; Distributions densities) — mirrors oracle/octo_oracle_core.inc
+template <int N>
+__device__ __forceinline__ void prior_apply(const octo_prior& pr, const Dual<N>& y, Dual<N>& x, Dual<N>& lp) {
+    double a = -INFINITY, b = INFINITY;
+    if (pr.kind == OCTO_PRIOR_UNIFORM || pr.kind == OCTO_PRIOR_LOGUNIFORM) { a = pr.p0; b = pr.p1; }
+    else if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) { a = pr.lo; b = pr.hi; }
+    else if (pr.kind == OCTO_PRIOR_SINE) { a = 0.0 + 2.220446049250313e-16; b = PI - 2.220446049250313e-16; }
+    Dual<N> ladj;
+    if (isfinite(a) && isfinite(b)) {
+        const double sg = 1.0 / (1.0 + exp(-y.v));
+        x = chain(y, (b - a) * sg + a, (b - a) * sg * (1.0 - sg));
+        ladj = dlog(((x + (-a)) * (dconst<N>(b) - x)) * (1.0 / (b - a)));
+    } else if (isfinite(a)) {
+        const double ey = exp(y.v);
+        x = chain(y, ey + a, ey);
+        ladj = dlog(x + (-a));
+    } else if (isfinite(b)) {
+        const double ey = exp(y.v);
+        x = chain(y, b - ey, -ey);
+        ladj = dlog(dconst<N>(b) - x);
+    } else {
+        x = y; ladj = dconst<N>(0.0);
+    }
+    switch (pr.kind) {
+        case OCTO_PRIOR_UNIFORM: lp = dconst<N>((x.v >= a && x.v <= b) ? -log(b - a) : -INFINITY); break;
+        case OCTO_PRIOR_LOGUNIFORM: lp = (x.v >= a && x.v <= b) ? dlog(dconst<N>(1.0) / (x * log(b / a))) : dconst<N>(-INFINITY); break;
+        case OCTO_PRIOR_NORMAL: case OCTO_PRIOR_TRUNCNORMAL: {
+            const Dual<N> z = (x + (-pr.p0)) * (1.0 / pr.p1);
+            lp = (-(z * z + LOG2PI)) * 0.5 + (-log(pr.p1));
+            if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) {
+                const double lo = isfinite(pr.lo) ? 0.5 * erfc(-((pr.lo - pr.p0) / pr.p1) * 0.70710678118654752440) : 0.0;
+                const double hi = isfinite(pr.hi) ? 0.5 * erfc(-((pr.hi - pr.p0) / pr.p1) * 0.70710678118654752440) : 1.0;
+                lp = lp + (-log(hi - lo));
+                if (!(x.v >= pr.lo && x.v <= pr.hi)) lp = dconst<N>(-INFINITY);
+            }
+            break;
+        }
+        case OCTO_PRIOR_SINE: lp = (x.v > 0.0 && x.v < PI) ? dlog(dsin(x) * 0.5) : dconst<N>(-INFINITY); break;
+        default: lp = dconst<N>(NAN);
+    }
+    lp = lp + ladj;
+}
+
+// logpdf(LogNormal(log(1.0), 0.1), sqrt(x² + y²))   src/variables.jl:309-323
+template <int N>
+__device__ __forceinline__ Dual<N> unit_length(const Dual<N>& x, const Dual<N>& y) {
+    const Dual<N> r = dsqrt(x * x + y * y);
+    const Dual<N> z = dlog(r) * 10.0;
+    return (-(z * z + LOG2PI)) * 0.5 - dlog(r * 0.1);
+}
+
+// θ_at_epoch_to_tperi   src/parameterizations.jl:34-67
+template <int N>
+__device__ __forceinline__ Dual<N> tperi(const Dual<N>& th, double theta_epoch, const Dual<N>& M, const Dual<N>& e, const Dual<N>& a,
+                                         const Dual<N>& inc, const Dual<N>& w, const Dual<N>& O, double k_yr, double yd) {
+    const Dual<N> cO = dcos(O), sO = dsin(O), cw = dcos(w), sw = dsin(w), ci = dcos(inc);
+    const Dual<N> A = cO * cw - sO * sw * ci, B = sO * cw + cO * sw * ci;
+    const Dual<N> F = -(cO * sw) - sO * cw * ci, G = -(sO * sw) + cO * cw * ci;
+    const Dual<N> ct = dcos(th), st = dsin(th);
+    const Dual<N> det = A * G - F * B;
+    const Dual<N> xr = (G * ct - F * st) / det, yr = (A * st - B * ct) / det;
+    const Dual<N> nu = datan2(yr, xr);
+    const Dual<N> s1 = dsqrt(dconst<N>(1.0) - e * e);
+    const Dual<N> sn = dsin(nu), cn = dcos(nu);
+    const Dual<N> MA = datan2(-(s1 * sn), -e - cn) + PI - (e * s1 * sn) / (e * cn + 1.0);
+    const Dual<N> period_yrs = dsqrt(a * a * a / M) * (k_yr / yd);
+    const Dual<N> n = dconst<N>(TWO_PI) / period_yrs;
+    return dconst<N>(theta_epoch) - (MA / n) * yd;
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_model_fwd(ModelArgs a) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.W) return;
+    const int D = a.D;
+    bool finite_in = true;
+    for (int k = 0; k < D; ++k) finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + w]);   // logdensitymodel.jl:120-124
+    Dual<N> x[N];
+    Dual<N> lp = dconst<N>(0.0);
+    bool healed = false;
+    for (int k = 0; k < D; ++k) {
+        Dual<N> p;
+        prior_apply(a.priors[k], dvar<N>(a.theta_t[(int64_t)k * a.ld + w], k), x[k], p);
+        if (!healed) {
+            if (!isfinite(p.v)) { lp = dconst<N>(-1.7976931348623157e308); healed = true; }   // variables.jl:1229-1236
+            else lp = lp + p;
+        }
+    }
+    const int n_in = a.n_el + a.n_nu;
+    // pass 0: everything but tperi; pass 1: tperi (needs the planet's other elements)
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int k = 0; k < n_in; ++k) {
+            octo_source sc;
+            if (k < a.n_el) sc = a.esrc[k];
+            else if (a.nsrc) sc = a.nsrc[k - a.n_el];
+            else {
+                const int r = (k - a.n_el) % OCTO_N_NUIS; const int kind = a.obs[(k - a.n_el) / OCTO_N_NUIS].kind;
+                sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
+                sc.value = (kind <= OCTO_ASTROM_SEPPA && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+            }
+            if ((sc.kind == OCTO_SRC_TPERI) != (pass == 1)) continue;
+            Dual<N> val;
+            if (sc.kind == OCTO_SRC_CONST) val = dconst<N>(sc.value);
+            else if (sc.kind == OCTO_SRC_THETA) val = x[sc.i0];
+            else {
+                const Dual<N> ang = datan2(x[sc.i1], x[sc.i0]);
+                if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(x[sc.i0], x[sc.i1]);
+                if (sc.kind == OCTO_SRC_CIRCULAR) val = ang * (sc.value / TWO_PI);      // atan(y, x) / 2π * domain, variables.jl:284
+                else {
+                    // re-read the planet's resolved elements (values + Jacobian rows) written in pass 0
+                    const int p = k / OCTO_N_EL;
+                    Dual<N> el[OCTO_N_EL];
+                    for (int q = 0; q < OCTO_N_EL; ++q) {
+                        const int kk = p * OCTO_N_EL + q;
+                        el[q].v = a.elems[(int64_t)kk * a.ldw + w];
+                        DFOR el[q].d[k_] = (k_ < D) ? a.J[((int64_t)kk * D + k_) * a.ldw + w] : 0.0;
+                    }
+                    val = tperi(ang, sc.value, el[OCTO_EL_M], el[OCTO_EL_E], el[OCTO_EL_A], el[OCTO_EL_I], el[OCTO_EL_W], el[OCTO_EL_O], a.k_yr, a.yd);
+                }
+            }
+            double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
+            *dst = val.v;
+            DFOR { if (k_ < D) a.J[((int64_t)k * D + k_) * a.ldw + w] = val.d[k_]; }
+        }
+    }
+    a.lpp[w] = finite_in ? lp.v : -INFINITY;
+    DFOR { if (k_ < D) a.glp[(int64_t)k_ * a.ldw + w] = healed ? 0.0 : lp.d[k_]; }
+}
+
+__global__ __launch_bounds__(256) void k_model_bwd(ModelArgs a) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.W) return;
+    const double lpp = a.lpp[w], ll = a.ll[w];
+    // ℓπcallback: non-finite θ_t or prior -> return it without the likelihood (logdensitymodel.jl:120-133)
+    double lp = isfinite(lpp) ? lpp + ll : lpp;
+    if (isnan(lp)) lp = -INFINITY;
+    a.lp_out[w] = lp;
+    if (!a.grad_out) return;
+    const bool ok = isfinite(lp);
+    const int n_in = a.n_el + a.n_nu;
+    for (int d = 0; d < a.D; ++d) {
+        double g = a.glp[(int64_t)d * a.ldw + w];
+        for (int k = 0; k < n_in; ++k) {
+            const double gk = k < a.n_el ? a.g_el[(int64_t)k * a.ldw + w] : (a.g_nu ? a.g_nu[(int64_t)(k - a.n_el) * a.ldw + w] : 0.0);
+            g = fma(a.J[((int64_t)k * a.D + d) * a.ldw + w], gk, g);
+        }
+        a.grad_out[(int64_t)d * a.ld + w] = ok ? g : 0.0;
+    }
+}
+#undef DFOR
+
+}  // namespace octo

@@ -61,6 +61,19 @@ class OctoPlanetDesc(C.Structure):
     _fields_ = [("orbit_kind", C.c_int32), ("has_mass", C.c_int32)]
 
 
+PRIOR_UNIFORM, PRIOR_LOGUNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_SINE = 0, 1, 2, 3, 4
+SRC_CONST, SRC_THETA, SRC_CIRCULAR, SRC_TPERI = 0, 1, 2, 3
+SRC_FLAG_UNITLEN = 1
+
+
+class OctoPrior(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pad", C.c_int32), ("p0", C.c_double), ("p1", C.c_double), ("lo", C.c_double), ("hi", C.c_double)]
+
+
+class OctoSource(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("i0", C.c_int32), ("i1", C.c_int32), ("flags", C.c_int32), ("value", C.c_double)]
+
+
 class OctoError(RuntimeError):
     def __init__(self, status, msg=""):
         super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
@@ -122,6 +135,11 @@ _SIGS = {
     "octo_ofti_destroy": (C.c_int32, [C.c_void_p]),
     "octo_ofti_eval": (C.c_int32, [C.c_void_p, C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),
     "octo_ofti_eval_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "octo_model_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(OctoPrior), C.c_int32, C.POINTER(OctoSource), C.POINTER(OctoSource),
+                                      C.POINTER(C.c_void_p)]),
+    "octo_model_destroy": (C.c_int32, [C.c_void_p]),
+    "octo_model_logpost": (C.c_int32, [C.c_void_p, C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),
+    "octo_model_logpost_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "octo_timing_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "octo_timing_read": (C.c_int32, [C.c_void_p, c_double_p, C.POINTER(C.c_int64), C.c_int32]),
     "octo_pt_swap_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,

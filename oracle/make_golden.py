@@ -223,8 +223,68 @@ def ofti_cases():
     print("wrote", p, p.stat().st_size, "bytes")
 
 
+def model_cases():
+    """tests/golden/model.json — the full callback ℓπcallback/∇ℓπcallback (src/logdensitymodel.jl:110-177) for
+    (1) the D = 11 model every reference test uses (test/integration/sampling.jl:29-64: tutorial 8-epoch table,
+        a~Uniform(0,100), e~Uniform(0,0.99), i~Sine(), ω,Ω,θ~UniformCircular(), tp=θ_at_epoch_to_tperi(θ,50000;…),
+        M~truncated(Normal(1.2,0.1),lower=0.1), plx~truncated(Normal(50,0.02),lower=0.1)), and
+    (2) a D = 26 two-planet model with relative astrometry (jitter, northangle priors), absolute RV (offset, jitter
+        priors), LogUniform / Normal / two-sided truncated priors and masses."""
+    rng = np.random.default_rng(20260929 + 41)
+    P = lambda kind, p0=0.0, p1=0.0, lo=None, hi=None: dict(kind=kind, p0=p0, p1=p1, lo=lo, hi=hi)
+    S = lambda kind, i0=0, i1=0, flags=0, value=0.0: dict(kind=kind, i0=i0, i1=i1, flags=flags, value=value)
+    N01 = P(2, 0.0, 1.0)
+    out = []
+    # ---- (1)
+    ep2 = [50000, 50120, 50240, 50360, 50480, 50600, 50720, 50840]
+    ra2 = [-505.76, -502.57, -498.21, -492.68, -485.98, -478.11, -469.08, -458.90]      # sampling.jl:32-33 (rounded table)
+    dec2 = [-66.93, -37.47, -7.93, 21.64, 51.15, 80.54, 109.73, 138.65]
+    obs = [astrom(0, ep2, ra2, dec2, [10.0] * 8, [10.0] * 8, cor=[0.0] * 8)]
+    priors = [P(3, 1.2, 0.1, 0.1, None), P(3, 50.0, 0.02, 0.1, None), P(0, 0.0, 100.0), P(0, 0.0, 0.99), P(4)] + [N01] * 6
+    esrc = [S(1, 2), S(1, 3), S(1, 4), S(2, 5, 6, 1, 2 * np.pi), S(2, 7, 8, 1, 2 * np.pi), S(3, 9, 10, 1, 50000.0), S(1, 0), S(1, 1), S(0)]
+    W = 10
+    th = rng.normal(0, 1, (11, W))
+    th[2] = rng.normal(-1.6, 0.4, W)          # a = 100·logistic(·) ~ 10-25 AU
+    th[0] = np.log(rng.normal(1.2, 0.05, W) - 0.1); th[1] = np.log(rng.normal(50.0, 0.02, W) - 0.1)
+    th[:, 0] = [np.log(1.1), np.log(49.9), -2.0, -2.0, 0.1, 0.78, 0.62, 0.96, 0.28, -0.5, 0.8]
+    res = [mpo.model_logpost_and_grad(C, [VIS], obs, priors, esrc, None, list(th[:, w])) for w in range(W)]
+    out.append(dict(name="D11_reference_test_model", planets=[VIS], obs=obs, priors=priors, esrc=esrc, nsrc=None, theta_t=th.tolist(),
+                    lp=[fl(r[0]) for r in res], grad=np.array([[fl(v) for v in r[1]] for r in res]).T.tolist()))
+    print(f"  D11: lp[0]={out[-1]['lp'][0]:.12g}", flush=True)
+    # ---- (2)
+    ep6 = 50000.0 + 137.0 * np.arange(7)
+    ra6 = rng.normal(0, 300, 7); dec6 = rng.normal(0, 300, 7)
+    epr = 50010.0 + 91.0 * np.arange(9); rv6 = rng.normal(0, 40, 9)
+    obs2 = [astrom(1, ep6, ra6, dec6, [8.0] * 7, [9.0] * 7, cor=[0.3] * 7), rvtab("RV_ABS", -1, epr, rv6, [5.0] * 9)]
+    # θ order: system [M, plx], system obs (rv) [offset, jitter], planet b [a, e, i, ωx, ωy, Ωx, Ωy, tp, mass],
+    #          planet c [a, e, i, ωx, ωy, Ωx, Ωy, θx, θy, mass], c's astrometry [jitter, northangle]
+    priors2 = [P(3, 1.2, 0.1, 0.5, 2.0), P(2, 50.0, 0.5),                     # M two-sided truncated, plx Normal
+               P(2, 0.0, 30.0), P(1, 0.1, 50.0),                             # rv offset, jitter
+               P(1, 1.0, 5.0), P(0, 0.0, 0.9), P(4), N01, N01, N01, N01, P(0, 49000.0, 51000.0), P(1, 0.5, 50.0),
+               P(1, 8.0, 40.0), P(0, 0.0, 0.9), P(4), N01, N01, N01, N01, N01, N01, P(0, 0.0, 30.0),
+               P(1, 0.1, 20.0), P(2, 0.0, 0.05)]
+    D2 = len(priors2)
+    esrc2 = [S(1, 4), S(1, 5), S(1, 6), S(2, 7, 8, 1, 2 * np.pi), S(2, 9, 10, 1, 2 * np.pi), S(1, 11), S(1, 0), S(1, 1), S(1, 12),
+             S(1, 13), S(1, 14), S(1, 15), S(2, 16, 17, 1, 2 * np.pi), S(2, 18, 19, 1, 2 * np.pi), S(3, 20, 21, 1, 50000.0), S(1, 0), S(1, 1), S(1, 22)]
+    nsrc2 = [S(1, 23), S(0, value=1.0), S(1, 24), S(1, 2), S(1, 3), S(0)]
+    W2 = 6
+    th2 = rng.normal(0, 1, (D2, W2))
+    th2[1] = 50.0 + 0.5 * rng.normal(0, 1, W2)        # plx ~ Normal(50, 0.5): identity link, keep it physical
+    th2[24] = 0.05 * rng.normal(0, 1, W2)             # northangle ~ Normal(0, 0.05)
+    res2 = [mpo.model_logpost_and_grad(C, [VISM, VISM], obs2, priors2, esrc2, nsrc2, list(th2[:, w])) for w in range(W2)]
+    out.append(dict(name="D25_two_planet_rv", planets=[VISM, VISM], obs=obs2, priors=priors2, esrc=esrc2, nsrc=nsrc2, theta_t=th2.tolist(),
+                    lp=[fl(r[0]) for r in res2], grad=np.array([[fl(v) for v in r[1]] for r in res2]).T.tolist()))
+    print(f"  D{D2}: lp[0]={out[-1]['lp'][0]:.12g}", flush=True)
+    p = ROOT / "tests" / "golden" / "model.json"
+    p.write_text(json.dumps(dict(consts=C, cases=out, generator="oracle/make_golden.py model_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(ROOT / "oracle"))
-    if "--ofti-only" not in sys.argv:
+    if "--ofti-only" not in sys.argv and "--model-only" not in sys.argv:
         main()
-    ofti_cases()
+    if "--model-only" not in sys.argv:
+        ofti_cases()
+    if "--ofti-only" not in sys.argv:
+        model_cases()

@@ -245,3 +245,124 @@ def ofti_linear_solve(c, epochs, ra, dec, s_ra, s_dec, cor, sigma_abfg, e, a, tp
     pq = (mu.T * b)[0]
     lm = -(dq - pq + mp.log(mp.det(S)) - 4 * mp.log(lam) + ldc) / 2 - N * mp.log(2 * mp.pi)
     return mu[0], mu[1], mu[2], mu[3], lm
+
+
+# ------------------------------------------------------------------------------------------- standard parameterisation
+PRIOR_KINDS = {"UNIFORM": 0, "LOGUNIFORM": 1, "NORMAL": 2, "TRUNCNORMAL": 3, "SINE": 4}
+_EPS = mp.mpf(2) ** -52
+
+
+def _prior(pr, y):
+    """(x, logpdf_with_trans) for one prior dict(kind, p0, p1, lo, hi) at unconstrained y — closed forms, 60 digits."""
+    kind = pr["kind"]
+    inf = mp.inf
+    if kind in (0, 1):
+        a, b = mp.mpf(pr["p0"]), mp.mpf(pr["p1"])
+    elif kind == 3:
+        a = -inf if pr["lo"] is None else mp.mpf(pr["lo"])
+        b = inf if pr["hi"] is None else mp.mpf(pr["hi"])
+    elif kind == 4:
+        a, b = _EPS, mp.pi - _EPS          # Float64 eps: minimum/maximum of Sine() in the reference (distributions.jl:31-32)
+        a, b = mp.mpf(2.220446049250313e-16), mp.mpf(3.141592653589793) - mp.mpf(2.220446049250313e-16)
+    else:
+        a, b = -inf, inf
+    if a > -inf and b < inf:
+        sg = 1 / (1 + mp.exp(-y))
+        x = (b - a) * sg + a
+        ladj = mp.log(b - a) + mp.log(sg) + mp.log(1 - sg)          # log |dx/dy|
+    elif a > -inf:
+        x = mp.exp(y) + a
+        ladj = y
+    elif b < inf:
+        x = b - mp.exp(y)
+        ladj = y
+    else:
+        x, ladj = y, mp.mpf(0)
+    if kind == 0:
+        lp = -mp.log(b - a)
+    elif kind == 1:
+        lp = -mp.log(x) - mp.log(mp.log(b / a))
+    elif kind in (2, 3):
+        mu, sg_ = mp.mpf(pr["p0"]), mp.mpf(pr["p1"])
+        lp = -((x - mu) / sg_) ** 2 / 2 - mp.log(sg_) - mp.log(2 * mp.pi) / 2
+        if kind == 3:
+            lo = mp.ncdf((a - mu) / sg_) if a > -inf else mp.mpf(0)
+            hi = mp.ncdf((b - mu) / sg_) if b < inf else mp.mpf(1)
+            lp -= mp.log(hi - lo)
+    else:
+        lp = mp.log(mp.sin(x) / 2)
+    return x, lp + ladj
+
+
+def _tperi(c, th, epoch, M, e, a, inc, w, O):
+    """Epoch of periastron such that the position angle at `epoch` is th — textbook route: PA -> true anomaly in the
+    orbital plane -> eccentric -> mean anomaly -> tp (independent of the reference's matrix-solve formulation)."""
+    # direction on the sky at PA th: (east, north) = (sin th, cos th); invert the rotation for the in-plane angle u = ν + ω
+    # east = r (cos u sinΩ + sin u cos i cosΩ), north = r (cos u cosΩ − sin u cos i sinΩ)
+    # => cos u ∝ north cosΩ + east sinΩ ; sin u cos i ∝ east cosΩ − north sinΩ
+    east, north = mp.sin(th), mp.cos(th)
+    cu = north * mp.cos(O) + east * mp.sin(O)
+    su = (east * mp.cos(O) - north * mp.sin(O)) / mp.cos(inc)
+    nu = mp.atan2(su, cu) - w
+    E = 2 * mp.atan(mp.sqrt((1 - e) / (1 + e)) * mp.tan(nu / 2))
+    MA = E - e * mp.sin(E)
+    MA = MA - 2 * mp.pi * mp.floor(MA / (2 * mp.pi))          # the reference's formula yields MA in [0, 2π)
+    P_d = mp.mpf(c["kepler_year_to_julian_day"]) * mp.sqrt(a ** 3 / M)
+    return mp.mpf(epoch) - MA / (2 * mp.pi) * P_d
+
+
+def model_logpost(c, planets, obs, priors, esrc, nsrc, theta_t):
+    """One walker. priors: list of dicts; esrc/nsrc: lists of dict(kind, i0, i1, flags, value). Returns lp (mpf)."""
+    x = []
+    lp = mp.mpf(0)
+    for pr, y in zip(priors, theta_t):
+        xi, l = _prior(pr, mp.mpf(y))
+        x.append(xi)
+        lp += l
+    n_pl = len(planets)
+    elems = [[None] * N_EL for _ in range(n_pl)]
+    ul = mp.mpf(0)
+
+    def unit_len(i0, i1):
+        r = mp.sqrt(x[i0] ** 2 + x[i1] ** 2)
+        return -mp.log(r) - mp.log(mp.mpf("0.1") * mp.sqrt(2 * mp.pi)) - mp.log(r) ** 2 / (2 * mp.mpf("0.01"))
+
+    def resolve(sc, p):
+        nonlocal ul
+        if sc["kind"] == 0:
+            return mp.mpf(sc["value"])
+        if sc["kind"] == 1:
+            return x[sc["i0"]]
+        ang = mp.atan2(x[sc["i1"]], x[sc["i0"]])
+        if sc["flags"] & 1:
+            ul += unit_len(sc["i0"], sc["i1"])
+        if sc["kind"] == 2:
+            return ang / (2 * mp.pi) * mp.mpf(sc["value"])
+        e_ = elems[p]
+        return _tperi(c, ang, sc["value"], e_[6], e_[1], e_[0], e_[2], e_[3], e_[4])
+    for want in (False, True):
+        for k, sc in enumerate(esrc):
+            if (sc["kind"] == 3) == want:
+                elems[k // N_EL][k % N_EL] = resolve(sc, k // N_EL)
+    nuis = None
+    if nsrc is not None:
+        flat = [resolve(sc, 0) for sc in nsrc]
+        nuis = [flat[i * N_NUIS:(i + 1) * N_NUIS] for i in range(len(obs))]
+    else:
+        nuis = [[mp.mpf(0), mp.mpf(1), mp.mpf(0)] if (KINDS[o["kind"]] if isinstance(o["kind"], str) else o["kind"]) <= 1 else [mp.mpf(0)] * 3 for o in obs]
+    return lp + ul + ln_like(c, planets, obs, elems, nuis)
+
+
+def model_logpost_and_grad(c, planets, obs, priors, esrc, nsrc, theta_t, h=mp.mpf(10) ** -25):
+    th = [mp.mpf(v) for v in theta_t]
+    f0 = model_logpost(c, planets, obs, priors, esrc, nsrc, th)
+    g = []
+    for k in range(len(th)):
+        t0 = th[k]
+        th[k] = t0 + h
+        fp = model_logpost(c, planets, obs, priors, esrc, nsrc, th)
+        th[k] = t0 - h
+        fm = model_logpost(c, planets, obs, priors, esrc, nsrc, th)
+        th[k] = t0
+        g.append((fp - fm) / (2 * h))
+    return f0, g

@@ -273,6 +273,35 @@ int32_t octo_oracle_ofti(const octo_consts* c, const double* epochs, const doubl
     return OCTO_OK;
 }
 
+int32_t octo_oracle_model_logpost(const octo_consts* c, const octo_obs_desc* obs, int32_t n_obs,
+                                  const octo_planet_desc* planets, int32_t n_planets,
+                                  const octo_prior* priors, int32_t D, const octo_source* elem_src, const octo_source* nuis_src,
+                                  const double* theta_t, int64_t ld, int64_t W, double* lp_out, double* grad_out, int32_t n_threads) {
+    if (!c || !planets || !priors || !elem_src || !theta_t || !lp_out || D < 1 || D > 64 || W < 0 || ld < W) return OCTO_EINVAL;
+    const int np = !grad_out ? 0 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 8) num_threads(n_threads)
+    for (int64_t w = 0; w < W; ++w) {
+        double th[64], g[64];
+        for (int k = 0; k < D; ++k) th[k] = theta_t[(int64_t)k * ld + w];
+        double lp;
+        switch (np) {
+            case 0:  lp = model_logpost_np0(c, obs, n_obs, planets, n_planets, priors, D, elem_src, nuis_src, th, NULL); break;
+            case 8:  lp = model_logpost_np8(c, obs, n_obs, planets, n_planets, priors, D, elem_src, nuis_src, th, g); break;
+            case 16: lp = model_logpost_np16(c, obs, n_obs, planets, n_planets, priors, D, elem_src, nuis_src, th, g); break;
+            case 32: lp = model_logpost_np32(c, obs, n_obs, planets, n_planets, priors, D, elem_src, nuis_src, th, g); break;
+            default: lp = model_logpost_np64(c, obs, n_obs, planets, n_planets, priors, D, elem_src, nuis_src, th, g); break;
+        }
+        lp_out[w] = lp;
+        if (grad_out) for (int k = 0; k < D; ++k) grad_out[(int64_t)k * ld + w] = isfinite(lp) ? g[k] : 0.0;
+    }
+    return OCTO_OK;
+}
+
 int32_t octo_oracle_consts_default(octo_consts* out) {
     if (!out) return OCTO_EINVAL;
     /* [PO] PlanetOrbits.jl constants (recalled from the public source; the host passes the

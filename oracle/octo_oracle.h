@@ -21,6 +21,10 @@ int32_t octo_oracle_consts_default(octo_consts* out);
 int32_t octo_oracle_ofti(const octo_consts* c, const double* epochs, const double* ra, const double* dec, const double* s_ra,
                          const double* s_dec, const double* cor, int64_t N, double sigma_abfg, const double* nl5, double* out5);
 int32_t octo_oracle_max_partials(void);
+int32_t octo_oracle_model_logpost(const octo_consts* c, const octo_obs_desc* obs, int32_t n_obs,
+                                  const octo_planet_desc* planets, int32_t n_planets,
+                                  const octo_prior* priors, int32_t D, const octo_source* elem_src, const octo_source* nuis_src,
+                                  const double* theta_t, int64_t ld, int64_t W, double* lp_out, double* grad_out, int32_t n_threads);
 #ifdef __cplusplus
 }
 #endif

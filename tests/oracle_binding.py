@@ -42,6 +42,10 @@ def load_oracle():
     lib.octo_oracle_orbitsolve.argtypes = [C.POINTER(capi.OctoConsts), C.c_int32, dp, C.c_double, dp]
     lib.octo_oracle_consts_default.restype = C.c_int32
     lib.octo_oracle_consts_default.argtypes = [C.POINTER(capi.OctoConsts)]
+    lib.octo_oracle_model_logpost.restype = C.c_int32
+    lib.octo_oracle_model_logpost.argtypes = [C.POINTER(capi.OctoConsts), C.POINTER(capi.OctoObsDesc), C.c_int32,
+                                              C.POINTER(capi.OctoPlanetDesc), C.c_int32, C.POINTER(capi.OctoPrior), C.c_int32,
+                                              C.POINTER(capi.OctoSource), C.POINTER(capi.OctoSource), dp, C.c_int64, C.c_int64, dp, dp, C.c_int32]
     lib.octo_oracle_ofti.restype = C.c_int32
     lib.octo_oracle_ofti.argtypes = [C.POINTER(capi.OctoConsts), dp, dp, dp, dp, dp, dp, C.c_int64, C.c_double, dp, dp]
     _lib = lib
@@ -103,3 +107,36 @@ def oracle_ofti(epochs, ra, dec, s_ra, s_dec, cor, sigma_abfg, nl, consts=None):
                                     capi._dptr(x), capi._dptr(out)) == 0
         abfg[:, w] = out[:4]; lm[w] = out[4]
     return abfg, lm
+
+
+def make_priors(priors):
+    """list of dict(kind, p0, p1, lo, hi) -> ctypes array (None bounds = open)."""
+    arr = (capi.OctoPrior * len(priors))()
+    for k, p in enumerate(priors):
+        arr[k].kind = int(p["kind"]); arr[k].p0 = float(p["p0"]); arr[k].p1 = float(p["p1"])
+        arr[k].lo = -np.inf if p["lo"] is None else float(p["lo"]); arr[k].hi = np.inf if p["hi"] is None else float(p["hi"])
+    return arr
+
+
+def make_sources(srcs):
+    arr = (capi.OctoSource * max(len(srcs), 1))()
+    for k, s in enumerate(srcs):
+        arr[k].kind, arr[k].i0, arr[k].i1, arr[k].flags, arr[k].value = int(s["kind"]), int(s["i0"]), int(s["i1"]), int(s["flags"]), float(s["value"])
+    return arr
+
+
+def oracle_model_logpost(obs_tables, planets, priors, esrc, nsrc, theta_t, grad=True, consts=None, n_threads=1):
+    """priors / esrc / nsrc: ctypes arrays (make_priors / make_sources, or a LogDensityModel mirror's _c_* arrays)."""
+    lib = load_oracle()
+    consts = consts or oracle_consts()
+    th = np.ascontiguousarray(theta_t, dtype=np.float64)
+    D, W = th.shape
+    obs_arr, keep = capi.pack_obs(obs_tables)
+    pl_arr = capi.pack_planets(planets)
+    lp = np.empty(W)
+    g = np.zeros_like(th) if grad else None
+    st = lib.octo_oracle_model_logpost(C.byref(consts), obs_arr, len(obs_tables), pl_arr, len(planets), priors, D, esrc, nsrc,
+                                       capi._dptr(th), W, W, capi._dptr(lp), capi._dptr(g), n_threads)
+    assert st == 0, st
+    del keep
+    return lp, g

@@ -1,0 +1,153 @@
+"""
+Standard parameterisation on the device: the whole ℓπcallback / ∇ℓπcallback
+(src/logdensitymodel.jl:110-177) for models made of the reference's standard building blocks.
+CPU: oracle restatement vs the 60-digit fixture. GPU: the HIP path vs fixture and oracle, and the reference's
+own model-level tests re-expressed through the LogDensityModel mirror.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import KIND_IDS
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def model_golden():
+    return json.loads((ROOT / "tests" / "golden" / "model.json").read_text())["cases"]
+
+
+def _tables(case):
+    obs = [dict(kind=KIND_IDS[o["kind"]], planet=o["planet"],
+                **{k: (None if o[k] is None else np.asarray(o[k], dtype=np.float64)) for k in ("epoch", "y1", "y2", "s1", "s2", "cor")}) for o in case["obs"]]
+    return obs, case["planets"]
+
+
+def _check(lp, g, case, rtol_lp=1e-12, rtol_g=1e-9):
+    ref_lp = np.asarray(case["lp"]); ref_g = np.asarray(case["grad"])
+    assert np.all(np.abs(lp - ref_lp) <= rtol_lp * np.maximum(1, np.abs(ref_lp))), np.max(np.abs(lp - ref_lp) / np.maximum(1, np.abs(ref_lp)))
+    scale = np.abs(ref_g).max(axis=1, keepdims=True)
+    tol = rtol_g * np.abs(ref_g) + 1e-12 * scale
+    assert np.all(np.abs(g - ref_g) <= tol), np.max(np.abs(g - ref_g) / tol)
+
+
+def test_oracle_model_vs_golden(oracle, model_golden):
+    for case in model_golden:
+        obs, planets = _tables(case)
+        lp, g = oracle.oracle_model_logpost(obs, planets, oracle.make_priors(case["priors"]), oracle.make_sources(case["esrc"]),
+                                            None if case["nsrc"] is None else oracle.make_sources(case["nsrc"]), np.asarray(case["theta_t"]))
+        _check(lp, g, case)
+        lp0, _ = oracle.oracle_model_logpost(obs, planets, oracle.make_priors(case["priors"]), oracle.make_sources(case["esrc"]),
+                                             None if case["nsrc"] is None else oracle.make_sources(case["nsrc"]), np.asarray(case["theta_t"]), grad=False)
+        assert np.array_equal(lp0, lp)
+
+
+def test_oracle_model_edges(oracle, model_golden):
+    case = model_golden[0]
+    obs, planets = _tables(case)
+    th = np.asarray(case["theta_t"])[:, :3].copy()
+    th[3, 0] = np.nan                    # non-finite θ_t -> -Inf   (logdensitymodel.jl:120-124)
+    th[3, 1] = 800.0                     # logistic saturates: e == upper bound -> Jacobian term -Inf -> "healed" prior
+    lp, g = oracle.oracle_model_logpost(obs, planets, oracle.make_priors(case["priors"]), oracle.make_sources(case["esrc"]), None, th)
+    assert np.isneginf(lp[0]) and np.all(g[:, 0] == 0)
+    assert lp[1] < -1e300 or np.isneginf(lp[1])
+    assert np.isfinite(lp[2])
+
+
+def _reference_test_model(pkg, table=None):
+    """The model of test/integration/sampling.jl:29-64, through the mirror."""
+    table = table or dict(epoch=[50000, 50120, 50240, 50360, 50480, 50600, 50720, 50840],
+                          ra=[-505.76, -502.57, -498.21, -492.68, -485.98, -478.11, -469.08, -458.90],
+                          dec=[-66.93, -37.47, -7.93, 21.64, 51.15, 80.54, 109.73, 138.65],
+                          σ_ra=[10.0] * 8, σ_dec=[10.0] * 8, cor=[0.0] * 8)
+    astrom_like = pkg.PlanetRelAstromLikelihood(table, name="sampling_test")
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[astrom_like],
+                   variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                           Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+    return pkg.System(name="TestSys", companions=[b], observations=[],
+                      variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1)))
+
+
+@pytest.mark.gpu
+def test_gpu_model_vs_golden_and_oracle(pkg, oracle, model_golden):
+    case = model_golden[0]
+    model = pkg.LogDensityModel(_reference_test_model(pkg))
+    assert model.D == 11                                                    # test/integration/sampling.jl:70
+    assert model.names == ["M", "plx", "b_a", "b_e", "b_i", "b_ωx", "b_ωy", "b_Ωx", "b_Ωy", "b_θx", "b_θy"]
+    # the mirror derives the same priors / sources as the hand-written fixture
+    for k, p in enumerate(case["priors"]):
+        assert model._c_priors[k].kind == p["kind"] and model._c_priors[k].p0 == p["p0"] and model._c_priors[k].p1 == p["p1"]
+    for k, s in enumerate(case["esrc"]):
+        c = model._c_esrc[k]
+        assert (c.kind, c.i0, c.i1, c.flags, c.value) == (s["kind"], s["i0"], s["i1"], s["flags"], s["value"])
+    th = np.asarray(case["theta_t"])
+    lp, g = model.logdensity_and_gradient(th)
+    _check(lp, g, case)
+    assert np.array_equal(model.ℓπcallback(th), lp)
+    lp1, g1 = model.logdensity_and_gradient(th[:, 0])                       # single θ_t, like the reference's callback
+    assert lp1 == lp[0] and np.array_equal(g1, g[:, 0])
+    obs, planets = _tables(case)
+    lp_o, g_o = oracle.oracle_model_logpost(obs, planets, model._c_priors, model._c_esrc, None, th)
+    assert np.all(np.abs(lp - lp_o) <= 1e-12 * np.abs(lp_o))
+    model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_two_planet_rv(pkg, oracle, model_golden):
+    case = model_golden[1]
+    o_a, o_r = case["obs"]
+    astrom = pkg.PlanetRelAstromObs(dict(epoch=o_a["epoch"], ra=o_a["y1"], dec=o_a["y2"], σ_ra=o_a["s1"], σ_dec=o_a["s2"], cor=o_a["cor"]), name="GPI astrom",
+                                    variables=pkg.variables(jitter=pkg.LogUniform(0.1, 20.0), northangle=pkg.Normal(0.0, 0.05)))
+    rv = pkg.StarAbsoluteRVObs(dict(epoch=o_r["epoch"], rv=o_r["y1"], σ_rv=o_r["s1"]), name="HARPS",
+                               variables=pkg.variables(offset=pkg.Normal(0.0, 30.0), jitter=pkg.LogUniform(0.1, 50.0)))
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[],
+                   variables=pkg.variables(a=pkg.LogUniform(1.0, 5.0), e=pkg.Uniform(0.0, 0.9), i=pkg.Sine(), ω=pkg.UniformCircular(), Ω=pkg.UniformCircular(),
+                                           tp=pkg.Uniform(49000.0, 51000.0), mass=pkg.LogUniform(0.5, 50.0)))
+    c = pkg.Planet(name="c", basis="Visual{KepOrbit}", observations=[astrom],
+                   variables=pkg.variables(a=pkg.LogUniform(8.0, 40.0), e=pkg.Uniform(0.0, 0.9), i=pkg.Sine(), ω=pkg.UniformCircular(), Ω=pkg.UniformCircular(),
+                                           θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000.0), mass=pkg.Uniform(0.0, 30.0)))
+    sys_ = pkg.System(name="two", companions=[b, c], observations=[rv],
+                      variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.5, upper=2.0), plx=pkg.Normal(50.0, 0.5)))
+    model = pkg.LogDensityModel(sys_)
+    assert model.D == len(case["priors"]) == 25
+    assert model.names[:4] == ["M", "plx", "HARPS_offset", "HARPS_jitter"] and model.names[-2:] == ["c_GPI_astrom_jitter", "c_GPI_astrom_northangle"]
+    th = np.asarray(case["theta_t"])
+    lp, g = model.logdensity_and_gradient(th)
+    _check(lp, g, case, rtol_lp=1e-12, rtol_g=1e-9)
+    model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_reference_style(pkg):
+    """test/integration/sampling.jl:136-192 ("Autodiff Gradient Comparison") and :70-76 re-expressed: the device
+    gradient w.r.t. θ_t equals a finite-difference gradient of the device value (atol=1e-3, rtol=1e-4 there), prior draws
+    map through link/invlink, and a good starting point has ℓπ > -1000."""
+    table = dict(epoch=[50000, 50120, 50240, 50360], ra=[-505.76, -502.57, -498.21, -492.68], dec=[-66.93, -37.47, -7.93, 21.64],
+                 σ_ra=[10.0] * 4, σ_dec=[10.0] * 4, cor=[0.0] * 4)
+    model = pkg.LogDensityModel(_reference_test_model(pkg, table))
+    assert model.D == 11
+    rng = np.random.default_rng(42)
+    θ = model.sample_priors(rng, 64)
+    θ_t = model.link(θ)
+    assert np.allclose(model.invlink(θ_t), θ, rtol=1e-12, atol=1e-12)
+    lp, grad = model.logdensity_and_gradient(θ_t)
+    assert np.all(np.isfinite(lp))
+    for w in range(4):
+        for k in range(11):
+            h = 1e-6
+            tp, tm = θ_t[:, w].copy(), θ_t[:, w].copy()
+            tp[k] += h; tm[k] -= h
+            fd = (model.ℓπcallback(tp) - model.ℓπcallback(tm)) / (2 * h)
+            assert abs(fd - grad[k, w]) <= 1e-3 + 1e-4 * abs(fd), (w, k, fd, grad[k, w])
+    # batched starting-point search, as guess_starting_position does with prior draws (src/initialization.jl:14-66)
+    big = model.link(model.sample_priors(rng, 200_000))
+    best = np.max(model.ℓπcallback(big))
+    assert best > -1000                                                        # test/integration/sampling.jl:76
+    # host-side Derived variables agree with what the device resolved (elements fed to the likelihood kernel)
+    elems, nuis = model.kernel_inputs(θ[:, :8])
+    ll = model.ln_like.ln_like_arrays(elems, None)
+    assert np.all(np.isfinite(ll))
+    model.close()

@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--epochs", type=int, default=10_000)
     ap.add_argument("--walkers", type=int, default=10_000, help="walkers per GPU")
-    ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti"], default="grad")
+    ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti", "logpost"], default="grad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for single-GPU dry runs")
@@ -127,6 +127,34 @@ def main():
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                               "config": {"workload": f"ofti_linear_solve: {args.epochs} RA/Dec epochs x {args.walkers} walkers, forward"}}))
         solver.close()
+        return
+    if args.workload == "logpost":
+        # the whole ∇ℓπcallback (src/logdensitymodel.jl:169-177) on the device for the D = 11 model of the
+        # reference's tests: θ_t -> invlink -> priors -> elements -> likelihood + gradient -> chain rule back to θ_t
+        cfg0 = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3)
+        astrom = pkg.PlanetRelAstromObs(cfg0["table"], name="astrom")
+        b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[astrom],
+                       variables=pkg.variables(a=pkg.LogUniform(1, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                               Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+        sysm = pkg.System(name="bench", companions=[b], variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1),
+                                                                              plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1)))
+        model = pkg.LogDensityModel(sysm, device=dev_index)
+        θt = torch.tensor(model.link(model.sample_priors(np.random.default_rng(20260929 + 7), args.walkers)), device=dev)
+        for _ in range(args.warmup):
+            model.logpost_device(θt, grad=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.logpost_device(θt, grad=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"metric": "epoch-likelihood evals/sec, full log-posterior + gradient w.r.t. theta_t (D=11)",
+                              "value": args.epochs * args.walkers * args.steps / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": f"LogDensityModel D={model.D}: {args.epochs} RA/Dec epochs x {args.walkers} walkers, theta_t resident in HBM"}}))
+        model.close()
         return
     if args.workload == "two_planet":
         c4 = synth.config_two_planet()

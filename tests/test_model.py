@@ -151,3 +151,33 @@ def test_gpu_model_reference_style(pkg):
     ll = model.ln_like.ln_like_arrays(elems, None)
     assert np.all(np.isfinite(ll))
     model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batched_callers(pkg):
+    """guess_starting_position (src/initialization.jl:14-66) and octofit_rejection (src/sampling.jl:168-256)
+    on the batch path. Data are simulated from a known orbit; the rejection posterior must recover it (the reference's
+    statistical-recovery style, e.g. test/integration/multi_planet.jl:70)."""
+    import synth
+    rng = np.random.default_rng(5)
+    t = 50000.0 + 150.0 * np.arange(6)
+    ra, dec = synth.truth_radec(t)                      # a=10, e=0.3, i=1.0, ω=0.5, Ω=2.0, tp=50000, M=1.2, plx=50
+    table = dict(epoch=t, ra=ra + rng.normal(0, 100.0, 6), dec=dec + rng.normal(0, 100.0, 6), σ_ra=np.full(6, 100.0), σ_dec=np.full(6, 100.0))
+    obs = pkg.PlanetRelAstromObs(table, name="sim")
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[obs],
+                   variables=pkg.variables(a=pkg.LogUniform(5, 20), e=pkg.Uniform(0.0, 0.6), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                           Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+    sys_ = pkg.System(name="sim", companions=[b], variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.05), lower=0.1),
+                                                                          plx=pkg.truncated(pkg.Normal(50.0, 0.1), lower=0.1)))
+    model = pkg.LogDensityModel(sys_)
+    best, best_lp = pkg.guess_starting_position(rng, model, N=400_000)
+    assert best.shape == (model.D,) and best_lp > -200
+    assert best_lp == model.ℓπcallback(model.link(best))                    # returned params reproduce the returned logpost
+    chain = pkg.octofit_rejection(rng, model, draws=2_000_000)             #   (test/unit/initialization.jl:55)
+    assert chain["n_accepted"] >= 8 and chain["samples"].shape == (model.D, chain["n_accepted"])
+    assert np.all(np.isfinite(chain["logpost"])) and np.all(chain["loglike"] <= np.max(chain["loglike"]))
+    a = chain["samples"][model.names.index("b_a")]
+    assert 6.0 < np.median(a) < 15.0                                         # truth a = 10 (prior 5-20)
+    ll = pkg.rejection_evaluate_likelihoods(model, chain["samples"])
+    assert np.allclose(ll, chain["loglike"], rtol=0, atol=0)
+    model.close()

@@ -550,7 +550,7 @@ extern "C" {
 int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prior* priors, int32_t D, const octo_source* elem_src,
                           const octo_source* nuis_src, octo_model** out) {
     if (!ctx || !ds || !priors || !elem_src || !out) return fail(ctx, OCTO_EINVAL, "octo_model_create: null argument");
-    if (D < 1 || D > 32) return fail(ctx, OCTO_EINVAL, "octo_model_create: 1 <= D <= 32 supported");
+    if (D < 1 || D > 64) return fail(ctx, OCTO_EINVAL, "octo_model_create: 1 <= D <= 64 supported");
     if (ds->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_model_create: dataset lives on another device");
     *out = nullptr;
     const int n_el = ds->n_planets * OCTO_N_EL, n_nu = ds->n_obs * OCTO_N_NUIS;
@@ -633,15 +633,17 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     a.ll = d_ll; a.g_el = d_gel; a.g_nu = m->has_nuis ? d_gnu : nullptr;
     a.lp_out = d_lp; a.grad_out = d_grad;
     a.k_yr = ctx->consts.kepler_year_to_julian_day; a.yd = ctx->consts.year2day_julian;
-    const dim3 g64((unsigned)((W + 63) / 64));
-    if (m->D <= 16) hipLaunchKernelGGL(k_model_fwd<16>, g64, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(k_model_fwd<32>, g64, dim3(64), 0, st, a);
+    {
+        const int DB = std::min(m->D, 16);
+        hipLaunchKernelGGL(k_model_fwd, dim3((unsigned)((W + 63) / 64), (unsigned)((m->D + DB - 1) / DB)), dim3(64, DB),
+                           sizeof(double) * 4 * m->D * WAVE, st, a);
+    }
     HIPCHK(ctx, hipGetLastError());
     const bool grad = d_grad != nullptr;
     int rc = octo_eval_device(ctx, m->ds, a.elems, m->has_nuis ? a.nuis : nullptr, L, W, d_ll, grad ? d_gel : nullptr,
                               (grad && m->has_nuis) ? d_gnu : nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_model_bwd, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_model_bwd, dim3((unsigned)((W + 255) / 256), (unsigned)(d_grad ? m->D : 1)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;
 }

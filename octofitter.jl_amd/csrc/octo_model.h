@@ -122,25 +122,45 @@ __device__ __forceinline__ Dual<N> tperi(const Dual<N>& th, double theta_epoch, 
     return dconst<N>(theta_epoch) - (MA / n) * yd;
 }
 
-template <int N>
-__global__ __launch_bounds__(64) void k_model_fwd(ModelArgs a) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= a.W) return;
+// block = 64 walkers × DB partials (DB = min(D, 16) waves), grid = (walker tiles, ⌈D/DB⌉). Thread (w, d) carries the
+// value and ONE partial (∂/∂θ_t[d]) of every quantity, so a wave is 64 walkers × one partial: uniform control flow,
+// coalesced Jacobian rows, D× the parallelism of a thread-per-walker layout. The diagonal part — invlink and
+// logpdf_with_trans of every prior — is computed once per walker by the block's waves (prior k by wave k mod DB) and
+// shared through LDS: x[k], dx/dθ_t[k], p[k], dp/dθ_t[k].
+__global__ __launch_bounds__(1024) void k_model_fwd(ModelArgs a) {
+    constexpr int N = 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];      // [4][D][64]
+    const int lane = threadIdx.x;
+    const int wy = threadIdx.y, DB = blockDim.y;
+    const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
+    const int64_t wl = w < a.W ? w : a.W - 1;
+    const int d = blockIdx.y * DB + wy;
     const int D = a.D;
+    double* Lx = lds; double* Ldx = lds + (int64_t)D * WAVE; double* Lp = lds + 2 * (int64_t)D * WAVE; double* Ldp = lds + 3 * (int64_t)D * WAVE;
+    for (int k = wy; k < D; k += DB) {
+        Dual<N> xk, p;
+        prior_apply(a.priors[k], dvar<N>(a.theta_t[(int64_t)k * a.ld + wl], 0), xk, p);
+        Lx[k * WAVE + lane] = xk.v; Ldx[k * WAVE + lane] = xk.d[0]; Lp[k * WAVE + lane] = p.v; Ldp[k * WAVE + lane] = p.d[0];
+    }
+    __syncthreads();
+    if (w >= a.W || d >= D) return;
     bool finite_in = true;
     for (int k = 0; k < D; ++k) finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + w]);   // logdensitymodel.jl:120-124
-    Dual<N> x[N];
     Dual<N> lp = dconst<N>(0.0);
     bool healed = false;
     for (int k = 0; k < D; ++k) {
-        Dual<N> p;
-        prior_apply(a.priors[k], dvar<N>(a.theta_t[(int64_t)k * a.ld + w], k), x[k], p);
+        const double pv = Lp[k * WAVE + lane];
         if (!healed) {
-            if (!isfinite(p.v)) { lp = dconst<N>(-1.7976931348623157e308); healed = true; }   // variables.jl:1229-1236
-            else lp = lp + p;
+            if (!isfinite(pv)) { lp = dconst<N>(-1.7976931348623157e308); healed = true; }     // variables.jl:1229-1236
+            else { lp.v += pv; if (k == d) lp.d[0] += Ldp[k * WAVE + lane]; }
         }
     }
+    auto nat = [&](int k) {      // natural-domain θ[k] with this thread's partial
+        Dual<N> xk; xk.v = Lx[k * WAVE + lane]; xk.d[0] = (k == d) ? Ldx[k * WAVE + lane] : 0.0;
+        return xk;
+    };
     const int n_in = a.n_el + a.n_nu;
+    Dual<N> el[MAXP * OCTO_N_EL];
     // pass 0: everything but tperi; pass 1: tperi (needs the planet's other elements)
     for (int pass = 0; pass < 2; ++pass) {
         for (int k = 0; k < n_in; ++k) {
@@ -155,51 +175,48 @@ __global__ __launch_bounds__(64) void k_model_fwd(ModelArgs a) {
             if ((sc.kind == OCTO_SRC_TPERI) != (pass == 1)) continue;
             Dual<N> val;
             if (sc.kind == OCTO_SRC_CONST) val = dconst<N>(sc.value);
-            else if (sc.kind == OCTO_SRC_THETA) val = x[sc.i0];
+            else if (sc.kind == OCTO_SRC_THETA) val = nat(sc.i0);
             else {
-                const Dual<N> ang = datan2(x[sc.i1], x[sc.i0]);
-                if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(x[sc.i0], x[sc.i1]);
+                const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
+                const Dual<N> ang = datan2(cy, cx);
+                if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(cx, cy);
                 if (sc.kind == OCTO_SRC_CIRCULAR) val = ang * (sc.value / TWO_PI);      // atan(y, x) / 2π * domain, variables.jl:284
                 else {
-                    // re-read the planet's resolved elements (values + Jacobian rows) written in pass 0
-                    const int p = k / OCTO_N_EL;
-                    Dual<N> el[OCTO_N_EL];
-                    for (int q = 0; q < OCTO_N_EL; ++q) {
-                        const int kk = p * OCTO_N_EL + q;
-                        el[q].v = a.elems[(int64_t)kk * a.ldw + w];
-                        DFOR el[q].d[k_] = (k_ < D) ? a.J[((int64_t)kk * D + k_) * a.ldw + w] : 0.0;
-                    }
-                    val = tperi(ang, sc.value, el[OCTO_EL_M], el[OCTO_EL_E], el[OCTO_EL_A], el[OCTO_EL_I], el[OCTO_EL_W], el[OCTO_EL_O], a.k_yr, a.yd);
+                    const Dual<N>* e_ = el + (k / OCTO_N_EL) * OCTO_N_EL;
+                    val = tperi(ang, sc.value, e_[OCTO_EL_M], e_[OCTO_EL_E], e_[OCTO_EL_A], e_[OCTO_EL_I], e_[OCTO_EL_W], e_[OCTO_EL_O], a.k_yr, a.yd);
                 }
             }
-            double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
-            *dst = val.v;
-            DFOR { if (k_ < D) a.J[((int64_t)k * D + k_) * a.ldw + w] = val.d[k_]; }
+            if (k < a.n_el) el[k] = val;
+            if (d == 0) {
+                double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
+                *dst = val.v;
+            }
+            a.J[((int64_t)k * D + d) * a.ldw + w] = val.d[0];
         }
     }
-    a.lpp[w] = finite_in ? lp.v : -INFINITY;
-    DFOR { if (k_ < D) a.glp[(int64_t)k_ * a.ldw + w] = healed ? 0.0 : lp.d[k_]; }
+    if (d == 0) a.lpp[w] = finite_in ? lp.v : -INFINITY;
+    a.glp[(int64_t)d * a.ldw + w] = healed ? 0.0 : lp.d[0];
 }
 
+// grid = (walker tiles of 256, D): thread (w, d) produces grad[d][w] = ∂(prior)/∂θ_t[d] + Σ_k J[k][d]·ḡ[k].
 __global__ __launch_bounds__(256) void k_model_bwd(ModelArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
     if (w >= a.W) return;
     const double lpp = a.lpp[w], ll = a.ll[w];
     // ℓπcallback: non-finite θ_t or prior -> return it without the likelihood (logdensitymodel.jl:120-133)
     double lp = isfinite(lpp) ? lpp + ll : lpp;
     if (isnan(lp)) lp = -INFINITY;
-    a.lp_out[w] = lp;
+    if (d == 0) a.lp_out[w] = lp;
     if (!a.grad_out) return;
     const bool ok = isfinite(lp);
     const int n_in = a.n_el + a.n_nu;
-    for (int d = 0; d < a.D; ++d) {
-        double g = a.glp[(int64_t)d * a.ldw + w];
-        for (int k = 0; k < n_in; ++k) {
-            const double gk = k < a.n_el ? a.g_el[(int64_t)k * a.ldw + w] : (a.g_nu ? a.g_nu[(int64_t)(k - a.n_el) * a.ldw + w] : 0.0);
-            g = fma(a.J[((int64_t)k * a.D + d) * a.ldw + w], gk, g);
-        }
-        a.grad_out[(int64_t)d * a.ld + w] = ok ? g : 0.0;
+    double g = a.glp[(int64_t)d * a.ldw + w];
+    for (int k = 0; k < n_in; ++k) {
+        const double gk = k < a.n_el ? a.g_el[(int64_t)k * a.ldw + w] : (a.g_nu ? a.g_nu[(int64_t)(k - a.n_el) * a.ldw + w] : 0.0);
+        g = fma(a.J[((int64_t)k * a.D + d) * a.ldw + w], gk, g);
     }
+    a.grad_out[(int64_t)d * a.ld + w] = ok ? g : 0.0;
 }
 #undef DFOR
 

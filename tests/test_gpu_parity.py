@@ -332,3 +332,64 @@ def test_kepler_device_solver(pkg, oracle):
     # invalid inputs
     En, _, _ = _kepler_device(pkg, np.array([1.0, 1.0, np.nan]), np.array([1.0, -0.1, 0.3]))
     assert np.all(np.isnan(En))
+
+
+def test_c_abi_argument_checking_and_strides(pkg, oracle):
+    """Status codes for API misuse (no exception crosses the boundary), and ld > W / W not a multiple of 64."""
+    capi = pkg.capi
+    lib = capi.load_library()
+    ctx = C.c_void_p()
+    assert lib.octo_ctx_create(C.byref(ctx), 0) == capi.OCTO_OK
+    assert lib.octo_ctx_create(C.byref(C.c_void_p()), 99) == capi.OCTO_ENODEV
+    cfg = synth.config_astrom(n_epochs=33, n_walkers=70, seed=2)
+    t = cfg["table"]
+    tab = dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)
+    ds = C.c_void_p()
+    # bad planet index, unknown kind, too many planets, |cor| too large, absolute RV without mass
+    for bad in (dict(tab, planet=3), dict(tab, kind=9), dict(tab, cor=np.full(33, 0.999999))):
+        arr, keep = capi.pack_obs([bad])
+        assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
+        assert b"octo_dataset_create" in lib.octo_last_error(ctx)
+    arr, keep = capi.pack_obs([tab])
+    assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)] * 5), 5, C.byref(ds)) == capi.OCTO_EINVAL
+    rv = dict(kind=2, planet=-1, epoch=t["epoch"], y1=t["ra"], y2=None, s1=t["σ_ra"], s2=None, cor=None)
+    arr2, keep2 = capi.pack_obs([rv])
+    assert lib.octo_dataset_create(ctx, arr2, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
+    assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_OK
+    assert lib.octo_dataset_n_rows(ds) == 33
+    # strided buffers: ld = 96 > W = 70
+    W, ld = 70, 96
+    el = np.full((9, ld), np.nan); el[:, :W] = cfg["elems"]
+    ll = np.full(ld, 7.0); g = np.full((9, ld), 7.0)
+    dp = capi._dptr
+    assert lib.octo_eval(ctx, ds, dp(el), None, ld, W, dp(ll), dp(g), None) == capi.OCTO_OK
+    assert np.all(ll[W:] == 7.0) and np.all(g[:, W:] == 7.0)                   # nothing written past W
+    ll_o, g_o, _ = oracle.oracle_eval([tab], [dict(orbit_kind=0, has_mass=False)], cfg["elems"], None, grad=True,
+                                      active=synth.active_mask(1, 1, mass=False, nuis=False))
+    _cmp_oracle("strided", ll[:W], g[:, :W], None, ll_o, g_o, None)
+    # misuse
+    assert lib.octo_eval(ctx, ds, dp(el), None, 10, W, dp(ll), None, None) == capi.OCTO_EINVAL      # ld < W
+    assert lib.octo_eval(ctx, ds, None, None, ld, W, dp(ll), None, None) == capi.OCTO_EINVAL         # null elems
+    assert lib.octo_eval(ctx, ds, dp(el), None, ld, W, dp(ll), None, dp(g)) == capi.OCTO_EINVAL      # g_nuis without nuis
+    assert lib.octo_eval(ctx, ds, dp(el), None, ld, 0, dp(ll), None, None) == capi.OCTO_OK           # empty batch is fine
+    c = capi.default_consts(); c.pc2au = -1.0
+    assert lib.octo_consts_set(ctx, C.byref(c)) == capi.OCTO_EINVAL
+    assert lib.octo_dataset_destroy(ds) == 0 and lib.octo_ctx_destroy(ctx) == 0
+    assert lib.octo_dataset_destroy(None) == 0 and lib.octo_ctx_destroy(None) == 0
+
+
+def test_custom_constants_reach_the_kernel(pkg, oracle):
+    """octo_consts_set: the host's PlanetOrbits constants are the ones the kernels use (parity is a property of formulas,
+    not of digits baked into a kernel)."""
+    gb = _gpu()
+    cfg = synth.config_astrom(n_epochs=20, n_walkers=65, seed=4)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    c = pkg.capi.default_consts()
+    c.kepler_year_to_julian_day = 365.2422; c.pc2au = 206264.80624709636; c.rad2as = 206264.80624709636 * 1.0001
+    ll, g, _ = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=True, consts=c)
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, cfg["elems"], None, grad=True, consts=c, active=synth.active_mask(1, 1, mass=False, nuis=False))
+    _cmp_oracle("custom consts", ll, g, None, ll_o, g_o, None)
+    ll_d, _, _ = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=False)
+    assert np.max(np.abs(ll_d - ll)) > 1e-3            # and they do change the answer

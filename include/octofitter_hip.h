@@ -20,7 +20,8 @@
  *                            src/likelihoods/relative-astrometry.jl:20-95 (table,
  *                            sorted by epoch :46-47, optional cor :67-81),
  *                            OctofitterRadialVelocity/src/rv-absolute.jl:56-113,
- *                            rv-absolute-margin.jl:60-84, rv-relative.jl:60-101.
+ *                            rv-absolute-margin.jl:60-84, rv-relative.jl:60-101;
+ *                            src/likelihoods/prior-observable.jl:56-76 (O'Neil wrapper).
  *   octo_consts_set       <- PlanetOrbits.* physical constants used through
  *                            src/parameterizations.jl:62-64,215-216 and
  *                            src/Octofitter.jl:43 (mjup2msol).
@@ -60,7 +61,9 @@ extern "C" {
 #define OCTO_RV_ABS       2  /* StarAbsoluteRVObs (no GP, zero trend)                    */
 #define OCTO_RV_ABS_MARG  3  /* MarginalizedStarAbsoluteRVObs (zero trend)               */
 #define OCTO_RV_REL       4  /* PlanetRelativeRVObs (no GP, zero trend)                  */
-#define OCTO_N_KINDS      5
+#define OCTO_ONEIL_RADEC  5  /* ObsPriorAstromONeil2019 wrapping an (ra, dec) table: the wrapped ln_like PLUS the    */
+#define OCTO_ONEIL_SEPPA  6  /*   observable-based prior 2 log(Σ_j |…|·∛P/√(1−e²)), src/likelihoods/prior-observable.jl:78-137 */
+#define OCTO_N_KINDS      7
 
 /* ---- orbit parameterisations (PlanetOrbits.jl types) --------------------- */
 #define OCTO_ORBIT_VISUAL_KEP 0  /* Visual{KepOrbit}: a,e,i,ω,Ω,tp,M,plx               */

@@ -10,7 +10,7 @@ maintainer would drop into Octofitter.jl).
 from .host import capi  # noqa: F401
 from .host.observations import (  # noqa: F401
     PlanetRelAstromObs, PlanetRelAstromLikelihood, StarAbsoluteRVObs, StarAbsoluteRVLikelihood,
-    MarginalizedStarAbsoluteRVObs, PlanetRelativeRVObs, PlanetRelativeRVLikelihood,
+    MarginalizedStarAbsoluteRVObs, PlanetRelativeRVObs, PlanetRelativeRVLikelihood, ObsPriorAstromONeil2019,
 )
 from .host.system import Planet, System, make_ln_like, BatchedLnLike  # noqa: F401
 from .host.sharding import shard_range, ShardedLnLike  # noqa: F401,E402

@@ -223,7 +223,8 @@ int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Task* tk
     if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, tk, grad, nuis, st);
     if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, tk, grad, nuis, st);
     if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR>(ctx, ds, a, tk, grad, nuis, st);
-    if ((km & KM_MARG) == 0) return dispatch2<P, KM_ALL & ~KM_MARG>(ctx, ds, a, tk, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL>(ctx, ds, a, tk, grad, nuis, st);
+    if ((km & (KM_MARG | KM_ONEIL)) == 0) return dispatch2<P, KM_ALL & ~KM_MARG & ~KM_ONEIL>(ctx, ds, a, tk, grad, nuis, st);
     return dispatch2<P, KM_ALL>(ctx, ds, a, tk, grad, nuis, st);
 }
 
@@ -320,7 +321,8 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
         const octo_obs_desc& d = obs[o];
         if (d.kind < 0 || d.kind >= OCTO_N_KINDS) return bail(OCTO_EINVAL, "octo_dataset_create: unknown observation kind");
         if (d.n_epochs < 0 || d.n_epochs > 0x7fffffff) return bail(OCTO_EINVAL, "octo_dataset_create: bad n_epochs");
-        const bool astrom = d.kind == OCTO_ASTROM_RADEC || d.kind == OCTO_ASTROM_SEPPA;
+        const bool oneil = d.kind == OCTO_ONEIL_RADEC || d.kind == OCTO_ONEIL_SEPPA;
+        const bool astrom = d.kind == OCTO_ASTROM_RADEC || d.kind == OCTO_ASTROM_SEPPA || oneil;
         const bool planet_obs = astrom || d.kind == OCTO_RV_REL;
         if (planet_obs && (d.planet < 0 || d.planet >= n_planets)) return bail(OCTO_EINVAL, "octo_dataset_create: planet index out of range");
         if (d.n_epochs > 0 && (!d.epoch || !d.y1 || !d.s1 || (astrom && (!d.y2 || !d.s2))))
@@ -330,7 +332,15 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
         if (!planet_obs)   // every planet contributes to absolute RV and requires a mass (rv-absolute.jl:146-155)
             for (int p = 0; p < n_planets; ++p)
                 if (!planets[p].has_mass) return bail(OCTO_EINVAL, "octo_dataset_create: absolute RV needs a mass on every planet");
-        ds->kind_mask |= 1 << d.kind;
+        switch (d.kind) {
+            case OCTO_ASTROM_RADEC: ds->kind_mask |= KM_RADEC; break;
+            case OCTO_ASTROM_SEPPA: ds->kind_mask |= KM_SEPPA; break;
+            case OCTO_RV_ABS: ds->kind_mask |= KM_RVABS; break;
+            case OCTO_RV_ABS_MARG: ds->kind_mask |= KM_MARG; break;
+            case OCTO_RV_REL: ds->kind_mask |= KM_RVREL; break;
+            case OCTO_ONEIL_RADEC: ds->kind_mask |= KM_RADEC | KM_ONEIL; break;
+            default: ds->kind_mask |= KM_SEPPA | KM_ONEIL; break;
+        }
         if (astrom && d.cor) ds->kind_mask |= KM_COR;
         const int64_t n = d.n_epochs;
         std::vector<double> raw((size_t)n * ROW_STRIDE, 0.0), pre((size_t)n * ROW_STRIDE, 0.0);
@@ -569,7 +579,7 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
         for (int k = 0; k < n_nu; ++k) {
             if (!check_src(nuis_src[k], false)) return fail(ctx, OCTO_EINVAL, "octo_model_create: bad nuisance source");
             const int r = k % OCTO_N_NUIS; const int kind = ds->h_obs[k / OCTO_N_NUIS].kind;
-            const double dflt = (kind <= OCTO_ASTROM_SEPPA && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+            const double dflt = ((kind <= OCTO_ASTROM_SEPPA || kind >= OCTO_ONEIL_RADEC) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
             if (nuis_src[k].kind != OCTO_SRC_CONST || nuis_src[k].value != dflt) has_nuis = true;
         }
     HIPCHK(ctx, hipSetDevice(ctx->device));

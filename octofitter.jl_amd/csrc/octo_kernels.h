@@ -23,9 +23,9 @@ constexpr int WPB = 4;          // waves per k_main block (row split + LDS combi
 constexpr int FIN_G = 4;        // task groups per walker in k_finish
 
 // kind mask bits
-constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16, KM_COR = 32;
+constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16, KM_COR = 32, KM_ONEIL = 64;
 constexpr int KM_RV = KM_RVABS | KM_MARG | KM_RVREL;
-constexpr int KM_ALL = 63;
+constexpr int KM_ALL = 127;
 
 struct DevObs {
     int32_t kind, planet, has_cor, pad;
@@ -74,7 +74,12 @@ struct Layout {
     static constexpr int N_NU = (GRAD && NUIS) ? 3 : 0;
     static constexpr int OFF_MARG = OFF_NU + N_NU;
     static constexpr int N_MARG = HAS_MARG ? 3 : 0;
-    static constexpr int OFF_PL = OFF_MARG + N_MARG;
+    // O'Neil observable-based prior (prior-observable.jl:123-135): Σ_j |t_j| and, for the gradient, Σ sgn·∂t/∂e, Σ sgn·∂t/∂M̄A,
+    // Σ sgn·∂t/∂M̄A·(t−tp) — scaled by 2/Σ|t_j| in k_finish
+    static constexpr bool HAS_ONEIL = (KM & KM_ONEIL) != 0;
+    static constexpr int OFF_ONEIL = OFF_MARG + N_MARG;
+    static constexpr int N_ONEIL = HAS_ONEIL ? (GRAD ? 4 : 1) : 0;
+    static constexpr int OFF_PL = OFF_ONEIL + N_ONEIL;
     // per planet, all weighted by the planet's coefficient in the model:
     //   U1 Σ cosE·r̄a  U2 Σ sinE·r̄a  U3 Σ cosE·d̄ec  U4 Σ sinE·d̄ec  U5 Σ r̄a  U6 Σ d̄ec
     //   GE Σ M̄·sinE (+ direct RV terms)  GM Σ M̄  GT Σ M̄·(t−tp)  [GC ∂/∂(m/M)]  [GK ∂/∂K  GW ∂/∂ω direct]
@@ -176,7 +181,9 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
 #pragma unroll
     for (int k = 0; k < L::NACC; ++k) acc[k] = 0.0;
 
-    const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA;
+    const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_RADEC ||
+                           ob.kind == OCTO_ONEIL_SEPPA;
+    const bool oneil = L::HAS_ONEIL && ob.kind >= OCTO_ONEIL_RADEC;
 
     if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
         // coefficient of each planet's sky offset in the model (relative-astrometry.jl:117-138):
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
             sincos(na, &sn, &cn);
             j2 = jit * jit;
         }
-        const bool seppa = (KM & KM_SEPPA) && ob.kind == OCTO_ASTROM_SEPPA;
+        const bool seppa = (KM & KM_SEPPA) && (ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_SEPPA);
         const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE;
         for (int j = 0; j < n_rows; ++j) {
             const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
@@ -212,6 +219,35 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
                 s[p] = kepler_solve<1>(t, pc[p]);
                 rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
                 dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
+            }
+            if constexpr (L::HAS_ONEIL) {
+                if (oneil) {
+                    // M = meananom(sol) = E − e sin E; t = 3M(e + cos E) + 2(−2 + e² + e cos E) sin E   prior-observable.jl:129-133
+                    double sE = 0.0, cE = 0.0, ee = 0.0, invD = 0.0, dtp = 0.0;
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const bool me = (P == 1) || (p == ob.planet);
+                        sE = me ? s[p].sE : sE; cE = me ? s[p].cE : cE; ee = me ? pc[p].e : ee; invD = me ? s[p].invD : invD; dtp = me ? s[p].dt : dtp;
+                    }
+                    double E = 0.0;                                  // E ∈ [−π, π], as the solver returns it (eccanom(sol))
+#pragma unroll
+                    for (int p = 0; p < P; ++p) E = ((P == 1) || (p == ob.planet)) ? s[p].E : E;
+                    const double Mm = fma(-ee, sE, E);
+                    const double c2 = fma(ee, ee + cE, -2.0);       // −2 + e² + e cos E
+                    const double tt = fma(3.0 * Mm, ee + cE, 2.0 * c2 * sE);
+                    acc[L::OFF_ONEIL] += fabs(tt);
+                    if constexpr (GRAD) {
+                        const double sg = tt < 0.0 ? -1.0 : 1.0;
+                        const double D = fma(-ee, cE, 1.0);
+                        const double tM = 3.0 * (ee + cE);                                        // ∂t/∂M
+                        const double tE = fma(-3.0 * Mm, sE, 2.0 * fma(c2, cE, -(ee * sE * sE))) + tM * D;      // total ∂t/∂E (M = E − e sinE)
+                        const double te = fma(2.0 * sE, 2.0 * ee + cE, 3.0 * Mm) - tM * sE;       // total ∂t/∂e at fixed E
+                        const double Mb = sg * tE * invD;                                          // through E(M̄A, e)
+                        acc[L::OFF_ONEIL + 1] += sg * te + Mb * sE;
+                        acc[L::OFF_ONEIL + 2] += Mb;
+                        acc[L::OFF_ONEIL + 3] = fma(Mb, dtp, acc[L::OFF_ONEIL + 3]);
+                    }
+                }
             }
             if constexpr (P == 1) {
                 ra_m = rap[0]; dec_m = dep[0];
@@ -451,7 +487,7 @@ template <int P, bool GRAD, bool NUIS, int KM>
 __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
     constexpr int NPL = P * L::PL_N;
-    constexpr int NOBS_ACC = 7;              // S, 3 marg, 3 nuis per observation
+    constexpr int NOBS_ACC = 11;             // S, 3 marg, 3 nuis, 4 O'Neil per observation
     constexpr int LDS_ROWS = NOBS_ACC > L::PL_N ? NOBS_ACC : L::PL_N;
     static_assert(LDS_ROWS <= 12, "k_finish LDS scratch is sized for 12 rows");
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -464,9 +500,13 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     for (int k = 0; k < NPL; ++k) gp[k] = 0.0;
     // LDS scratch: [max(NOBS_ACC, PL_N)][FIN_G][64], reused per observation and per planet (two barriers each)
     double ll = 0.0;
+    double oneil_g[L::HAS_ONEIL && GRAD ? P * 6 : 1];     // per planet: ΔGE, ΔGM, ΔGT, Δā, ΔM̄tot, Δē from O'Neil terms
+#pragma unroll
+    for (int k = 0; k < (L::HAS_ONEIL && GRAD ? P * 6 : 1); ++k) oneil_g[k] = 0.0;
     int t = 0;
     for (int o = 0; o < a.n_obs; ++o) {
         double S = 0.0, mA = 0.0, mB = 0.0, mC = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0, cst = 0.0;
+        double on0 = 0.0, on1 = 0.0, on2 = 0.0, on3 = 0.0;
         int t_end = t;
         while (t_end < a.n_tasks && a.tasks[t_end].obs == o) { cst += a.task_const[t_end]; ++t_end; }
         for (int tt = t + grp; tt < t_end; tt += FIN_G) {
@@ -482,6 +522,14 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                 nu1 += pt[(int64_t)(L::OFF_NU + 1) * a.ldw];
                 nu2 += pt[(int64_t)(L::OFF_NU + 2) * a.ldw];
             }
+            if constexpr (L::HAS_ONEIL) {
+                on0 += pt[(int64_t)(L::OFF_ONEIL + 0) * a.ldw];
+                if constexpr (GRAD) {
+                    on1 += pt[(int64_t)(L::OFF_ONEIL + 1) * a.ldw];
+                    on2 += pt[(int64_t)(L::OFF_ONEIL + 2) * a.ldw];
+                    on3 += pt[(int64_t)(L::OFF_ONEIL + 3) * a.ldw];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < NPL; ++k) gp[k] += pt[(int64_t)(L::OFF_PL + k) * a.ldw];
         }
@@ -489,6 +537,7 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
         double* lo = lds + grp * WAVE + lane;
         lo[0 * FIN_G * WAVE] = S; lo[1 * FIN_G * WAVE] = mA; lo[2 * FIN_G * WAVE] = mB; lo[3 * FIN_G * WAVE] = mC;
         lo[4 * FIN_G * WAVE] = nu0; lo[5 * FIN_G * WAVE] = nu1; lo[6 * FIN_G * WAVE] = nu2;
+        lo[7 * FIN_G * WAVE] = on0; lo[8 * FIN_G * WAVE] = on1; lo[9 * FIN_G * WAVE] = on2; lo[10 * FIN_G * WAVE] = on3;
         __syncthreads();
         if (grp == 0) {
             const int kind = a.obs[o].kind;
@@ -510,11 +559,26 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                 // !NUIS: S = Σ q, cst = Σ(−log2π·k − ½ log|Σ|)
                 llo = cst - 0.5 * v[0];
             }
+            if constexpr (L::HAS_ONEIL) {
+                if (kind >= OCTO_ONEIL_RADEC && a.obs[o].n > 0) {
+                    // ln_prior = 2 log(Σ|t_j| · ∛P / √(1−e²)), P = period/365.25   prior-observable.jl:96,136-139
+                    const int ip = a.obs[o].planet;
+                    const double* el = a.elems + (int64_t)ip * OCTO_N_EL * a.ld + wl;
+                    const double sma = el[OCTO_EL_A * a.ld], e = el[OCTO_EL_E * a.ld], Mt = el[OCTO_EL_M * a.ld];
+                    const double Pyr = a.c.k_yr * sqrt(sma * sma * sma / Mt) / 365.25;
+                    llo += 2.0 * log(v[7] * cbrt(Pyr) / sqrt(1.0 - e * e));
+                    if constexpr (GRAD) {
+                        const double f = 2.0 / v[7];
+                        oneil_g[ip * 6 + 0] += f * v[8]; oneil_g[ip * 6 + 1] += f * v[9]; oneil_g[ip * 6 + 2] += f * v[10];
+                        oneil_g[ip * 6 + 3] += 1.0 / sma; oneil_g[ip * 6 + 4] += -1.0 / (3.0 * Mt); oneil_g[ip * 6 + 5] += 2.0 * e / (1.0 - e * e);
+                    }
+                }
+            }
             ll += llo;                   // observations are summed in the order given (system.jl:93,186)
             if constexpr (L::N_NU > 0) {
                 if (w < a.W) {
                     double* gn = a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w;
-                    const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA;
+                    const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA || kind >= OCTO_ONEIL_RADEC;
                     gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : v[4];
                     gn[(int64_t)a.ld] = v[5];
                     gn[(int64_t)2 * a.ld] = astrom ? v[6] : 0.0;
@@ -570,6 +634,11 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
             const double A = cO * cw - sO * sw * ci, B = sO * cw + cO * sw * ci;
             const double F = -cO * sw - sO * cw * ci, G = -sO * sw + cO * cw * ci;
             double ab = 0, eb = g[L::GE], ib = 0, wb = 0, Ob = 0, tpb, Mb = 0, plxb = 0, massb = 0, Pb = 0;
+            double gM = g[L::GM], gT = g[L::GT];
+            if constexpr (L::HAS_ONEIL) {
+                eb += oneil_g[p * 6 + 0] + oneil_g[p * 6 + 5]; gM += oneil_g[p * 6 + 1]; gT += oneil_g[p * 6 + 2];
+                ab += oneil_g[p * 6 + 3]; Mb += oneil_g[p * 6 + 4];
+            }
             if (!radvel) {
                 // adjoints of cB, cG, cA, cF (mas per unit X = cosE − e, Y = β sinE) from the running sums
                 const double gB = g[L::U1] - e * g[L::U5], gG = beta * g[L::U2];
@@ -596,8 +665,8 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                 wb += g[L::GW];
             }
             // M = 2π (t − tp)/P_d
-            tpb = -(TWO_PI / P_d) * g[L::GM];
-            Pb += -(TWO_PI / (P_d * P_d)) * g[L::GT];
+            tpb = -(TWO_PI / P_d) * gM;
+            Pb += -(TWO_PI / (P_d * P_d)) * gT;
             // P_d = k · a^{3/2} · M_tot^{−1/2}
             ab += Pb * 1.5 * P_d / sma;
             Mb += -0.5 * Pb * P_d / Mt;

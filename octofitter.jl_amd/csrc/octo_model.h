@@ -170,7 +170,7 @@ __global__ __launch_bounds__(1024) void k_model_fwd(ModelArgs a) {
             else {
                 const int r = (k - a.n_el) % OCTO_N_NUIS; const int kind = a.obs[(k - a.n_el) / OCTO_N_NUIS].kind;
                 sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
-                sc.value = (kind <= OCTO_ASTROM_SEPPA && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+                sc.value = ((kind <= OCTO_ASTROM_SEPPA || kind >= OCTO_ONEIL_RADEC) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
             }
             if ((sc.kind == OCTO_SRC_TPERI) != (pass == 1)) continue;
             Dual<N> val;

@@ -18,7 +18,8 @@ LIB_PATH = PKG_DIR / "lib" / "liboctofitter_hip.so"
 OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV = 0, 1, 2, 3, 4
 STATUS_NAMES = {0: "OCTO_OK", 1: "OCTO_EINVAL", 2: "OCTO_EHIP", 3: "OCTO_ENOMEM", 4: "OCTO_ENODEV"}
 
-ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL = 0, 1, 2, 3, 4
+ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL, ONEIL_RADEC, ONEIL_SEPPA = 0, 1, 2, 3, 4, 5, 6
+ASTROM_KINDS = (ASTROM_RADEC, ASTROM_SEPPA, ONEIL_RADEC, ONEIL_SEPPA)
 ORBIT_VISUAL_KEP, ORBIT_RADVEL = 0, 1
 N_EL, N_NUIS = 9, 3
 EL_A, EL_E, EL_I, EL_W, EL_O, EL_TP, EL_M, EL_PLX, EL_MASS = range(9)

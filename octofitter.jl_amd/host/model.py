@@ -75,7 +75,7 @@ class LogDensityModel:
         for obs, ip, plname, key in fn.obs_entries:
             ov = getattr(obs, "variables", None) or {}
             scope = ("plobs", plname, id(obs)) if ip >= 0 else ("sysobs", id(obs))
-            if obs.kind in (capi.ASTROM_RADEC, capi.ASTROM_SEPPA):
+            if obs.kind in capi.ASTROM_KINDS:
                 rows = (("jitter", 0.0), ("platescale", 1.0), ("northangle", 0.0))
             else:
                 rows = (("offset", 0.0), ("jitter", 0.0), (None, 0.0))

@@ -120,6 +120,38 @@ class PlanetRelAstromObs(AbstractObs):
 PlanetRelAstromLikelihood = PlanetRelAstromObs   # backwards-compat alias, relative-astrometry.jl:98
 
 
+class ObsPriorAstromONeil2019(AbstractObs):
+    """Observable-based prior of O'Neil et al. 2019 wrapped around a relative-astrometry table
+    (src/likelihoods/prior-observable.jl:56-76): ln_like = ln_like(wrapped) + 2 log(Σ_j |…| ∛P / √(1−e²)).
+    As in the reference it exposes the wrapped table (so its epochs are gathered a second time when both objects are
+    attached) and the wrapped observation's variables, under the name "obspri_<name>"."""
+    nuisance_names = ("jitter", "platescale", "northangle")
+
+    def __init__(self, obs):
+        if not isinstance(obs, PlanetRelAstromObs):
+            raise NotImplementedError("ObsPriorAstromONeil2019 is on the HIP path for PlanetRelAstromObs only")
+        self.wrapped_like = obs
+        self.table = obs.table
+        self.variables = obs.variables
+        self.is_seppa = obs.is_seppa
+        self.kind = capi.ONEIL_SEPPA if obs.is_seppa else capi.ONEIL_RADEC
+
+    @property
+    def name(self):
+        return self.likelihoodname()
+
+    def likelihoodname(self):
+        return "obspri_" + self.wrapped_like.likelihoodname()      # prior-observable.jl:68
+
+    def __len__(self):
+        return len(self.wrapped_like)
+
+    def _c_table(self, planet_index):
+        t = self.wrapped_like._c_table(planet_index)
+        t["kind"] = self.kind
+        return t
+
+
 class _RVBase(AbstractObs):
     nuisance_names = ("offset", "jitter")
 

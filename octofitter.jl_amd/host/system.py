@@ -182,7 +182,7 @@ class BatchedLnLike:
                 θobs = θ.get("planets", {}).get(plname, {}).get("observations", {}).get(key, {})
             else:
                 θobs = θ.get("observations", {}).get(key, {})
-            if obs.kind in (capi.ASTROM_RADEC, capi.ASTROM_SEPPA):
+            if obs.kind in capi.ASTROM_KINDS:
                 defaults = (("jitter", 0.0), ("platescale", 1.0), ("northangle", 0.0))   # relative-astrometry.jl:170-172
             else:
                 defaults = (("offset", 0.0), ("jitter", 0.0))
@@ -205,7 +205,7 @@ class BatchedLnLike:
             out["planets"][pl.name]["observations"] = {}
         if g_nuis is not None:
             for io, (obs, ip, plname, key) in enumerate(self.obs_entries):
-                names = ("jitter", "platescale", "northangle") if obs.kind in (capi.ASTROM_RADEC, capi.ASTROM_SEPPA) else ("offset", "jitter")
+                names = ("jitter", "platescale", "northangle") if obs.kind in capi.ASTROM_KINDS else ("offset", "jitter")
                 d = {nm: g_nuis[io * capi.N_NUIS + k] for k, nm in enumerate(names)}
                 if ip >= 0:
                     out["planets"][plname]["observations"][key] = d

@@ -187,6 +187,19 @@ def main():
     cases.append(run_case("F7_kepler_edges", [VIS], [astrom(0, ep7, ra7, dec7, [10.0] * len(ep7), [10.0] * len(ep7))], el7, None,
                           "eccentricity / mean-anomaly edge grid incl. t == tp"))
 
+    # ---- F8: ObsPriorAstromONeil2019 (src/likelihoods/prior-observable.jl:78-137) on the F3 / F4 tables ---------
+    o8 = astrom(0, ep4, [100.0, 110.0, 120.0], [100.0, 95.0, 90.0], [5.0] * 3, [5.0] * 3); o8["kind"] = "ONEIL_RADEC"
+    el8 = el4.copy(); el8[5] = 57990.3    # keep every epoch away from tp: |·| in the O'Neil term has a kink at M = 0
+    cases.append(run_case("F8_oneil_jitter", [VIS], [o8], el8, nu4, "test/unit/distributions.jl:103-131 with wrap=true (the wrapper alone)"))
+    o8b = astrom(0, ep2, ra3, dec3, s3, s3, cor=cor3); o8b["kind"] = "ONEIL_RADEC"
+    cases.append(run_case("F8_oneil_cor_plus_plain", [VIS], [astrom(0, ep2, ra3, dec3, s3, s3, cor=cor3), o8b], el2[:, :8], np.concatenate([nu3, nu3]),
+                          "astrometry table and its O'Neil wrapper both attached (test/unit-tests.jl:465-468): wrapped epochs counted twice"))
+    o8c = astrom(0, ep2, pa3, sep3, [0.02] * 8, s3, seppa=True); o8c["kind"] = "ONEIL_SEPPA"
+    cases.append(run_case("F8_oneil_seppa_nonuis", [VIS], [o8c], el2[:, :8], None, "sep/PA table under the wrapper, no nuisance block"))
+    o8d = astrom(1, ep6, ra6, dec6, [8.0] * 7, [9.0] * 7); o8d["kind"] = "ONEIL_RADEC"
+    cases.append(run_case("F8_oneil_two_planet", [VISM, VISM], [o8d, rvtab("RV_ABS", -1, epr, rv6, [5.0] * 9)], el6, None,
+                          "wrapper on the outer planet of the F6 system (inner-barycentre term active) + absolute RV"))
+
     OUT.parent.mkdir(parents=True, exist_ok=True)
     OUT.write_text(json.dumps(dict(consts=C, cases=cases, generator="oracle/make_golden.py (mpmath %s, dps=%d)" % (mp.__version__, mp.mp.dps)), indent=0))
     print("wrote", OUT, OUT.stat().st_size, "bytes")

@@ -26,7 +26,7 @@ import mpmath as mp
 
 mp.mp.dps = 60
 
-KINDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4}
+KINDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4, "ONEIL_RADEC": 5, "ONEIL_SEPPA": 6}
 ORBIT_VISUAL_KEP, ORBIT_RADVEL = 0, 1
 EL = ["a", "e", "i", "w", "O", "tp", "M", "plx", "mass"]
 N_EL, N_NUIS = 9, 3
@@ -106,6 +106,19 @@ def ln_like_terms(c, planets, obs, elems, nuis):
         nz = nuis[io] if nuis is not None else None
         ip = ob["planet"]
         ll = mp.mpf(0)
+        oneil = kind in (5, 6)
+        if oneil:
+            kind -= 5
+            # O'Neil et al. 2019 observable-based prior, as the reference evaluates it (prior-observable.jl:96-139):
+            # 2 log( Σ_j |3M(e + cos E) + 2(−2 + e² + e cos E) sin E| · ∛P / √(1−e²) ), P in Julian years, M = E − e sin E
+            o_ = orbs[ip]
+            jac = mp.mpf(0)
+            for t in ob["epoch"]:
+                E = solve(o_, t)["E"]
+                Mm = E - o_["e"] * mp.sin(E)
+                jac += abs(3 * Mm * (o_["e"] + mp.cos(E)) + 2 * (-2 + o_["e"] ** 2 + o_["e"] * mp.cos(E)) * mp.sin(E))
+            if len(ob["epoch"]) > 0:
+                terms.append(2 * mp.log(jac * mp.cbrt(o_["P_d"] / mp.mpf("365.25")) / mp.sqrt(1 - o_["e"] ** 2)))
         if kind in (0, 1):
             jitter = nz[0] if nz is not None else mp.mpf(0)
             plate = nz[1] if nz is not None else mp.mpf(1)
@@ -349,7 +362,7 @@ def model_logpost(c, planets, obs, priors, esrc, nsrc, theta_t):
         flat = [resolve(sc, 0) for sc in nsrc]
         nuis = [flat[i * N_NUIS:(i + 1) * N_NUIS] for i in range(len(obs))]
     else:
-        nuis = [[mp.mpf(0), mp.mpf(1), mp.mpf(0)] if (KINDS[o["kind"]] if isinstance(o["kind"], str) else o["kind"]) <= 1 else [mp.mpf(0)] * 3 for o in obs]
+        nuis = [[mp.mpf(0), mp.mpf(1), mp.mpf(0)] if (KINDS[o["kind"]] if isinstance(o["kind"], str) else o["kind"]) in (0, 1, 5, 6) else [mp.mpf(0)] * 3 for o in obs]
     return lp + ul + ln_like(c, planets, obs, elems, nuis)
 
 

@@ -27,7 +27,7 @@ def oracle():
     return ob
 
 
-KIND_IDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4}
+KIND_IDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4, "ONEIL_RADEC": 5, "ONEIL_SEPPA": 6}
 
 
 def case_tables(case):

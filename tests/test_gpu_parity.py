@@ -393,3 +393,28 @@ def test_custom_constants_reach_the_kernel(pkg, oracle):
     _cmp_oracle("custom consts", ll, g, None, ll_o, g_o, None)
     ll_d, _, _ = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=False)
     assert np.max(np.abs(ll_d - ll)) > 1e-3            # and they do change the answer
+
+
+def test_oneil_wrapper_receives_theta_obs(pkg):
+    """test/unit/distributions.jl:102-152 ("wrapped likelihood receives θ_obs"): the sensitivity of ln_like to jitter is
+    the same with and without the ObsPriorAstromONeil2019 wrapper (its Jacobian term does not depend on jitter), and > 1."""
+    tbl = dict(epoch=[58000.0, 58200.0, 58400.0], ra=[100.0, 110.0, 120.0], dec=[100.0, 95.0, 90.0], σ_ra=[5.0] * 3, σ_dec=[5.0] * 3)
+
+    def jitter_sensitivity(wrap):
+        radec = pkg.PlanetRelAstromLikelihood(tbl, name="d_radec")
+        obs = pkg.ObsPriorAstromONeil2019(radec) if wrap else radec
+        b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=(obs,))
+        sys_ = pkg.System(name="jitter_prop_test", companions=(b,))
+        key = "obspri_d_radec" if wrap else "d_radec"
+        θ = dict(M=1.0, plx=50.0, planets=dict(b=dict(a=10.0, e=0.2, i=0.5, ω=0.3, Ω=0.4, tp=58000.0,
+                                                      observations={key: dict(jitter=np.array([0.001, 300.0]))})))
+        fn = pkg.make_ln_like(sys_, θ)
+        ll = fn(θ)
+        fn.close()
+        return ll[1] - ll[0], ll
+
+    d_plain, ll_plain = jitter_sensitivity(False)
+    d_wrapped, ll_wrapped = jitter_sensitivity(True)
+    assert d_plain > 1
+    assert abs(d_wrapped - d_plain) <= 1e-9 * abs(d_plain)
+    assert abs((ll_wrapped[0] - ll_plain[0]) - (ll_wrapped[1] - ll_plain[1])) < 1e-9 and ll_wrapped[0] != ll_plain[0]

@@ -43,8 +43,8 @@ BYTES_PER_WALKER = 64.0 + 72.0  # read 8 elements, write ll + 8 adjoints
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--epochs", type=int, default=10_000)
     ap.add_argument("--walkers", type=int, default=10_000, help="walkers per GPU")
     ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti", "logpost"], default="grad")

@@ -53,6 +53,7 @@ struct octo_ofti {
 
 struct octo_ctx {
     int device = 0;
+    int n_cus = 256;
     hipStream_t stream = nullptr;
     octo_consts consts;
     std::string err;
@@ -140,28 +141,49 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int chunk, TaskTable** out) {
     return OCTO_OK;
 }
 
-int pick_chunk(const octo_dataset* ds, int64_t W) {
+// Rows per wave. The work of a row is the same for every walker and row (the Kepler solve is non-iterative), so a static
+// partition is balanced by construction; what is left to choose is the grain. Measured on MI355X at 1e4 × 1e4
+// (tools/sweep, profiles/README.md): k_main is flat within 2 % for 16-120 rows per wave and degrades beyond — a single
+// "round" of long waves (grid = what the chip holds at once) is ~8 % SLOWER than ~4 rounds of shorter ones, because
+// lock-stepped waves line up their prologue loads, LDS combines and partial stores instead of overlapping them with
+// other waves' arithmetic. So: aim for ≈4 rounds of the resident capacity (occupancy × CUs for the exact kernel variant).
+int pick_chunk(const octo_dataset* ds, int64_t W, int64_t capacity_blocks) {
     if (const char* ev = std::getenv("OCTO_CHUNK")) {   // tuning knob for experiments
         const int v = std::atoi(ev);
         if (v > 0) return v;
     }
-    // enough waves to fill 256 CUs × 4 SIMDs several times over, small enough tasks for an even tail
     const int64_t cols = (W + WAVE - 1) / WAVE;
-    const int64_t target_waves = 16384;
-    int64_t want_tasks = std::max<int64_t>(1, (target_waves + cols - 1) / cols);
-    int64_t chunk = (ds->n_rows + want_tasks - 1) / want_tasks;
-    chunk = std::max<int64_t>(chunk, 32);
-    chunk = std::min<int64_t>(chunk, 4096);
-    // quantise so that repeated calls with similar W reuse a table
-    int64_t q = 32;
-    while (q < chunk) q += (q < 256 ? 32 : 128);
-    return (int)q;
+    const int64_t rows = std::max<int64_t>(ds->n_rows, 1);
+    capacity_blocks = std::max<int64_t>(capacity_blocks, 256);
+    const int64_t want_tasks = std::max<int64_t>(1, (4 * capacity_blocks + cols - 1) / cols);
+    int64_t chunk = (rows + want_tasks * WPB - 1) / (want_tasks * WPB);
+    chunk = std::min<int64_t>(std::max<int64_t>(chunk, 16), 2048);
+    // quantise so that repeated calls with similar W reuse a task table
+    return (int)((chunk + 7) / 8 * 8);
 }
 
 template <int P, bool GRAD, bool NUIS, int KM>
-int launch_all(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Task* tt_tasks, hipStream_t st) {
+int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*, hipStream_t st) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
+    octo_dataset* ds = const_cast<octo_dataset*>(cds);   // task-table cache only
+    // Occupancy of the GRADIENT variant, also for forward-only launches: both then use the same row partition, so the
+    // forward value and the value returned with a gradient are the same sum in the same order — bit-identical, like the
+    // primal of a ForwardDiff dual.
+    static int blocks_per_cu = 0;                         // per (P, NUIS, KM)
+    if (blocks_per_cu == 0) {
+        using LG = Layout<P, true, NUIS, KM>;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM>, WAVE * WPB, sizeof(double) * LG::NACC * WAVE) != hipSuccess || nb < 1)
+            nb = 2;
+        blocks_per_cu = nb;
+    }
+    TaskTable* tt = nullptr;
+    int rc0 = get_tasks(ctx, ds, pick_chunk(ds, a.W, (int64_t)blocks_per_cu * ctx->n_cus), &tt);
+    if (rc0) return rc0;
+    const Task* tt_tasks = tt->h_tasks.data();
+    a.tasks = tt->d_tasks; a.task_const = a.nuis ? tt->d_const_raw : tt->d_const_pre;
+    a.n_tasks = tt->n_tasks; a.chunk = tt->chunk;
     const int64_t need = (int64_t)a.n_tasks * L::NACC * a.ldw;
     int rc = grow(ctx, ctx->d_partials, ctx->cap_part, need);
     if (rc) return rc;
@@ -272,6 +294,10 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     if (!ctx) return OCTO_ENOMEM;
     ctx->device = device_id;
     octo_consts_default(&ctx->consts);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
+    }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return OCTO_EHIP;
@@ -420,9 +446,6 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     if (ctx->timing && ctx->ev_used >= 4096) { int rc = drain_timing(ctx); if (rc) return rc; }
-    TaskTable* tt = nullptr;
-    int rc = get_tasks(ctx, ds, pick_chunk(ds, W), &tt);
-    if (rc) return rc;
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     if (ldw > ctx->cap_w) {
         int64_t c1 = ctx->cap_w, c2 = ctx->cap_w;
@@ -437,8 +460,8 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     }
     EvalArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.obs = ds->d_obs; a.tasks = tt->d_tasks; a.task_const = d_nuis ? tt->d_const_raw : tt->d_const_pre;
-    a.n_obs = ds->n_obs; a.n_tasks = tt->n_tasks; a.n_planets = ds->n_planets; a.chunk = tt->chunk;
+    a.obs = ds->d_obs;
+    a.n_obs = ds->n_obs; a.n_planets = ds->n_planets;
     for (int p = 0; p < ds->n_planets; ++p) { a.orbit_kind[p] = ds->planets[p].orbit_kind; a.has_mass[p] = ds->planets[p].has_mass; }
     a.elems = d_elems; a.nuis = d_nuis; a.ld = ld; a.W = W;
     a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w;
@@ -446,10 +469,10 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     a.c = dev_consts(ctx->consts);
     const bool grad = d_g_elems != nullptr, nuis = d_nuis != nullptr;
     switch (ds->n_planets) {
-        case 1: return dispatch1<1>(ctx, ds, a, tt->h_tasks.data(), grad, nuis, st);
-        case 2: return dispatch1<2>(ctx, ds, a, tt->h_tasks.data(), grad, nuis, st);
-        case 3: return dispatch1<3>(ctx, ds, a, tt->h_tasks.data(), grad, nuis, st);
-        default: return dispatch1<4>(ctx, ds, a, tt->h_tasks.data(), grad, nuis, st);
+        case 1: return dispatch1<1>(ctx, ds, a, nullptr, grad, nuis, st);
+        case 2: return dispatch1<2>(ctx, ds, a, nullptr, grad, nuis, st);
+        case 3: return dispatch1<3>(ctx, ds, a, nullptr, grad, nuis, st);
+        default: return dispatch1<4>(ctx, ds, a, nullptr, grad, nuis, st);
     }
 }
 

@@ -235,8 +235,9 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
 
 /* Measurement hook used by bench.py: average duration in milliseconds of the
  * dominant (epoch-loop) kernel over the launches since the last reset, from
- * hipEvents recorded on the launch stream. Enabled by octo_timing_enable. */
-int32_t octo_timing_enable(octo_ctx* ctx, int32_t on);
+ * hipEvents recorded on the launch stream. octo_timing_enable(ctx, n): n = 0 off, n >= 1 bracket the kernel of every
+ * n-th evaluation (an event pair costs a few µs of stream time, so a timed region samples rather than brackets all). */
+int32_t octo_timing_enable(octo_ctx* ctx, int32_t every_n);
 int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int32_t reset);
 
 /* Parallel-tempering swap step on device-resident log-likelihoods gathered from

@@ -66,7 +66,8 @@ struct octo_ctx {
     double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
     int64_t cap_in = 0, cap_out = 0;
     // timing
-    bool timing = false;
+    int timing_every = 0;                       // 0 = off, n = bracket every n-th evaluation's k_main with events
+    int64_t timing_seq = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double t_ms = 0.0;
@@ -214,7 +215,8 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
             a.marg = ctx->d_marg;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ctx->timing) {
+        const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
+        if (timed) {
             if (ctx->ev_used == ctx->ev_pool.size()) {
                 hipEvent_t x, y;
                 HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
@@ -225,7 +227,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
         }
         hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
                            sizeof(double) * L::NACC * WAVE, st, a);
-        if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, st));
+        if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
     }
     hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * FIN_G),
                        sizeof(double) * 12 * FIN_G * WAVE, st, a);
@@ -445,7 +447,7 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     octo_dataset* ds = const_cast<octo_dataset*>(cds);   // task-table cache only
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    if (ctx->timing && ctx->ev_used >= 4096) { int rc = drain_timing(ctx); if (rc) return rc; }
+    if (ctx->timing_every > 0 && ctx->ev_used >= 4096) { int rc = drain_timing(ctx); if (rc) return rc; }
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     if (ldw > ctx->cap_w) {
         int64_t c1 = ctx->cap_w, c2 = ctx->cap_w;
@@ -546,7 +548,8 @@ int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int6
 
 int32_t octo_timing_enable(octo_ctx* ctx, int32_t on) {
     if (!ctx) return OCTO_EINVAL;
-    ctx->timing = on != 0;
+    ctx->timing_every = on > 0 ? on : 0;
+    ctx->timing_seq = 0;
     return OCTO_OK;
 }
 

@@ -63,6 +63,7 @@ struct octo_ctx {
     int32_t* d_valid = nullptr;
     double* d_partials = nullptr;
     double* d_marg = nullptr;
+    double* d_sctab = nullptr;                  // sin/cos grid of sincos_table, [SCT_N][2]
     double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
     int64_t cap_in = 0, cap_out = 0;
     // timing
@@ -173,9 +174,8 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
     // primal of a ForwardDiff dual.
     static int blocks_per_cu = 0;                         // per (P, NUIS, KM)
     if (blocks_per_cu == 0) {
-        using LG = Layout<P, true, NUIS, KM>;
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM>, WAVE * WPB, sizeof(double) * LG::NACC * WAVE) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM>, WAVE * WPB, (main_lds_bytes<P, true, NUIS, KM>())) != hipSuccess || nb < 1)
             nb = 2;
         blocks_per_cu = nb;
     }
@@ -206,7 +206,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
                 if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) {
                     a.task0 = t0;
                     hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)(t1 - t0)), dim3(WAVE * WPB),
-                                       sizeof(double) * L0::NACC * WAVE, st, a);
+                                       (main_lds_bytes<P, false, NUIS, KM>()), st, a);
                 }
                 t0 = t1;
             }
@@ -226,7 +226,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
             HIPCHK(ctx, hipEventRecord(e0, st));
         }
         hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
-                           sizeof(double) * L::NACC * WAVE, st, a);
+                           (main_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
         if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
     }
     hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * FIN_G),
@@ -304,6 +304,20 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
         delete ctx;
         return OCTO_EHIP;
     }
+    {
+        // sin/cos at the grid points k·SCT_STEP (exact products), k = −(SCT_HALF+SCT_PAD) … +(SCT_HALF+SCT_PAD)
+        std::vector<double> tab(2 * SCT_N);
+        for (int i = 0; i < SCT_N; ++i) {
+            const double x = (double)(i - (SCT_HALF + SCT_PAD)) * SCT_STEP;
+            tab[2 * i] = std::sin(x); tab[2 * i + 1] = std::cos(x);
+        }
+        if (hipMalloc((void**)&ctx->d_sctab, sizeof(double) * tab.size()) != hipSuccess ||
+            hipMemcpy(ctx->d_sctab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return OCTO_ENOMEM;
+        }
+    }
     *out = ctx;
     return OCTO_OK;
 }
@@ -313,7 +327,7 @@ int32_t octo_ctx_destroy(octo_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg);
+    (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg); (void)hipFree(ctx->d_sctab);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out);
     delete ctx;
     return OCTO_OK;
@@ -466,7 +480,7 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     a.n_obs = ds->n_obs; a.n_planets = ds->n_planets;
     for (int p = 0; p < ds->n_planets; ++p) { a.orbit_kind[p] = ds->planets[p].orbit_kind; a.has_mass[p] = ds->planets[p].has_mass; }
     a.elems = d_elems; a.nuis = d_nuis; a.ld = ld; a.W = W;
-    a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w;
+    a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w; a.sctab = ctx->d_sctab;
     a.ll_out = d_ll; a.g_elems = d_g_elems; a.g_nuis = d_g_nuis;
     a.c = dev_consts(ctx->consts);
     const bool grad = d_g_elems != nullptr, nuis = d_nuis != nullptr;

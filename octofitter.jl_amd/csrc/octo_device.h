@@ -124,6 +124,30 @@ __device__ __forceinline__ void sincos_halfangle(double x, double& s, double& c)
     c = fma(-t, sh, 1.0);
 }
 
+// sin and cos of the FP32-valued starter through a table in LDS: x = k·SCT_STEP + r with k = round(x/SCT_STEP), the grid
+// point's (sin, cos) read as one ds_read_b128, and a rotation by r (|r| <= 3.1e-3: sin r to r⁵, cos r − 1 to r⁴, error
+// < 1e-17). 13 FP64 instructions + 5 cheap ones instead of 24: the hot loop is FP64-issue bound and LDS is otherwise
+// idle. SCT_STEP is 2π/1024 cut to 37 significant bits, so k·SCT_STEP is exact and the host fills the table with the
+// sin/cos of exactly those grid points (octo_api.hip: make_sincos_table). Indices are clamped: a non-finite or
+// out-of-range starter (invalid walker) reads a valid slot and produces garbage that k_finish discards.
+constexpr int SCT_HALF = 512;                         // grid steps per π
+constexpr int SCT_PAD = 8;                            // guard steps beyond ±π (the FP32 starter may land a hair outside)
+constexpr int SCT_N = 2 * (SCT_HALF + SCT_PAD) + 1;   // 1041 entries, 16.3 KB
+constexpr double SCT_STEP = 0x1.921fb5444p-8;
+constexpr float SCT_INV_STEP_F = 162.97466f;
+
+__device__ __forceinline__ void sincos_table(float xf, double x, const double2* tab, double& s, double& c) {
+    int k = (int)__builtin_rintf(xf * SCT_INV_STEP_F);
+    k = min(max(k, -(SCT_HALF + SCT_PAD)), SCT_HALF + SCT_PAD);
+    const double2 g = tab[k + (SCT_HALF + SCT_PAD)];
+    const double r = fma(-(double)k, SCT_STEP, x);
+    const double r2 = r * r;
+    const double sr = r * fma(r2, fma(r2, OCTO_KT[17], OCTO_KT[18]), 1.0);
+    const double cm1 = r2 * fma(r2, OCTO_KT[20], -0.5);
+    s = g.x + fma(g.x, cm1, g.y * sr);
+    c = g.y + fma(g.y, cm1, -(g.x * sr));
+}
+
 // v_rcp_f64 (≈2^-23) + NR Newton steps (each doubles the correct bits): NR = 1 -> 2^-46, NR = 2 -> full.
 template <int NR>
 __device__ __forceinline__ double rcp_nr(double x) {
@@ -135,8 +159,9 @@ __device__ __forceinline__ double rcp_nr(double x) {
 
 // Eccentric anomaly and the quantities every projection needs. INV_NR: Newton steps on 1/(1 − e cos E)
 // (1 when it only feeds adjoints, 2 when it feeds a model value, -1 when nobody needs it).
-template <int INV_NR>
-__device__ __forceinline__ KSol kepler_solve(double t, const PC& pc) {
+// tab: the block's LDS copy of the sin/cos table, or null for the polynomial sincos (kernels without the table).
+template <int INV_NR, bool TAB = false>
+__device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const double2* tab = nullptr) {
     KSol s;
     // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
     s.dt = t - pc.tp;
@@ -160,16 +185,25 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc) {
     const double E1 = (double)E1f;
     // ---- one fifth-order correction, eqs (21)-(29), FP64
     double s1, c1;
-    sincos_halfangle(E1, s1, c1);
+    if constexpr (TAB) sincos_table(E1f, E1, tab, s1, c1);
+    else sincos_halfangle(E1, s1, c1);
     const double e = pc.e;
     const double f2 = e * s1;
     const double hf2 = 0.5 * f2, q24 = f2 * (1.0 / 24.0);
     const double sf3 = (e * (1.0 / 6.0)) * c1;
     const double f1 = fma(-e, c1, 1.0);
     const double f0 = (E1 - M) - f2;
-    const double d3 = -(f0 * f1) * __builtin_amdgcn_rcp(fma(f1, f1, -(f0 * hf2)));   // Halley, one raw reciprocal
-    const double d4 = -f0 * rcp_nr<1>(fma(d3, fma(d3, sf3, hf2), f1));
-    const double d5 = -f0 * rcp_nr<1>(fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1));
+    // One hardware reciprocal for the three divisions: the denominators are f1·(den4 + O(δ²)), den4, den4 + O(δ³), so
+    // each reciprocal is a Newton step away from the previous one (prototype: tools/kepler_proto.py, same error).
+    const double r3 = __builtin_amdgcn_rcp(fma(f1, f1, -(f0 * hf2)));                // ≈2^-23
+    const double d3 = -(f0 * f1) * r3;                                               // Halley
+    const double den4 = fma(d3, fma(d3, sf3, hf2), f1);
+    double r4 = f1 * r3;
+    r4 = fma(fma(-den4, r4, 1.0), r4, r4);
+    const double d4 = -f0 * r4;
+    const double den5 = fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1);
+    const double r5 = fma(fma(-den5, r4, 1.0), r4, r4);
+    const double d5 = -f0 * r5;
     s.E = E1 + d5;                                                   // eq. (29); dead code unless a caller reads it
     // ---- sin/cos(E1 + δ5) by rotation; |δ5| < 5e-4: sin δ = δ(1 − δ²/6) (+1e-19), cos δ − 1 = δ²(−1/2 + δ²/24) (+1e-23)
     const double dd = d5 * d5;

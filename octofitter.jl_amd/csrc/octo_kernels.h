@@ -58,6 +58,7 @@ struct EvalArgs {
     double* partials;             // [n_tasks*NACC][ldw]
     const double* marg;           // [n_obs*2][ldw]: μ̂ and A of each marginalised-RV table (grad pass) or null
     double* marg_out;
+    const double* sctab;          // [SCT_N][2] sin/cos grid (octo_device.h: sincos_table), copied to LDS by every k_main block
     int64_t ldw;
     double* ll_out; double* g_elems; double* g_nuis;
     DevConsts c;
@@ -157,6 +158,9 @@ __global__ __launch_bounds__(256) void k_kepler(const double* __restrict__ MA, c
 
 // ------------------------------------------------------------------------------------ k_main
 template <int P, bool GRAD, bool NUIS, int KM>
+constexpr size_t main_lds_bytes() { return sizeof(double) * (2 * SCT_N + Layout<P, GRAD, NUIS, KM>::NACC * WAVE); }
+
+template <int P, bool GRAD, bool NUIS, int KM>
 __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -173,6 +177,15 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     const int r_hi = min(r_lo + a.chunk, tk.nrows);
     const int row_first = tk.row0 + r_lo, n_rows = r_hi - r_lo;
 
+    // LDS: [sin/cos table: SCT_N double2][combine buffer: NACC × 64 doubles]
+    const double2* const tab = reinterpret_cast<const double2*>(lds);
+    double* const comb = lds + 2 * SCT_N;
+    {
+        const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
+        double2* t = reinterpret_cast<double2*>(lds);
+        for (int i = threadIdx.x; i < SCT_N; i += WAVE * WPB) t[i] = g[i];
+    }
+
     PC pc[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) load_pc(pc[p], a.wc, a.ldw, p, wl);
@@ -180,6 +193,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     double acc[L::NACC];
 #pragma unroll
     for (int k = 0; k < L::NACC; ++k) acc[k] = 0.0;
+    __syncthreads();                                    // table filled
 
     const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_RADEC ||
                            ob.kind == OCTO_ONEIL_SEPPA;
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
             double ra_m, dec_m;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                s[p] = kepler_solve<1>(t, pc[p]);
+                s[p] = kepler_solve<1, true>(t, pc[p], tab);
                 rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
                 dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
             }
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
             double model = off;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                s[p] = kepler_solve<2>(t, pc[p]);
+                s[p] = kepler_solve<2, true>(t, pc[p], tab);
                 cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
                 snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
                 V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
@@ -436,17 +450,17 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         }
     }
     // ---- combine the block's waves through LDS in a fixed order (deterministic), one partial per (tile, task).
-    // Waves take turns through one NACC×64 buffer, so the footprint stays <= 28 KB for the widest layout.
+    // Waves take turns through one NACC×64 buffer, so the footprint stays <= 28 KB (+ the table) for the widest layout.
 #pragma unroll 1
     for (int q = 1; q < WPB; ++q) {
         if (wv == q) {
 #pragma unroll
-            for (int k = 0; k < L::NACC; ++k) lds[k * WAVE + lane] = acc[k];
+            for (int k = 0; k < L::NACC; ++k) comb[k * WAVE + lane] = acc[k];
         }
         __syncthreads();
         if (wv == 0) {
 #pragma unroll
-            for (int k = 0; k < L::NACC; ++k) acc[k] += lds[k * WAVE + lane];
+            for (int k = 0; k < L::NACC; ++k) acc[k] += comb[k * WAVE + lane];
         }
         __syncthreads();
     }

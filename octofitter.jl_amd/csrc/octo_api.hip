@@ -145,10 +145,14 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int chunk, TaskTable** out) {
 
 // Rows per wave. The work of a row is the same for every walker and row (the Kepler solve is non-iterative), so a static
 // partition is balanced by construction; what is left to choose is the grain. Measured on MI355X at 1e4 × 1e4
-// (tools/sweep, profiles/README.md): k_main is flat within 2 % for 16-120 rows per wave and degrades beyond — a single
-// "round" of long waves (grid = what the chip holds at once) is ~8 % SLOWER than ~4 rounds of shorter ones, because
-// lock-stepped waves line up their prologue loads, LDS combines and partial stores instead of overlapping them with
-// other waves' arithmetic. So: aim for ≈4 rounds of the resident capacity (occupancy × CUs for the exact kernel variant).
+// (tools/sweep_chunk.py, profiles/README.md): the step time is flat within 1 % for 48-96 rows per wave and rises on both
+// sides — short blocks pay their prologue (table fill, per-walker constants), LDS combine and partial store more often
+// and leave more partials for k_finish to read; a single "round" of long blocks (grid = what the chip holds at once) is
+// ~8 % slower because lock-stepped waves line up those phases instead of overlapping them with other waves'
+// arithmetic. So: aim for ≈3 rounds of the resident capacity (occupancy × CUs for the exact kernel variant).
+// (A persistent kernel pulling (task, tile) items from an atomic queue, with and without a tapered item size, was
+// measured against this grid-mapped launch in the same run and was not faster at any batch size: the hardware
+// dispatcher already backfills freed slots fast enough for an FP64-issue-bound kernel.)
 int pick_chunk(const octo_dataset* ds, int64_t W, int64_t capacity_blocks) {
     if (const char* ev = std::getenv("OCTO_CHUNK")) {   // tuning knob for experiments
         const int v = std::atoi(ev);
@@ -157,7 +161,7 @@ int pick_chunk(const octo_dataset* ds, int64_t W, int64_t capacity_blocks) {
     const int64_t cols = (W + WAVE - 1) / WAVE;
     const int64_t rows = std::max<int64_t>(ds->n_rows, 1);
     capacity_blocks = std::max<int64_t>(capacity_blocks, 256);
-    const int64_t want_tasks = std::max<int64_t>(1, (4 * capacity_blocks + cols - 1) / cols);
+    const int64_t want_tasks = std::max<int64_t>(1, (3 * capacity_blocks + cols - 1) / cols);
     int64_t chunk = (rows + want_tasks * WPB - 1) / (want_tasks * WPB);
     chunk = std::min<int64_t>(std::max<int64_t>(chunk, 16), 2048);
     // quantise so that repeated calls with similar W reuse a task table
@@ -784,7 +788,7 @@ int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d
         c = std::min<int64_t>(std::max<int64_t>(c, 32), 4096);
         chunk = (int)((c + 31) / 32 * 32);
     }
-    a.rows = h->d_rows; a.n_rows = (int32_t)h->n; a.chunk = chunk;
+    a.rows = h->d_rows; a.n_rows = (int32_t)h->n; a.chunk = chunk; a.sctab = ctx->d_sctab;
     a.n_tasks = (int32_t)((h->n + (int64_t)chunk * WPB - 1) / ((int64_t)chunk * WPB));
     a.nl = d_nl; a.ld = ld; a.W = W; a.ldw = cols * WAVE;
     int rc = grow(ctx, ctx->d_partials, ctx->cap_part, (int64_t)std::max(a.n_tasks, 1) * OFTI_NACC * a.ldw);
@@ -793,7 +797,7 @@ int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d
     a.k_yr = ctx->consts.kepler_year_to_julian_day; a.lambda = h->lambda; a.data_quad = h->data_quad;
     a.log_det_data_cov = h->log_det_data_cov; a.log_det_prior_inv = h->log_det_prior_inv; a.n_log2pi = h->n_log2pi;
     if (a.n_tasks > 0)
-        hipLaunchKernelGGL(k_ofti_main, dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB), sizeof(double) * OFTI_NACC * WAVE, st, a);
+        hipLaunchKernelGGL(k_ofti_main, dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB), sizeof(double) * (2 * SCT_N + OFTI_NACC * WAVE), st, a);
     hipLaunchKernelGGL(k_ofti_finish, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;

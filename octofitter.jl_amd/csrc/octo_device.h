@@ -128,21 +128,35 @@ __device__ __forceinline__ void sincos_halfangle(double x, double& s, double& c)
 // point's (sin, cos) read as one ds_read_b128, and a rotation by r (|r| <= 3.1e-3: sin r to r⁵, cos r − 1 to r⁴, error
 // < 1e-17). 13 FP64 instructions + 5 cheap ones instead of 24: the hot loop is FP64-issue bound and LDS is otherwise
 // idle. SCT_STEP is 2π/1024 cut to 37 significant bits, so k·SCT_STEP is exact and the host fills the table with the
-// sin/cos of exactly those grid points (octo_api.hip: make_sincos_table). Indices are clamped: a non-finite or
-// out-of-range starter (invalid walker) reads a valid slot and produces garbage that k_finish discards.
+// sin/cos of exactly those grid points (octo_ctx_create). The index is NOT clamped (a clamp costs two more instructions
+// per row): for a valid walker (0 <= e < 1) the starter lies within ±(π + 1e-3), inside the guard entries; an invalid
+// walker (e >= 1, non-finite elements) may produce any index, which reads garbage from the block's LDS or, beyond the
+// allocation, zero (out-of-range DS reads return 0 and never fault) — k_finish discards that walker's sums.
 constexpr int SCT_HALF = 512;                         // grid steps per π
 constexpr int SCT_PAD = 8;                            // guard steps beyond ±π (the FP32 starter may land a hair outside)
 constexpr int SCT_N = 2 * (SCT_HALF + SCT_PAD) + 1;   // 1041 entries, 16.3 KB
 constexpr double SCT_STEP = 0x1.921fb5444p-8;
 constexpr float SCT_INV_STEP_F = 162.97466f;
 
-__device__ __forceinline__ void sincos_table(float xf, double x, const double2* tab, double& s, double& c) {
-    int k = (int)__builtin_rintf(xf * SCT_INV_STEP_F);
-    k = min(max(k, -(SCT_HALF + SCT_PAD)), SCT_HALF + SCT_PAD);
-    const double2 g = tab[k + (SCT_HALF + SCT_PAD)];
+// c5 = 1/120 is carried in a VGPR by the caller: both coefficients of the inner Horner step as SGPRs would exceed the
+// one-scalar-operand limit of a VOP3 and cost a v_mov_b64 per row.
+struct SinCosTab {
+    const double2* tab;
+    double c5;
+};
+
+__device__ __forceinline__ SinCosTab make_sincos_tab(const double2* lds_tab) {
+    SinCosTab t{lds_tab, OCTO_KT[17]};
+    asm("" : "+v"(t.c5));      // not volatile: a volatile asm counts as a memory clobber and demotes the s_loads of the rows
+    return t;
+}
+
+__device__ __forceinline__ void sincos_table(float xf, double x, const SinCosTab& T, double& s, double& c) {
+    const int k = (int)__builtin_rintf(xf * SCT_INV_STEP_F);
+    const double2 g = T.tab[k + (SCT_HALF + SCT_PAD)];
     const double r = fma(-(double)k, SCT_STEP, x);
     const double r2 = r * r;
-    const double sr = r * fma(r2, fma(r2, OCTO_KT[17], OCTO_KT[18]), 1.0);
+    const double sr = r * fma(r2, fma(r2, T.c5, OCTO_KT[18]), 1.0);
     const double cm1 = r2 * fma(r2, OCTO_KT[20], -0.5);
     s = g.x + fma(g.x, cm1, g.y * sr);
     c = g.y + fma(g.y, cm1, -(g.x * sr));
@@ -161,7 +175,7 @@ __device__ __forceinline__ double rcp_nr(double x) {
 // (1 when it only feeds adjoints, 2 when it feeds a model value, -1 when nobody needs it).
 // tab: the block's LDS copy of the sin/cos table, or null for the polynomial sincos (kernels without the table).
 template <int INV_NR, bool TAB = false>
-__device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const double2* tab = nullptr) {
+__device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCosTab& tab = SinCosTab{nullptr, 0.0}) {
     KSol s;
     // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
     s.dt = t - pc.tp;
@@ -181,7 +195,7 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const doubl
     const float x = fabsf(r) + __builtin_amdgcn_sqrtf(disc);
     const float w = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (2.0f / 3.0f));   // cbrt(x²)
     const float den = fmaf(w, w + q, q2);
-    const float E1f = fmaf(2.0f * r * w, __builtin_amdgcn_rcpf(den), Mf) * __builtin_amdgcn_rcpf(d);
+    const float E1f = fmaf(Mf, den, 2.0f * r * w) * __builtin_amdgcn_rcpf(den * d);     // (2rw/den + M)/d, one reciprocal
     const double E1 = (double)E1f;
     // ---- one fifth-order correction, eqs (21)-(29), FP64
     double s1, c1;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     const int row_first = tk.row0 + r_lo, n_rows = r_hi - r_lo;
 
     // LDS: [sin/cos table: SCT_N double2][combine buffer: NACC × 64 doubles]
-    const double2* const tab = reinterpret_cast<const double2*>(lds);
+    const SinCosTab tab = make_sincos_tab(reinterpret_cast<const double2*>(lds));
     double* const comb = lds + 2 * SCT_N;
     {
         const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
@@ -709,6 +709,7 @@ struct OftiArgs {
     int64_t ld, W, ldw;
     double* partials;         // [n_tasks*13][ldw]
     double* abfg; double* logml;
+    const double* sctab;      // sin/cos grid, as EvalArgs::sctab
     double k_yr, lambda /* 1/σ_ABFG² */, data_quad, log_det_data_cov, log_det_prior_inv, n_log2pi;
 };
 
@@ -722,6 +723,14 @@ __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
     const int row0 = (int)blockIdx.y * task_rows;
     const int nrows = min(task_rows, a.n_rows - row0);
     const int r_lo = min(wv * a.chunk, nrows), r_hi = min(r_lo + a.chunk, nrows);
+    // LDS: [sin/cos table][combine buffer], as in k_main
+    const SinCosTab tab = make_sincos_tab(reinterpret_cast<const double2*>(lds));
+    double* const comb = lds + 2 * SCT_N;
+    {
+        const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
+        double2* t = reinterpret_cast<double2*>(lds);
+        for (int i = threadIdx.x; i < SCT_N; i += WAVE * WPB) t[i] = g[i];
+    }
     PC pc = {};
     {
         const double e = a.nl[0 * a.ld + wl], sma = a.nl[1 * a.ld + wl], tp = a.nl[2 * a.ld + wl], Mt = a.nl[3 * a.ld + wl];
@@ -732,11 +741,12 @@ __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
     double acc[OFTI_NACC];
 #pragma unroll
     for (int k = 0; k < OFTI_NACC; ++k) acc[k] = 0.0;
+    __syncthreads();                                    // table filled
     const double* __restrict__ rows = a.rows + (int64_t)(row0 + r_lo) * ROW_STRIDE;
     for (int j = 0; j < r_hi - r_lo; ++j) {
         const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
         const double t = rw[0], wrr = rw[1], wdd = rw[2], wrd = rw[3], pp = rw[4], qq = rw[5];
-        const KSol s = kepler_solve<-1>(t, pc);
+        const KSol s = kepler_solve<-1, true>(t, pc, tab);
         const double x = s.cE - pc.e, y = s.sE * pc.beta;            // :343-345
         const double xx = x * x, xy = x * y, yy = y * y;
         acc[0] = fma(wrr, xx, acc[0]); acc[1] = fma(wrr, xy, acc[1]); acc[2] = fma(wrr, yy, acc[2]);
@@ -749,12 +759,12 @@ __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
     for (int q = 1; q < WPB; ++q) {
         if (wv == q) {
 #pragma unroll
-            for (int k = 0; k < OFTI_NACC; ++k) lds[k * WAVE + lane] = acc[k];
+            for (int k = 0; k < OFTI_NACC; ++k) comb[k * WAVE + lane] = acc[k];
         }
         __syncthreads();
         if (wv == 0) {
 #pragma unroll
-            for (int k = 0; k < OFTI_NACC; ++k) acc[k] += lds[k * WAVE + lane];
+            for (int k = 0; k < OFTI_NACC; ++k) acc[k] += comb[k * WAVE + lane];
         }
         __syncthreads();
     }

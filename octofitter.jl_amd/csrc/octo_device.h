@@ -180,9 +180,10 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
     s.dt = t - pc.tp;
     const double u = s.dt * pc.invP;
-    const double M = (u - rint(u)) * TWO_PI;
+    const double frac = u - rint(u);
+    const double M = frac * TWO_PI;                   // folds into f0's FMA below
     // ---- Markley (1995) starter, eqs (20),(5),(9),(10),(14),(15), in FP32
-    const float Mf = (float)M;
+    const float Mf = (float)frac * (float)TWO_PI;     // scale in FP32: one FP64 multiply less per row
     const float ef = pc.ef, omef = pc.omef;
     const float alpha = fmaf(pc.k1f, (float)PI - fabsf(Mf), (float)MK_K0);
     const float d = fmaf(alpha, ef, 3.0f * omef);

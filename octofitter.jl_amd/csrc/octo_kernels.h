@@ -20,7 +20,7 @@ namespace octo {
 constexpr int MAXP = 4;
 constexpr int ROW_STRIDE = 8;   // doubles per observation row record (64 B = one s_load_dwordx16)
 constexpr int WPB = 4;          // waves per k_main block (row split + LDS combine)
-constexpr int FIN_G = 4;        // task groups per walker in k_finish
+constexpr int FIN_G = 8;        // task groups per walker in k_finish (block = 64 walkers x 8 groups: more loads in flight)
 
 // kind mask bits
 constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16, KM_COR = 32, KM_ONEIL = 64;

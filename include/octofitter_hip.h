@@ -63,7 +63,24 @@ extern "C" {
 #define OCTO_RV_REL       4  /* PlanetRelativeRVObs (no GP, zero trend)                  */
 #define OCTO_ONEIL_RADEC  5  /* ObsPriorAstromONeil2019 wrapping an (ra, dec) table: the wrapped ln_like PLUS the    */
 #define OCTO_ONEIL_SEPPA  6  /*   observable-based prior 2 log(Σ_j |…|·∛P/√(1−e²)), src/likelihoods/prior-observable.jl:78-137 */
-#define OCTO_N_KINDS      7
+#define OCTO_HGCA         7  /* HGCAInstantaneousObs (src/likelihoods/hgca.jl:28-219): Hipparcos-Gaia proper-motion   */
+                             /*   anomaly of the primary from the companions' reflex positions and velocities at a    */
+                             /*   handful of epochs. System table (planet = -1). Rows: epoch, y1 = measured axis      */
+                             /*   (OCTO_HGCA_RA / _DEC), y2 = mission (OCTO_HGCA_HIP / _GAIA); s1, s2, cor NULL.      */
+                             /*   `extra` = the OCTO_HGCA_N_EXTRA catalogue numbers below. Its two per-walker          */
+                             /*   "nuisances" are the system's proper motion: slot 0 = pmra, slot 1 = pmdec [mas/yr]   */
+                             /*   (θ_system.pmra / .pmdec, hgca.jl:266-267), so `nuis` is required with this kind.     */
+#define OCTO_N_KINDS      8
+
+#define OCTO_HGCA_RA   0
+#define OCTO_HGCA_DEC  1
+#define OCTO_HGCA_HIP  0
+#define OCTO_HGCA_GAIA 1
+/* extra[] of an OCTO_HGCA table: three epochs' (pmra, pmdec, σ_pmra·factor, σ_pmdec·factor, correlation), mas/yr:
+ * Hipparcos [0..4], Hipparcos-Gaia scaled position difference [5..9], Gaia [10..14]   (hgca.jl:127-145, 182-203) */
+#define OCTO_HGCA_N_EXTRA 15
+#define OCTO_NU_HGCA_PMRA  0
+#define OCTO_NU_HGCA_PMDEC 1
 
 /* ---- orbit parameterisations (PlanetOrbits.jl types) --------------------- */
 #define OCTO_ORBIT_VISUAL_KEP 0  /* Visual{KepOrbit}: a,e,i,ω,Ω,tp,M,plx               */
@@ -115,6 +132,8 @@ typedef struct octo_obs_desc {
     const double* s1;      /* σ_ra | σ_pa | σ_rv                                            */
     const double* s2;      /* σ_dec | σ_sep | NULL                                          */
     const double* cor;     /* correlation column or NULL (astrometry only)                  */
+    const double* extra;   /* per-table constants (OCTO_HGCA: [OCTO_HGCA_N_EXTRA]) or NULL  */
+    int64_t n_extra;
 } octo_obs_desc;
 
 typedef struct octo_planet_desc {

@@ -11,6 +11,7 @@ from .host import capi  # noqa: F401
 from .host.observations import (  # noqa: F401
     PlanetRelAstromObs, PlanetRelAstromLikelihood, StarAbsoluteRVObs, StarAbsoluteRVLikelihood,
     MarginalizedStarAbsoluteRVObs, PlanetRelativeRVObs, PlanetRelativeRVLikelihood, ObsPriorAstromONeil2019,
+    HGCAInstantaneousObs, HGCAInstantaneousLikelihood,
 )
 from .host.system import Planet, System, make_ln_like, BatchedLnLike  # noqa: F401
 from .host.sharding import shard_range, ShardedLnLike  # noqa: F401,E402

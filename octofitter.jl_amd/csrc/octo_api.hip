@@ -14,6 +14,7 @@
 
 #include "octo_kernels.h"
 #include "octo_model.h"
+#include "octo_hgca.h"
 #include "octofitter_hip.h"
 
 using namespace octo;
@@ -36,6 +37,7 @@ struct octo_dataset {
     int n_obs = 0, n_planets = 0;
     int kind_mask = 0;
     int64_t n_rows = 0;
+    int n_hgca = 0;                      // OCTO_HGCA tables: evaluated by k_hgca, not by the epoch-loop kernel
     std::vector<DevObs> h_obs;
     std::vector<std::vector<double>> h_rowconst_pre, h_rowconst_raw;   // per obs, per row
     DevObs* d_obs = nullptr;
@@ -63,6 +65,8 @@ struct octo_ctx {
     int32_t* d_valid = nullptr;
     double* d_partials = nullptr;
     double* d_marg = nullptr;
+    double* d_extra = nullptr;                  // k_hgca output: ll and input-gradient of the non-epoch-loop terms
+    int64_t cap_extra = 0;
     double* d_sctab = nullptr;                  // sin/cos grid of sincos_table, [SCT_N][2]
     double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
     int64_t cap_in = 0, cap_out = 0;
@@ -118,6 +122,7 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int chunk, TaskTable** out) {
     tt.chunk = chunk;
     std::vector<double> cpre, craw;
     for (int o = 0; o < ds->n_obs; ++o) {
+        if (ds->h_obs[o].kind == OCTO_HGCA) continue;          // no epoch-loop rows (k_hgca)
         const int64_t n = ds->h_obs[o].n;
         const int64_t span = (int64_t)chunk * WPB;    // one block = WPB waves x chunk rows
         for (int64_t r0 = 0; r0 < n; r0 += span) {
@@ -233,6 +238,18 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
                            (main_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
         if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
     }
+    a.extra = nullptr;
+    if (ds->n_hgca > 0) {
+        if constexpr (NUIS) {
+            const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
+            rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
+            if (rc) return rc;
+            a.extra = ctx->d_extra;
+            hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)cols, (unsigned)n_dir), dim3(WAVE), 0, st, a);
+        } else {
+            return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
+        }
+    }
     hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * FIN_G),
                        sizeof(double) * 12 * FIN_G * WAVE, st, a);
     HIPCHK(ctx, hipGetLastError());
@@ -331,7 +348,7 @@ int32_t octo_ctx_destroy(octo_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg); (void)hipFree(ctx->d_sctab);
+    (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg); (void)hipFree(ctx->d_sctab); (void)hipFree(ctx->d_extra);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out);
     delete ctx;
     return OCTO_OK;
@@ -367,6 +384,38 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
         const octo_obs_desc& d = obs[o];
         if (d.kind < 0 || d.kind >= OCTO_N_KINDS) return bail(OCTO_EINVAL, "octo_dataset_create: unknown observation kind");
         if (d.n_epochs < 0 || d.n_epochs > 0x7fffffff) return bail(OCTO_EINVAL, "octo_dataset_create: bad n_epochs");
+        if (d.kind == OCTO_HGCA) {
+            // rows {epoch, axis, mission}; `extra` = the 15 catalogue numbers; evaluated by k_hgca
+            if (d.n_epochs > 0 && (!d.epoch || !d.y1 || !d.y2)) return bail(OCTO_EINVAL, "octo_dataset_create: missing column");
+            if (!d.extra || d.n_extra != OCTO_HGCA_N_EXTRA) return bail(OCTO_EINVAL, "octo_dataset_create: OCTO_HGCA needs extra[15]");
+            for (int p = 0; p < n_planets; ++p)       // mass * mjup2msol of every Visual planet is read (hgca.jl:279-290)
+                if (planets[p].orbit_kind == OCTO_ORBIT_VISUAL_KEP && !planets[p].has_mass)
+                    return bail(OCTO_EINVAL, "octo_dataset_create: OCTO_HGCA needs a mass on every Visual{KepOrbit} planet");
+            for (int k = 0; k < 3; ++k)
+                if (!(d.extra[5 * k + 2] > 0.0) || !(d.extra[5 * k + 3] > 0.0) || !(std::fabs(d.extra[5 * k + 4]) < 1.0))
+                    return bail(OCTO_EINVAL, "octo_dataset_create: OCTO_HGCA covariance is not positive definite");
+            const int64_t n = d.n_epochs;
+            std::vector<double> raw((size_t)std::max<int64_t>(n, 1) * ROW_STRIDE, 0.0);
+            for (int64_t r = 0; r < n; ++r) {
+                const int ax = (int)d.y1[r], ms = (int)d.y2[r];
+                if ((ax != OCTO_HGCA_RA && ax != OCTO_HGCA_DEC) || (ms != OCTO_HGCA_HIP && ms != OCTO_HGCA_GAIA))
+                    return bail(OCTO_EINVAL, "octo_dataset_create: OCTO_HGCA rows need y1 in {RA, DEC}, y2 in {HIP, GAIA}");
+                raw[(size_t)r * ROW_STRIDE] = d.epoch[r]; raw[(size_t)r * ROW_STRIDE + 1] = ax; raw[(size_t)r * ROW_STRIDE + 2] = ms;
+            }
+            DevObs& h = ds->h_obs[o];
+            h.kind = d.kind; h.planet = -1; h.has_cor = 0; h.pad = 0; h.n = n;
+            double *dr = nullptr, *dx = nullptr;
+            if (hipMalloc((void**)&dr, sizeof(double) * raw.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_dataset_create: hipMalloc failed");
+            ds->d_bufs.push_back(dr);
+            if (hipMalloc((void**)&dx, sizeof(double) * OCTO_HGCA_N_EXTRA) != hipSuccess) return bail(OCTO_ENOMEM, "octo_dataset_create: hipMalloc failed");
+            ds->d_bufs.push_back(dx);
+            if (hipMemcpy(dr, raw.data(), sizeof(double) * raw.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dx, d.extra, sizeof(double) * OCTO_HGCA_N_EXTRA, hipMemcpyHostToDevice) != hipSuccess)
+                return bail(OCTO_EHIP, "octo_dataset_create: upload failed");
+            h.raw = dr; h.pre = dx;
+            ds->n_hgca += 1;
+            continue;
+        }
         const bool oneil = d.kind == OCTO_ONEIL_RADEC || d.kind == OCTO_ONEIL_SEPPA;
         const bool astrom = d.kind == OCTO_ASTROM_RADEC || d.kind == OCTO_ASTROM_SEPPA || oneil;
         const bool planet_obs = astrom || d.kind == OCTO_RV_REL;

@@ -1,0 +1,137 @@
+// octo_hgca.h — HGCAInstantaneousObs on the device: the Hipparcos–Gaia proper-motion anomaly of the
+// primary from the companions' reflex position and velocity at a handful of epochs (src/likelihoods/hgca.jl:155-400).
+// This term has no long epoch loop (4·N_ave rows), so it does not go through k_main: one thread per (walker, input
+// direction) carries the value and ONE partial of every quantity as a forward-mode dual — what ForwardDiff does in the
+// reference — and writes ∂ll/∂input[dir] directly; no reduction is needed. k_finish adds the results to the epoch-loop sums.
+#pragma once
+#include "octo_model.h"
+
+namespace octo {
+
+// Reflex position [mas] and proper motion [mas/yr] of the primary due to one companion at time t, along RA or Dec.
+// E-form of PlanetOrbits' raoff/decoff/pmra/pmdec(sol, mass): X = cos E − e, Y = √(1−e²) sin E, Thiele-Innes
+// projection, Ė = n/(1 − e cos E); the reference's ν-form is restated in oracle/octo_oracle_core.inc.
+struct HgcaPlanet {
+    Dual<1> e, beta, tp, n_day, T, cA, cB, cF, cG, fac;
+    PC pc;     // value-only constants for the Kepler solve
+};
+
+__device__ __forceinline__ void hgca_solve(const HgcaPlanet& h, double t, int axis, double yd, Dual<1>& pos, Dual<1>& vel) {
+    using D = Dual<1>;
+    const KSol s = kepler_solve<-1>(t, h.pc);
+    // ∂E/∂M = 1/(1 − e cos E), ∂E/∂e = sin E/(1 − e cos E); M = n (t − tp)
+    const double invD = 1.0 / (1.0 - h.e.v * s.cE);
+    const D MA = h.n_day * (dconst<1>(t) - h.tp);
+    D E; E.v = 0.0; E.d[0] = (MA.d[0] + s.sE * h.e.d[0]) * invD;
+    const D sE = chain(E, s.sE, s.cE), cE = chain(E, s.cE, -s.sE);
+    const D X = cE - h.e, Y = h.beta * sE;
+    const D Edot = h.n_day / (dconst<1>(1.0) - h.e * cE);
+    const D c1 = axis == OCTO_HGCA_RA ? h.cB : h.cA, c2 = axis == OCTO_HGCA_RA ? h.cG : h.cF;
+    pos = h.fac * (h.T * (c1 * X + c2 * Y));
+    vel = h.fac * (h.T * (c2 * (h.beta * cE) - c1 * sE) * Edot * yd);
+}
+
+// logpdf(MvNormal([σ1² ρσ1σ2; ρσ1σ2 σ2²]), [r1, r2])
+__device__ __forceinline__ Dual<1> hgca_logpdf2(const Dual<1>& r1, const Dual<1>& r2, double s1, double s2, double rho) {
+    const double omr = 1.0 - rho * rho;
+    const Dual<1> z1 = r1 * (1.0 / s1), z2 = r2 * (1.0 / s2);
+    const Dual<1> q = (z1 * z1 - (z1 * z2) * (2.0 * rho) + z2 * z2) * (1.0 / omr);
+    return q * (-0.5) + (-LOG2PI - 0.5 * log(s1 * s1 * s2 * s2 * omr));
+}
+
+// grid = (walker tiles of 64, P·9 + n_obs·3 input directions), block = 64
+template <int P>
+__global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
+    using D = Dual<1>;
+    const int64_t w = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    const int64_t wl = w < a.W ? w : a.W - 1;
+    const int dir = blockIdx.y;
+    HgcaPlanet hp[P];
+    bool visual[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        visual[p] = a.orbit_kind[p] == OCTO_ORBIT_VISUAL_KEP;
+        D el[OCTO_N_EL];
+#pragma unroll
+        for (int k = 0; k < OCTO_N_EL; ++k) {
+            const double v = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl];
+            el[k] = (dir == p * OCTO_N_EL + k) ? dvar<1>(v, 0) : dconst<1>(v);
+        }
+        if (!a.has_mass[p]) el[OCTO_EL_MASS] = dconst<1>(0.0);
+        D inc = el[OCTO_EL_I], Om = el[OCTO_EL_O];
+        inc.v = inc.v - PI * floor(inc.v / PI);                // KepOrbit ctor invariants, as in k_setup
+        Om.v = Om.v - TWO_PI * floor(Om.v / TWO_PI);
+        const D sma = el[OCTO_EL_A], e = el[OCTO_EL_E], Mt = el[OCTO_EL_M];
+        const D P_d = dsqrt(sma * sma * sma / Mt) * a.c.k_yr;   // parameterizations.jl:62
+        HgcaPlanet& h = hp[p];
+        h.e = e; h.tp = el[OCTO_EL_TP];
+        h.beta = dsqrt(dconst<1>(1.0) - e * e);
+        h.n_day = dconst<1>(TWO_PI) / P_d;
+        h.T = sma * el[OCTO_EL_PLX] * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
+        const D si_ = dsin(inc), ci = dcos(inc), sw = dsin(el[OCTO_EL_W]), cw = dcos(el[OCTO_EL_W]), sO = dsin(Om), cO = dcos(Om);
+        (void)si_;
+        h.cA = cO * cw - sO * sw * ci; h.cB = sO * cw + cO * sw * ci;
+        h.cF = -(cO * sw) - sO * cw * ci; h.cG = -(sO * sw) + cO * cw * ci;
+        h.fac = -(el[OCTO_EL_MASS] * a.c.mjup2msol) / Mt;      // q(sol, M_planet) = −M_planet/M_tot · q(sol)
+        h.pc = PC{};
+        h.pc.invP = 1.0 / P_d.v; h.pc.tp = h.tp.v; h.pc.e = e.v;
+        h.pc.ef = (float)e.v; h.pc.omef = (float)(1.0 - e.v); h.pc.k1f = (float)(MK_K1N / (1.0 + e.v));
+    }
+    D ll = dconst<1>(0.0);
+    for (int o = 0; o < a.n_obs; ++o) {
+        const DevObs ob = a.obs[o];
+        if (ob.kind != OCTO_HGCA) continue;
+        D pm_sys[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double v = a.nuis[((int64_t)o * OCTO_N_NUIS + k) * a.ld + wl];
+            pm_sys[k] = (dir == P * OCTO_N_EL + o * OCTO_N_NUIS + k) ? dvar<1>(v, 0) : dconst<1>(v);
+        }
+        D pos[2][2], pm[2][2];
+        double ep[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        int cnt[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) { pos[m][ax] = dconst<1>(0.0); pm[m][ax] = dconst<1>(0.0); }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (!visual[p]) continue;                           // hgca.jl:255-262
+            for (int64_t j = 0; j < ob.n; ++j) {
+                const double* rw = ob.raw + j * ROW_STRIDE;     // wave-uniform
+                const double t = rw[0];
+                const int ax = (int)rw[1], m = (int)rw[2];
+                D q, v;
+                hgca_solve(hp[p], t, ax, a.c.yd, q, v);
+                // the counters and epoch sums advance once per (planet, row), as in the reference (:276-278)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa)
+                        if (mm == m && aa == ax) { cnt[mm][aa] += 1; ep[mm][aa] += t; pos[mm][aa] = pos[mm][aa] + q; pm[mm][aa] = pm[mm][aa] + v; }
+            }
+        }
+        D model[3][2];
+#pragma unroll
+        for (int ax = 0; ax < 2; ++ax) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {                       // :301-308, 353-360
+                const double ic = 1.0 / (double)cnt[m][ax];
+                pos[m][ax] = pos[m][ax] * ic; pm[m][ax] = pm[m][ax] * ic + pm_sys[ax]; ep[m][ax] *= ic;
+            }
+            model[0][ax] = pm[0][ax];
+            model[1][ax] = (pos[1][ax] - pos[0][ax]) * (a.c.yd / (ep[1][ax] - ep[0][ax])) + pm_sys[ax];   // :379-382
+            model[2][ax] = pm[1][ax];
+        }
+        const double* x = ob.pre;                              // the 15 catalogue numbers
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            ll = ll + hgca_logpdf2(model[k][0] + (-x[5 * k]), model[k][1] + (-x[5 * k + 1]), x[5 * k + 2], x[5 * k + 3], x[5 * k + 4]);
+    }
+    if (w < a.W) {
+        if (dir == 0) a.extra[w] = ll.v;
+        a.extra[(int64_t)(1 + dir) * a.ldw + w] = ll.d[0];
+    }
+}
+
+}  // namespace octo

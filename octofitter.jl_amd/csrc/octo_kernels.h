@@ -58,6 +58,8 @@ struct EvalArgs {
     double* partials;             // [n_tasks*NACC][ldw]
     const double* marg;           // [n_obs*2][ldw]: μ̂ and A of each marginalised-RV table (grad pass) or null
     double* marg_out;
+    double* extra;                // [1 + P*9 + n_obs*3][ldw]: ll and input-gradient of the terms computed outside the epoch loop
+                                  // (k_hgca), added by k_finish; or null
     const double* sctab;          // [SCT_N][2] sin/cos grid (octo_device.h: sincos_table), copied to LDS by every k_main block
     int64_t ldw;
     double* ll_out; double* g_elems; double* g_nuis;
@@ -596,6 +598,10 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                     gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : v[4];
                     gn[(int64_t)a.ld] = v[5];
                     gn[(int64_t)2 * a.ld] = astrom ? v[6] : 0.0;
+                    if (kind == OCTO_HGCA) {      // ∂/∂(pmra, pmdec) from k_hgca
+                        const double* x = a.extra + (int64_t)(1 + P * OCTO_N_EL + o * OCTO_N_NUIS) * a.ldw + w;
+                        gn[0] = x[0]; gn[(int64_t)a.ld] = x[a.ldw]; gn[(int64_t)2 * a.ld] = 0.0;
+                    }
                 }
             }
         }
@@ -620,6 +626,7 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
         }
     }
     if (grp != 0 || w >= a.W) return;
+    if (a.extra) ll += a.extra[w];
     const bool ok = a.valid[w] != 0 && isfinite(ll);
     a.ll_out[w] = ok ? ll : -INFINITY;
     if constexpr (GRAD) {
@@ -690,7 +697,10 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
             }
             const double out[OCTO_N_EL] = {ab, eb, radvel ? 0.0 : ib, wb, radvel ? 0.0 : Ob, tpb, Mb, radvel ? 0.0 : plxb, massb};
 #pragma unroll
-            for (int k = 0; k < OCTO_N_EL; ++k) ge[(int64_t)k * a.ld] = ok ? out[k] : 0.0;
+            for (int k = 0; k < OCTO_N_EL; ++k) {
+                const double x = a.extra ? a.extra[(int64_t)(1 + p * OCTO_N_EL + k) * a.ldw + w] : 0.0;
+                ge[(int64_t)k * a.ld] = ok ? out[k] + x : 0.0;
+            }
         }
     }
 }

@@ -18,7 +18,8 @@ LIB_PATH = PKG_DIR / "lib" / "liboctofitter_hip.so"
 OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV = 0, 1, 2, 3, 4
 STATUS_NAMES = {0: "OCTO_OK", 1: "OCTO_EINVAL", 2: "OCTO_EHIP", 3: "OCTO_ENOMEM", 4: "OCTO_ENODEV"}
 
-ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL, ONEIL_RADEC, ONEIL_SEPPA = 0, 1, 2, 3, 4, 5, 6
+ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL, ONEIL_RADEC, ONEIL_SEPPA, HGCA = 0, 1, 2, 3, 4, 5, 6, 7
+HGCA_RA, HGCA_DEC, HGCA_HIP, HGCA_GAIA, HGCA_N_EXTRA = 0, 1, 0, 1, 15
 ASTROM_KINDS = (ASTROM_RADEC, ASTROM_SEPPA, ONEIL_RADEC, ONEIL_SEPPA)
 ORBIT_VISUAL_KEP, ORBIT_RADVEL = 0, 1
 N_EL, N_NUIS = 9, 3
@@ -55,6 +56,8 @@ class OctoObsDesc(C.Structure):
         ("s1", c_double_p),
         ("s2", c_double_p),
         ("cor", c_double_p),
+        ("extra", c_double_p),
+        ("n_extra", C.c_int64),
     ]
 
 
@@ -93,15 +96,16 @@ def pack_obs(obs_tables):
     keep = []
     for k, t in enumerate(obs_tables):
         cols = {}
-        for name in ("epoch", "y1", "y2", "s1", "s2", "cor"):
+        for name in ("epoch", "y1", "y2", "s1", "s2", "cor", "extra"):
             v = t.get(name)
             cols[name] = None if v is None else np.ascontiguousarray(v, dtype=np.float64)
         keep.append(cols)
         arr[k].kind = int(t["kind"])
         arr[k].planet = int(t["planet"])
         arr[k].n_epochs = int(cols["epoch"].shape[0])
-        for name in ("epoch", "y1", "y2", "s1", "s2", "cor"):
+        for name in ("epoch", "y1", "y2", "s1", "s2", "cor", "extra"):
             setattr(arr[k], name, _dptr(cols[name]))
+        arr[k].n_extra = 0 if cols["extra"] is None else int(cols["extra"].shape[0])
     return arr, keep
 
 

@@ -8,6 +8,7 @@ parity tests read like the reference's own tests:
   StarAbsoluteRVObs               OctofitterRadialVelocity/src/rv-absolute.jl:56-113
   MarginalizedStarAbsoluteRVObs   OctofitterRadialVelocity/src/rv-absolute-margin.jl:60-84
   PlanetRelativeRVObs             OctofitterRadialVelocity/src/rv-relative.jl:60-101
+  HGCAInstantaneousObs            src/likelihoods/hgca.jl:28-152
 
 A "table" is anything column-like: a dict of equal-length sequences, or a list of row dicts.
 Priors / Derived variable blocks are host-side model specification and stay in the reference
@@ -199,3 +200,62 @@ class PlanetRelativeRVObs(_RVBase):
 
 StarAbsoluteRVLikelihood = StarAbsoluteRVObs
 PlanetRelativeRVLikelihood = PlanetRelativeRVObs
+
+
+class HGCAInstantaneousObs(AbstractObs):
+    """Hipparcos-Gaia Catalog of Accelerations, instantaneous model (src/likelihoods/hgca.jl:28-152): the proper
+    motion and position of the primary at 1..N_ave epochs around the Hipparcos and Gaia epochs, averaged.
+
+    The reference looks the star up by `gaia_id` in the HGCA FITS catalogue (a DataDeps download). There is no network
+    here, so the catalogue ROW is passed in: `hgca` is a mapping with the catalogue's own column names
+    (epoch_ra_hip, epoch_dec_hip, epoch_ra_gaia, epoch_dec_gaia [Julian years]; pmra_hip, pmdec_hip, pmra_hip_error,
+    pmdec_hip_error, pmra_pmdec_hip, and the same for _hg and _gaia). A system-level observation; it reads
+    θ_system.pmra / .pmdec (hgca.jl:266-267) and every Visual{KepOrbit} planet's `mass`."""
+    kind = capi.HGCA
+    nuisance_names = ()
+    name = "HGCA"                                           # likelihoodname(::HGCAInstantaneousObs), hgca.jl:41
+    _J2000_MJD = 51544.5
+    _JULIAN_YEAR = 365.25
+
+    def __init__(self, *, hgca=None, gaia_id=None, N_ave=1, factor=1, variables=None):
+        if hgca is None:
+            raise NotImplementedError("the HGCA catalogue (DataDeps download) is not available here: pass the "
+                                      f"catalogue row as hgca=dict(...) (gaia_id={gaia_id!r})")
+        h = {k: float(np.asarray(v).reshape(-1)[0]) for k, v in dict(hgca).items()}
+        self.hgca = h
+        self.variables = variables
+        self.N_ave, self.factor = int(N_ave), float(factor)
+        to_mjd = lambda yr: (yr - 2000.0) * self._JULIAN_YEAR + self._J2000_MJD          # hgca.jl:80-84
+        e_ra_hip, e_dec_hip = to_mjd(h["epoch_ra_hip"]), to_mjd(h["epoch_dec_hip"])
+        e_ra_gaia, e_dec_gaia = to_mjd(h["epoch_ra_gaia"]), to_mjd(h["epoch_dec_gaia"])
+        dt_gaia, dt_hip = 1038.0, 4 * 365.25                                              # :87-88
+        if self.N_ave == 1:
+            δ_hip = δ_gaia = [0.0]
+        else:
+            δ_hip = np.linspace(-dt_hip / 2, dt_hip / 2, self.N_ave)
+            δ_gaia = np.linspace(-dt_gaia / 2, dt_gaia / 2, self.N_ave)
+        rows = []
+        for δ in δ_hip:                                                                   # :101-110, row order kept
+            rows.append((e_ra_hip + δ, capi.HGCA_RA, capi.HGCA_HIP))
+            rows.append((e_dec_hip + δ, capi.HGCA_DEC, capi.HGCA_HIP))
+        for δ in δ_gaia:
+            rows.append((e_ra_gaia + δ, capi.HGCA_RA, capi.HGCA_GAIA))
+            rows.append((e_dec_gaia + δ, capi.HGCA_DEC, capi.HGCA_GAIA))
+        rows = np.asarray(rows, dtype=np.float64)
+        self.table = {"epoch": rows[:, 0], "meas": rows[:, 1], "inst": rows[:, 2]}
+        ex = []
+        for tag in ("hip", "hg", "gaia"):                                                 # dist_hip, dist_hg, dist_gaia :127-145
+            ex += [h[f"pmra_{tag}"], h[f"pmdec_{tag}"], h[f"pmra_{tag}_error"] * self.factor,
+                   h[f"pmdec_{tag}_error"] * self.factor, h[f"pmra_pmdec_{tag}"]]
+        self.extra = np.asarray(ex, dtype=np.float64)
+
+    def __len__(self):
+        return len(self.table["epoch"])
+
+    def _c_table(self, planet_index):
+        t = self.table
+        return dict(kind=self.kind, planet=-1, epoch=t["epoch"], y1=t["meas"], y2=t["inst"], s1=None, s2=None, cor=None,
+                    extra=self.extra)
+
+
+HGCAInstantaneousLikelihood = HGCAInstantaneousObs

@@ -42,6 +42,8 @@ class Planet:
         for o in self.observations:
             if not isinstance(o, AbstractObs):
                 raise TypeError(f"planet observation {o!r} is not an AbstractObs")
+            if o.kind in (capi.RV_ABS, capi.RV_ABS_MARG, capi.HGCA):
+                raise ValueError(f"{type(o).__name__} is a system-level observation")
 
 
 class System:
@@ -85,11 +87,11 @@ class BatchedLnLike:
         self.obs_entries = []   # (obs, planet_index or -1, planet_name or None, θ_obs key)
         for ip, pl in enumerate(system.planets):
             for obs in pl.observations:
-                if obs.kind in (capi.RV_ABS, capi.RV_ABS_MARG):
+                if obs.kind in (capi.RV_ABS, capi.RV_ABS_MARG, capi.HGCA):
                     raise ValueError(f"{type(obs).__name__} is a system-level observation")
                 self.obs_entries.append((obs, ip, pl.name, normalizename(obs.likelihoodname())))
         for obs in system.observations:
-            if obs.kind not in (capi.RV_ABS, capi.RV_ABS_MARG):
+            if obs.kind not in (capi.RV_ABS, capi.RV_ABS_MARG, capi.HGCA):
                 raise ValueError(f"{type(obs).__name__} must be attached to a planet")
             self.obs_entries.append((obs, -1, None, normalizename(obs.likelihoodname())))
         self.n_planets = len(system.planets)
@@ -105,6 +107,11 @@ class BatchedLnLike:
             for pl, d in zip(system.planets, self.planet_desc):
                 if not d["has_mass"]:
                     raise KeyError(f"planet {pl.name} has no `mass` variable but the system has absolute RV data")
+        # HGCA reads mass * mjup2msol of every Visual{KepOrbit} planet (hgca.jl:279-290)
+        if any(e[0].kind == capi.HGCA for e in self.obs_entries):
+            for pl, d in zip(system.planets, self.planet_desc):
+                if d["orbit_kind"] == capi.ORBIT_VISUAL_KEP and not d["has_mass"]:
+                    raise KeyError(f"planet {pl.name} has no `mass` variable but the system has HGCA data")
         self.obs_tables = [e[0]._c_table(e[1]) for e in self.obs_entries]
         # ---- C side ------------------------------------------------------------------------------
         self._ctx = C.c_void_p()
@@ -182,6 +189,14 @@ class BatchedLnLike:
                 θobs = θ.get("planets", {}).get(plname, {}).get("observations", {}).get(key, {})
             else:
                 θobs = θ.get("observations", {}).get(key, {})
+            if obs.kind == capi.HGCA:
+                # its two per-walker inputs are SYSTEM variables, θ_system.pmra / .pmdec (hgca.jl:266-267)
+                for k, nm in enumerate(("pmra", "pmdec")):
+                    if nm not in θ:
+                        raise KeyError(f"HGCAInstantaneousObs requires the system variable `{nm}`")
+                    buf[io * capi.N_NUIS + k, :] = θ[nm]
+                any_nuis = True
+                continue
             if obs.kind in capi.ASTROM_KINDS:
                 defaults = (("jitter", 0.0), ("platescale", 1.0), ("northangle", 0.0))   # relative-astrometry.jl:170-172
             else:
@@ -205,6 +220,10 @@ class BatchedLnLike:
             out["planets"][pl.name]["observations"] = {}
         if g_nuis is not None:
             for io, (obs, ip, plname, key) in enumerate(self.obs_entries):
+                if obs.kind == capi.HGCA:
+                    out["pmra"] = out.get("pmra", 0.0) + g_nuis[io * capi.N_NUIS]
+                    out["pmdec"] = out.get("pmdec", 0.0) + g_nuis[io * capi.N_NUIS + 1]
+                    continue
                 names = ("jitter", "platescale", "northangle") if obs.kind in capi.ASTROM_KINDS else ("offset", "jitter")
                 d = {nm: g_nuis[io * capi.N_NUIS + k] for k, nm in enumerate(names)}
                 if ip >= 0:

@@ -293,11 +293,64 @@ def model_cases():
     print("wrote", p, p.stat().st_size, "bytes")
 
 
+def hgca_table(hg, N_ave, factor=1.0):
+    """Rows and catalogue numbers of an HGCAInstantaneousObs built from a catalogue row (src/likelihoods/hgca.jl:80-145),
+    in the C-ABI form (include/octofitter_hip.h: OCTO_HGCA)."""
+    mjd = lambda yr: (yr - 2000.0) * 365.25 + 51544.5
+    d_hip = [0.0] if N_ave == 1 else np.linspace(-4 * 365.25 / 2, 4 * 365.25 / 2, N_ave)
+    d_gaia = [0.0] if N_ave == 1 else np.linspace(-1038.0 / 2, 1038.0 / 2, N_ave)
+    rows = []
+    for d in d_hip:
+        rows += [(mjd(hg["epoch_ra_hip"]) + d, 0, 0), (mjd(hg["epoch_dec_hip"]) + d, 1, 0)]
+    for d in d_gaia:
+        rows += [(mjd(hg["epoch_ra_gaia"]) + d, 0, 1), (mjd(hg["epoch_dec_gaia"]) + d, 1, 1)]
+    rows = np.asarray(rows, dtype=np.float64)
+    extra = []
+    for tag in ("hip", "hg", "gaia"):
+        extra += [hg[f"pmra_{tag}"], hg[f"pmdec_{tag}"], hg[f"pmra_{tag}_error"] * factor, hg[f"pmdec_{tag}_error"] * factor, hg[f"pmra_pmdec_{tag}"]]
+    return dict(kind="HGCA", planet=-1, epoch=rows[:, 0].tolist(), y1=rows[:, 1].tolist(), y2=rows[:, 2].tolist(), s1=None, s2=None, cor=None,
+                extra=[float(x) for x in extra])
+
+
+# A catalogue row with the magnitudes of a nearby accelerating star (values made up for the fixture; the HGCA FITS file
+# is a download the reference performs at run time and is not available here).
+HGCA_ROW = dict(epoch_ra_hip=1991.13, epoch_dec_hip=1991.31, epoch_ra_gaia=2016.05, epoch_dec_gaia=2016.22,
+                pmra_hip=4.71, pmdec_hip=-1.86, pmra_hip_error=0.61, pmdec_hip_error=0.49, pmra_pmdec_hip=0.21,
+                pmra_hg=4.352, pmdec_hg=-2.013, pmra_hg_error=0.031, pmdec_hg_error=0.024, pmra_pmdec_hg=-0.12,
+                pmra_gaia=4.61, pmdec_gaia=-1.72, pmra_gaia_error=0.052, pmdec_gaia_error=0.041, pmra_pmdec_gaia=0.33)
+
+
+def hgca_cases():
+    """F9: HGCAInstantaneousObs (src/likelihoods/hgca.jl:155-400) — alone, averaged, and next to astrometry on two planets."""
+    rng = np.random.default_rng(20260929)
+    W = 4
+    def planet(a_lo, a_hi, m_lo, m_hi):
+        return np.stack([rng.uniform(a_lo, a_hi, W), rng.uniform(0, 0.6, W), np.arccos(rng.uniform(-1, 1, W)), rng.uniform(0, 6.28, W), rng.uniform(0, 6.28, W),
+                         50000 + rng.uniform(0, 4000, W), np.full(W, 1.2), np.full(W, 50.0), rng.uniform(m_lo, m_hi, W)])
+    pm = lambda: col(rng.normal(4.3, 0.2, W), rng.normal(-2.0, 0.2, W), np.zeros(W))
+    out = []
+    el1 = planet(6, 14, 10, 60)
+    out.append(run_case("F9_hgca_instantaneous", [VISM], [hgca_table(HGCA_ROW, 1)], el1, pm(), "one planet, N_ave = 1 (4 rows): hip, hip-gaia and gaia terms"))
+    out.append(run_case("F9_hgca_averaged_factor", [VISM], [hgca_table(HGCA_ROW, 5, factor=1.7)], el1, pm(), "N_ave = 5 (20 rows), error inflation factor 1.7"))
+    el2 = np.concatenate([planet(2, 4, 2, 12), planet(9, 16, 10, 40)])
+    ep = 55000.0 + 211.0 * np.arange(6)
+    tab = astrom(1, ep, rng.normal(0, 400, 6), rng.normal(0, 400, 6), [6.0] * 6, [7.0] * 6)
+    nu = np.concatenate([col(rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W)), pm()])
+    out.append(run_case("F9_hgca_two_planet_astrom", [VISM, VISM], [tab, hgca_table(HGCA_ROW, 3)], el2, nu,
+                        "two massive planets (the reference divides the summed reflex motion by planets x N_ave, hgca.jl:276-308) + astrometry on the outer one"))
+    p = ROOT / "tests" / "golden" / "hgca.json"
+    p.write_text(json.dumps(dict(consts=C, cases=out, generator="oracle/make_golden.py hgca_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(ROOT / "oracle"))
-    if "--ofti-only" not in sys.argv and "--model-only" not in sys.argv:
+    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only") if f in sys.argv]
+    if not only:
         main()
-    if "--model-only" not in sys.argv:
+    if not only or "--ofti-only" in only:
         ofti_cases()
-    if "--ofti-only" not in sys.argv:
+    if not only or "--model-only" in only:
         model_cases()
+    if not only or "--hgca-only" in only:
+        hgca_cases()

@@ -26,7 +26,7 @@ import mpmath as mp
 
 mp.mp.dps = 60
 
-KINDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4, "ONEIL_RADEC": 5, "ONEIL_SEPPA": 6}
+KINDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4, "ONEIL_RADEC": 5, "ONEIL_SEPPA": 6, "HGCA": 7}
 ORBIT_VISUAL_KEP, ORBIT_RADVEL = 0, 1
 EL = ["a", "e", "i", "w", "O", "tp", "M", "plx", "mass"]
 N_EL, N_NUIS = 9, 3
@@ -106,6 +106,41 @@ def ln_like_terms(c, planets, obs, elems, nuis):
         nz = nuis[io] if nuis is not None else None
         ip = ob["planet"]
         ll = mp.mpf(0)
+        if kind == 7:
+            # HGCAInstantaneousObs (hgca.jl:155-400), formulated independently of the C restatement: the primary's
+            # reflex position is −m/M_tot × the companion's offset, its proper motion is the TIME DERIVATIVE of that
+            # position (numerical, 60 digits) — no velocity formula is assumed here.
+            pm_sys = [nz[0], nz[1]] if nz is not None else [mp.mpf(0), mp.mpf(0)]
+            yr = mp.mpf(c["year2day_julian"])
+            pos = [[mp.mpf(0)] * 2 for _ in range(2)]; pmv = [[mp.mpf(0)] * 2 for _ in range(2)]
+            ep = [[mp.mpf(0)] * 2 for _ in range(2)]; cnt = [[0, 0], [0, 0]]
+            for p in range(n_pl):
+                if planets[p]["orbit_kind"] != ORBIT_VISUAL_KEP:
+                    continue
+                fac = -m_sol[p] / orbs[p]["M"]
+                for j, t in enumerate(ob["epoch"]):
+                    ax, m = int(ob["y1"][j]), int(ob["y2"][j])
+                    key = "ra" if ax == 0 else "dec"
+                    f = lambda tt, o=orbs[p], key=key: solve(o, tt)[key]
+                    cnt[m][ax] += 1              # once per (planet, row), as the reference counts (hgca.jl:276-278)
+                    ep[m][ax] += mp.mpf(t)
+                    pos[m][ax] += fac * f(mp.mpf(t))
+                    pmv[m][ax] += fac * mp.diff(f, mp.mpf(t)) * yr      # mas/day -> mas/yr (mp.diff raises the working precision itself)
+            for m in range(2):
+                for ax in range(2):
+                    pos[m][ax] /= cnt[m][ax]; ep[m][ax] /= cnt[m][ax]
+                    pmv[m][ax] = pmv[m][ax] / cnt[m][ax] + pm_sys[ax]
+            model = [[pmv[0][0], pmv[0][1]],
+                     [(pos[1][ax] - pos[0][ax]) / (ep[1][ax] - ep[0][ax]) * yr + pm_sys[ax] for ax in range(2)],
+                     [pmv[1][0], pmv[1][1]]]
+            x = [mp.mpf(v) for v in ob["extra"]]
+            for k in range(3):
+                r1, r2 = model[k][0] - x[5 * k], model[k][1] - x[5 * k + 1]
+                s1, s2, rho = x[5 * k + 2], x[5 * k + 3], x[5 * k + 4]
+                det = (s1 * s2) ** 2 * (1 - rho * rho)
+                q = ((r1 / s1) ** 2 - 2 * rho * (r1 / s1) * (r2 / s2) + (r2 / s2) ** 2) / (1 - rho * rho)
+                terms.append(-log2pi - mp.log(det) / 2 - q / 2)
+            continue
         oneil = kind in (5, 6)
         if oneil:
             kind -= 5

@@ -27,7 +27,7 @@ def oracle():
     return ob
 
 
-KIND_IDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4, "ONEIL_RADEC": 5, "ONEIL_SEPPA": 6}
+KIND_IDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4, "ONEIL_RADEC": 5, "ONEIL_SEPPA": 6, "HGCA": 7}
 
 
 def case_tables(case):
@@ -35,7 +35,8 @@ def case_tables(case):
     obs = []
     for ob in case["obs"]:
         obs.append(dict(kind=KIND_IDS[ob["kind"]], planet=ob["planet"],
-                        **{k: (None if ob[k] is None else np.asarray(ob[k], dtype=np.float64)) for k in ("epoch", "y1", "y2", "s1", "s2", "cor")}))
+                        **{k: (None if ob[k] is None else np.asarray(ob[k], dtype=np.float64)) for k in ("epoch", "y1", "y2", "s1", "s2", "cor")},
+                        extra=None if ob.get("extra") is None else np.asarray(ob["extra"], dtype=np.float64)))
     elems = np.asarray(case["elems"], dtype=np.float64)
     nuis = None if case["nuis"] is None else np.asarray(case["nuis"], dtype=np.float64)
     return obs, case["planets"], elems, nuis
@@ -44,7 +45,10 @@ def case_tables(case):
 @pytest.fixture(scope="session")
 def golden():
     with open(ROOT / "tests" / "golden" / "fixtures.json") as f:
-        return json.load(f)
+        g = json.load(f)
+    with open(ROOT / "tests" / "golden" / "hgca.json") as f:      # F9: HGCAInstantaneousObs (oracle/make_golden.py --hgca-only)
+        g["cases"] = g["cases"] + json.load(f)["cases"]
+    return g
 
 
 def rel_err(x, ref, scale=None):

@@ -419,3 +419,45 @@ def test_oneil_wrapper_receives_theta_obs(pkg):
     assert d_plain > 1
     assert abs(d_wrapped - d_plain) <= 1e-9 * abs(d_plain)
     assert abs((ll_wrapped[0] - ll_plain[0]) - (ll_wrapped[1] - ll_plain[1])) < 1e-9 and ll_wrapped[0] != ll_plain[0]
+
+
+def test_hgca_mirror_vs_oracle(pkg, oracle):
+    """HGCAInstantaneousObs through the mirror (System observation reading θ_system.pmra/.pmdec, hgca.jl:266-267) next to
+    relative astrometry, against the reference-order oracle fed the same tables; gradient comes back under the
+    reference's names."""
+    from test_host import HGCA_ROW
+    rng = np.random.default_rng(77)
+    W = 70
+    hg = pkg.HGCAInstantaneousObs(hgca=HGCA_ROW, N_ave=3)
+    ep = 55000.0 + 300.0 * np.arange(5)
+    ast = pkg.PlanetRelAstromObs(dict(epoch=ep, ra=rng.normal(0, 300, 5), dec=rng.normal(0, 300, 5), σ_ra=[5.0] * 5, σ_dec=[6.0] * 5), name="gpi")
+    b = pkg.Planet(name="b", observations=(ast,))
+    c = pkg.Planet(name="c", observations=())
+    sys_ = pkg.System(name="hgca_sys", companions=(b, c), observations=(hg,))
+    def planet(lo, hi, mlo, mhi):
+        return dict(a=rng.uniform(lo, hi, W), e=rng.uniform(0, 0.6, W), i=np.arccos(rng.uniform(-1, 1, W)), ω=rng.uniform(0, 6.28, W),
+                    Ω=rng.uniform(0, 6.28, W), tp=50000 + rng.uniform(0, 4000, W), mass=rng.uniform(mlo, mhi, W))
+    θ = dict(M=1.2, plx=50.0, pmra=rng.normal(4.3, 0.2, W), pmdec=rng.normal(-2.0, 0.2, W),
+             planets=dict(b=planet(8, 15, 10, 40), c=planet(2, 4, 1, 10)))
+    θ["planets"]["b"]["observations"] = dict(gpi=dict(jitter=rng.uniform(0, 3, W)))
+    fn = pkg.make_ln_like(sys_, θ)
+    ll, g = fn.ln_like_and_grad(θ)
+    ll_f = fn(θ)
+    elems, nuis = fn.pack(θ)
+    assert np.array_equal(ll, ll_f)
+    ll_o, g_o, gn_o = oracle.oracle_eval(fn.obs_tables, fn.planet_desc, elems, nuis, grad=True)
+    assert np.all(rel_err(ll, ll_o, 1.0) < LL_RTOL)
+    assert np.all(rel_err(g["pmra"], gn_o[3], np.abs(gn_o[3]).max()) < 1e-10) and np.all(rel_err(g["pmdec"], gn_o[4], np.abs(gn_o[4]).max()) < 1e-10)
+    for ip, nm in enumerate(("b", "c")):
+        for k, key in enumerate(("a", "e", "i", "ω", "Ω", "tp", "M", "plx", "mass")):
+            ref = g_o[ip * 9 + k]
+            assert np.all(rel_err(g["planets"][nm][key], ref, np.abs(ref).max()) < 1e-9), (nm, key)
+    # without the system proper motion the reference errors (θ_system.pmra); so does the mirror
+    θ_bad = {k: v for k, v in θ.items() if k != "pmra"}
+    with pytest.raises(KeyError):
+        fn(θ_bad)
+    fn.close()
+    # a Visual planet without a mass cannot feed the reflex motion
+    θ_nm = dict(θ, planets=dict(b=θ["planets"]["b"], c={k: v for k, v in θ["planets"]["c"].items() if k != "mass"}))
+    with pytest.raises(KeyError):
+        pkg.make_ln_like(sys_, θ_nm)

@@ -101,3 +101,32 @@ def test_shard_range(pkg):
         assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         pkg.shard_range(4, 4, 4)
+
+
+HGCA_ROW = dict(epoch_ra_hip=1991.13, epoch_dec_hip=1991.31, epoch_ra_gaia=2016.05, epoch_dec_gaia=2016.22,
+                pmra_hip=4.71, pmdec_hip=-1.86, pmra_hip_error=0.61, pmdec_hip_error=0.49, pmra_pmdec_hip=0.21,
+                pmra_hg=4.352, pmdec_hg=-2.013, pmra_hg_error=0.031, pmdec_hg_error=0.024, pmra_pmdec_hg=-0.12,
+                pmra_gaia=4.61, pmdec_gaia=-1.72, pmra_gaia_error=0.052, pmdec_gaia_error=0.041, pmra_pmdec_gaia=0.33)
+
+
+def test_hgca_constructor(pkg):
+    """HGCAInstantaneousObs (src/likelihoods/hgca.jl:58-152): rows hip(ra, dec) per δt then gaia(ra, dec) per δt, epochs in MJD
+    from Julian years, error inflation `factor` on the three covariances, likelihoodname "HGCA"."""
+    o = pkg.HGCAInstantaneousObs(hgca=HGCA_ROW, N_ave=1)
+    assert len(o) == 4 and o.likelihoodname() == "HGCA"
+    mjd = lambda yr: (yr - 2000.0) * 365.25 + 51544.5
+    assert np.allclose(o.table["epoch"], [mjd(1991.13), mjd(1991.31), mjd(2016.05), mjd(2016.22)], rtol=0, atol=1e-9)
+    assert o.table["meas"].tolist() == [0, 1, 0, 1] and o.table["inst"].tolist() == [0, 0, 1, 1]
+    o5 = pkg.HGCAInstantaneousObs(hgca=HGCA_ROW, N_ave=5, factor=2)
+    assert len(o5) == 20
+    assert np.isclose(o5.table["epoch"][0], mjd(1991.13) - 2 * 365.25) and np.isclose(o5.table["epoch"][8], mjd(1991.13) + 2 * 365.25)
+    assert np.isclose(o5.table["epoch"][10], mjd(2016.05) - 519.0)
+    assert np.allclose(o5.extra[[2, 3, 7, 8, 12, 13]], 2 * o.extra[[2, 3, 7, 8, 12, 13]]) and np.allclose(o5.extra[[0, 1, 4]], o.extra[[0, 1, 4]])
+    with pytest.raises(NotImplementedError):
+        pkg.HGCAInstantaneousObs(gaia_id=756291174721509376)      # the catalogue download is not available
+    b = pkg.Planet(name="b", observations=())
+    with pytest.raises(ValueError):
+        pkg.Planet(name="c", observations=(o,))                   # a system-level observation
+    t = o._c_table(-1)
+    assert t["kind"] == pkg.capi.HGCA and t["planet"] == -1 and len(t["extra"]) == pkg.capi.HGCA_N_EXTRA
+    assert b.name == "b"

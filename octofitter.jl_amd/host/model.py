@@ -75,6 +75,16 @@ class LogDensityModel:
         for obs, ip, plname, key in fn.obs_entries:
             ov = getattr(obs, "variables", None) or {}
             scope = ("plobs", plname, id(obs)) if ip >= 0 else ("sysobs", id(obs))
+            if obs.kind == capi.HGCA:
+                # θ_system.pmra / .pmdec (hgca.jl:266-267): system variables, not observation variables
+                for nm in ("pmra", "pmdec"):
+                    if nm not in sysvars:
+                        raise KeyError(f"HGCAInstantaneousObs requires the system variable `{nm}`")
+                    spec = sysvars[nm]
+                    nsrc.append((capi.SRC_CONST, 0, 0, 0, float(spec)) if isinstance(spec, (int, float))
+                                else self._source(spec, ("sys",), nm, sysvars, ("sys",), used_circ))
+                nsrc.append((capi.SRC_CONST, 0, 0, 0, 0.0))
+                continue
             if obs.kind in capi.ASTROM_KINDS:
                 rows = (("jitter", 0.0), ("platescale", 1.0), ("northangle", 0.0))
             else:

@@ -181,3 +181,40 @@ def test_gpu_batched_callers(pkg):
     ll = pkg.rejection_evaluate_likelihoods(model, chain["samples"])
     assert np.allclose(ll, chain["loglike"], rtol=0, atol=0)
     model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_hgca(pkg, oracle):
+    """A joint fit in the reference's style (docs: astrometry + HGCAInstantaneousObs): system variables pmra, pmdec feed the
+    HGCA term (hgca.jl:266-267), the planet's mass its reflex motion. Device ℓπ and ∇ℓπ w.r.t. θ_t against the oracle's
+    restatement of the whole callback, and the gradient against finite differences (test/integration/sampling.jl:136-192)."""
+    from test_host import HGCA_ROW
+    table = dict(epoch=[50000, 50120, 50240, 50360], ra=[-505.76, -502.57, -498.21, -492.68], dec=[-66.93, -37.47, -7.93, 21.64],
+                 σ_ra=[10.0] * 4, σ_dec=[10.0] * 4)
+    astrom_like = pkg.PlanetRelAstromLikelihood(table, name="astrom")
+    hg = pkg.HGCAInstantaneousObs(hgca=HGCA_ROW, N_ave=2)
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[astrom_like],
+                   variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                           Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000),
+                                           mass=pkg.LogUniform(1.0, 100.0)))
+    sys_ = pkg.System(name="HGCASys", companions=[b], observations=[hg],
+                      variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1),
+                                              pmra=pkg.Normal(4.3, 1.0), pmdec=pkg.Normal(-2.0, 1.0)))
+    model = pkg.LogDensityModel(sys_)
+    assert model.D == 14 and model.names[:4] == ["M", "plx", "pmra", "pmdec"] and model.names[-1] == "b_mass"
+    rng = np.random.default_rng(3)
+    θ_t = model.link(model.sample_priors(rng, 96))
+    lp, g = model.logdensity_and_gradient(θ_t)
+    assert np.all(np.isfinite(lp))
+    fn = model.ln_like
+    lp_o, g_o = oracle.oracle_model_logpost(fn.obs_tables, fn.planet_desc, model._c_priors, model._c_esrc, model._c_nsrc, θ_t)
+    assert np.all(np.abs(lp - lp_o) <= 1e-12 * np.maximum(1, np.abs(lp_o)))
+    scale = np.abs(g_o).max(axis=1, keepdims=True)
+    assert np.all(np.abs(g - g_o) <= 1e-9 * np.abs(g_o) + 1e-11 * scale), np.max(np.abs(g - g_o) / (np.abs(g_o) + scale))
+    for k in (2, 3, 13):          # pmra, pmdec, mass: the inputs only the HGCA term sees
+        h = 1e-6
+        tp, tm = θ_t[:, 0].copy(), θ_t[:, 0].copy()
+        tp[k] += h; tm[k] -= h
+        fd = (model.ℓπcallback(tp) - model.ℓπcallback(tm)) / (2 * h)
+        assert abs(fd - g[k, 0]) <= 1e-3 + 1e-4 * abs(fd), (k, fd, g[k, 0])
+    model.close()

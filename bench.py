@@ -243,12 +243,13 @@ def main():
     }
     if rank == 0:
         ach = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-        traffic, flops_per_eval = None, None
+        traffic, flops_per_eval, issue = None, None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists() and args.workload == "grad" and (n_rows, W) == (10_000, 10_000):
             try:      # PMC figures are per launch of exactly this workload; measured off-line (separate --pmc passes)
                 j = json.loads(pmc.read_text())
                 traffic, flops_per_eval = j.get("hbm_bytes_per_launch"), j.get("fp64_flops_per_eval")
+                issue = j.get("issue_model")
             except Exception:
                 traffic = None
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -262,7 +263,11 @@ def main():
             tf = flops_per_eval * float(W) * n_rows / (kern_ms * 1e-3) / 1e12
             res["roofline"]["valu"] = {"bound": "fp64_vector", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
                                        "fp64_flops_per_eval": flops_per_eval,
-                                       "note": "FP64 flops only (FMA = 2); VALU issue slots are ~100 % busy at the sustained ~2.0 GHz clock"}
+                                       "note": "FP64 flops only (FMA = 2); VALU issue slots are ~100 % busy at the sustained ~2.1 GHz clock"}
+            if issue:
+                # time the chip needs just to ISSUE this kernel's VALU instructions (measured mix x measured cost per class)
+                t_issue = issue["ns_per_row_per_wave"] * 1e-6 * n_rows * ((W + 63) // 64) / issue["simds"]
+                res["roofline"]["valu"].update({"issue_bound_ms": t_issue, "issue_frac": t_issue / kern_ms})
         if not args.no_cpu_baseline and cfg is not None and world == 1 and args.workload in ("grad",):
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg, fn.obs_tables, fn.planet_desc, args.cpu_seconds)

@@ -13,7 +13,7 @@
 #
 # Eligibility follows SURVEY.md §8(b): tables the kernels implement go to the device; epoch-free prior-like
 # terms (UnitLengthPrior, UserLikelihood, PlanetOrderPrior, ...) are evaluated on the host and added; any other
-# epoch-bearing observation (HGCA, GP RV, images, ...) makes the model ineligible and the constructor throws, so
+# epoch-bearing observation (full HGCA line fit, GP RV, images, ...) makes the model ineligible and the constructor throws, so
 # callers keep using model.ℓπcallback.
 module OctofitterHIP
 
@@ -24,6 +24,7 @@ const LIB = get(ENV, "OCTOFITTER_HIP_LIB", "liboctofitter_hip.so")
 
 const OCTO_OK = Int32(0)
 const ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
+const ONEIL_RADEC, ONEIL_SEPPA, HGCA = Int32(5), Int32(6), Int32(7)
 const ORBIT_VISUAL_KEP, ORBIT_RADVEL = Int32(0), Int32(1)
 const N_EL, N_NUIS = 9, 3
 const EL_KEYS = (:a, :e, :i, :ω, :Ω, :tp, :M, :plx, :mass)
@@ -35,6 +36,7 @@ end
 struct OctoObsDesc           # mirrors `octo_obs_desc`
     kind::Int32; planet::Int32; n_epochs::Int64
     epoch::Ptr{Float64}; y1::Ptr{Float64}; y2::Ptr{Float64}; s1::Ptr{Float64}; s2::Ptr{Float64}; cor::Ptr{Float64}
+    extra::Ptr{Float64}; n_extra::Int64
 end
 struct OctoPlanetDesc        # mirrors `octo_planet_desc`
     orbit_kind::Int32; has_mass::Int32
@@ -69,6 +71,18 @@ function _table(obs, i_planet)
         return kind, Int32(i_planet - 1), [cols..., cor]
     end
     T = nameof(typeof(obs))
+    if T === :ObsPriorAstromONeil2019 && obs.wrapped_like isa PlanetRelAstromObs      # prior-observable.jl:56-76
+        kind, planet, cols = _table(obs.wrapped_like, i_planet)
+        return (kind == ASTROM_SEPPA ? ONEIL_SEPPA : ONEIL_RADEC), planet, cols
+    end
+    if T === :HGCAInstantaneousObs                                                     # hgca.jl:58-152
+        h = obs.hgca
+        meas = Float64[m === :ra ? 0 : 1 for m in t.meas]; inst = Float64[i === :hip ? 0 : 1 for i in t.inst]
+        cov(d) = (s = sqrt.(Octofitter.diag(d.Σ)); (s[1], s[2], d.Σ[1, 2] / (s[1] * s[2])))   # includes `factor`
+        extra = Float64[h.pmra_hip, h.pmdec_hip, cov(h.dist_hip)..., h.pmra_hg, h.pmdec_hg, cov(h.dist_hg)...,
+                        h.pmra_gaia, h.pmdec_gaia, cov(h.dist_gaia)...]
+        return HGCA, Int32(-1), [_f64(t.epoch), meas, inst, Float64[], Float64[], Float64[], extra]
+    end
     kind = T === :StarAbsoluteRVObs ? RV_ABS : T === :MarginalizedStarAbsoluteRVObs ? RV_ABS_MARG :
            T === :PlanetRelativeRVObs ? RV_REL : nothing
     kind === nothing && return nothing
@@ -92,7 +106,8 @@ function GPUBatchedLikelihood(model; device::Integer=0)
         kind, planet, cols = tb
         append!(columns, cols)
         p(c) = isempty(c) ? Ptr{Float64}(C_NULL) : pointer(c)
-        push!(descs, OctoObsDesc(kind, planet, length(cols[1]), p(cols[1]), p(cols[2]), p(cols[3]), p(cols[4]), p(cols[5]), p(cols[6])))
+        ex = length(cols) >= 7 ? cols[7] : Float64[]
+        push!(descs, OctoObsDesc(kind, planet, length(cols[1]), p(cols[1]), p(cols[2]), p(cols[3]), p(cols[4]), p(cols[5]), p(cols[6]), p(ex), length(ex)))
         push!(entries, (obs, ip, normalizename(likelihoodname(obs))))
     end
     # evaluation order of the generated closure: planet observations planet by planet, then system ones (system.jl:229-235)
@@ -146,7 +161,9 @@ function kernel_inputs(g::GPUBatchedLikelihood, θ)
     for (io, (obs, ip, key)) in enumerate(g.obs_entries)
         src = ip > 0 ? θ.planets[ip].observations : θ.observations
         θobs = hasproperty(src, key) ? getproperty(src, key) : (;)
-        if obs isa PlanetRelAstromObs                                     # relative-astrometry.jl:170-172
+        if nameof(typeof(obs)) === :HGCAInstantaneousObs                  # θ_system.pmra / .pmdec, hgca.jl:266-267
+            x[o0+(io-1)*N_NUIS+1] = θ.pmra; x[o0+(io-1)*N_NUIS+2] = θ.pmdec; x[o0+(io-1)*N_NUIS+3] = zero(T)
+        elseif obs isa PlanetRelAstromObs || nameof(typeof(obs)) === :ObsPriorAstromONeil2019   # relative-astrometry.jl:170-172
             x[o0+(io-1)*N_NUIS+1] = hasproperty(θobs, :jitter) ? θobs.jitter : zero(T)
             x[o0+(io-1)*N_NUIS+2] = hasproperty(θobs, :platescale) ? θobs.platescale : one(T)
             x[o0+(io-1)*N_NUIS+3] = hasproperty(θobs, :northangle) ? θobs.northangle : zero(T)

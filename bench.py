@@ -48,13 +48,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--epochs", type=int, default=10_000)
-    ap.add_argument("--walkers", type=int, default=10_000, help="walkers per GPU")
+    ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default 10000; 8192 = 8 temperatures x 1024 for --workload pt)")
     ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti", "logpost"], default="grad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for single-GPU dry runs")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device index (dry runs of the N>1 path on one GPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.walkers is None:      # BASELINE config 5: 64 temperatures x 1024 walkers over 8 GPUs = 8 x 1024 per GPU
+        args.walkers = 8192 if args.workload == "pt" else 10_000
+    return args
 
 
 def cpu_baseline(cfg, obs_tables, planets, seconds):

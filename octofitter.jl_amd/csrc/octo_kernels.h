@@ -195,6 +195,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     double acc[L::NACC];
 #pragma unroll
     for (int k = 0; k < L::NACC; ++k) acc[k] = 0.0;
+    LogProd lp;                                         // Π of the rows' variance terms (nuisance path only)
     __syncthreads();                                    // table filled
 
     const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_RADEC ||
@@ -308,17 +309,28 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
                 g1 = -a1; g2 = -a2;
             } else {
                 const double v1 = fma(c3, c3, j2), v2 = fma(c4, c4, j2);   // hypot(σ, jitter)², :234-235
-                const double cor = (L::HAS_COR && ob.has_cor) ? c5 : 0.0;
-                const double omc = 1.0 - cor * cor;
-                const double ic = 1.0 / omc;
-                const double i1 = rsqrt(v1), i2 = rsqrt(v2);
-                const double z1 = r1 * i1, z2 = r2 * i2;
-                const double h1 = (z1 - cor * z2) * ic, h2 = (z2 - cor * z1) * ic;
-                const double qf = z1 * h1 + z2 * h2;
-                acc[L::OFF_S] += log(v1 * v2 * omc) + qf;                  // ll = −n·log2π − ½Σ(...)
-                g1 = -h1 * i1; g2 = -h2 * i2;
+                const double v12 = v1 * v2;
+                const double iv12 = rcp_nr<2>(v12);                       // one reciprocal for 1/v1 and 1/v2
+                const double iv1 = iv12 * v2, iv2 = iv12 * v1;
+                double a1, a2;                                             // Σ⁻¹ r
+                if (L::HAS_COR && ob.has_cor) {
+                    const double cor = c5;
+                    const double omc = 1.0 - cor * cor;
+                    const double ic = rcp_nr<2>(omc);
+                    const double is = rsqrt(v12);                          // 1/(σ1 σ2)
+                    a1 = fma(r1, iv1, -(cor * r2 * is)) * ic;
+                    a2 = fma(r2, iv2, -(cor * r1 * is)) * ic;
+                    lp.mul(v12 * omc);
+                } else {
+                    a1 = r1 * iv1; a2 = r2 * iv2;
+                    lp.mul(v12);
+                }
+                // ll = −n·log2π − ½Σ(log|Σ| + rᵀΣ⁻¹r); the logs via lp. Explicit FMAs: the forward-only and the gradient
+                // instantiation must round this sum identically (the compiler would contract it differently around q1, q2)
+                acc[L::OFF_S] = fma(r1, a1, fma(r2, a2, acc[L::OFF_S]));
+                g1 = -a1; g2 = -a2;
                 if constexpr (GRAD) {
-                    acc[L::OFF_NU + OCTO_NU_JITTER] += jit * ((z1 * h1 - 1.0) * i1 * i1 + (z2 * h2 - 1.0) * i2 * i2);
+                    acc[L::OFF_NU + OCTO_NU_JITTER] += jit * fma(fma(r1, a1, -1.0), iv1, fma(r2, a2, -1.0) * iv2);
                     if (seppa) {
                         acc[L::OFF_NU + OCTO_NU_PLATESCALE] = fma(g2, y2, acc[L::OFF_NU + OCTO_NU_PLATESCALE]);
                         acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += g1;
@@ -404,20 +416,19 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
             }
             const double resid = rv - model;
             double iv, var = 1.0;
-            if constexpr (NUIS) { var = fma(c2, c2, j2); iv = 1.0 / var; } else { iv = c2; }
+            if constexpr (NUIS) { var = fma(c2, c2, j2); iv = rcp_nr<2>(var); lp.mul(var); } else { iv = c2; }
             double rvb;   // ∂ll/∂model
             if (marg) {
                 // rv-absolute-margin.jl:171-180
                 acc[L::OFF_MARG + 0] += iv;
                 acc[L::OFF_MARG + 1] = fma(-2.0 * resid, iv, acc[L::OFF_MARG + 1]);
                 acc[L::OFF_MARG + 2] = fma(resid * resid, iv, acc[L::OFF_MARG + 2]);
-                if constexpr (NUIS) acc[L::OFF_S] += log(TWO_PI * var);
                 const double dm = resid - mu_hat;
                 rvb = 2.0 * dm * iv;
                 if constexpr (GRAD && NUIS)
                     acc[L::OFF_NU + OCTO_NU_RV_JITTER] += 2.0 * jit * iv * (dm * dm * iv - 1.0 + iv * iA);
             } else {
-                if constexpr (NUIS) acc[L::OFF_S] += log(var) + resid * resid * iv;
+                if constexpr (NUIS) acc[L::OFF_S] = fma(resid * resid, iv, acc[L::OFF_S]);
                 else acc[L::OFF_S] = fma(resid * resid, iv, acc[L::OFF_S]);
                 rvb = resid * iv;
                 if constexpr (GRAD && NUIS) {
@@ -450,6 +461,12 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
                 }
             }
         }
+    }
+    if constexpr (NUIS) {
+        // Σ log|Σ_row| (astrometry), Σ log var (RV), Σ log(2π var) (marginalised RV, rv-absolute-margin.jl:179) of this wave's rows
+        double lg = lp.log_value();
+        if ((KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG) lg = fma((double)n_rows, LOG2PI, lg);
+        acc[L::OFF_S] += lg;
     }
     // ---- combine the block's waves through LDS in a fixed order (deterministic), one partial per (tile, task).
     // Waves take turns through one NACC×64 buffer, so the footprint stays <= 28 KB (+ the table) for the widest layout.

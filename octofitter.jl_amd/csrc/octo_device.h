@@ -171,6 +171,28 @@ __device__ __forceinline__ double rcp_nr(double x) {
     return r;
 }
 
+// 1/√x: v_rsq_f64 (≈2^-23) + two Newton steps y ← y(1.5 − 0.5·x·y²).
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+
+// Julia's `x % 2π` (truncated remainder, sign of x) for |x| < 2^50: q = trunc(x/2π), r = x − q·fl(2π) by one FMA, which
+// is the exact remainder whenever q is the right integer; a q that is off by one (x within an ulp of a multiple) is
+// repaired by one add. Replaces ocml fmod on the sep/PA path (relative-astrometry.jl:196).
+__device__ __forceinline__ double rem_2pi_trunc(double x) {
+    const double q = trunc(x * (1.0 / TWO_PI));
+    double r = fma(-q, TWO_PI, x);
+    r = (x >= 0.0 && r < 0.0) ? r + TWO_PI : r;
+    r = (x < 0.0 && r > 0.0) ? r - TWO_PI : r;
+    r = (r >= TWO_PI) ? r - TWO_PI : r;
+    r = (r <= -TWO_PI) ? r + TWO_PI : r;
+    return r;
+}
+
 // Σ_rows log(x_row) as log(Π x_row): one multiply and a mantissa/exponent split per row instead of one FP64 log (≈45
 // instructions) per row; one real log per wave at the end. The running mantissa stays in [0.5, 1), so nothing
 // over- or underflows whatever the σ's; 0, Inf and NaN factors propagate to the final log as they would through a sum

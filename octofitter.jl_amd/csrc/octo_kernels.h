@@ -278,14 +278,15 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
             if (seppa) {
                 // relative-astrometry.jl:192-202
                 const double rho2 = fma(ra_m, ra_m, dec_m * dec_m);
-                const double rho = sqrt(rho2);
-                irho = 1.0 / rho;
+                irho = rsqrt_nr(rho2);                         // ρ = ρ²·(1/ρ) enters r2 through one explicit FMA below: a separate
+                                                               // product would be contracted differently by the forward-only and
+                                                               // the gradient instantiation, and their values must agree bitwise
                 const double pa = atan2(ra_m, dec_m);
                 double dpa = (y1 + na) - pa + PI;
-                dpa = fmod(dpa, TWO_PI) - PI;                  // Julia `%`: truncated remainder
+                dpa = rem_2pi_trunc(dpa) - PI;                 // Julia `%`: truncated remainder
                 dpa = dpa < -PI ? dpa + TWO_PI : dpa;
                 r1 = dpa;
-                r2 = fma(y2, ps, -rho);
+                r2 = fma(-rho2, irho, y2 * ps);
             } else {
                 // relative-astrometry.jl:210-215: the data are rotated by −northangle and scaled
                 if constexpr (NUIS) {

@@ -218,8 +218,7 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
     s.dt = t - pc.tp;
     const double u = s.dt * pc.invP;
-    const double frac = u - rint(u);
-    const double M = frac * TWO_PI;                   // folds into f0's FMA below
+    const double frac = u - rint(u);                  // M = 2π·frac enters f0 through an FMA below
     // ---- Markley (1995) starter, eqs (20),(5),(9),(10),(14),(15), in FP32
     const float Mf = (float)frac * (float)TWO_PI;     // scale in FP32: one FP64 multiply less per row
     const float ef = pc.ef, omef = pc.omef;
@@ -245,7 +244,7 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     const double hf2 = 0.5 * f2, q24 = f2 * (1.0 / 24.0);
     const double sf3 = (e * (1.0 / 6.0)) * c1;
     const double f1 = fma(-e, c1, 1.0);
-    const double f0 = (E1 - M) - f2;
+    const double f0 = fma(-e, s1, fma(-frac, TWO_PI, E1));           // E1 − e sin E1 − M
     // One hardware reciprocal for the three divisions: the denominators are f1·(den4 + O(δ²)), den4, den4 + O(δ³), so
     // each reciprocal is a Newton step away from the previous one (prototype: tools/kepler_proto.py, same error).
     const double r3 = __builtin_amdgcn_rcp(fma(f1, f1, -(f0 * hf2)));                // ≈2^-23

@@ -53,6 +53,7 @@ enum : int {
     WC_F32B,      // packed {float k1 = MK_K1N/(1+e), float 0}
     WC_CGB, WC_CFB,   // CG·β, CF·β          ra = CB·cosE + CGB·sinE − CBE,  dec = CA·cosE + CFB·sinE − CAE
     WC_CBE, WC_CAE,   // CB·e, CA·e
+    WC_SINI, WC_COSI, WC_SINO, WC_COSO,   // of the reduced angles (i mod π, Ω mod 2π); read by k_finish only
     NWC
 };
 

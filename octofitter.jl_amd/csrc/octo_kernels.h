@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
         o[WC_CBE * a.ldw] = T * B * e; o[WC_CAE * a.ldw] = T * A * e;
         o[WC_K * a.ldw] = K; o[WC_COSW * a.ldw] = cw; o[WC_SINW * a.ldw] = sw;
         o[WC_MU * a.ldw] = mass * a.c.mjup2msol / Mt; o[WC_A * a.ldw] = sma;
+        o[WC_SINI * a.ldw] = si; o[WC_COSI * a.ldw] = ci; o[WC_SINO * a.ldw] = sO; o[WC_COSO * a.ldw] = cO;
     }
     if (a.nuis) {
         for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok = ok && isfinite(a.nuis[(int64_t)k * a.ld + w]);
@@ -657,17 +658,16 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
             double* ge = a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w;
             const double* g = &gp[p * L::PL_N];
             const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
-            const double sma = el[OCTO_EL_A * a.ld], e = el[OCTO_EL_E * a.ld], om = el[OCTO_EL_W * a.ld];
+            const double sma = el[OCTO_EL_A * a.ld], e = el[OCTO_EL_E * a.ld];
             const double Mt = el[OCTO_EL_M * a.ld];
-            double inc = radvel ? 0.0 : el[OCTO_EL_I * a.ld], Om = radvel ? 0.0 : el[OCTO_EL_O * a.ld];
             const double plx = radvel ? 1.0 : el[OCTO_EL_PLX * a.ld];
             const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
-            inc = inc - PI * floor(inc / PI);
-            Om = Om - TWO_PI * floor(Om / TWO_PI);
-            const double P_d = a.c.k_yr * sqrt(sma * sma * sma / Mt);
-            const double beta = sqrt(1.0 - e * e);
-            double si, ci, sw, cw, sO, cO;
-            sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO);
+            // per-walker constants k_setup already derived: no second round of sincos/sqrt in this latency-bound kernel
+            const double* wc = a.wc + (int64_t)p * NWC * a.ldw + w;
+            const double P_d = 1.0 / wc[WC_INVP * a.ldw];
+            const double beta = wc[WC_BETA * a.ldw];
+            const double si = wc[WC_SINI * a.ldw], ci = wc[WC_COSI * a.ldw], sO = wc[WC_SINO * a.ldw], cO = wc[WC_COSO * a.ldw];
+            const double sw = wc[WC_SINW * a.ldw], cw = wc[WC_COSW * a.ldw];
             const double kappa = a.c.mas_per_au_per_plx;
             const double sm = plx * kappa, T = sma * sm;
             const double A = cO * cw - sO * sw * ci, B = sO * cw + cO * sw * ci;

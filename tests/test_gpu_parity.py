@@ -6,7 +6,7 @@ GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
   * the reference tests' self-consistency properties, through the host mirror.
 
 Tolerances. The north_star bar is "log-likelihood and gradient within 1e-8 relative"; the tests hold the HIP path
-to 1000x tighter, close to what tools/parity_report.py measures on the GPU (ll ~5e-15, gradients ~5e-15 of scale):
+to 1000x tighter, close to what tests/parity_report.py measures on the GPU (ll ~5e-15, gradients ~5e-15 of scale):
   ll      |Δ| <= 1e-12 · max(|ll|, 1)          (1e-9 where the reference's marginalised-RV formula cancels)
   grad    |Δ| <= 1e-9 · |g| + 1e-13 · (S + max_w S),  S = Σ_rows |∂ll_row/∂θ|  (the rounding floor of a sum whose
           terms cancel; for oracle comparisons S is replaced by 10x the row maximum of |g| over the batch)

@@ -182,6 +182,41 @@ def test_full_size_properties(oracle):
     _cmp_oracle("full size sample", ll[idx], g[:, idx], None, ll_o, g_o, None)
 
 
+def test_full_size_nuisance_path(oracle):
+    """The raw-σ path at full size (1e4 RA/Dec epochs × 4096 walkers with per-walker jitter, platescale, northangle,
+    relative-astrometry.jl:234-252): the kernel sums the rows' log-variances as the log of a renormalised product, so
+    check determinism, forward == gradient value, additivity over a split of the table (a different partition of that
+    product) and the oracle on a seeded sample of walkers at the full epoch count."""
+    gb = _gpu()
+    cfg = synth.config_astrom(n_walkers=4096)
+    W = 4096
+    t = cfg["table"]
+    mk = lambda sl: dict(kind=0, planet=0, epoch=t["epoch"][sl], y1=t["ra"][sl], y2=t["dec"][sl], s1=t["σ_ra"][sl], s2=t["σ_dec"][sl], cor=None)
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    rng = np.random.default_rng(5)
+    nu = np.stack([rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W)])
+    nu[0, :7] = [0.0, 1e-12, 1e-3, 50.0, 1e3, 1e-300, 1e6]            # jitter extremes: product of 1e4 variances spans ±1e5 decades
+    full = gb.GpuPath([mk(slice(None))], planets)
+    ll, g, gn = full.eval(cfg["elems"], nu, grad=True)
+    ll2, g2, gn2 = full.eval(cfg["elems"], nu, grad=True)
+    assert np.array_equal(ll, ll2) and np.array_equal(g, g2) and np.array_equal(gn, gn2), "not deterministic"
+    llf, _, _ = full.eval(cfg["elems"], nu, grad=False)
+    assert np.array_equal(ll, llf)
+    full.close()
+    assert np.all(np.isfinite(ll))
+    split = gb.GpuPath([mk(slice(0, 4321)), mk(slice(4321, None))], planets)
+    nu2 = np.concatenate([nu, nu])
+    ll_s, g_s, gn_s = split.eval(cfg["elems"], nu2, grad=True)
+    split.close()
+    assert np.all(rel_err(ll_s, ll, 1.0) < 1e-12)
+    assert np.all(np.abs(g_s - g) <= 1e-11 * np.abs(g).max(axis=1, keepdims=True))
+    assert np.all(np.abs(gn_s[:3] + gn_s[3:] - gn) <= 1e-11 * np.abs(gn).max(axis=1, keepdims=True))
+    idx = np.concatenate([np.arange(7), np.random.default_rng(0).choice(np.arange(7, W), 17, replace=False)])
+    ll_o, g_o, gn_o = oracle.oracle_eval([mk(slice(None))], planets, cfg["elems"][:, idx], nu[:, idx], grad=True,
+                                         active=synth.active_mask(1, 1, mass=False, nuis=True), n_threads=0)
+    _cmp_oracle("full size nuisance sample", ll[idx], g[:, idx], gn[:, idx], ll_o, g_o, gn_o)
+
+
 def test_mirror_reference_properties(pkg, oracle):
     """test/unit/likelihoods.jl:32-95 and test/unit/distributions.jl:102-152 through the host mirror's
     PlanetRelAstromObs / Planet / System / make_ln_like surface, on the HIP path."""

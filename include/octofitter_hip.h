@@ -85,6 +85,9 @@ extern "C" {
 /* ---- orbit parameterisations (PlanetOrbits.jl types) --------------------- */
 #define OCTO_ORBIT_VISUAL_KEP 0  /* Visual{KepOrbit}: a,e,i,ω,Ω,tp,M,plx               */
 #define OCTO_ORBIT_RADVEL     1  /* RadialVelocityOrbit: a,e,ω,tp,M (i,Ω,plx ignored)  */
+#define OCTO_ORBIT_THIELE_INNES 2 /* ThieleInnesOrbit: e,tp,M,plx and the Thiele-Innes constants A,B,F,G [mas] in the element rows
+                                   * OCTO_EL_TI_A/B/F/G below; a = α/plx with α from A,B,F,G (src/parameterizations.jl:15-19).
+                                   * Astrometry, the O'Neil prior and HGCA only (no RV tables with this basis). */
 
 /* ---- element rows: elems[(planet*OCTO_N_EL + k) * ld + w] ---------------- */
 #define OCTO_EL_A     0   /* semi-major axis [AU]                 */
@@ -97,6 +100,11 @@ extern "C" {
 #define OCTO_EL_PLX   7   /* parallax [mas]                       */
 #define OCTO_EL_MASS  8   /* companion mass [M_jup]               */
 #define OCTO_N_EL     9
+/* the same rows for an OCTO_ORBIT_THIELE_INNES planet: A, B, F, G replace a, i, ω, Ω */
+#define OCTO_EL_TI_A  0
+#define OCTO_EL_TI_B  2
+#define OCTO_EL_TI_F  3
+#define OCTO_EL_TI_G  4
 
 /* ---- nuisance rows: nuis[(obs*OCTO_N_NUIS + k) * ld + w] ----------------- */
 /* astrometry kinds */
@@ -234,6 +242,7 @@ typedef struct octo_prior {
 #define OCTO_SRC_TPERI    3   /* θ_at_epoch_to_tperi(atan(θ[i1], θ[i0]), value; M, e, a, i, ω, Ω) of this planet  */
 #define OCTO_SRC_FLAG_UNITLEN 1   /* this use of the (i0, i1) pair also contributes its UnitLengthPrior term (set it on exactly
                                      one source per UniformCircular variable; variables.jl:309-323) */
+#define OCTO_SRC_FLAG_TI      2   /* OCTO_SRC_TPERI of a Thiele-Innes planet: θ_at_epoch_to_tperi(θ, value; plx, M, e, A, B, F, G) */
 typedef struct octo_source {
     int32_t kind, i0, i1, flags;
     double value;

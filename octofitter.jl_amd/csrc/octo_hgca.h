@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
     bool visual[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        visual[p] = a.orbit_kind[p] == OCTO_ORBIT_VISUAL_KEP;
+        visual[p] = a.orbit_kind[p] != OCTO_ORBIT_RADVEL;      // Visual{KepOrbit} or ThieleInnesOrbit (hgca.jl:255-262)
+        const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
         D el[OCTO_N_EL];
 #pragma unroll
         for (int k = 0; k < OCTO_N_EL; ++k) {
@@ -58,20 +59,29 @@ __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
             el[k] = (dir == p * OCTO_N_EL + k) ? dvar<1>(v, 0) : dconst<1>(v);
         }
         if (!a.has_mass[p]) el[OCTO_EL_MASS] = dconst<1>(0.0);
-        D inc = el[OCTO_EL_I], Om = el[OCTO_EL_O];
-        inc.v = inc.v - PI * floor(inc.v / PI);                // KepOrbit ctor invariants, as in k_setup
-        Om.v = Om.v - TWO_PI * floor(Om.v / TWO_PI);
-        const D sma = el[OCTO_EL_A], e = el[OCTO_EL_E], Mt = el[OCTO_EL_M];
-        const D P_d = dsqrt(sma * sma * sma / Mt) * a.c.k_yr;   // parameterizations.jl:62
+        const D e = el[OCTO_EL_E], Mt = el[OCTO_EL_M];
         HgcaPlanet& h = hp[p];
+        D sma;
+        if (ti) {
+            // constants in mas; a = α/plx   (src/parameterizations.jl:14-19)
+            h.cA = el[OCTO_EL_TI_A]; h.cB = el[OCTO_EL_TI_B]; h.cF = el[OCTO_EL_TI_F]; h.cG = el[OCTO_EL_TI_G];
+            const D u = (h.cA * h.cA + h.cB * h.cB + h.cF * h.cF + h.cG * h.cG) * 0.5, v = h.cA * h.cG - h.cB * h.cF;
+            sma = dsqrt(u + dsqrt((u + v) * (u - v))) / el[OCTO_EL_PLX];
+            h.T = dconst<1>(1.0);
+        } else {
+            D inc = el[OCTO_EL_I], Om = el[OCTO_EL_O];
+            inc.v = inc.v - PI * floor(inc.v / PI);                // KepOrbit ctor invariants, as in k_setup
+            Om.v = Om.v - TWO_PI * floor(Om.v / TWO_PI);
+            sma = el[OCTO_EL_A];
+            h.T = sma * el[OCTO_EL_PLX] * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
+            const D ci = dcos(inc), sw = dsin(el[OCTO_EL_W]), cw = dcos(el[OCTO_EL_W]), sO = dsin(Om), cO = dcos(Om);
+            h.cA = cO * cw - sO * sw * ci; h.cB = sO * cw + cO * sw * ci;
+            h.cF = -(cO * sw) - sO * cw * ci; h.cG = -(sO * sw) + cO * cw * ci;
+        }
+        const D P_d = dsqrt(sma * sma * sma / Mt) * a.c.k_yr;   // parameterizations.jl:62
         h.e = e; h.tp = el[OCTO_EL_TP];
         h.beta = dsqrt(dconst<1>(1.0) - e * e);
         h.n_day = dconst<1>(TWO_PI) / P_d;
-        h.T = sma * el[OCTO_EL_PLX] * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
-        const D si_ = dsin(inc), ci = dcos(inc), sw = dsin(el[OCTO_EL_W]), cw = dcos(el[OCTO_EL_W]), sO = dsin(Om), cO = dcos(Om);
-        (void)si_;
-        h.cA = cO * cw - sO * sw * ci; h.cB = sO * cw + cO * sw * ci;
-        h.cF = -(cO * sw) - sO * cw * ci; h.cG = -(sO * sw) + cO * cw * ci;
         h.fac = -(el[OCTO_EL_MASS] * a.c.mjup2msol) / Mt;      // q(sol, M_planet) = −M_planet/M_tot · q(sol)
         h.pc = PC{};
         h.pc.invP = 1.0 / P_d.v; h.pc.tp = h.tp.v; h.pc.e = e.v;

@@ -99,30 +99,41 @@ __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
     for (int p = 0; p < a.n_planets; ++p) {
         const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + w;
         const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
-        const double sma = el[OCTO_EL_A * a.ld], e = el[OCTO_EL_E * a.ld], om = el[OCTO_EL_W * a.ld];
+        const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
+        const double e = el[OCTO_EL_E * a.ld], om = el[OCTO_EL_W * a.ld];
         const double tp = el[OCTO_EL_TP * a.ld], Mt = el[OCTO_EL_M * a.ld];
+        double sma = el[OCTO_EL_A * a.ld];
         double inc = radvel ? 0.0 : el[OCTO_EL_I * a.ld];
         double Om = radvel ? 0.0 : el[OCTO_EL_O * a.ld];
         const double plx = radvel ? 1.0 : el[OCTO_EL_PLX * a.ld];
         const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
         ok = ok && isfinite(sma) && isfinite(e) && isfinite(inc) && isfinite(om) && isfinite(Om) && isfinite(tp) &&
              isfinite(Mt) && isfinite(plx) && isfinite(mass);
+        double T, A, B, F, G, si, ci, sw, cw, sO, cO;
+        if (ti) {
+            // ThieleInnesOrbit: rows a, i, ω, Ω carry A, B, F, G [mas]; a = α/plx   (src/parameterizations.jl:14-19)
+            A = sma; B = inc; F = om; G = Om;
+            const double u = 0.5 * (A * A + B * B + F * F + G * G), v = A * G - B * F;
+            sma = sqrt(u + sqrt((u + v) * (u - v))) / plx;
+            T = 1.0;
+            si = ci = sw = cw = sO = cO = 0.0;
+        } else {
+            // PlanetOrbits KepOrbit ctor invariants: i = rem(i, π, RoundDown), Ω = rem2pi(Ω, RoundDown)
+            inc = inc - PI * floor(inc / PI);
+            Om = Om - TWO_PI * floor(Om / TWO_PI);
+            sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO);
+            if (radvel) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
+            // Thiele-Innes constants (parameterizations.jl:34-37) scaled to mas: T = a · cart2angle
+            T = radvel ? 0.0 : sma * plx * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
+            A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
+            F = -cO * sw - sO * cw * ci; G = -sO * sw + cO * cw * ci;
+        }
         ok = ok && (e >= 0.0) && (e < 1.0) && (sma > 0.0) && (Mt > 0.0) && (plx > 0.0);
-        // PlanetOrbits KepOrbit ctor invariants: i = rem(i, π, RoundDown), Ω = rem2pi(Ω, RoundDown)
-        inc = inc - PI * floor(inc / PI);
-        Om = Om - TWO_PI * floor(Om / TWO_PI);
         const double P_d = a.c.k_yr * sqrt(sma * sma * sma / Mt);       // parameterizations.jl:62
         const double ome2 = 1.0 - e * e;
         const double beta = sqrt(ome2);
-        double si, ci, sw, cw, sO, cO;
-        sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO);
-        if (radvel) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
-        // Thiele-Innes constants (parameterizations.jl:34-37) scaled to mas: T = a · cart2angle
-        const double T = radvel ? 0.0 : sma * plx * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
-        const double A = cO * cw - sO * sw * ci, B = sO * cw + cO * sw * ci;
-        const double F = -cO * sw - sO * cw * ci, G = -sO * sw + cO * cw * ci;
         // K = ((2π a)/P_yr)/√(1−e²) · au2m · sec2year · sin i
-        const double K = (TWO_PI * sma / (P_d / a.c.yd)) / beta * a.c.au2m * a.c.sec2yr * si;
+        const double K = (TWO_PI * sma / (P_d / a.c.yd)) / beta * a.c.au2m * a.c.sec2yr * si;   // 0 for a ThieleInnesOrbit (no RV tables there)
         double* o = a.wc + (int64_t)p * NWC * a.ldw + w;
         o[WC_INVP * a.ldw] = 1.0 / P_d; o[WC_TP * a.ldw] = tp; o[WC_E * a.ldw] = e; o[WC_BETA * a.ldw] = beta;
         o[WC_EOB * a.ldw] = e / beta;
@@ -599,7 +610,8 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                     // ln_prior = 2 log(Σ|t_j| · ∛P / √(1−e²)), P = period/365.25   prior-observable.jl:96,136-139
                     const int ip = a.obs[o].planet;
                     const double* el = a.elems + (int64_t)ip * OCTO_N_EL * a.ld + wl;
-                    const double sma = el[OCTO_EL_A * a.ld], e = el[OCTO_EL_E * a.ld], Mt = el[OCTO_EL_M * a.ld];
+                    const double sma = a.wc[((int64_t)ip * NWC + WC_A) * a.ldw + wl];      // derived for a ThieleInnesOrbit
+                    const double e = el[OCTO_EL_E * a.ld], Mt = el[OCTO_EL_M * a.ld];
                     const double Pyr = a.c.k_yr * sqrt(sma * sma * sma / Mt) / 365.25;
                     llo += 2.0 * log(v[7] * cbrt(Pyr) / sqrt(1.0 - e * e));
                     if constexpr (GRAD) {
@@ -658,20 +670,24 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
             double* ge = a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w;
             const double* g = &gp[p * L::PL_N];
             const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
-            const double sma = el[OCTO_EL_A * a.ld], e = el[OCTO_EL_E * a.ld];
+            const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
+            const double e = el[OCTO_EL_E * a.ld];
             const double Mt = el[OCTO_EL_M * a.ld];
             const double plx = radvel ? 1.0 : el[OCTO_EL_PLX * a.ld];
             const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
             // per-walker constants k_setup already derived: no second round of sincos/sqrt in this latency-bound kernel
             const double* wc = a.wc + (int64_t)p * NWC * a.ldw + w;
+            const double sma = wc[WC_A * a.ldw];                 // the element itself, or α/plx of a ThieleInnesOrbit
             const double P_d = 1.0 / wc[WC_INVP * a.ldw];
             const double beta = wc[WC_BETA * a.ldw];
             const double si = wc[WC_SINI * a.ldw], ci = wc[WC_COSI * a.ldw], sO = wc[WC_SINO * a.ldw], cO = wc[WC_COSO * a.ldw];
             const double sw = wc[WC_SINW * a.ldw], cw = wc[WC_COSW * a.ldw];
             const double kappa = a.c.mas_per_au_per_plx;
-            const double sm = plx * kappa, T = sma * sm;
-            const double A = cO * cw - sO * sw * ci, B = sO * cw + cO * sw * ci;
-            const double F = -cO * sw - sO * cw * ci, G = -sO * sw + cO * cw * ci;
+            const double sm = plx * kappa, T = ti ? 1.0 : sma * sm;
+            // unit Thiele-Innes constants of a Campbell orbit, or the [mas] constants a ThieleInnesOrbit is parameterised by
+            const double A = ti ? el[OCTO_EL_TI_A * a.ld] : cO * cw - sO * sw * ci, B = ti ? el[OCTO_EL_TI_B * a.ld] : sO * cw + cO * sw * ci;
+            const double F = ti ? el[OCTO_EL_TI_F * a.ld] : -cO * sw - sO * cw * ci, G = ti ? el[OCTO_EL_TI_G * a.ld] : -sO * sw + cO * cw * ci;
+            double tiAb = 0, tiBb = 0, tiFb = 0, tiGb = 0;
             double ab = 0, eb = g[L::GE], ib = 0, wb = 0, Ob = 0, tpb, Mb = 0, plxb = 0, massb = 0, Pb = 0;
             double gM = g[L::GM], gT = g[L::GT];
             if constexpr (L::HAS_ONEIL) {
@@ -686,7 +702,8 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                 eb -= T * (B * g[L::U5] + A * g[L::U6]);
                 eb -= (e / beta) * T * (G * g[L::U2] + F * g[L::U4]);
                 const double Bb = T * gB, Gb = T * gG, Ab = T * gA, Fb = T * gF;
-                const double Tb = B * gB + G * gG + A * gA + F * gF;
+                tiAb = gA; tiBb = gB; tiFb = gF; tiGb = gG;
+                const double Tb = ti ? 0.0 : B * gB + G * gG + A * gA + F * gF;
                 ab += Tb * sm; plxb += Tb * sma * kappa;
                 ib = Ab * (sO * sw * si) + Bb * (-cO * sw * si) + Fb * (sO * cw * si) + Gb * (-cO * cw * si);
                 wb = Ab * (-cO * sw - sO * cw * ci) + Bb * (-sO * sw + cO * cw * ci) + Fb * (-cO * cw + sO * sw * ci) + Gb * (-sO * cw - cO * sw * ci);
@@ -713,7 +730,19 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                 const double mu = mass * a.c.mjup2msol / Mt;
                 if (a.has_mass[p]) { massb = g[L::GC] * a.c.mjup2msol / Mt; Mb += -g[L::GC] * mu / Mt; }
             }
-            const double out[OCTO_N_EL] = {ab, eb, radvel ? 0.0 : ib, wb, radvel ? 0.0 : Ob, tpb, Mb, radvel ? 0.0 : plxb, massb};
+            double out[OCTO_N_EL] = {ab, eb, radvel ? 0.0 : ib, wb, radvel ? 0.0 : Ob, tpb, Mb, radvel ? 0.0 : plxb, massb};
+            if (ti) {
+                // a = α/plx, α² = u + √(u² − v²), u = (A²+B²+F²+G²)/2, v = AG − BF  (src/parameterizations.jl:15-18): push ā back
+                const double u = 0.5 * (A * A + B * B + F * F + G * G), v = A * G - B * F;
+                const double sq = sqrt((u + v) * (u - v)), alpha = sma * plx;
+                const double alphab = ab / plx;
+                const double ub = alphab * (1.0 + u / sq) / (2.0 * alpha), vb = -alphab * (v / sq) / (2.0 * alpha);
+                out[OCTO_EL_TI_A] = tiAb + ub * A + vb * G;
+                out[OCTO_EL_TI_B] = tiBb + ub * B - vb * F;
+                out[OCTO_EL_TI_F] = tiFb + ub * F - vb * B;
+                out[OCTO_EL_TI_G] = tiGb + ub * G + vb * A;
+                out[OCTO_EL_PLX] = -ab * sma / plx;
+            }
 #pragma unroll
             for (int k = 0; k < OCTO_N_EL; ++k) {
                 const double x = a.extra ? a.extra[(int64_t)(1 + p * OCTO_N_EL + k) * a.ldw + w] : 0.0;

@@ -105,11 +105,20 @@ __device__ __forceinline__ Dual<N> unit_length(const Dual<N>& x, const Dual<N>& 
 
 // θ_at_epoch_to_tperi   src/parameterizations.jl:34-67
 template <int N>
-__device__ __forceinline__ Dual<N> tperi(const Dual<N>& th, double theta_epoch, const Dual<N>& M, const Dual<N>& e, const Dual<N>& a,
-                                         const Dual<N>& inc, const Dual<N>& w, const Dual<N>& O, double k_yr, double yd) {
-    const Dual<N> cO = dcos(O), sO = dsin(O), cw = dcos(w), sw = dsin(w), ci = dcos(inc);
-    const Dual<N> A = cO * cw - sO * sw * ci, B = sO * cw + cO * sw * ci;
-    const Dual<N> F = -(cO * sw) - sO * cw * ci, G = -(sO * sw) + cO * cw * ci;
+// Thiele-Innes planets (ti): the arguments a, inc, w, O carry A, B, F, G [mas] and a = α/plx (:14-19).
+__device__ __forceinline__ Dual<N> tperi(const Dual<N>& th, double theta_epoch, const Dual<N>& M, const Dual<N>& e, const Dual<N>& a_in,
+                                         const Dual<N>& inc, const Dual<N>& w, const Dual<N>& O, double k_yr, double yd,
+                                         bool ti = false, const Dual<N>* plx = nullptr) {
+    Dual<N> A, B, F, G, a = a_in;
+    if (ti) {
+        A = a_in; B = inc; F = w; G = O;
+        const Dual<N> u = (A * A + B * B + F * F + G * G) * 0.5, v = A * G - B * F;
+        a = dsqrt(u + dsqrt((u + v) * (u - v))) / *plx;
+    } else {
+        const Dual<N> cO = dcos(O), sO = dsin(O), cw = dcos(w), sw = dsin(w), ci = dcos(inc);
+        A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
+        F = -(cO * sw) - sO * cw * ci; G = -(sO * sw) + cO * cw * ci;
+    }
     const Dual<N> ct = dcos(th), st = dsin(th);
     const Dual<N> det = A * G - F * B;
     const Dual<N> xr = (G * ct - F * st) / det, yr = (A * st - B * ct) / det;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(1024) void k_model_fwd(ModelArgs a) {
             else {
                 const int r = (k - a.n_el) % OCTO_N_NUIS; const int kind = a.obs[(k - a.n_el) / OCTO_N_NUIS].kind;
                 sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
-                sc.value = ((kind <= OCTO_ASTROM_SEPPA || kind >= OCTO_ONEIL_RADEC) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+                sc.value = ((kind <= OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
             }
             if ((sc.kind == OCTO_SRC_TPERI) != (pass == 1)) continue;
             Dual<N> val;
@@ -183,7 +192,8 @@ __global__ __launch_bounds__(1024) void k_model_fwd(ModelArgs a) {
                 if (sc.kind == OCTO_SRC_CIRCULAR) val = ang * (sc.value / TWO_PI);      // atan(y, x) / 2π * domain, variables.jl:284
                 else {
                     const Dual<N>* e_ = el + (k / OCTO_N_EL) * OCTO_N_EL;
-                    val = tperi(ang, sc.value, e_[OCTO_EL_M], e_[OCTO_EL_E], e_[OCTO_EL_A], e_[OCTO_EL_I], e_[OCTO_EL_W], e_[OCTO_EL_O], a.k_yr, a.yd);
+                    val = tperi(ang, sc.value, e_[OCTO_EL_M], e_[OCTO_EL_E], e_[OCTO_EL_A], e_[OCTO_EL_I], e_[OCTO_EL_W], e_[OCTO_EL_O], a.k_yr, a.yd,
+                                (sc.flags & OCTO_SRC_FLAG_TI) != 0, &e_[OCTO_EL_PLX]);
                 }
             }
             if (k < a.n_el) el[k] = val;

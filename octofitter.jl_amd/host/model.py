@@ -21,7 +21,7 @@ import numpy as np
 from . import capi
 from .observations import normalizename
 from .priors import Prior, UniformCircular, θ_at_epoch_to_tperi
-from .system import BatchedLnLike, System, _BASIS, _EL_KEYS
+from .system import BatchedLnLike, System, _BASIS, el_keys
 
 _K_YR, _YD = 365.2568983840419, 365.25
 
@@ -54,7 +54,7 @@ class LogDensityModel:
         for ip, pl in enumerate(system.planets):
             pv = pl.variables or {}
             radvel = _BASIS[pl.basis] == capi.ORBIT_RADVEL
-            for k, keys in enumerate(_EL_KEYS):
+            for k, keys in enumerate(el_keys(pl.basis)):
                 spec, scope, name = None, None, None
                 for key in keys:
                     if key in pv:
@@ -70,7 +70,8 @@ class LogDensityModel:
                         esrc.append((capi.SRC_CONST, 0, 0, 0, 0.0))
                         continue
                     raise KeyError(f"planet {pl.name}: missing orbital element {keys[0]}")
-                esrc.append(self._source(spec, scope, name, pv, ("pl", pl.name), used_circ))
+                esrc.append(self._source(spec, scope, name, pv, ("pl", pl.name), used_circ,
+                                         ti=_BASIS[pl.basis] == capi.ORBIT_THIELE_INNES))
         nsrc = []
         for obs, ip, plname, key in fn.obs_entries:
             ov = getattr(obs, "variables", None) or {}
@@ -124,7 +125,7 @@ class LogDensityModel:
                 self.names += [prefix + name + "x", prefix + name + "y"]
                 self._circ[scope + (name,)] = (ix, ix + 1, spec.domain)
 
-    def _source(self, spec, scope, name, block, block_scope, used_circ):
+    def _source(self, spec, scope, name, block, block_scope, used_circ, ti=False):
         if isinstance(spec, Prior):
             return (capi.SRC_THETA, self._index[scope + (name,)], 0, 0, 0.0)
         if isinstance(spec, UniformCircular):
@@ -142,7 +143,8 @@ class LogDensityModel:
                 raise ValueError("θ_at_epoch_to_tperi expects θ ~ UniformCircular() (domain 2π)")
             flag = 0 if key in used_circ else capi.SRC_FLAG_UNITLEN
             used_circ.add(key)
-            return (capi.SRC_TPERI, ix, iy, flag, spec.theta_epoch)
+            # a ThieleInnesOrbit planet uses θ_at_epoch_to_tperi(θ, epoch; plx, M, e, A, B, F, G)   (parameterizations.jl:8-19)
+            return (capi.SRC_TPERI, ix, iy, flag | (capi.SRC_FLAG_TI if ti else 0), spec.theta_epoch)
         return (capi.SRC_CONST, 0, 0, 0, float(spec))
 
     # ------------------------------------------------------------------------------------------------ callbacks
@@ -220,6 +222,9 @@ class LogDensityModel:
             if kind == capi.SRC_CIRCULAR:
                 return ang / (2 * np.pi) * val
             e_ = elems[p * capi.N_EL:(p + 1) * capi.N_EL]
+            if src[3] & capi.SRC_FLAG_TI:
+                return _tperi(ang, val, e_[capi.EL_M], e_[capi.EL_E], None, None, None, None,
+                              abfg=(e_[capi.EL_A], e_[capi.EL_I], e_[capi.EL_W], e_[capi.EL_O]), plx=e_[capi.EL_PLX])
             return _tperi(ang, val, e_[capi.EL_M], e_[capi.EL_E], e_[capi.EL_A], e_[capi.EL_I], e_[capi.EL_W], e_[capi.EL_O])
         elems = np.zeros((n_el, W))
         for want_tperi in (False, True):
@@ -242,12 +247,18 @@ class LogDensityModel:
             pass
 
 
-def _tperi(θ, theta_epoch, M, e, a, i, ω, Ω):
+def _tperi(θ, theta_epoch, M, e, a, i, ω, Ω, abfg=None, plx=None):
     """NumPy θ_at_epoch_to_tperi (src/parameterizations.jl:6-69) — host convenience for arr2nt-style inspection."""
-    A = np.cos(Ω) * np.cos(ω) - np.sin(Ω) * np.sin(ω) * np.cos(i)
-    B = np.sin(Ω) * np.cos(ω) + np.cos(Ω) * np.sin(ω) * np.cos(i)
-    F = -np.cos(Ω) * np.sin(ω) - np.sin(Ω) * np.cos(ω) * np.cos(i)
-    G = -np.sin(Ω) * np.sin(ω) + np.cos(Ω) * np.cos(ω) * np.cos(i)
+    if abfg is not None:
+        A, B, F, G = abfg
+        u = (A ** 2 + B ** 2 + F ** 2 + G ** 2) / 2
+        v = A * G - B * F
+        a = np.sqrt(u + np.sqrt((u + v) * (u - v))) / plx
+    else:
+        A = np.cos(Ω) * np.cos(ω) - np.sin(Ω) * np.sin(ω) * np.cos(i)
+        B = np.sin(Ω) * np.cos(ω) + np.cos(Ω) * np.sin(ω) * np.cos(i)
+        F = -np.cos(Ω) * np.sin(ω) - np.sin(Ω) * np.cos(ω) * np.cos(i)
+        G = -np.sin(Ω) * np.sin(ω) + np.cos(Ω) * np.cos(ω) * np.cos(i)
     det = A * G - F * B
     xr = (G * np.cos(θ) - F * np.sin(θ)) / det
     yr = (A * np.sin(θ) - B * np.cos(θ)) / det

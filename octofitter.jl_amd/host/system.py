@@ -28,7 +28,13 @@ from . import capi
 from .observations import AbstractObs, normalizename
 
 _EL_KEYS = (("a",), ("e",), ("i",), ("ω", "w", "omega"), ("Ω", "O", "Omega"), ("tp",), ("M",), ("plx",), ("mass",))
-_BASIS = {"Visual{KepOrbit}": capi.ORBIT_VISUAL_KEP, "RadialVelocityOrbit": capi.ORBIT_RADVEL}
+# ThieleInnesOrbit(; e, tp, M, plx, A, B, F, G): the constants [mas] travel in the rows of a, i, ω, Ω (include/octofitter_hip.h)
+_EL_KEYS_TI = (("A",), ("e",), ("B",), ("F",), ("G",), ("tp",), ("M",), ("plx",), ("mass",))
+_BASIS = {"Visual{KepOrbit}": capi.ORBIT_VISUAL_KEP, "RadialVelocityOrbit": capi.ORBIT_RADVEL, "ThieleInnesOrbit": capi.ORBIT_THIELE_INNES}
+
+
+def el_keys(basis):
+    return _EL_KEYS_TI if _BASIS[basis] == capi.ORBIT_THIELE_INNES else _EL_KEYS
 
 
 class Planet:
@@ -170,7 +176,7 @@ class BatchedLnLike:
         elems = np.zeros((self.n_planets * capi.N_EL, W))
         for ip, pl in enumerate(self.system.planets):
             θp = θ.get("planets", {}).get(pl.name, {})
-            for k, keys in enumerate(_EL_KEYS):
+            for k, keys in enumerate(el_keys(pl.basis)):
                 v = _lookup(θp, keys)
                 if v is None:
                     v = _lookup(θ, keys)      # planet-level wins, as in merge(θ_system, θ_planet)
@@ -216,7 +222,7 @@ class BatchedLnLike:
     def unpack_grad(self, g_elems, g_nuis):
         out = dict(planets={}, observations={})
         for ip, pl in enumerate(self.system.planets):
-            out["planets"][pl.name] = {keys[0]: g_elems[ip * capi.N_EL + k] for k, keys in enumerate(_EL_KEYS)}
+            out["planets"][pl.name] = {keys[0]: g_elems[ip * capi.N_EL + k] for k, keys in enumerate(el_keys(pl.basis))}
             out["planets"][pl.name]["observations"] = {}
         if g_nuis is not None:
             for io, (obs, ip, plname, key) in enumerate(self.obs_entries):

@@ -25,9 +25,10 @@ const LIB = get(ENV, "OCTOFITTER_HIP_LIB", "liboctofitter_hip.so")
 const OCTO_OK = Int32(0)
 const ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
 const ONEIL_RADEC, ONEIL_SEPPA, HGCA = Int32(5), Int32(6), Int32(7)
-const ORBIT_VISUAL_KEP, ORBIT_RADVEL = Int32(0), Int32(1)
+const ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES = Int32(0), Int32(1), Int32(2)
 const N_EL, N_NUIS = 9, 3
 const EL_KEYS = (:a, :e, :i, :ω, :Ω, :tp, :M, :plx, :mass)
+const EL_KEYS_TI = (:A, :e, :B, :F, :G, :tp, :M, :plx, :mass)     # ThieleInnesOrbit: constants [mas] in the rows of a, i, ω, Ω
 
 struct OctoConsts            # mirrors `octo_consts`
     kepler_year_to_julian_day::Float64; year2day_julian::Float64; au2m::Float64; sec2year_julian::Float64
@@ -121,7 +122,7 @@ function GPUBatchedLikelihood(model; device::Integer=0)
     has_mass = Bool[]
     for (ip, pl) in enumerate(system.planets)
         OT = Octofitter.orbittype(pl)
-        ok = OT <: Visual{<:KepOrbit} ? ORBIT_VISUAL_KEP : OT <: RadialVelocityOrbit ? ORBIT_RADVEL :
+        ok = OT <: Visual{<:KepOrbit} ? ORBIT_VISUAL_KEP : OT <: RadialVelocityOrbit ? ORBIT_RADVEL : OT <: ThieleInnesOrbit ? ORBIT_THIELE_INNES :
              error("orbit type $OT is not on the HIP path")
         hm = hasproperty(θ0.planets[ip], :mass)                 # relative-astrometry.jl:122
         push!(planets, OctoPlanetDesc(ok, hm)); push!(has_mass, hm)
@@ -153,7 +154,8 @@ function kernel_inputs(g::GPUBatchedLikelihood, θ)
     x = Vector{T}(undef, g.n_planets * N_EL + length(g.obs_entries) * N_NUIS)
     for ip in 1:g.n_planets
         θp = merge(θ, θ.planets[ip])                                    # system.jl:117
-        for (k, key) in enumerate(EL_KEYS)
+        keys = Octofitter.orbittype(g.model.system.planets[ip]) <: ThieleInnesOrbit ? EL_KEYS_TI : EL_KEYS
+        for (k, key) in enumerate(keys)
             x[(ip-1)*N_EL+k] = hasproperty(θp, key) ? getproperty(θp, key) : zero(T)
         end
     end

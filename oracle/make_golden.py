@@ -343,9 +343,74 @@ def hgca_cases():
     print("wrote", p, p.stat().st_size, "bytes")
 
 
+TI = dict(orbit_kind=2, has_mass=False)
+TIM = dict(orbit_kind=2, has_mass=True)
+
+
+def campbell_to_ti(el):
+    """[9][W] Campbell elements -> the same orbits as ThieleInnesOrbit rows (A, e, B, F, G, tp, M, plx, mass), constants in mas
+    (a·plx·rad2as/pc2au times the rotation-matrix entries, src/parameterizations.jl:34-37)."""
+    a, e, inc, w, O, tp, M, plx, mass = el
+    T = a * plx * C["rad2as"] / C["pc2au"]
+    cO, sO, cw, sw, ci = np.cos(O), np.sin(O), np.cos(w), np.sin(w), np.cos(inc)
+    return np.stack([T * (cO * cw - sO * sw * ci), e, T * (sO * cw + cO * sw * ci), T * (-cO * sw - sO * cw * ci), T * (-sO * sw + cO * cw * ci), tp, M, plx, mass])
+
+
+def ti_cases():
+    """F10: ThieleInnesOrbit basis (docs/src/thiele-innes.md; constants A, B, F, G in mas, a = α/plx as in
+    src/parameterizations.jl:14-19) — astrometry, O'Neil prior, a Thiele-Innes + Campbell pair with the inner-barycentre
+    term, HGCA; and the tutorial's D = 9 model through the whole callback."""
+    rng = np.random.default_rng(20260929 + 10)
+    W = 5
+    def planet(a_lo, a_hi, m_lo, m_hi):
+        return np.stack([rng.uniform(a_lo, a_hi, W), rng.uniform(0, 0.6, W), np.arccos(rng.uniform(-1, 1, W)), rng.uniform(0, 6.28, W), rng.uniform(0, 6.28, W),
+                         50000 + rng.uniform(0, 4000, W), np.full(W, 1.2), np.full(W, 50.0), rng.uniform(m_lo, m_hi, W)])
+    out = []
+    ep = 50000.0 + 120.0 * np.arange(8)
+    tab = astrom(0, ep, rng.normal(0, 400, 8), rng.normal(0, 400, 8), [10.0] * 8, [9.0] * 8, cor=list(rng.uniform(-0.5, 0.5, 8)))
+    el1 = campbell_to_ti(planet(6, 14, 0, 0))
+    nu = col(rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W))
+    out.append(run_case("F10_ti_astrom_cor_nuis", [TI], [tab], el1, nu, "relative astrometry with cor + nuisances on a Thiele-Innes planet"))
+    o = dict(tab); o["kind"] = "ONEIL_RADEC"
+    out.append(run_case("F10_ti_oneil_nonuis", [TI], [o], el1, None, "O'Neil observable prior on a Thiele-Innes planet (period from the derived a)"))
+    inner, outer = planet(2, 4, 2, 12), planet(9, 16, 10, 40)
+    el2 = np.concatenate([campbell_to_ti(inner), outer])
+    tab2 = astrom(1, ep, rng.normal(0, 400, 8), rng.normal(0, 400, 8), [6.0] * 8, [7.0] * 8)
+    out.append(run_case("F10_ti_inner_campbell_outer", [TIM, VISM], [tab2], el2, None,
+                        "massive Thiele-Innes inner planet perturbing astrometry of a Campbell outer planet (ordering by the derived a)"))
+    pm = col(rng.normal(4.3, 0.2, W), rng.normal(-2.0, 0.2, W), np.zeros(W))
+    el3 = campbell_to_ti(planet(6, 14, 10, 60))
+    out.append(run_case("F10_ti_hgca", [TIM], [hgca_table(HGCA_ROW, 2)], el3, pm, "HGCA proper-motion anomaly from a Thiele-Innes planet"))
+    p = ROOT / "tests" / "golden" / "ti.json"
+    p.write_text(json.dumps(dict(consts=C, cases=out, generator="oracle/make_golden.py ti_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+    # ---- the tutorial model (docs/src/thiele-innes.md): e~U(0,0.5), A,B,F,G~Normal(0,1000), θ~UniformCircular,
+    # tp = θ_at_epoch_to_tperi(θ, 50000; plx, M, e, A, B, F, G), M, plx as in the Campbell tutorial. D = 9.
+    P = lambda kind, p0=0.0, p1=0.0, lo=None, hi=None: dict(kind=kind, p0=p0, p1=p1, lo=lo, hi=hi)
+    S = lambda kind, i0=0, i1=0, flags=0, value=0.0: dict(kind=kind, i0=i0, i1=i1, flags=flags, value=value)
+    ep2 = [50000, 50120, 50240, 50360, 50480, 50600, 50720, 50840]
+    ra2 = [-505.76, -502.57, -498.21, -492.68, -485.98, -478.11, -469.08, -458.90]
+    dec2 = [-66.93, -37.47, -7.93, 21.64, 51.15, 80.54, 109.73, 138.65]
+    obs = [astrom(0, ep2, ra2, dec2, [10.0] * 8, [10.0] * 8, cor=[0.0] * 8)]
+    # θ order: system [M, plx], planet b [e, A, B, F, G, θx, θy]
+    priors = [P(3, 1.2, 0.1, 0.1, None), P(3, 50.0, 0.02, 0.1, None), P(0, 0.0, 0.5)] + [P(2, 0.0, 1000.0)] * 4 + [P(2, 0.0, 1.0)] * 2
+    esrc = [S(1, 3), S(1, 2), S(1, 4), S(1, 5), S(1, 6), S(3, 7, 8, 1 | 2, 50000.0), S(1, 0), S(1, 1), S(0)]
+    Wm = 8
+    th = rng.normal(0, 1, (9, Wm))
+    th[0] = np.log(rng.normal(1.2, 0.05, Wm) - 0.1); th[1] = np.log(rng.normal(50.0, 0.02, Wm) - 0.1)
+    th[3:7] = rng.normal(0, 400, (4, Wm))      # A, B, F, G ~ Normal(0, 1000): identity link
+    res = [mpo.model_logpost_and_grad(C, [TI], obs, priors, esrc, None, list(th[:, w])) for w in range(Wm)]
+    case = dict(name="D9_thiele_innes_tutorial", planets=[TI], obs=obs, priors=priors, esrc=esrc, nsrc=None, theta_t=th.tolist(),
+                lp=[fl(r[0]) for r in res], grad=np.array([[fl(v) for v in r[1]] for r in res]).T.tolist())
+    print(f"  D9 TI: lp[0]={case['lp'][0]:.12g}", flush=True)
+    p = ROOT / "tests" / "golden" / "ti_model.json"
+    p.write_text(json.dumps(dict(consts=C, cases=[case], generator="oracle/make_golden.py ti_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(ROOT / "oracle"))
-    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only") if f in sys.argv]
+    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only") if f in sys.argv]
     if not only:
         main()
     if not only or "--ofti-only" in only:
@@ -354,3 +419,5 @@ if __name__ == "__main__":
         model_cases()
     if not only or "--hgca-only" in only:
         hgca_cases()
+    if not only or "--ti-only" in only:
+        ti_cases()

@@ -27,7 +27,7 @@ import mpmath as mp
 mp.mp.dps = 60
 
 KINDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4, "ONEIL_RADEC": 5, "ONEIL_SEPPA": 6, "HGCA": 7}
-ORBIT_VISUAL_KEP, ORBIT_RADVEL = 0, 1
+ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES = 0, 1, 2
 EL = ["a", "e", "i", "w", "O", "tp", "M", "plx", "mass"]
 N_EL, N_NUIS = 9, 3
 
@@ -57,7 +57,22 @@ def kepler_newton(MA, e):
     return E
 
 
+def _ti_sma(A, B, F, G, plx):
+    """Semi-major axis [AU] of a Thiele-Innes orbit with constants in mas: the constants are a·plx times a rotation
+    matrix [[A, F], [B, G]] = R(Ω)·diag(1, cos i)·R(ω) whose singular values are 1 and |cos i|, so a·plx is the larger
+    singular value of the 2x2 matrix — computed here from its SVD invariants, not from the reference's u, v formula."""
+    fro2 = A * A + B * B + F * F + G * G          # σ1² + σ2²
+    det = A * G - B * F                           # ±σ1 σ2
+    s1 = mp.sqrt((fro2 + mp.sqrt(fro2 * fro2 - 4 * det * det)) / 2)
+    return s1 / plx
+
+
 def _orbit(c, kind, el):
+    if kind == ORBIT_THIELE_INNES:
+        A, e, B, F, G, tp, M, plx, _mass = el      # rows a, i, ω, Ω carry A, B, F, G [mas]
+        a = _ti_sma(A, B, F, G, plx)
+        P_d = mp.mpf(c["kepler_year_to_julian_day"]) * mp.sqrt(a ** 3 / M)
+        return dict(ti=(A, B, F, G), a=a, e=e, tp=tp, M=M, P_d=P_d, K=mp.nan, w=mp.mpf(0), i=mp.mpf(0), O=mp.mpf(0), mas_per_au=mp.mpf(1))
     a, e, inc, w, O, tp, M, plx, _mass = el
     P_d = mp.mpf(c["kepler_year_to_julian_day"]) * mp.sqrt(a ** 3 / M)
     P_yr = P_d / mp.mpf(c["year2day_julian"])
@@ -76,6 +91,11 @@ def solve(o, t):
     MA = 2 * mp.pi * (mp.mpf(t) - o["tp"]) / o["P_d"]
     E = kepler_newton(MA, o["e"])
     e = o["e"]
+    if "ti" in o:
+        # sky offsets are linear in the orbital-plane coordinates in units of a: (ΔDec, ΔRA) = [[A, F], [B, G]] · (X, Y)
+        A, B, F, G = o["ti"]
+        X, Y = mp.cos(E) - e, mp.sqrt(1 - e * e) * mp.sin(E)
+        return dict(E=E, nu=mp.atan2(Y, X), r=o["a"] * mp.sqrt(X * X + Y * Y), ra=B * X + G * Y, dec=A * X + F * Y, rv=mp.nan)
     Xo = o["a"] * (mp.cos(E) - e)                       # orbital-plane coordinates, periapsis on +X
     Yo = o["a"] * mp.sqrt(1 - e * e) * mp.sin(E)
     r = mp.sqrt(Xo * Xo + Yo * Yo)
@@ -115,7 +135,7 @@ def ln_like_terms(c, planets, obs, elems, nuis):
             pos = [[mp.mpf(0)] * 2 for _ in range(2)]; pmv = [[mp.mpf(0)] * 2 for _ in range(2)]
             ep = [[mp.mpf(0)] * 2 for _ in range(2)]; cnt = [[0, 0], [0, 0]]
             for p in range(n_pl):
-                if planets[p]["orbit_kind"] != ORBIT_VISUAL_KEP:
+                if planets[p]["orbit_kind"] == ORBIT_RADVEL:
                     continue
                 fac = -m_sol[p] / orbs[p]["M"]
                 for j, t in enumerate(ob["epoch"]):
@@ -342,6 +362,22 @@ def _prior(pr, y):
     return x, lp + ladj
 
 
+def _tperi_ti(c, th, epoch, M, e, A, B, F, G, plx):
+    """Thiele-Innes variant: the sky direction at position angle th is (ΔDec, ΔRA) ∝ (cos th, sin th) = [[A, F], [B, G]]·(X, Y);
+    invert for the in-plane direction, which is the true anomaly (periapsis on +X)."""
+    north, east = mp.cos(th), mp.sin(th)
+    det = A * G - F * B
+    X = (G * north - F * east) / det
+    Y = (A * east - B * north) / det
+    nu = mp.atan2(Y, X)
+    E = 2 * mp.atan(mp.sqrt((1 - e) / (1 + e)) * mp.tan(nu / 2))
+    MA = E - e * mp.sin(E)
+    MA = MA - 2 * mp.pi * mp.floor(MA / (2 * mp.pi))
+    a = _ti_sma(A, B, F, G, plx)
+    P_d = mp.mpf(c["kepler_year_to_julian_day"]) * mp.sqrt(a ** 3 / M)
+    return mp.mpf(epoch) - MA / (2 * mp.pi) * P_d
+
+
 def _tperi(c, th, epoch, M, e, a, inc, w, O):
     """Epoch of periastron such that the position angle at `epoch` is th — textbook route: PA -> true anomaly in the
     orbital plane -> eccentric -> mean anomaly -> tp (independent of the reference's matrix-solve formulation)."""
@@ -387,6 +423,8 @@ def model_logpost(c, planets, obs, priors, esrc, nsrc, theta_t):
         if sc["kind"] == 2:
             return ang / (2 * mp.pi) * mp.mpf(sc["value"])
         e_ = elems[p]
+        if sc["flags"] & 2:      # OCTO_SRC_FLAG_TI
+            return _tperi_ti(c, ang, sc["value"], e_[6], e_[1], e_[0], e_[2], e_[3], e_[4], e_[7])
         return _tperi(c, ang, sc["value"], e_[6], e_[1], e_[0], e_[2], e_[3], e_[4])
     for want in (False, True):
         for k, sc in enumerate(esrc):

@@ -48,6 +48,8 @@ def golden():
         g = json.load(f)
     with open(ROOT / "tests" / "golden" / "hgca.json") as f:      # F9: HGCAInstantaneousObs (oracle/make_golden.py --hgca-only)
         g["cases"] = g["cases"] + json.load(f)["cases"]
+    with open(ROOT / "tests" / "golden" / "ti.json") as f:        # F10: ThieleInnesOrbit basis (oracle/make_golden.py --ti-only)
+        g["cases"] = g["cases"] + json.load(f)["cases"]
     return g
 
 

@@ -17,7 +17,8 @@ ROOT = Path(__file__).resolve().parent.parent
 
 @pytest.fixture(scope="module")
 def model_golden():
-    return json.loads((ROOT / "tests" / "golden" / "model.json").read_text())["cases"]
+    return (json.loads((ROOT / "tests" / "golden" / "model.json").read_text())["cases"]
+            + json.loads((ROOT / "tests" / "golden" / "ti_model.json").read_text())["cases"])      # [2]: Thiele-Innes tutorial model
 
 
 def _tables(case):
@@ -217,4 +218,52 @@ def test_gpu_model_hgca(pkg, oracle):
         tp[k] += h; tm[k] -= h
         fd = (model.ℓπcallback(tp) - model.ℓπcallback(tm)) / (2 * h)
         assert abs(fd - g[k, 0]) <= 1e-3 + 1e-4 * abs(fd), (k, fd, g[k, 0])
+    model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_thiele_innes_tutorial(pkg, oracle, model_golden):
+    """docs/src/thiele-innes.md / test/unit/constructors.jl:124-153: a planet on the ThieleInnesOrbit basis — A, B, F, G ~
+    Normal(0, 1000) mas, tp = θ_at_epoch_to_tperi(θ, 50000; plx, M, e, A, B, F, G). Whole callback against the 60-digit
+    fixture and the oracle; and the same physical orbit gives the same likelihood in both bases."""
+    case = model_golden[2]
+    table = dict(epoch=case["obs"][0]["epoch"], ra=case["obs"][0]["y1"], dec=case["obs"][0]["y2"], σ_ra=case["obs"][0]["s1"],
+                 σ_dec=case["obs"][0]["s2"], cor=case["obs"][0]["cor"])
+    astrom_like = pkg.PlanetRelAstromObs(table, name="GPI")
+    b = pkg.Planet(name="b", basis="ThieleInnesOrbit", observations=[astrom_like],
+                   variables=pkg.variables(e=pkg.Uniform(0.0, 0.5), A=pkg.Normal(0, 1000), B=pkg.Normal(0, 1000), F=pkg.Normal(0, 1000),
+                                           G=pkg.Normal(0, 1000), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000.0)))
+    sys_ = pkg.System(name="TutoriaPrime", companions=[b], observations=[],
+                      variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1)))
+    model = pkg.LogDensityModel(sys_)
+    assert model.D == 9 and model.names == ["M", "plx", "b_e", "b_A", "b_B", "b_F", "b_G", "b_θx", "b_θy"]
+    for k, s_ in enumerate(case["esrc"]):
+        c = model._c_esrc[k]
+        assert (c.kind, c.i0, c.i1, c.flags, c.value) == (s_["kind"], s_["i0"], s_["i1"], s_["flags"], s_["value"])
+    th = np.asarray(case["theta_t"])
+    lp, g = model.logdensity_and_gradient(th)
+    _check(lp, g, case)
+    obs, planets = _tables(case)
+    lp_o, g_o = oracle.oracle_model_logpost(obs, planets, model._c_priors, model._c_esrc, None, th)
+    assert np.all(np.abs(lp - lp_o) <= 1e-12 * np.abs(lp_o))
+    # same orbit, two bases: ln_like(Campbell a, i, ω, Ω) == ln_like(Thiele-Innes A, B, F, G = a·plx·R)
+    rng = np.random.default_rng(8)
+    W = 33
+    a, e, inc, w, O = rng.uniform(5, 20, W), rng.uniform(0, 0.5, W), np.arccos(rng.uniform(-1, 1, W)), rng.uniform(0, 6.28, W), rng.uniform(0, 6.28, W)
+    tp = 50000 + rng.uniform(0, 3000, W)
+    T = a * 50.0
+    cO, sO, cw, sw, ci = np.cos(O), np.sin(O), np.cos(w), np.sin(w), np.cos(inc)
+    θ_ti = dict(M=1.2, plx=50.0, planets=dict(b=dict(e=e, tp=tp, A=T * (cO * cw - sO * sw * ci), B=T * (sO * cw + cO * sw * ci),
+                                                      F=T * (-cO * sw - sO * cw * ci), G=T * (-sO * sw + cO * cw * ci))))
+    ll_ti, g_ti = model.ln_like.ln_like_and_grad(θ_ti)
+    bc = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromObs(table, name="GPI")])
+    θ_c = dict(M=1.2, plx=50.0, planets=dict(b=dict(a=a, e=e, i=inc, ω=w, Ω=O, tp=tp)))
+    fc = pkg.make_ln_like(pkg.System(name="c", companions=[bc]), θ_c)
+    ll_c, g_c = fc.ln_like_and_grad(θ_c)
+    fc.close()
+    assert np.all(np.abs(ll_ti - ll_c) <= 1e-12 * np.abs(ll_c))
+    for key in ("e", "tp", "M"):
+        ref = g_c["planets"]["b"][key]
+        assert np.all(np.abs(g_ti["planets"]["b"][key] - ref) <= 1e-9 * np.abs(ref).max()), key
+    assert set(g_ti["planets"]["b"]) >= {"A", "B", "F", "G"}
     model.close()

@@ -391,6 +391,20 @@ def test_c_abi_argument_checking_and_strides(pkg, oracle):
     rv = dict(kind=2, planet=-1, epoch=t["epoch"], y1=t["ra"], y2=None, s1=t["σ_ra"], s2=None, cor=None)
     arr2, keep2 = capi.pack_obs([rv])
     assert lib.octo_dataset_create(ctx, arr2, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
+    # RV tables with a ThieleInnesOrbit planet; HGCA without its catalogue numbers, with bad row codes, with a mass-less planet
+    assert lib.octo_dataset_create(ctx, arr2, 1, capi.pack_planets([dict(orbit_kind=2, has_mass=True)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
+    hg = dict(kind=7, planet=-1, epoch=t["epoch"][:4], y1=np.array([0., 1, 0, 1]), y2=np.array([0., 0, 1, 1]), s1=None, s2=None, cor=None,
+              extra=np.array([1., 1, .1, .1, 0] * 3))
+    for bad in (dict(hg, extra=None), dict(hg, extra=np.ones(7)), dict(hg, y1=np.array([0., 2, 0, 1])), dict(hg, extra=np.array([1., 1, .1, .1, 1.5] * 3))):
+        arr3, keep3 = capi.pack_obs([bad])
+        assert lib.octo_dataset_create(ctx, arr3, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=True)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
+    arr3, keep3 = capi.pack_obs([hg])
+    assert lib.octo_dataset_create(ctx, arr3, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
+    assert lib.octo_dataset_create(ctx, arr3, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=True)]), 1, C.byref(ds)) == capi.OCTO_OK
+    el0 = np.ascontiguousarray(cfg["elems"]); ll0 = np.empty(70)
+    assert lib.octo_eval(ctx, ds, capi._dptr(el0), None, 70, 70, capi._dptr(ll0), None, None) == capi.OCTO_EINVAL   # HGCA needs nuis (pmra, pmdec)
+    assert b"pmra" in lib.octo_last_error(ctx)
+    assert lib.octo_dataset_destroy(ds) == 0
     assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_OK
     assert lib.octo_dataset_n_rows(ds) == 33
     # strided buffers: ld = 96 > W = 70

@@ -671,14 +671,19 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
     };
     for (int k = 0; k < D; ++k)
         if (priors[k].kind < OCTO_PRIOR_UNIFORM || priors[k].kind > OCTO_PRIOR_SINE) return fail(ctx, OCTO_EINVAL, "octo_model_create: unknown prior kind");
-    for (int k = 0; k < n_el; ++k) if (!check_src(elem_src[k], true)) return fail(ctx, OCTO_EINVAL, "octo_model_create: bad element source");
+    for (int k = 0; k < n_el; ++k) {
+        if (!check_src(elem_src[k], true)) return fail(ctx, OCTO_EINVAL, "octo_model_create: bad element source");
+        if (elem_src[k].kind == OCTO_SRC_TPERI && k % OCTO_N_EL != OCTO_EL_TP)
+            return fail(ctx, OCTO_EINVAL, "octo_model_create: OCTO_SRC_TPERI belongs in the tp row");
+    }
     bool has_nuis = false;
     if (nuis_src)
         for (int k = 0; k < n_nu; ++k) {
             if (!check_src(nuis_src[k], false)) return fail(ctx, OCTO_EINVAL, "octo_model_create: bad nuisance source");
             const int r = k % OCTO_N_NUIS; const int kind = ds->h_obs[k / OCTO_N_NUIS].kind;
-            const double dflt = ((kind <= OCTO_ASTROM_SEPPA || kind >= OCTO_ONEIL_RADEC) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
-            if (nuis_src[k].kind != OCTO_SRC_CONST || nuis_src[k].value != dflt) has_nuis = true;
+            const bool astrom = kind <= OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA;
+            const double dflt = (astrom && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+            if (nuis_src[k].kind != OCTO_SRC_CONST || nuis_src[k].value != dflt || kind == OCTO_HGCA) has_nuis = true;
         }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     octo_model* m = new (std::nothrow) octo_model();
@@ -742,7 +747,7 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     a.lp_out = d_lp; a.grad_out = d_grad;
     a.k_yr = ctx->consts.kepler_year_to_julian_day; a.yd = ctx->consts.year2day_julian;
     {
-        const int DB = std::min(m->D, 16);
+        const int DB = std::min(m->D, 8);
         hipLaunchKernelGGL(k_model_fwd, dim3((unsigned)((W + 63) / 64), (unsigned)((m->D + DB - 1) / DB)), dim3(64, DB),
                            sizeof(double) * 4 * m->D * WAVE, st, a);
     }

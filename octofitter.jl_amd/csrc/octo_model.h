@@ -32,6 +32,10 @@ template <int N> __device__ __forceinline__ Dual<N> dsqrt(const Dual<N>& a) { co
 template <int N> __device__ __forceinline__ Dual<N> dlog(const Dual<N>& a) { return chain(a, log(a.v), 1.0 / a.v); }
 template <int N> __device__ __forceinline__ Dual<N> dsin(const Dual<N>& a) { return chain(a, sin(a.v), cos(a.v)); }
 template <int N> __device__ __forceinline__ Dual<N> dcos(const Dual<N>& a) { return chain(a, cos(a.v), -sin(a.v)); }
+template <int N> __device__ __forceinline__ void dsincos(const Dual<N>& a, Dual<N>& s, Dual<N>& c) {
+    double sv, cv; sincos(a.v, &sv, &cv);
+    s = chain(a, sv, cv); c = chain(a, cv, -sv);
+}
 template <int N> __device__ __forceinline__ Dual<N> datan2(const Dual<N>& y, const Dual<N>& x) {
     Dual<N> r; r.v = atan2(y.v, x.v); const double ih = 1.0 / (x.v * x.v + y.v * y.v);
     DFOR r.d[k_] = (x.v * y.d[k_] - y.v * x.d[k_]) * ih; return r;
@@ -115,28 +119,32 @@ __device__ __forceinline__ Dual<N> tperi(const Dual<N>& th, double theta_epoch, 
         const Dual<N> u = (A * A + B * B + F * F + G * G) * 0.5, v = A * G - B * F;
         a = dsqrt(u + dsqrt((u + v) * (u - v))) / *plx;
     } else {
-        const Dual<N> cO = dcos(O), sO = dsin(O), cw = dcos(w), sw = dsin(w), ci = dcos(inc);
+        Dual<N> cO, sO, cw, sw;
+        dsincos(O, sO, cO); dsincos(w, sw, cw);
+        const Dual<N> ci = dcos(inc);
         A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
         F = -(cO * sw) - sO * cw * ci; G = -(sO * sw) + cO * cw * ci;
     }
-    const Dual<N> ct = dcos(th), st = dsin(th);
+    Dual<N> ct, st;
+    dsincos(th, st, ct);
     const Dual<N> det = A * G - F * B;
     const Dual<N> xr = (G * ct - F * st) / det, yr = (A * st - B * ct) / det;
     const Dual<N> nu = datan2(yr, xr);
     const Dual<N> s1 = dsqrt(dconst<N>(1.0) - e * e);
-    const Dual<N> sn = dsin(nu), cn = dcos(nu);
+    Dual<N> sn, cn;
+    dsincos(nu, sn, cn);
     const Dual<N> MA = datan2(-(s1 * sn), -e - cn) + PI - (e * s1 * sn) / (e * cn + 1.0);
     const Dual<N> period_yrs = dsqrt(a * a * a / M) * (k_yr / yd);
     const Dual<N> n = dconst<N>(TWO_PI) / period_yrs;
     return dconst<N>(theta_epoch) - (MA / n) * yd;
 }
 
-// block = 64 walkers × DB partials (DB = min(D, 16) waves), grid = (walker tiles, ⌈D/DB⌉). Thread (w, d) carries the
+// block = 64 walkers × DB partials (DB = min(D, 8) waves), grid = (walker tiles, ⌈D/DB⌉). Thread (w, d) carries the
 // value and ONE partial (∂/∂θ_t[d]) of every quantity, so a wave is 64 walkers × one partial: uniform control flow,
 // coalesced Jacobian rows, D× the parallelism of a thread-per-walker layout. The diagonal part — invlink and
 // logpdf_with_trans of every prior — is computed once per walker by the block's waves (prior k by wave k mod DB) and
 // shared through LDS: x[k], dx/dθ_t[k], p[k], dp/dθ_t[k].
-__global__ __launch_bounds__(1024) void k_model_fwd(ModelArgs a) {
+__global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     constexpr int N = 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];      // [4][D][64]
     const int lane = threadIdx.x;
@@ -168,41 +176,56 @@ __global__ __launch_bounds__(1024) void k_model_fwd(ModelArgs a) {
         Dual<N> xk; xk.v = Lx[k * WAVE + lane]; xk.d[0] = (k == d) ? Ldx[k * WAVE + lane] : 0.0;
         return xk;
     };
-    const int n_in = a.n_el + a.n_nu;
-    Dual<N> el[MAXP * OCTO_N_EL];
-    // pass 0: everything but tperi; pass 1: tperi (needs the planet's other elements)
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int k = 0; k < n_in; ++k) {
-            octo_source sc;
-            if (k < a.n_el) sc = a.esrc[k];
-            else if (a.nsrc) sc = a.nsrc[k - a.n_el];
-            else {
-                const int r = (k - a.n_el) % OCTO_N_NUIS; const int kind = a.obs[(k - a.n_el) / OCTO_N_NUIS].kind;
-                sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
-                sc.value = ((kind <= OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
-            }
-            if ((sc.kind == OCTO_SRC_TPERI) != (pass == 1)) continue;
-            Dual<N> val;
-            if (sc.kind == OCTO_SRC_CONST) val = dconst<N>(sc.value);
-            else if (sc.kind == OCTO_SRC_THETA) val = nat(sc.i0);
-            else {
-                const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
-                const Dual<N> ang = datan2(cy, cx);
-                if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(cx, cy);
-                if (sc.kind == OCTO_SRC_CIRCULAR) val = ang * (sc.value / TWO_PI);      // atan(y, x) / 2π * domain, variables.jl:284
-                else {
-                    const Dual<N>* e_ = el + (k / OCTO_N_EL) * OCTO_N_EL;
-                    val = tperi(ang, sc.value, e_[OCTO_EL_M], e_[OCTO_EL_E], e_[OCTO_EL_A], e_[OCTO_EL_I], e_[OCTO_EL_W], e_[OCTO_EL_O], a.k_yr, a.yd,
-                                (sc.flags & OCTO_SRC_FLAG_TI) != 0, &e_[OCTO_EL_PLX]);
-                }
-            }
-            if (k < a.n_el) el[k] = val;
-            if (d == 0) {
-                double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
-                *dst = val.v;
-            }
-            a.J[((int64_t)k * D + d) * a.ldw + w] = val.d[0];
+    // Kernel inputs from the natural θ (arr2nt + Derived variables). The nine element rows of a planet are resolved with
+    // compile-time positions so that they live in registers (a dynamically indexed array lands in scratch memory and made
+    // this kernel 3x slower); θ_at_epoch_to_tperi comes last within a planet because it reads the planet's other elements.
+    auto plain = [&](const octo_source& sc) {      // OCTO_SRC_CONST / _THETA / _CIRCULAR
+        if (sc.kind == OCTO_SRC_CONST) return dconst<N>(sc.value);
+        if (sc.kind == OCTO_SRC_THETA) return nat(sc.i0);
+        const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
+        if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(cx, cy);
+        return datan2(cy, cx) * (sc.value / TWO_PI);                  // atan(y, x) / 2π * domain, variables.jl:284
+    };
+    auto emit = [&](int k, const Dual<N>& val) {
+        if (d == 0) {
+            double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
+            *dst = val.v;
         }
+        a.J[((int64_t)k * D + d) * a.ldw + w] = val.d[0];
+    };
+    for (int p = 0; p < a.n_planets; ++p) {
+        Dual<N> el[OCTO_N_EL];
+#pragma unroll
+        for (int j = 0; j < OCTO_N_EL; ++j) el[j] = dconst<N>(0.0);
+#pragma unroll 1
+        for (int kk = 0; kk < OCTO_N_EL; ++kk) {          // one copy of the code; the store is a select chain, not an indexed write
+            const octo_source sc = a.esrc[p * OCTO_N_EL + kk];
+            if (sc.kind == OCTO_SRC_TPERI) continue;
+            const Dual<N> val = plain(sc);
+#pragma unroll
+            for (int j = 0; j < OCTO_N_EL; ++j) { el[j].v = (j == kk) ? val.v : el[j].v; el[j].d[0] = (j == kk) ? val.d[0] : el[j].d[0]; }
+        }
+        {   // tp = θ_at_epoch_to_tperi(...) is the one derived element of the standard parameterisation
+            const octo_source sc = a.esrc[p * OCTO_N_EL + OCTO_EL_TP];
+            if (sc.kind == OCTO_SRC_TPERI) {
+                const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
+                if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(cx, cy);
+                el[OCTO_EL_TP] = tperi(datan2(cy, cx), sc.value, el[OCTO_EL_M], el[OCTO_EL_E], el[OCTO_EL_A], el[OCTO_EL_I], el[OCTO_EL_W],
+                                       el[OCTO_EL_O], a.k_yr, a.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &el[OCTO_EL_PLX]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < OCTO_N_EL; ++kk) emit(p * OCTO_N_EL + kk, el[kk]);
+    }
+    for (int k = 0; k < a.n_nu; ++k) {
+        octo_source sc;
+        if (a.nsrc) sc = a.nsrc[k];
+        else {
+            const int r = k % OCTO_N_NUIS; const int kind = a.obs[k / OCTO_N_NUIS].kind;
+            sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
+            sc.value = ((kind <= OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+        }
+        emit(a.n_el + k, plain(sc));
     }
     if (d == 0) a.lpp[w] = finite_in ? lp.v : -INFINITY;
     a.glp[(int64_t)d * a.ldw + w] = healed ? 0.0 : lp.d[0];

@@ -22,7 +22,7 @@ using namespace octo;
 namespace {
 
 struct TaskTable {
-    int chunk = 0;
+    int64_t key = 0;                 // > 0: target number of tasks of the plan; < 0: forced uniform rows-per-wave (OCTO_CHUNK)
     int n_tasks = 0;
     Task* d_tasks = nullptr;
     double* d_const_pre = nullptr;   // per-task constants for the no-nuisance path
@@ -113,21 +113,50 @@ int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
     return OCTO_OK;
 }
 
-// Build (or fetch) the task table for a row-chunk size. Tasks never straddle tables and tables keep
-// their order, so k_finish can sum each observation's partials contiguously and in a fixed order.
-int get_tasks(octo_ctx* ctx, octo_dataset* ds, int chunk, TaskTable** out) {
+// Relative cost of one row of a table (VALU instructions per row, from the ISA of the mixed-kind kernels): used only to
+// balance block durations across tables of different kinds.
+double row_cost(int kind) {
+    switch (kind) {
+        case OCTO_ASTROM_SEPPA: case OCTO_ONEIL_SEPPA: return 1.8;
+        case OCTO_RV_ABS: case OCTO_RV_ABS_MARG: case OCTO_RV_REL: return 1.35;
+        case OCTO_ONEIL_RADEC: return 1.1;
+        default: return 1.0;
+    }
+}
+
+// Build (or fetch) the row partition. One block = WPB waves × `chunk` rows of ONE table for one walker tile; tasks never
+// straddle tables and tables keep their order, so k_finish can sum each observation's partials contiguously and in a
+// fixed order. key > 0: about `key` tasks in total, shared between the tables in proportion to rows × row cost, each
+// table cut into EQUAL tasks (no ragged last task); key < 0: −key rows per wave everywhere (OCTO_CHUNK experiments).
+int get_tasks(octo_ctx* ctx, octo_dataset* ds, int64_t key, TaskTable** out) {
     for (auto& t : ds->tables)
-        if (t.chunk == chunk) { *out = &t; return OCTO_OK; }
+        if (t.key == key) { *out = &t; return OCTO_OK; }
+    if (ds->tables.size() >= 32) {                            // many different batch sizes: start over
+        for (auto& t : ds->tables) { (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw); }
+        ds->tables.clear();
+    }
     TaskTable tt;
-    tt.chunk = chunk;
+    tt.key = key;
     std::vector<double> cpre, craw;
+    double wsum = 0.0;
+    for (int o = 0; o < ds->n_obs; ++o)
+        if (ds->h_obs[o].kind != OCTO_HGCA) wsum += (double)ds->h_obs[o].n * row_cost(ds->h_obs[o].kind);
     for (int o = 0; o < ds->n_obs; ++o) {
         if (ds->h_obs[o].kind == OCTO_HGCA) continue;          // no epoch-loop rows (k_hgca)
         const int64_t n = ds->h_obs[o].n;
-        const int64_t span = (int64_t)chunk * WPB;    // one block = WPB waves x chunk rows
+        if (n <= 0) continue;
+        int64_t chunk;
+        if (key < 0) chunk = -key;
+        else {
+            int64_t t_o = std::llround((double)key * (double)n * row_cost(ds->h_obs[o].kind) / wsum);
+            t_o = std::min<int64_t>(std::max<int64_t>(t_o, 1), std::max<int64_t>(1, n / (16 * WPB)));   // >= 16 rows per wave
+            const int64_t rows_per_task = (n + t_o - 1) / t_o;
+            chunk = (rows_per_task + WPB - 1) / WPB;
+        }
+        const int64_t span = chunk * WPB;
         for (int64_t r0 = 0; r0 < n; r0 += span) {
             Task t;
-            t.obs = o; t.row0 = (int32_t)r0; t.nrows = (int32_t)std::min<int64_t>(span, n - r0); t.pad = 0;
+            t.obs = o; t.row0 = (int32_t)r0; t.nrows = (int32_t)std::min<int64_t>(span, n - r0); t.chunk = (int32_t)chunk;
             tt.h_tasks.push_back(t);
             double a = 0.0, b = 0.0;
             for (int64_t r = r0; r < r0 + t.nrows; ++r) { a += ds->h_rowconst_pre[o][r]; b += ds->h_rowconst_raw[o][r]; }
@@ -148,29 +177,28 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int chunk, TaskTable** out) {
     return OCTO_OK;
 }
 
-// Rows per wave. The work of a row is the same for every walker and row (the Kepler solve is non-iterative), so a static
-// partition is balanced by construction; what is left to choose is the grain. Measured on MI355X at 1e4 × 1e4
-// (tools/sweep_chunk.py, profiles/README.md): the step time is flat within 1 % for 48-96 rows per wave and rises on both
-// sides — short blocks pay their prologue (table fill, per-walker constants), LDS combine and partial store more often
-// and leave more partials for k_finish to read; a single "round" of long blocks (grid = what the chip holds at once) is
-// ~8 % slower because lock-stepped waves line up those phases instead of overlapping them with other waves'
-// arithmetic. So: aim for ≈3 rounds of the resident capacity (occupancy × CUs for the exact kernel variant).
+// How many tasks. The work of a row is the same for every walker (the Kepler solve is non-iterative), so a static
+// partition is balanced by construction; what is left to choose is the grain. Measured on MI355X (tools/sweep_chunk.py,
+// profiles/README.md): for the 7-blocks-per-CU single-planet kernels the step time at 1e4 × 1e4 is flat within 1 % for
+// 48-96 rows per wave and rises on both sides — short blocks pay their prologue (table fill, per-walker constants), LDS
+// combine and partial store more often and leave more partials for k_finish; one "round" of long blocks (grid = what
+// the chip holds at once) is ~8 % slower there because lock-stepped waves line up those phases instead of overlapping
+// them with other waves' arithmetic. The 2-blocks-per-CU multi-planet kernels have nothing to overlap with and are best
+// at exactly one round (config 4: 209 µs at 1 round, 215 at 2, 246 at 1.75). So: grid = R × resident capacity with
+// R = 3 at 6-7 blocks per CU down to 1 at 1-3, as EXACTLY as the table sizes allow (a fractional last round is idle
+// hardware), tasks equal within a table.
 // (A persistent kernel pulling (task, tile) items from an atomic queue, with and without a tapered item size, was
 // measured against this grid-mapped launch in the same run and was not faster at any batch size: the hardware
 // dispatcher already backfills freed slots fast enough for an FP64-issue-bound kernel.)
-int pick_chunk(const octo_dataset* ds, int64_t W, int64_t capacity_blocks) {
-    if (const char* ev = std::getenv("OCTO_CHUNK")) {   // tuning knob for experiments
+int64_t plan_key(int64_t W, int blocks_per_cu, int n_cus) {
+    if (const char* ev = std::getenv("OCTO_CHUNK")) {   // tuning knob for experiments: uniform rows per wave
         const int v = std::atoi(ev);
-        if (v > 0) return v;
+        if (v > 0) return -(int64_t)v;
     }
     const int64_t cols = (W + WAVE - 1) / WAVE;
-    const int64_t rows = std::max<int64_t>(ds->n_rows, 1);
-    capacity_blocks = std::max<int64_t>(capacity_blocks, 256);
-    const int64_t want_tasks = std::max<int64_t>(1, (3 * capacity_blocks + cols - 1) / cols);
-    int64_t chunk = (rows + want_tasks * WPB - 1) / (want_tasks * WPB);
-    chunk = std::min<int64_t>(std::max<int64_t>(chunk, 16), 2048);
-    // quantise so that repeated calls with similar W reuse a task table
-    return (int)((chunk + 7) / 8 * 8);
+    const int64_t capacity = std::max<int64_t>((int64_t)blocks_per_cu * n_cus, 256);
+    const int64_t rounds = std::min<int64_t>(std::max<int64_t>(std::llround(blocks_per_cu * 3.0 / 7.0), 1), 3);
+    return std::max<int64_t>(1, rounds * capacity / cols);
 }
 
 template <int P, bool GRAD, bool NUIS, int KM>
@@ -189,11 +217,11 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
         blocks_per_cu = nb;
     }
     TaskTable* tt = nullptr;
-    int rc0 = get_tasks(ctx, ds, pick_chunk(ds, a.W, (int64_t)blocks_per_cu * ctx->n_cus), &tt);
+    int rc0 = get_tasks(ctx, ds, plan_key(a.W, blocks_per_cu, ctx->n_cus), &tt);
     if (rc0) return rc0;
     const Task* tt_tasks = tt->h_tasks.data();
     a.tasks = tt->d_tasks; a.task_const = a.nuis ? tt->d_const_raw : tt->d_const_pre;
-    a.n_tasks = tt->n_tasks; a.chunk = tt->chunk;
+    a.n_tasks = tt->n_tasks;
     const int64_t need = (int64_t)a.n_tasks * L::NACC * a.ldw;
     int rc = grow(ctx, ctx->d_partials, ctx->cap_part, need);
     if (rc) return rc;

@@ -35,7 +35,7 @@ struct DevObs {
 };
 
 struct Task {
-    int32_t obs, row0, nrows, pad;
+    int32_t obs, row0, nrows, chunk;   // chunk = rows per wave: the block's WPB waves split the task's nrows
 };
 
 struct DevConsts {
@@ -46,7 +46,7 @@ struct EvalArgs {
     const DevObs* obs;
     const Task* tasks;
     const double* task_const;     // [n_tasks] walker-independent additive constant of the task's rows
-    int32_t n_obs, n_tasks, n_planets, chunk;   // chunk = rows per wave inside a task
+    int32_t n_obs, n_tasks, n_planets, pad1;
     int32_t task0, pad0;                        // first task of this launch (k_main grid.y is relative to it)
     int32_t orbit_kind[MAXP];
     int32_t has_mass[MAXP];
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     const Task tk = a.tasks[task];                      // wave-uniform: scalar loads
     const DevObs ob = a.obs[tk.obs];
     // this wave's slice of the task's rows
-    const int r_lo = min(wv * a.chunk, tk.nrows);
-    const int r_hi = min(r_lo + a.chunk, tk.nrows);
+    const int r_lo = min(wv * tk.chunk, tk.nrows);
+    const int r_hi = min(r_lo + tk.chunk, tk.nrows);
     const int row_first = tk.row0 + r_lo, n_rows = r_hi - r_lo;
 
     // LDS: [sin/cos table: SCT_N double2][combine buffer: NACC × 64 doubles]

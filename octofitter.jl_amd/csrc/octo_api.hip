@@ -190,14 +190,17 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int64_t key, TaskTable** out) {
 // (A persistent kernel pulling (task, tile) items from an atomic queue, with and without a tapered item size, was
 // measured against this grid-mapped launch in the same run and was not faster at any batch size: the hardware
 // dispatcher already backfills freed slots fast enough for an FP64-issue-bound kernel.)
-int64_t plan_key(int64_t W, int blocks_per_cu, int n_cus) {
+int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
     if (const char* ev = std::getenv("OCTO_CHUNK")) {   // tuning knob for experiments: uniform rows per wave
         const int v = std::atoi(ev);
         if (v > 0) return -(int64_t)v;
     }
     const int64_t cols = (W + WAVE - 1) / WAVE;
     const int64_t capacity = std::max<int64_t>((int64_t)blocks_per_cu * n_cus, 256);
-    const int64_t rounds = std::min<int64_t>(std::max<int64_t>(std::llround(blocks_per_cu * 3.0 / 7.0), 1), 3);
+    int64_t rounds = std::min<int64_t>(std::max<int64_t>(std::llround(blocks_per_cu * 3.0 / 7.0), 1), 3);
+    // few walker tiles: fewer rounds rather than blocks shorter than ~48 rows per wave (W = 4096: 166 µs at 1 round, 177 at 3)
+    while (rounds > 1 && n_rows * cols < 48 * WPB * rounds * capacity) --rounds;
+    if (const char* ev = std::getenv("OCTO_ROUNDS")) { const int v = std::atoi(ev); if (v > 0) rounds = v; }   // experiments
     return std::max<int64_t>(1, rounds * capacity / cols);
 }
 
@@ -217,7 +220,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
         blocks_per_cu = nb;
     }
     TaskTable* tt = nullptr;
-    int rc0 = get_tasks(ctx, ds, plan_key(a.W, blocks_per_cu, ctx->n_cus), &tt);
+    int rc0 = get_tasks(ctx, ds, plan_key(a.W, ds->n_rows, blocks_per_cu, ctx->n_cus), &tt);
     if (rc0) return rc0;
     const Task* tt_tasks = tt->h_tasks.data();
     a.tasks = tt->d_tasks; a.task_const = a.nuis ? tt->d_const_raw : tt->d_const_pre;

@@ -176,3 +176,27 @@ def test_invalid_walkers_are_minus_inf(oracle):
     ll, g, _ = oracle.oracle_eval([tab], [dict(orbit_kind=0, has_mass=False)], bad, None, grad=True)
     assert np.isfinite(ll[0]) and np.all(np.isneginf(ll[1:]))
     assert np.all(g[:, 1:] == 0.0)
+
+
+def test_thiele_innes_semi_major_axis_known_answers(oracle):
+    """The reference's own known answers for the Thiele-Innes angular semi-major axis (test/unit/nss.jl:3-27, function
+    src/nss.jl:502-508 — the same u, v, α as src/parameterizations.jl:14-19): A=10, B=0, F=0, G=±10 -> α = 10; constants
+    built from a_mas = 50, i = 1.2, Ω = 0.8, ω = 2.5 -> α = 50. The oracle's ThieleInnesOrbit derives a = α/plx and from it
+    the mean motion, which is what these numbers pin."""
+    c = oracle.oracle_consts()
+    M, plx = 1.3, 40.0
+    def alpha_from_oracle(A, B, F, G):
+        el = np.array([A, 0.2, B, F, G, 50000.0, M, plx, 0.0])       # rows a, i, ω, Ω carry A, B, F, G
+        n = oracle.oracle_orbitsolve(el, 50123.0, orbit_kind=2)["n"]    # rad / yr
+        P_yr = 2 * np.pi / n
+        a = (M * (P_yr * c.year2day_julian / c.kepler_year_to_julian_day) ** 2) ** (1 / 3)
+        return a * plx
+    assert abs(alpha_from_oracle(10.0, 0.0, 0.0, 10.0) - 10.0) < 1e-12
+    assert abs(alpha_from_oracle(10.0, 0.0, 0.0, -10.0) - 10.0) < 1e-12
+    a_mas, i, O, w = 50.0, 1.2, 0.8, 2.5
+    A = a_mas * (np.cos(O) * np.cos(w) - np.sin(O) * np.sin(w) * np.cos(i))
+    B = a_mas * (np.sin(O) * np.cos(w) + np.cos(O) * np.sin(w) * np.cos(i))
+    F = a_mas * (-np.cos(O) * np.sin(w) - np.sin(O) * np.cos(w) * np.cos(i))
+    G = a_mas * (-np.sin(O) * np.sin(w) + np.cos(O) * np.cos(w) * np.cos(i))
+    assert abs(alpha_from_oracle(A, B, F, G) - a_mas) < 1e-8          # the reference's tolerance
+    assert abs(alpha_from_oracle(A, B, F, G) - a_mas) < 1e-12

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
 
     const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_RADEC ||
                            ob.kind == OCTO_ONEIL_SEPPA;
-    const bool oneil = L::HAS_ONEIL && ob.kind >= OCTO_ONEIL_RADEC;
+    const bool oneil = L::HAS_ONEIL && (ob.kind == OCTO_ONEIL_RADEC || ob.kind == OCTO_ONEIL_SEPPA);
 
     if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
         // coefficient of each planet's sky offset in the model (relative-astrometry.jl:117-138):
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                 llo = cst - 0.5 * v[0];
             }
             if constexpr (L::HAS_ONEIL) {
-                if (kind >= OCTO_ONEIL_RADEC && a.obs[o].n > 0) {
+                if ((kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && a.obs[o].n > 0) {
                     // ln_prior = 2 log(Σ|t_j| · ∛P / √(1−e²)), P = period/365.25   prior-observable.jl:96,136-139
                     const int ip = a.obs[o].planet;
                     const double* el = a.elems + (int64_t)ip * OCTO_N_EL * a.ld + wl;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
             if constexpr (L::N_NU > 0) {
                 if (w < a.W) {
                     double* gn = a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w;
-                    const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA || kind >= OCTO_ONEIL_RADEC;
+                    const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA;
                     gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : v[4];
                     gn[(int64_t)a.ld] = v[5];
                     gn[(int64_t)2 * a.ld] = astrom ? v[6] : 0.0;

@@ -1,0 +1,113 @@
+"""Randomised GPU-vs-oracle sweep over systems the unit tests do not enumerate: 1-3 planets on mixed bases (Campbell,
+Thiele-Innes, radial-velocity-only), random subsets of every observation kind incl. the O'Neil wrapper and HGCA, with and
+without the nuisance block, random table and batch sizes (ragged tiles). Run on a GPU box:
+    python tests/stress_parity.py [n_systems] [seed]
+Prints the worst errors; exits non-zero if a case breaks the bars of tests/test_gpu_parity.py. Not collected by pytest."""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import oracle_binding as ob, gpu_binding as gb
+
+HG = np.array([4.71, -1.86, 0.61, 0.49, 0.21, 4.352, -2.013, 0.031, 0.024, -0.12, 4.61, -1.72, 0.052, 0.041, 0.33])
+
+
+def planet_elems(rng, W, kind, a_lo, a_hi):
+    a, e = rng.uniform(a_lo, a_hi, W), rng.uniform(0, 0.85, W)
+    inc, w, O = np.arccos(rng.uniform(-1, 1, W)), rng.uniform(-7, 7, W), rng.uniform(-7, 7, W)
+    tp, M, plx, mass = 50000 + rng.uniform(-3000, 3000, W), rng.uniform(0.8, 1.6, W), rng.uniform(20, 60, W), rng.uniform(1, 40, W)
+    if kind == 2:
+        T = a * plx
+        cO, sO, cw, sw, ci = np.cos(O), np.sin(O), np.cos(w), np.sin(w), np.cos(inc)
+        return np.stack([T * (cO * cw - sO * sw * ci), e, T * (sO * cw + cO * sw * ci), T * (-cO * sw - sO * cw * ci), T * (-sO * sw + cO * cw * ci), tp, M, plx, mass])
+    return np.stack([a, e, inc, w, O, tp, M, plx, mass])
+
+
+def random_system(rng):
+    P = int(rng.integers(1, 4))
+    W = int(rng.choice([1, 7, 64, 65, 130, 200, 333]))
+    kinds_pl = [int(rng.choice([0, 0, 2, 1])) for _ in range(P)]
+    has_rv_basis = any(k == 1 for k in kinds_pl)
+    has_ti = any(k == 2 for k in kinds_pl)
+    planets = [dict(orbit_kind=k, has_mass=True) for k in kinds_pl]
+    elems = np.concatenate([planet_elems(rng, W, k, 2 + 6 * i, 6 + 6 * i) for i, k in enumerate(kinds_pl)])
+    obs = []
+    for ip, k in enumerate(kinds_pl):
+        n = int(rng.integers(1, 120))
+        ep = np.sort(50000 + rng.uniform(0, 4000, n))
+        if k != 1:
+            for _ in range(int(rng.integers(0, 3))):
+                seppa = rng.random() < 0.35
+                cor = rng.uniform(-0.8, 0.8, n) if rng.random() < 0.4 else None
+                ra, dec = rng.normal(0, 300, n), rng.normal(0, 300, n)
+                kind = (1 if seppa else 0) + (5 if rng.random() < 0.3 else 0)
+                y1, y2 = (np.arctan2(ra, dec), np.hypot(ra, dec)) if seppa else (ra, dec)
+                s1 = np.full(n, 0.03) if seppa else rng.uniform(3, 12, n)
+                obs.append(dict(kind=kind, planet=ip, epoch=ep, y1=y1, y2=y2, s1=s1, s2=rng.uniform(3, 12, n), cor=cor))
+        if not has_ti and rng.random() < 0.5:
+            obs.append(dict(kind=4, planet=ip, epoch=ep, y1=rng.normal(0, 500, n), y2=None, s1=rng.uniform(20, 80, n), s2=None, cor=None))
+    if not has_ti:
+        for kind in (2, 3):
+            if rng.random() < 0.4:
+                n = int(rng.integers(1, 150)); ep = np.sort(50000 + rng.uniform(0, 4000, n))
+                obs.append(dict(kind=kind, planet=-1, epoch=ep, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None))
+    hgca = (not has_rv_basis or any(k != 1 for k in kinds_pl)) and rng.random() < 0.4
+    if hgca:
+        N = int(rng.integers(1, 4))
+        rows = []
+        for d in np.linspace(-700, 700, N): rows += [(48348.0 + d, 0, 0), (48414.0 + d, 1, 0)]
+        for d in np.linspace(-500, 500, N): rows += [(57408.0 + d, 0, 1), (57470.0 + d, 1, 1)]
+        rows = np.array(rows)
+        obs.append(dict(kind=7, planet=-1, epoch=rows[:, 0], y1=rows[:, 1], y2=rows[:, 2], s1=None, s2=None, cor=None, extra=HG))
+    if not obs:
+        return None
+    nuis = np.zeros((len(obs) * 3, W))
+    for io, o in enumerate(obs):
+        if o["kind"] in (0, 1, 5, 6):
+            nuis[io * 3] = rng.uniform(0, 4, W); nuis[io * 3 + 1] = rng.normal(1, 0.01, W); nuis[io * 3 + 2] = rng.normal(0, 0.02, W)
+            nuis[io * 3, : W // 5] = 0.0
+        elif o["kind"] == 7:
+            nuis[io * 3] = rng.normal(4.3, 0.3, W); nuis[io * 3 + 1] = rng.normal(-2.0, 0.3, W)
+        else:
+            nuis[io * 3] = rng.normal(0, 10, W); nuis[io * 3 + 1] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+    use_nuis = hgca or rng.random() < 0.6
+    return obs, planets, elems, (nuis if use_nuis else None)
+
+
+def main():
+    n_sys = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    worst_ll = worst_g = 0.0
+    bad = 0
+    for k in range(n_sys):
+        sysm = None
+        while sysm is None:
+            sysm = random_system(rng)
+        obs, planets, elems, nuis = sysm
+        print(f"{k:3d} P={len(planets)} bases={[p['orbit_kind'] for p in planets]} kinds={[o['kind'] for o in obs]} rows={[len(o['epoch']) for o in obs]} W={elems.shape[1]} nuis={nuis is not None}: ", end="", flush=True)
+        ll, g, gn = gb.gpu_eval(obs, planets, elems, nuis, grad=True)
+        llf, _, _ = gb.gpu_eval(obs, planets, elems, nuis, grad=False)
+        ll_o, g_o, gn_o = ob.oracle_eval(obs, planets, elems, nuis, grad=True, n_threads=0)
+        ok = np.isfinite(ll_o)
+        same = np.array_equal(ll, llf) and np.array_equal(np.isfinite(ll), ok)
+        e_ll = np.max(np.abs(ll[ok] - ll_o[ok]) / np.maximum(1, np.abs(ll_o[ok]))) if ok.any() else 0.0
+        G = np.concatenate([g] + ([gn] if gn is not None else [])); Go = np.concatenate([g_o] + ([gn_o] if gn_o is not None else []))
+        # per-input scale, floored: an input the likelihood does not depend on has a true gradient of 0 ± rounding noise
+        scale = np.maximum(np.abs(Go[:, ok]).max(axis=1, keepdims=True), 1e-10 * np.abs(Go[:, ok]).max()) if ok.any() else 1.0
+        e_g = np.max(np.abs(G[:, ok] - Go[:, ok]) / np.maximum(scale, 1e-300)) if ok.any() else 0.0
+        marg = any(o["kind"] == 3 for o in obs)
+        ti = any(p["orbit_kind"] == 2 for p in planets)
+        # marginalised RV: cancellation in the reference's formula (rv-absolute-margin.jl:181). Thiele-Innes: a = α/plx with
+        # α² = u + √((u+v)(u−v)) loses digits in u − v near face-on orbits, in the reference's arithmetic as in ours.
+        lim_ll, lim_g = (1e-9, 1e-8) if marg else ((1e-10, 1e-7) if ti else (1e-12, 1e-9))
+        flag = "" if (same and e_ll < lim_ll and e_g < lim_g) else "   <-- FAIL"
+        bad += bool(flag)
+        worst_ll, worst_g = max(worst_ll, e_ll if not (marg or ti) else 0), max(worst_g, e_g if not (marg or ti) else 0)
+        print(f"ll {e_ll:.1e} grad/scale {e_g:.1e}{flag}", flush=True)
+    print(f"worst (no marginalised RV, no Thiele-Innes): ll {worst_ll:.2e} grad {worst_g:.2e}; failures {bad}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -510,3 +510,33 @@ def test_hgca_mirror_vs_oracle(pkg, oracle):
     θ_nm = dict(θ, planets=dict(b=θ["planets"]["b"], c={k: v for k, v in θ["planets"]["c"].items() if k != "mass"}))
     with pytest.raises(KeyError):
         pkg.make_ln_like(sys_, θ_nm)
+
+
+def test_hgca_next_to_oneil_and_marginalised_rv(oracle):
+    """Regression (found by tests/stress_parity.py): an OCTO_HGCA table in a system that also selects the O'Neil /
+    marginalised-RV kernel variant was taken for an O'Neil wrapper by k_finish (kind >= ONEIL) — ll = -Inf and an
+    out-of-bounds planet index. Every kind together, against the oracle."""
+    gb = _gpu()
+    rng = np.random.default_rng(12)
+    W, n = 130, 40
+    ep = np.sort(50000 + rng.uniform(0, 4000, n))
+    ra, dec = rng.normal(0, 300, n), rng.normal(0, 300, n)
+    rows = np.array([(48348.0, 0, 0), (48414.0, 1, 0), (57408.0, 0, 1), (57470.0, 1, 1)])
+    hg = np.array([4.71, -1.86, 0.61, 0.49, 0.21, 4.352, -2.013, 0.031, 0.024, -0.12, 4.61, -1.72, 0.052, 0.041, 0.33])
+    obs = [dict(kind=5, planet=0, epoch=ep, y1=ra, y2=dec, s1=np.full(n, 8.0), s2=np.full(n, 9.0), cor=None),
+           dict(kind=6, planet=1, epoch=ep, y1=np.arctan2(ra, dec), y2=np.hypot(ra, dec), s1=np.full(n, 0.03), s2=np.full(n, 9.0), cor=None),
+           dict(kind=3, planet=-1, epoch=ep, y1=rng.normal(0, 30, n), y2=None, s1=np.full(n, 4.0), s2=None, cor=None),
+           dict(kind=7, planet=-1, epoch=rows[:, 0], y1=rows[:, 1], y2=rows[:, 2], s1=None, s2=None, cor=None, extra=hg)]
+    planets = [dict(orbit_kind=0, has_mass=True)] * 2
+    def pl(lo, hi):
+        return np.stack([rng.uniform(lo, hi, W), rng.uniform(0, 0.6, W), np.arccos(rng.uniform(-1, 1, W)), rng.uniform(0, 6.28, W), rng.uniform(0, 6.28, W),
+                         50000 + rng.uniform(0, 4000, W), np.full(W, 1.2), np.full(W, 50.0), rng.uniform(2, 30, W)])
+    elems = np.concatenate([pl(3, 6), pl(9, 15)])
+    nuis = np.zeros((12, W))
+    nuis[0] = rng.uniform(0, 3, W); nuis[1] = 1.0; nuis[3] = rng.uniform(0, 3, W); nuis[4] = 1.0
+    nuis[7] = rng.uniform(0.5, 5, W); nuis[9] = rng.normal(4.3, 0.3, W); nuis[10] = rng.normal(-2.0, 0.3, W)
+    ll, g, gn = gb.gpu_eval(obs, planets, elems, nuis, grad=True)
+    ll_f, _, _ = gb.gpu_eval(obs, planets, elems, nuis, grad=False)
+    assert np.array_equal(ll, ll_f) and np.all(np.isfinite(ll))
+    ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, elems, nuis, grad=True)
+    _cmp_oracle("hgca+oneil+marg", ll, g, gn, ll_o, g_o, gn_o, ll_rtol=1e-9, g_rtol=1e-8)

@@ -24,7 +24,7 @@ def planet_elems(rng, W, kind, a_lo, a_hi):
     return np.stack([a, e, inc, w, O, tp, M, plx, mass])
 
 
-def random_system(rng):
+def random_system(rng, invalid=True):
     P = int(rng.integers(1, 4))
     W = int(rng.choice([1, 7, 64, 65, 130, 200, 333]))
     kinds_pl = [int(rng.choice([0, 0, 2, 1])) for _ in range(P)]
@@ -34,7 +34,7 @@ def random_system(rng):
     elems = np.concatenate([planet_elems(rng, W, k, 2 + 6 * i, 6 + 6 * i) for i, k in enumerate(kinds_pl)])
     obs = []
     for ip, k in enumerate(kinds_pl):
-        n = int(rng.integers(1, 120))
+        n = int(rng.integers(1, 120)) if rng.random() > 0.08 else 0      # now and then an empty table
         ep = np.sort(50000 + rng.uniform(0, 4000, n))
         if k != 1:
             for _ in range(int(rng.integers(0, 3))):
@@ -71,6 +71,9 @@ def random_system(rng):
             nuis[io * 3] = rng.normal(4.3, 0.3, W); nuis[io * 3 + 1] = rng.normal(-2.0, 0.3, W)
         else:
             nuis[io * 3] = rng.normal(0, 10, W); nuis[io * 3 + 1] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+    if invalid and W >= 7 and rng.random() < 0.5:      # a few walkers outside the domain: -Inf, zero gradient, nothing else disturbed
+        for w_bad, (row, val) in zip(rng.choice(W, 3, replace=False), ((1, 1.2), (6, -1.0), (5, np.nan))):
+            elems[int(rng.integers(0, P)) * 9 + row, w_bad] = val
     use_nuis = hgca or rng.random() < 0.6
     return obs, planets, elems, (nuis if use_nuis else None)
 
@@ -90,7 +93,7 @@ def main():
         llf, _, _ = gb.gpu_eval(obs, planets, elems, nuis, grad=False)
         ll_o, g_o, gn_o = ob.oracle_eval(obs, planets, elems, nuis, grad=True, n_threads=0)
         ok = np.isfinite(ll_o)
-        same = np.array_equal(ll, llf) and np.array_equal(np.isfinite(ll), ok)
+        same = np.array_equal(ll, llf) and np.array_equal(np.isfinite(ll), ok) and np.all(np.isneginf(ll[~ok])) and np.all(g[:, ~ok] == 0.0)
         e_ll = np.max(np.abs(ll[ok] - ll_o[ok]) / np.maximum(1, np.abs(ll_o[ok]))) if ok.any() else 0.0
         G = np.concatenate([g] + ([gn] if gn is not None else [])); Go = np.concatenate([g_o] + ([gn_o] if gn_o is not None else []))
         # per-input scale, floored: an input the likelihood does not depend on has a true gradient of 0 ± rounding noise

@@ -24,9 +24,12 @@ def planet_elems(rng, W, kind, a_lo, a_hi):
     return np.stack([a, e, inc, w, O, tp, M, plx, mass])
 
 
+SCALE = 1      # argv[3]: multiplies table sizes and batch sizes (partition planner at larger shapes)
+
+
 def random_system(rng, invalid=True):
     P = int(rng.integers(1, 4))
-    W = int(rng.choice([1, 7, 64, 65, 130, 200, 333]))
+    W = int(rng.choice([1, 7, 64, 65, 130, 200, 333])) * (1 if SCALE == 1 else int(rng.integers(1, SCALE + 1)))
     kinds_pl = [int(rng.choice([0, 0, 2, 1])) for _ in range(P)]
     has_rv_basis = any(k == 1 for k in kinds_pl)
     has_ti = any(k == 2 for k in kinds_pl)
@@ -34,7 +37,7 @@ def random_system(rng, invalid=True):
     elems = np.concatenate([planet_elems(rng, W, k, 2 + 6 * i, 6 + 6 * i) for i, k in enumerate(kinds_pl)])
     obs = []
     for ip, k in enumerate(kinds_pl):
-        n = int(rng.integers(1, 120)) if rng.random() > 0.08 else 0      # now and then an empty table
+        n = int(rng.integers(1, 120 * SCALE)) if rng.random() > 0.08 else 0      # now and then an empty table
         ep = np.sort(50000 + rng.uniform(0, 4000, n))
         if k != 1:
             for _ in range(int(rng.integers(0, 3))):
@@ -50,7 +53,7 @@ def random_system(rng, invalid=True):
     if not has_ti:
         for kind in (2, 3):
             if rng.random() < 0.4:
-                n = int(rng.integers(1, 150)); ep = np.sort(50000 + rng.uniform(0, 4000, n))
+                n = int(rng.integers(1, 150 * SCALE)); ep = np.sort(50000 + rng.uniform(0, 4000, n))
                 obs.append(dict(kind=kind, planet=-1, epoch=ep, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None))
     hgca = (not has_rv_basis or any(k != 1 for k in kinds_pl)) and rng.random() < 0.4
     if hgca:
@@ -79,6 +82,8 @@ def random_system(rng, invalid=True):
 
 
 def main():
+    global SCALE
+    SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     n_sys = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     worst_ll = worst_g = 0.0

@@ -205,7 +205,7 @@ int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
 }
 
 template <int P, bool GRAD, bool NUIS, int KM>
-int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*, hipStream_t st) {
+int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, hipStream_t st) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
     octo_dataset* ds = const_cast<octo_dataset*>(cds);   // task-table cache only
@@ -288,20 +288,20 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const Task*,
 }
 
 template <int P, int KM>
-int dispatch2(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Task* tk, bool grad, bool nuis, hipStream_t st) {
-    if (grad) return nuis ? launch_all<P, true, true, KM>(ctx, ds, a, tk, st) : launch_all<P, true, false, KM>(ctx, ds, a, tk, st);
-    return nuis ? launch_all<P, false, true, KM>(ctx, ds, a, tk, st) : launch_all<P, false, false, KM>(ctx, ds, a, tk, st);
+int dispatch2(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
+    if (grad) return nuis ? launch_all<P, true, true, KM>(ctx, ds, a, st) : launch_all<P, true, false, KM>(ctx, ds, a, st);
+    return nuis ? launch_all<P, false, true, KM>(ctx, ds, a, st) : launch_all<P, false, false, KM>(ctx, ds, a, st);
 }
 
 template <int P>
-int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Task* tk, bool grad, bool nuis, hipStream_t st) {
+int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
     const int km = ds->kind_mask;
-    if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, tk, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, tk, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR>(ctx, ds, a, tk, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL>(ctx, ds, a, tk, grad, nuis, st);
-    if ((km & (KM_MARG | KM_ONEIL)) == 0) return dispatch2<P, KM_ALL & ~KM_MARG & ~KM_ONEIL>(ctx, ds, a, tk, grad, nuis, st);
-    return dispatch2<P, KM_ALL>(ctx, ds, a, tk, grad, nuis, st);
+    if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR>(ctx, ds, a, grad, nuis, st);
+    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL>(ctx, ds, a, grad, nuis, st);
+    if ((km & (KM_MARG | KM_ONEIL)) == 0) return dispatch2<P, KM_ALL & ~KM_MARG & ~KM_ONEIL>(ctx, ds, a, grad, nuis, st);
+    return dispatch2<P, KM_ALL>(ctx, ds, a, grad, nuis, st);
 }
 
 int drain_timing(octo_ctx* ctx) {
@@ -553,12 +553,10 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     if (ctx->timing_every > 0 && ctx->ev_used >= 4096) { int rc = drain_timing(ctx); if (rc) return rc; }
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     if (ldw > ctx->cap_w) {
-        int64_t c1 = ctx->cap_w, c2 = ctx->cap_w;
         int64_t need = ldw;
         // both buffers share the walker capacity
         if (ctx->d_wc) { HIPCHK(ctx, hipFree(ctx->d_wc)); ctx->d_wc = nullptr; }
         if (ctx->d_valid) { HIPCHK(ctx, hipFree(ctx->d_valid)); ctx->d_valid = nullptr; }
-        (void)c1; (void)c2;
         HIPCHK(ctx, hipMalloc((void**)&ctx->d_wc, sizeof(double) * (size_t)need * NWC * MAXP));
         HIPCHK(ctx, hipMalloc((void**)&ctx->d_valid, sizeof(int32_t) * (size_t)need));
         ctx->cap_w = need;
@@ -574,10 +572,10 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     a.c = dev_consts(ctx->consts);
     const bool grad = d_g_elems != nullptr, nuis = d_nuis != nullptr;
     switch (ds->n_planets) {
-        case 1: return dispatch1<1>(ctx, ds, a, nullptr, grad, nuis, st);
-        case 2: return dispatch1<2>(ctx, ds, a, nullptr, grad, nuis, st);
-        case 3: return dispatch1<3>(ctx, ds, a, nullptr, grad, nuis, st);
-        default: return dispatch1<4>(ctx, ds, a, nullptr, grad, nuis, st);
+        case 1: return dispatch1<1>(ctx, ds, a, grad, nuis, st);
+        case 2: return dispatch1<2>(ctx, ds, a, grad, nuis, st);
+        case 3: return dispatch1<3>(ctx, ds, a, grad, nuis, st);
+        default: return dispatch1<4>(ctx, ds, a, grad, nuis, st);
     }
 }
 

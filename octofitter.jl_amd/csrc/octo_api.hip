@@ -27,6 +27,8 @@ struct TaskTable {
     Task* d_tasks = nullptr;
     double* d_const_pre = nullptr;   // per-task constants for the no-nuisance path
     double* d_const_raw = nullptr;   // per-task constants for the nuisance path
+    int32_t* d_obs_range = nullptr;  // [n_obs][2] task range of each observation
+    double* d_obs_const_pre = nullptr, *d_obs_const_raw = nullptr;   // [n_obs] Σ of the task constants, in task order
     std::vector<Task> h_tasks;
 };
 
@@ -132,7 +134,8 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int64_t key, TaskTable** out) {
     for (auto& t : ds->tables)
         if (t.key == key) { *out = &t; return OCTO_OK; }
     if (ds->tables.size() >= 32) {                            // many different batch sizes: start over
-        for (auto& t : ds->tables) { (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw); }
+        for (auto& t : ds->tables) { (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw);
+            (void)hipFree(t.d_obs_range); (void)hipFree(t.d_obs_const_pre); (void)hipFree(t.d_obs_const_raw); }
         ds->tables.clear();
     }
     TaskTable tt;
@@ -164,6 +167,22 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int64_t key, TaskTable** out) {
         }
     }
     tt.n_tasks = (int)tt.h_tasks.size();
+    {   // per observation: its task range and the sum of its task constants (same order a sequential device loop would use)
+        std::vector<int32_t> range(2 * std::max(ds->n_obs, 1), 0);
+        std::vector<double> opre(std::max(ds->n_obs, 1), 0.0), oraw(std::max(ds->n_obs, 1), 0.0);
+        int t = 0;
+        for (int o = 0; o < ds->n_obs; ++o) {
+            range[2 * o] = t;
+            while (t < tt.n_tasks && tt.h_tasks[t].obs == o) { opre[o] += cpre[t]; oraw[o] += craw[t]; ++t; }
+            range[2 * o + 1] = t;
+        }
+        HIPCHK(ctx, hipMalloc((void**)&tt.d_obs_range, sizeof(int32_t) * range.size()));
+        HIPCHK(ctx, hipMalloc((void**)&tt.d_obs_const_pre, sizeof(double) * opre.size()));
+        HIPCHK(ctx, hipMalloc((void**)&tt.d_obs_const_raw, sizeof(double) * oraw.size()));
+        HIPCHK(ctx, hipMemcpy(tt.d_obs_range, range.data(), sizeof(int32_t) * range.size(), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(tt.d_obs_const_pre, opre.data(), sizeof(double) * opre.size(), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(tt.d_obs_const_raw, oraw.data(), sizeof(double) * oraw.size(), hipMemcpyHostToDevice));
+    }
     if (tt.n_tasks > 0) {
         HIPCHK(ctx, hipMalloc((void**)&tt.d_tasks, sizeof(Task) * tt.n_tasks));
         HIPCHK(ctx, hipMalloc((void**)&tt.d_const_pre, sizeof(double) * tt.n_tasks));
@@ -224,6 +243,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, hipStream_t 
     if (rc0) return rc0;
     const Task* tt_tasks = tt->h_tasks.data();
     a.tasks = tt->d_tasks; a.task_const = a.nuis ? tt->d_const_raw : tt->d_const_pre;
+    a.obs_range = tt->d_obs_range; a.obs_const = a.nuis ? tt->d_obs_const_raw : tt->d_obs_const_pre;
     a.n_tasks = tt->n_tasks;
     const int64_t need = (int64_t)a.n_tasks * L::NACC * a.ldw;
     int rc = grow(ctx, ctx->d_partials, ctx->cap_part, need);
@@ -531,7 +551,8 @@ int32_t octo_dataset_destroy(octo_dataset* ds) {
     if (!ds) return OCTO_OK;
     (void)hipSetDevice(ds->device);
     for (double* p : ds->d_bufs) (void)hipFree(p);
-    for (auto& t : ds->tables) { (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw); }
+    for (auto& t : ds->tables) { (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw);
+            (void)hipFree(t.d_obs_range); (void)hipFree(t.d_obs_const_pre); (void)hipFree(t.d_obs_const_raw); }
     (void)hipFree(ds->d_obs);
     delete ds;
     return OCTO_OK;

@@ -46,6 +46,8 @@ struct EvalArgs {
     const DevObs* obs;
     const Task* tasks;
     const double* task_const;     // [n_tasks] walker-independent additive constant of the task's rows
+    const int32_t* obs_range;     // [n_obs][2] first and one-past-last task of each observation (tasks are grouped by observation)
+    const double* obs_const;      // [n_obs] Σ task_const over the observation's tasks, in task order
     int32_t n_obs, n_tasks, n_planets, pad1;
     int32_t task0, pad0;                        // first task of this launch (k_main grid.y is relative to it)
     int32_t orbit_kind[MAXP];
@@ -514,8 +516,7 @@ __global__ __launch_bounds__(256) void k_marg(EvalArgs a) {
         for (int o = 0; o < a.n_obs; ++o) {
             if (a.obs[o].kind != OCTO_RV_ABS_MARG) continue;
             double A = 0.0, B = 0.0;
-            for (int t = 0; t < a.n_tasks; ++t) {
-                if (a.tasks[t].obs != o) continue;
+            for (int t = a.obs_range[2 * o]; t < a.obs_range[2 * o + 1]; ++t) {
                 const double* pt = a.partials + (int64_t)t * L::NACC * a.ldw + w;
                 A += pt[(int64_t)(L::OFF_MARG + 0) * a.ldw];
                 B += pt[(int64_t)(L::OFF_MARG + 1) * a.ldw];
@@ -553,8 +554,10 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     for (int o = 0; o < a.n_obs; ++o) {
         double S = 0.0, mA = 0.0, mB = 0.0, mC = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0, cst = 0.0;
         double on0 = 0.0, on1 = 0.0, on2 = 0.0, on3 = 0.0;
-        int t_end = t;
-        while (t_end < a.n_tasks && a.tasks[t_end].obs == o) { cst += a.task_const[t_end]; ++t_end; }
+        t = a.obs_range[2 * o];
+        const int t_end = a.obs_range[2 * o + 1];
+        cst = a.obs_const[o];
+#pragma unroll 2
         for (int tt = t + grp; tt < t_end; tt += FIN_G) {
             const double* pt = a.partials + (int64_t)tt * L::NACC * a.ldw + wl;
             S += pt[(int64_t)L::OFF_S * a.ldw];
@@ -579,7 +582,6 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) gp[k] += pt[(int64_t)(L::OFF_PL + k) * a.ldw];
         }
-        t = t_end;
         double* lo = lds + grp * WAVE + lane;
         lo[0 * FIN_G * WAVE] = S; lo[1 * FIN_G * WAVE] = mA; lo[2 * FIN_G * WAVE] = mB; lo[3 * FIN_G * WAVE] = mC;
         lo[4 * FIN_G * WAVE] = nu0; lo[5 * FIN_G * WAVE] = nu1; lo[6 * FIN_G * WAVE] = nu2;

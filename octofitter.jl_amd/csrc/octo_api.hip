@@ -891,11 +891,20 @@ int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d
     std::memset(&a, 0, sizeof(a));
     const int64_t cols = (W + WAVE - 1) / WAVE;
     int chunk = 32;
-    {   // same sizing rule as the likelihood kernel
-        const int64_t want_tasks = std::max<int64_t>(1, (16384 + cols - 1) / cols);
-        int64_t c = (h->n + want_tasks - 1) / std::max<int64_t>(want_tasks, 1);
-        c = std::min<int64_t>(std::max<int64_t>(c, 32), 4096);
-        chunk = (int)((c + 31) / 32 * 32);
+    {   // same sizing rule as the likelihood kernel: an exact number of rounds of resident blocks, equal tasks
+        static int blocks_per_cu = 0;
+        if (blocks_per_cu == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ofti_main, WAVE * WPB, sizeof(double) * (2 * SCT_N + OFTI_NACC * WAVE)) != hipSuccess || nb < 1) nb = 2;
+            blocks_per_cu = nb;
+        }
+        const int64_t key = plan_key(W, h->n, blocks_per_cu, ctx->n_cus);
+        if (key < 0) chunk = (int)-key;
+        else {
+            const int64_t t_o = std::min<int64_t>(std::max<int64_t>(key, 1), std::max<int64_t>(1, h->n / (16 * WPB)));
+            const int64_t rows_per_task = (h->n + t_o - 1) / t_o;
+            chunk = (int)std::max<int64_t>(1, (rows_per_task + WPB - 1) / WPB);
+        }
     }
     a.rows = h->d_rows; a.n_rows = (int32_t)h->n; a.chunk = chunk; a.sctab = ctx->d_sctab;
     a.n_tasks = (int32_t)((h->n + (int64_t)chunk * WPB - 1) / ((int64_t)chunk * WPB));
@@ -907,7 +916,7 @@ int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d
     a.log_det_data_cov = h->log_det_data_cov; a.log_det_prior_inv = h->log_det_prior_inv; a.n_log2pi = h->n_log2pi;
     if (a.n_tasks > 0)
         hipLaunchKernelGGL(k_ofti_main, dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB), sizeof(double) * (2 * SCT_N + OFTI_NACC * WAVE), st, a);
-    hipLaunchKernelGGL(k_ofti_finish, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_ofti_finish, dim3((unsigned)cols), dim3(WAVE), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;
 }

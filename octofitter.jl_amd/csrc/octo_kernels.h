@@ -834,13 +834,14 @@ __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_ofti_finish(OftiArgs a) {
+__global__ __launch_bounds__(64) void k_ofti_finish(OftiArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.W) return;
     double v[OFTI_NACC];
 #pragma unroll
     for (int k = 0; k < OFTI_NACC; ++k) v[k] = 0.0;
-    for (int t = 0; t < a.n_tasks; ++t) {
+#pragma unroll 4
+    for (int t = 0; t < a.n_tasks; ++t) {      // independent loads: unrolled so that several tasks' partials are in flight
         const double* pt = a.partials + (int64_t)t * OFTI_NACC * a.ldw + w;
 #pragma unroll
         for (int k = 0; k < OFTI_NACC; ++k) v[k] += pt[(int64_t)k * a.ldw];

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
                 irho = rsqrt_nr(rho2);                         // ρ = ρ²·(1/ρ) enters r2 through one explicit FMA below: a separate
                                                                // product would be contracted differently by the forward-only and
                                                                // the gradient instantiation, and their values must agree bitwise
-                const double pa = atan2(ra_m, dec_m);
+                const double pa = atan2_fast(ra_m, dec_m);
                 double dpa = (y1 + na) - pa + PI;
                 dpa = rem_2pi_trunc(dpa) - PI;                 // Julia `%`: truncated remainder
                 dpa = dpa < -PI ? dpa + TWO_PI : dpa;

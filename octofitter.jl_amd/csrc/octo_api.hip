@@ -797,8 +797,10 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     a.lp_out = d_lp; a.grad_out = d_grad;
     a.k_yr = ctx->consts.kepler_year_to_julian_day; a.yd = ctx->consts.year2day_julian;
     {
-        const int DB = std::min(m->D, 8);
-        hipLaunchKernelGGL(k_model_fwd, dim3((unsigned)((W + 63) / 64), (unsigned)((m->D + DB - 1) / DB)), dim3(64, DB),
+        const int n_thr = (m->D + MODEL_NPART - 1) / MODEL_NPART;      // threads per walker, MODEL_NPART partials each
+        const int DBs = std::min(n_thr, 8), DB = std::max(DBs, std::min(m->D, 8));      // the priors are shared out over all DB waves
+        a.src_waves = DBs;
+        hipLaunchKernelGGL(k_model_fwd, dim3((unsigned)((W + 63) / 64), (unsigned)((n_thr + DBs - 1) / DBs)), dim3(64, DB),
                            sizeof(double) * 4 * m->D * WAVE, st, a);
     }
     HIPCHK(ctx, hipGetLastError());

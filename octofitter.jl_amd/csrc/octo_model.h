@@ -41,12 +41,16 @@ template <int N> __device__ __forceinline__ Dual<N> datan2(const Dual<N>& y, con
     DFOR r.d[k_] = (x.v * y.d[k_] - y.v * x.d[k_]) * ih; return r;
 }
 
+constexpr int MODEL_NPART = 4;   // k_model_fwd: partials per thread. The value path (sincos, atan2, …) is the expensive part of a dual;
+                                 // 4 partials per thread repeat it D/4 times per walker instead of D times
+
 struct ModelArgs {
     const octo_prior* priors;       // [D]
     const octo_source* esrc;        // [n_el]
     const octo_source* nsrc;        // [n_nu] or null
     const DevObs* obs;
     int32_t D, n_el, n_nu, n_planets;
+    int32_t src_waves, pad0;        // k_model_fwd: waves per block that resolve sources (the block may hold more, for the priors)
     const double* theta_t; int64_t ld, W, ldw;
     double* elems; double* nuis;    // [n_el][ldw], [n_nu][ldw]   (kernel inputs)
     double* J;                      // [(n_el+n_nu)*D][ldw]
@@ -145,22 +149,23 @@ __device__ __forceinline__ Dual<N> tperi(const Dual<N>& th, double theta_epoch, 
 // logpdf_with_trans of every prior — is computed once per walker by the block's waves (prior k by wave k mod DB) and
 // shared through LDS: x[k], dx/dθ_t[k], p[k], dp/dθ_t[k].
 __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
-    constexpr int N = 1;
+    constexpr int N = MODEL_NPART;      // partials carried per thread
     extern __shared__ __attribute__((aligned(16))) double lds[];      // [4][D][64]
     const int lane = threadIdx.x;
     const int wy = threadIdx.y, DB = blockDim.y;
     const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;
-    const int d = blockIdx.y * DB + wy;
+    const int DBs = min(DB, a.src_waves);           // waves that go on to resolve the sources; all DB waves share the priors
+    const int d0 = (blockIdx.y * DBs + wy) * N;     // this thread's partials: ∂/∂θ_t[d0 .. d0+N)
     const int D = a.D;
     double* Lx = lds; double* Ldx = lds + (int64_t)D * WAVE; double* Lp = lds + 2 * (int64_t)D * WAVE; double* Ldp = lds + 3 * (int64_t)D * WAVE;
     for (int k = wy; k < D; k += DB) {
-        Dual<N> xk, p;
-        prior_apply(a.priors[k], dvar<N>(a.theta_t[(int64_t)k * a.ld + wl], 0), xk, p);
+        Dual<1> xk, p;
+        prior_apply(a.priors[k], dvar<1>(a.theta_t[(int64_t)k * a.ld + wl], 0), xk, p);
         Lx[k * WAVE + lane] = xk.v; Ldx[k * WAVE + lane] = xk.d[0]; Lp[k * WAVE + lane] = p.v; Ldp[k * WAVE + lane] = p.d[0];
     }
     __syncthreads();
-    if (w >= a.W || d >= D) return;
+    if (w >= a.W || wy >= DBs || d0 >= D) return;
     bool finite_in = true;
     for (int k = 0; k < D; ++k) finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + w]);   // logdensitymodel.jl:120-124
     Dual<N> lp = dconst<N>(0.0);
@@ -169,11 +174,18 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         const double pv = Lp[k * WAVE + lane];
         if (!healed) {
             if (!isfinite(pv)) { lp = dconst<N>(-1.7976931348623157e308); healed = true; }     // variables.jl:1229-1236
-            else { lp.v += pv; if (k == d) lp.d[0] += Ldp[k * WAVE + lane]; }
+            else {
+                lp.v += pv;
+#pragma unroll
+                for (int j = 0; j < N; ++j) if (k == d0 + j) lp.d[j] += Ldp[k * WAVE + lane];
+            }
         }
     }
     auto nat = [&](int k) {      // natural-domain θ[k] with this thread's partial
-        Dual<N> xk; xk.v = Lx[k * WAVE + lane]; xk.d[0] = (k == d) ? Ldx[k * WAVE + lane] : 0.0;
+        Dual<N> xk; xk.v = Lx[k * WAVE + lane];
+        const double dx = Ldx[k * WAVE + lane];
+#pragma unroll
+        for (int j = 0; j < N; ++j) xk.d[j] = (k == d0 + j) ? dx : 0.0;
         return xk;
     };
     // Kernel inputs from the natural θ (arr2nt + Derived variables). The nine element rows of a planet are resolved with
@@ -187,11 +199,13 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         return datan2(cy, cx) * (sc.value / TWO_PI);                  // atan(y, x) / 2π * domain, variables.jl:284
     };
     auto emit = [&](int k, const Dual<N>& val) {
-        if (d == 0) {
+        if (d0 == 0) {
             double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
             *dst = val.v;
         }
-        a.J[((int64_t)k * D + d) * a.ldw + w] = val.d[0];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (d0 + j < D) a.J[((int64_t)k * D + d0 + j) * a.ldw + w] = val.d[j];
     };
     for (int p = 0; p < a.n_planets; ++p) {
         Dual<N> el[OCTO_N_EL];
@@ -203,7 +217,11 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
             if (sc.kind == OCTO_SRC_TPERI) continue;
             const Dual<N> val = plain(sc);
 #pragma unroll
-            for (int j = 0; j < OCTO_N_EL; ++j) { el[j].v = (j == kk) ? val.v : el[j].v; el[j].d[0] = (j == kk) ? val.d[0] : el[j].d[0]; }
+            for (int j = 0; j < OCTO_N_EL; ++j) {
+                el[j].v = (j == kk) ? val.v : el[j].v;
+#pragma unroll
+                for (int q = 0; q < N; ++q) el[j].d[q] = (j == kk) ? val.d[q] : el[j].d[q];
+            }
         }
         {   // tp = θ_at_epoch_to_tperi(...) is the one derived element of the standard parameterisation
             const octo_source sc = a.esrc[p * OCTO_N_EL + OCTO_EL_TP];
@@ -227,8 +245,10 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         }
         emit(a.n_el + k, plain(sc));
     }
-    if (d == 0) a.lpp[w] = finite_in ? lp.v : -INFINITY;
-    a.glp[(int64_t)d * a.ldw + w] = healed ? 0.0 : lp.d[0];
+    if (d0 == 0) a.lpp[w] = finite_in ? lp.v : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        if (d0 + j < D) a.glp[(int64_t)(d0 + j) * a.ldw + w] = healed ? 0.0 : lp.d[j];
 }
 
 // grid = (walker tiles of 256, D): thread (w, d) produces grad[d][w] = ∂(prior)/∂θ_t[d] + Σ_k J[k][d]·ḡ[k].

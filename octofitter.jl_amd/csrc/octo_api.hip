@@ -72,6 +72,8 @@ struct octo_ctx {
     double* d_sctab = nullptr;                  // sin/cos grid of sincos_table, [SCT_N][2]
     double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
     int64_t cap_in = 0, cap_out = 0;
+    double *h_in = nullptr, *h_out = nullptr;   // pinned mirrors of d_in / d_out for SMALL batches: one transfer each way instead of
+    int64_t cap_hin = 0, cap_hout = 0;          // one per array — what a single-chain sampler's per-gradient latency is made of
     // timing
     int timing_every = 0;                       // 0 = off, n = bracket every n-th evaluation's k_main with events
     int64_t timing_seq = 0;
@@ -400,6 +402,7 @@ int32_t octo_ctx_destroy(octo_ctx* ctx) {
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg); (void)hipFree(ctx->d_sctab); (void)hipFree(ctx->d_extra);
+    (void)hipHostFree(ctx->h_in); (void)hipHostFree(ctx->h_out);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out);
     delete ctx;
     return OCTO_OK;
@@ -622,17 +625,38 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
     rc = grow(ctx, ctx->d_out, ctx->cap_out, n_out);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, elems, sizeof(double) * ld, sizeof(double) * W, n_el,
-                                 hipMemcpyHostToDevice, st));
-    double* d_nuis = nullptr;
-    if (nuis) {
-        d_nuis = ctx->d_in + (int64_t)n_el * ldd;
-        HIPCHK(ctx, hipMemcpy2DAsync(d_nuis, sizeof(double) * ldd, nuis, sizeof(double) * ld, sizeof(double) * W, n_nu,
-                                     hipMemcpyHostToDevice, st));
-    }
+    double* d_nuis = nuis ? ctx->d_in + (int64_t)n_el * ldd : nullptr;
     double* d_ll = ctx->d_out;
     double* d_ge = g_elems ? ctx->d_out + ldd : nullptr;
     double* d_gn = g_nuis ? ctx->d_out + (int64_t)(1 + (g_elems ? n_el : 0)) * ldd : nullptr;
+    const bool small = (n_in + n_out) * (int64_t)sizeof(double) <= (1 << 18);     // <= 256 KB in total: latency, not bandwidth
+    if (small) {
+        auto grow_pinned = [&](double*& p, int64_t& cap, int64_t need) -> bool {
+            if (need <= cap) return true;
+            if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+            if (hipHostMalloc((void**)&p, sizeof(double) * (size_t)(2 * need), hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+            cap = 2 * need;
+            return true;
+        };
+        if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
+            return fail(ctx, OCTO_ENOMEM, "octo_eval: pinned staging allocation failed");
+        for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
+        if (nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, ctx->h_in, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, st));
+        rc = octo_eval_device(ctx, ds, ctx->d_in, d_nuis, ldd, W, d_ll, d_ge, d_gn, st);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        std::memcpy(ll_out, ctx->h_out, sizeof(double) * W);
+        if (g_elems) for (int r = 0; r < n_el; ++r) std::memcpy(g_elems + (size_t)r * ld, ctx->h_out + (d_ge - ctx->d_out) + (size_t)r * ldd, sizeof(double) * W);
+        if (g_nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(g_nuis + (size_t)r * ld, ctx->h_out + (d_gn - ctx->d_out) + (size_t)r * ldd, sizeof(double) * W);
+        return OCTO_OK;
+    }
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, elems, sizeof(double) * ld, sizeof(double) * W, n_el,
+                                 hipMemcpyHostToDevice, st));
+    if (nuis)
+        HIPCHK(ctx, hipMemcpy2DAsync(d_nuis, sizeof(double) * ldd, nuis, sizeof(double) * ld, sizeof(double) * W, n_nu,
+                                     hipMemcpyHostToDevice, st));
     rc = octo_eval_device(ctx, ds, ctx->d_in, d_nuis, ldd, W, d_ll, d_ge, d_gn, st);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ll_out, d_ll, sizeof(double) * W, hipMemcpyDeviceToHost, st));

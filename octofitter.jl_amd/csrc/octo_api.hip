@@ -107,6 +107,14 @@ DevConsts dev_consts(const octo_consts& c) {
     return d;
 }
 
+bool grow_pinned(double*& p, int64_t& cap, int64_t need) {
+    if (need <= cap) return true;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    if (hipHostMalloc((void**)&p, sizeof(double) * (size_t)(2 * need), hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+    cap = 2 * need;
+    return true;
+}
+
 template <typename T>
 int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
     if (need <= cap) return OCTO_OK;
@@ -631,13 +639,6 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
     double* d_gn = g_nuis ? ctx->d_out + (int64_t)(1 + (g_elems ? n_el : 0)) * ldd : nullptr;
     const bool small = (n_in + n_out) * (int64_t)sizeof(double) <= (1 << 18);     // <= 256 KB in total: latency, not bandwidth
     if (small) {
-        auto grow_pinned = [&](double*& p, int64_t& cap, int64_t need) -> bool {
-            if (need <= cap) return true;
-            if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-            if (hipHostMalloc((void**)&p, sizeof(double) * (size_t)(2 * need), hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
-            cap = 2 * need;
-            return true;
-        };
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_eval: pinned staging allocation failed");
         for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
@@ -848,6 +849,20 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     rc = grow(ctx, m->d_res, m->cap_res, (int64_t)(m->D + 1) * ldd);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
+    const int64_t n_in = (int64_t)m->D * ldd, n_out = (int64_t)(grad_out ? m->D + 1 : 1) * ldd;
+    if ((n_in + n_out) * (int64_t)sizeof(double) <= (1 << 18)) {      // small batch: one pinned transfer each way (see octo_eval)
+        if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
+            return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");
+        for (int r = 0; r < m->D; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, theta_t + (size_t)r * ld, sizeof(double) * W);
+        HIPCHK(ctx, hipMemcpyAsync(m->d_th, ctx->h_in, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, st));
+        rc = octo_model_logpost_device(ctx, m, m->d_th, ldd, W, m->d_res, grad_out ? m->d_res + ldd : nullptr, st);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, m->d_res, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        std::memcpy(lp_out, ctx->h_out, sizeof(double) * W);
+        if (grad_out) for (int r = 0; r < m->D; ++r) std::memcpy(grad_out + (size_t)r * ld, ctx->h_out + (size_t)(1 + r) * ldd, sizeof(double) * W);
+        return OCTO_OK;
+    }
     HIPCHK(ctx, hipMemcpy2DAsync(m->d_th, sizeof(double) * ldd, theta_t, sizeof(double) * ld, sizeof(double) * W, m->D, hipMemcpyHostToDevice, st));
     rc = octo_model_logpost_device(ctx, m, m->d_th, ldd, W, m->d_res, grad_out ? m->d_res + ldd : nullptr, st);
     if (rc) return rc;

@@ -274,7 +274,8 @@ int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int
  * by a counter-based RNG (seed, step) shared by all ranks:
  *   log A = (β_i − β_{i+1}) (ℓ_{i+1} − ℓ_i)     on log-likelihoods,
  * swapping the β-index of the two replicas, never their states.
- *   d_ll       [n_chains][n_temps]  log-likelihood of the replica currently holding chain c, slot t
+ *   d_ll       [n_temps][n_chains]  log-likelihood of replica r of chain c — the layout an all_gather over ranks that
+ *                                   each own a contiguous block of replicas produces, so no transpose is needed
  *   d_beta     [n_temps]            inverse-temperature ladder (slot order)
  *   d_slot2rep [n_chains][n_temps]  in/out permutation: which replica sits at ladder slot t
  * `parity` 0 swaps pairs (0,1),(2,3)…; 1 swaps (1,2),(3,4)…  */

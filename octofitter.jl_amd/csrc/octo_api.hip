@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_pt_swap(const double* __restrict__ ll, 
     const int t = parity + 2 * (int)(idx % n_pairs);
     int32_t* s2r = slot2rep + c * n_temps;
     const int ri = s2r[t], rj = s2r[t + 1];
-    const double li = ll[c * n_temps + ri], lj = ll[c * n_temps + rj];
+    const double li = ll[(int64_t)ri * n_chains + c], lj = ll[(int64_t)rj * n_chains + c];      // [replica][chain], as gathered
     const double logA = (beta[t] - beta[t + 1]) * (lj - li);
     // counter-based uniform in (0,1]: identical on every rank for the same (seed, step, chain, slot)
     const uint64_t h = mix64(mix64(mix64(seed ^ 0x6f63746f50545357ull) + step) + (uint64_t)c * 0x100000001b3ull + (uint64_t)t);

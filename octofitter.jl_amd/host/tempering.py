@@ -54,7 +54,7 @@ class TemperedSwap:
             ll_all = self._ll_all
         else:
             ll_all = ll_local
-        ll_cr = ll_all.view(self.n_temps, self.n_chains).t().contiguous()     # [n_chains][n_temps(replica)]
+        ll_cr = ll_all.view(self.n_temps, self.n_chains)                       # [replica][chain], exactly as gathered
         parity = int(step) % 2
         if self._swap_impl is not None:
             self._swap_impl(ll_cr, self.beta, self.slot2rep, parity, self.seed, int(step), self.accepted)
@@ -65,5 +65,5 @@ class TemperedSwap:
         self.fn._check(self.fn.lib.octo_pt_swap_device(
             self.fn._ctx, ll_cr.data_ptr(), self.beta.data_ptr(), self.slot2rep.data_ptr(), self.n_temps, self.n_chains,
             parity, C.c_uint64(self.seed), C.c_uint64(int(step)), self.accepted.data_ptr(), C.c_void_p(stream)), "octo_pt_swap_device")
-        self._keep = ll_cr     # keep the transposed buffer alive until the stream has consumed it
+        self._keep = ll_cr     # keep the buffer alive until the stream has consumed it
         return self.slot2rep

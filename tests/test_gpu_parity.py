@@ -272,13 +272,13 @@ def _pt_swap_reference(ll, beta, slot2rep, parity, seed, step):
         z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & M64
         z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & M64
         return z ^ (z >> 31)
-    n_chains, n_temps = ll.shape
+    n_temps, n_chains = ll.shape          # [replica][chain]
     out = slot2rep.copy()
     acc = np.zeros(n_temps, dtype=np.int32)
     for c in range(n_chains):
         for t in range(parity, n_temps - 1, 2):
             ri, rj = out[c, t], out[c, t + 1]
-            li, lj = ll[c, ri], ll[c, rj]
+            li, lj = ll[ri, c], ll[rj, c]
             logA = (beta[t] - beta[t + 1]) * (lj - li)
             h = mix((mix((mix(seed ^ 0x6f63746f50545357) + step) & M64) + c * 0x100000001b3 + t) & M64)
             u = ((h >> 11) + 1.0) * (1.0 / 9007199254740992.0)
@@ -295,7 +295,7 @@ def test_pt_swap_kernel(pkg):
     assert lib.octo_ctx_create(C.byref(ctx), 0) == 0
     rng = np.random.default_rng(2)
     n_chains, n_temps = 37, 16
-    ll = rng.normal(-100, 5, (n_chains, n_temps))
+    ll = rng.normal(-100, 5, (n_temps, n_chains))
     beta = np.linspace(1.0, 0.0, n_temps) ** 2
     s2r = np.stack([rng.permutation(n_temps) for _ in range(n_chains)]).astype(np.int32)
     d_ll = torch.tensor(ll, device="cuda:0"); d_beta = torch.tensor(beta, device="cuda:0")

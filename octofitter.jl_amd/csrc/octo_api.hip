@@ -722,6 +722,8 @@ struct octo_model {
     octo_prior* d_priors = nullptr;
     octo_source* d_esrc = nullptr;
     octo_source* d_nsrc = nullptr;
+    int32_t* d_circ = nullptr;   // [n_el + n_nu] LDS slot of each UniformCircular pair in k_model_fwd, or -1
+    int n_circ = 0;
     double* d_buf = nullptr;   // elems | nuis | J | lpp | glp | ll | g_el | g_nu, all [rows][ldw]
     int64_t cap_w = 0;
     double *d_th = nullptr, *d_res = nullptr;   // staging for host buffers
@@ -774,6 +776,16 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
         if (hipMalloc((void**)&m->d_nsrc, sizeof(octo_source) * n_nu) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
         if (hipMemcpy(m->d_nsrc, nuis_src, sizeof(octo_source) * n_nu, hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
     }
+    {
+        std::vector<int32_t> slot(n_el + n_nu, -1);
+        for (int k = 0; k < n_el + n_nu; ++k) {
+            if (k >= n_el && !nuis_src) break;
+            const octo_source& sc = k < n_el ? elem_src[k] : nuis_src[k - n_el];
+            if ((sc.kind == OCTO_SRC_CIRCULAR || sc.kind == OCTO_SRC_TPERI) && m->n_circ < MODEL_MAXCIRC) slot[k] = m->n_circ++;
+        }
+        if (hipMalloc((void**)&m->d_circ, sizeof(int32_t) * slot.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
+        if (hipMemcpy(m->d_circ, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
+    }
     *out = m;
     return OCTO_OK;
 }
@@ -781,7 +793,7 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
 int32_t octo_model_destroy(octo_model* m) {
     if (!m) return OCTO_OK;
     (void)hipSetDevice(m->device);
-    (void)hipFree(m->d_priors); (void)hipFree(m->d_esrc); (void)hipFree(m->d_nsrc); (void)hipFree(m->d_buf);
+    (void)hipFree(m->d_priors); (void)hipFree(m->d_esrc); (void)hipFree(m->d_nsrc); (void)hipFree(m->d_circ); (void)hipFree(m->d_buf);
     (void)hipFree(m->d_th); (void)hipFree(m->d_res);
     delete m;
     return OCTO_OK;
@@ -824,9 +836,9 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     {
         const int n_thr = (m->D + MODEL_NPART - 1) / MODEL_NPART;      // threads per walker, MODEL_NPART partials each
         const int DBs = std::min(n_thr, 8), DB = std::max(DBs, std::min(m->D, 8));      // the priors are shared out over all DB waves
-        a.src_waves = DBs;
+        a.src_waves = DBs; a.circ_slot = m->d_circ; a.n_circ = m->n_circ;
         hipLaunchKernelGGL(k_model_fwd, dim3((unsigned)((W + 63) / 64), (unsigned)((n_thr + DBs - 1) / DBs)), dim3(64, DB),
-                           sizeof(double) * 4 * m->D * WAVE, st, a);
+                           sizeof(double) * (4 * m->D + 6 * m->n_circ) * WAVE, st, a);
     }
     HIPCHK(ctx, hipGetLastError());
     const bool grad = d_grad != nullptr;

@@ -41,6 +41,7 @@ template <int N> __device__ __forceinline__ Dual<N> datan2(const Dual<N>& y, con
     DFOR r.d[k_] = (x.v * y.d[k_] - y.v * x.d[k_]) * ih; return r;
 }
 
+constexpr int MODEL_MAXCIRC = 12;   // UniformCircular pairs whose atan2 / UnitLengthPrior values are shared through LDS (more: computed in place)
 constexpr int MODEL_NPART = 4;   // k_model_fwd: partials per thread. The value path (sincos, atan2, …) is the expensive part of a dual;
                                  // 4 partials per thread repeat it D/4 times per walker instead of D times
 
@@ -50,7 +51,9 @@ struct ModelArgs {
     const octo_source* nsrc;        // [n_nu] or null
     const DevObs* obs;
     int32_t D, n_el, n_nu, n_planets;
-    int32_t src_waves, pad0;        // k_model_fwd: waves per block that resolve sources (the block may hold more, for the priors)
+    int32_t src_waves, n_circ;      // k_model_fwd: waves per block that resolve sources (the block may hold more, for the priors);
+                                    // number of UniformCircular pairs precomputed through LDS
+    const int32_t* circ_slot;       // [n_el + n_nu] LDS slot of a CIRCULAR / TPERI source's (atan2, UnitLength) values, or -1
     const double* theta_t; int64_t ld, W, ldw;
     double* elems; double* nuis;    // [n_el][ldw], [n_nu][ldw]   (kernel inputs)
     double* J;                      // [(n_el+n_nu)*D][ldw]
@@ -165,6 +168,20 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         Lx[k * WAVE + lane] = xk.v; Ldx[k * WAVE + lane] = xk.d[0]; Lp[k * WAVE + lane] = p.v; Ldp[k * WAVE + lane] = p.d[0];
     }
     __syncthreads();
+    // UniformCircular pairs (variables.jl:279-323): angle atan(y, x), its two partials, and the UnitLengthPrior term with its two
+    // partials depend on two natural parameters only. One wave computes them per pair, for all the threads of the walker — in
+    // place they were a ~350-instruction serial chain of atan2, sqrt and two logs, repeated by every thread.
+    double* Lc = lds + 4 * (int64_t)D * WAVE;           // [n_circ][6][64]
+    for (int k = wy; k < a.n_el + a.n_nu; k += DB) {
+        const int slot = a.circ_slot[k];
+        if (slot < 0) continue;
+        const octo_source sc = k < a.n_el ? a.esrc[k] : a.nsrc[k - a.n_el];
+        const Dual<2> cx = dvar<2>(Lx[sc.i0 * WAVE + lane], 0), cy = dvar<2>(Lx[sc.i1 * WAVE + lane], 1);
+        const Dual<2> ang = datan2(cy, cx), ul = unit_length(cx, cy);
+        double* o = Lc + (int64_t)slot * 6 * WAVE + lane;
+        o[0] = ang.v; o[WAVE] = ang.d[0]; o[2 * WAVE] = ang.d[1]; o[3 * WAVE] = ul.v; o[4 * WAVE] = ul.d[0]; o[5 * WAVE] = ul.d[1];
+    }
+    __syncthreads();
     if (w >= a.W || wy >= DBs || d0 >= D) return;
     bool finite_in = true;
     for (int k = 0; k < D; ++k) finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + w]);   // logdensitymodel.jl:120-124
@@ -191,12 +208,31 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     // Kernel inputs from the natural θ (arr2nt + Derived variables). The nine element rows of a planet are resolved with
     // compile-time positions so that they live in registers (a dynamically indexed array lands in scratch memory and made
     // this kernel 3x slower); θ_at_epoch_to_tperi comes last within a planet because it reads the planet's other elements.
-    auto plain = [&](const octo_source& sc) {      // OCTO_SRC_CONST / _THETA / _CIRCULAR
+    // atan(θy, θx) of a UniformCircular pair as a dual, adding its UnitLengthPrior term to lp when this source carries it
+    auto circ_angle = [&](const octo_source& sc, int k) {
+        const int slot = a.circ_slot[k];
+        if (slot < 0) {                                               // beyond the LDS budget: in place
+            const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
+            if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(cx, cy);
+            return datan2(cy, cx);
+        }
+        const double* c = Lc + (int64_t)slot * 6 * WAVE + lane;
+        const double dx = Ldx[sc.i0 * WAVE + lane], dy = Ldx[sc.i1 * WAVE + lane];    // ∂x/∂θ_t, ∂y/∂θ_t (diagonal)
+        Dual<N> ang; ang.v = c[0];
+        const bool ul = (sc.flags & OCTO_SRC_FLAG_UNITLEN) != 0;
+        if (ul) lp.v += c[3 * WAVE];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double sx = (sc.i0 == d0 + j) ? dx : 0.0, sy = (sc.i1 == d0 + j) ? dy : 0.0;
+            ang.d[j] = c[WAVE] * sx + c[2 * WAVE] * sy;
+            if (ul) lp.d[j] += c[4 * WAVE] * sx + c[5 * WAVE] * sy;
+        }
+        return ang;
+    };
+    auto plain = [&](const octo_source& sc, int k) {      // OCTO_SRC_CONST / _THETA / _CIRCULAR
         if (sc.kind == OCTO_SRC_CONST) return dconst<N>(sc.value);
         if (sc.kind == OCTO_SRC_THETA) return nat(sc.i0);
-        const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
-        if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(cx, cy);
-        return datan2(cy, cx) * (sc.value / TWO_PI);                  // atan(y, x) / 2π * domain, variables.jl:284
+        return circ_angle(sc, k) * (sc.value / TWO_PI);               // atan(y, x) / 2π * domain, variables.jl:284
     };
     auto emit = [&](int k, const Dual<N>& val) {
         if (d0 == 0) {
@@ -215,7 +251,7 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         for (int kk = 0; kk < OCTO_N_EL; ++kk) {          // one copy of the code; the store is a select chain, not an indexed write
             const octo_source sc = a.esrc[p * OCTO_N_EL + kk];
             if (sc.kind == OCTO_SRC_TPERI) continue;
-            const Dual<N> val = plain(sc);
+            const Dual<N> val = plain(sc, p * OCTO_N_EL + kk);
 #pragma unroll
             for (int j = 0; j < OCTO_N_EL; ++j) {
                 el[j].v = (j == kk) ? val.v : el[j].v;
@@ -226,9 +262,7 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         {   // tp = θ_at_epoch_to_tperi(...) is the one derived element of the standard parameterisation
             const octo_source sc = a.esrc[p * OCTO_N_EL + OCTO_EL_TP];
             if (sc.kind == OCTO_SRC_TPERI) {
-                const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
-                if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(cx, cy);
-                el[OCTO_EL_TP] = tperi(datan2(cy, cx), sc.value, el[OCTO_EL_M], el[OCTO_EL_E], el[OCTO_EL_A], el[OCTO_EL_I], el[OCTO_EL_W],
+                el[OCTO_EL_TP] = tperi(circ_angle(sc, p * OCTO_N_EL + OCTO_EL_TP), sc.value, el[OCTO_EL_M], el[OCTO_EL_E], el[OCTO_EL_A], el[OCTO_EL_I], el[OCTO_EL_W],
                                        el[OCTO_EL_O], a.k_yr, a.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &el[OCTO_EL_PLX]);
             }
         }
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
             sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
             sc.value = ((kind <= OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
         }
-        emit(a.n_el + k, plain(sc));
+        emit(a.n_el + k, plain(sc, a.n_el + k));
     }
     if (d0 == 0) a.lpp[w] = finite_in ? lp.v : -INFINITY;
 #pragma unroll

@@ -31,8 +31,18 @@ def main():
         e_ab = np.max(np.abs(np.asarray(abfg) - abfg_o) / np.maximum(np.abs(abfg_o).max(axis=0, keepdims=True), 1e-300))
         # n <= 2 epochs leave the 4 constants under-determined: the 4x4 system is held up by the prior alone (condition number
         # ~ σ_ABFG² × weights), and Julia's LU (restated by the oracle) and the device Cholesky both lose those digits
-        lim = (1e-6, 1e-7) if n <= 2 else (1e-9, 1e-8)
+        # (checked against 60 digits: the device value is the accurate one there, e.g. 3e-11 vs the LU restatement's 3e-5)
+        lim = (1e-4, 1e-6) if n <= 2 else (1e-9, 1e-8)
         flag = "" if (e_lm < lim[0] and e_ab < lim[1]) else "   <-- FAIL"
+        if flag or e_lm > 1e-8:      # who is off? the 60-digit value for the worst walker
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import mpmath as mp, mp_oracle as mo
+            wb = int(np.argmax(np.abs(lm - lm_o) / np.maximum(1, np.abs(lm_o))))
+            f = lambda v: [mp.mpf(float(x)) for x in v]
+            r = mo.ofti_linear_solve(mo.DEFAULT_CONSTS, f(ep), f(ra), f(dec), f(s_ra), f(s_dec), None if cor is None else f(cor), mp.mpf(sig),
+                                     *[mp.mpf(float(v)) for v in nl[:, wb]])
+            truth = float(r[-1] if not isinstance(r, dict) else r["log_marginal_likelihood"])
+            print(f"\n     walker {wb}: 60-digit logml {truth:.15g}; device {lm[wb]:.15g} (err {abs(lm[wb]-truth):.1e}); LU oracle {lm_o[wb]:.15g} (err {abs(lm_o[wb]-truth):.1e})")
         bad += bool(flag); worst = [max(worst[0], e_lm), max(worst[1], e_ab)]
         print(f"{k:3d} n={n} W={W} cor={cor is not None} sigma={sig:.3g}: logml {e_lm:.1e} ABFG {e_ab:.1e}{flag}", flush=True)
     print(f"worst: logml {worst[0]:.2e} ABFG {worst[1]:.2e}; failures {bad}")

@@ -260,7 +260,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, hipStream_t 
     if (rc) return rc;
     a.partials = ctx->d_partials;
     const dim3 gsetup((unsigned)((a.W + 255) / 256));
-    hipLaunchKernelGGL(k_setup, gsetup, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_setup, dim3(gsetup.x, (unsigned)a.n_planets), dim3(256), 0, st, a);
     if (a.n_tasks > 0) {
         if (GRAD && L::HAS_MARG && (ds->kind_mask & KM_MARG)) {
             // marginalised RV: forward pre-pass over those tables' tasks for μ̂ and A, then the gradient pass
@@ -590,7 +590,7 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
         if (ctx->d_wc) { HIPCHK(ctx, hipFree(ctx->d_wc)); ctx->d_wc = nullptr; }
         if (ctx->d_valid) { HIPCHK(ctx, hipFree(ctx->d_valid)); ctx->d_valid = nullptr; }
         HIPCHK(ctx, hipMalloc((void**)&ctx->d_wc, sizeof(double) * (size_t)need * NWC * MAXP));
-        HIPCHK(ctx, hipMalloc((void**)&ctx->d_valid, sizeof(int32_t) * (size_t)need));
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_valid, sizeof(int32_t) * (size_t)need * MAXP));
         ctx->cap_w = need;
     }
     EvalArgs a;

@@ -56,7 +56,7 @@ struct EvalArgs {
     const double* nuis;           // [n_obs*3][ld] or null
     int64_t ld, W;
     double* wc;                   // [P*NWC][ldw]
-    int32_t* valid;               // [ldw]
+    int32_t* valid;               // [n_planets][ldw]
     double* partials;             // [n_tasks*NACC][ldw]
     const double* marg;           // [n_obs*2][ldw]: μ̂ and A of each marginalised-RV table (grad pass) or null
     double* marg_out;
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.W) return;
     bool ok = true;
-    for (int p = 0; p < a.n_planets; ++p) {
+    {
+        const int p = blockIdx.y;                          // one thread per (walker, planet)
         const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + w;
         const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
         const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
@@ -148,10 +149,10 @@ __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
         o[WC_MU * a.ldw] = mass * a.c.mjup2msol / Mt; o[WC_A * a.ldw] = sma;
         o[WC_SINI * a.ldw] = si; o[WC_COSI * a.ldw] = ci; o[WC_SINO * a.ldw] = sO; o[WC_COSO * a.ldw] = cO;
     }
-    if (a.nuis) {
+    if (a.nuis && blockIdx.y == 0) {
         for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok = ok && isfinite(a.nuis[(int64_t)k * a.ld + w]);
     }
-    a.valid[w] = ok ? 1 : 0;
+    a.valid[(int64_t)blockIdx.y * a.ldw + w] = ok ? 1 : 0;      // k_finish ANDs the planets' flags
 }
 
 // ------------------------------------------------------------------------------------ k_kepler
@@ -660,7 +661,9 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     }
     if (grp != 0 || w >= a.W) return;
     if (a.extra) ll += a.extra[w];
-    const bool ok = a.valid[w] != 0 && isfinite(ll);
+    bool ok = isfinite(ll);
+#pragma unroll
+    for (int p = 0; p < P; ++p) ok = ok && a.valid[(int64_t)p * a.ldw + w] != 0;
     a.ll_out[w] = ok ? ll : -INFINITY;
     if constexpr (GRAD) {
         if (!ok && L::N_NU > 0) {

@@ -85,6 +85,7 @@ extern "C" {
 /* ---- orbit parameterisations (PlanetOrbits.jl types) --------------------- */
 #define OCTO_ORBIT_VISUAL_KEP 0  /* Visual{KepOrbit}: a,e,i,ω,Ω,tp,M,plx               */
 #define OCTO_ORBIT_RADVEL     1  /* RadialVelocityOrbit: a,e,ω,tp,M (i,Ω,plx ignored)  */
+#define OCTO_ORBIT_KEP        3  /* plain KepOrbit: a,e,i,ω,Ω,tp,M — no parallax, so RV tables only (K carries sin i)  */
 #define OCTO_ORBIT_THIELE_INNES 2 /* ThieleInnesOrbit: e,tp,M,plx and the Thiele-Innes constants A,B,F,G [mas] in the element rows
                                    * OCTO_EL_TI_A/B/F/G below; a = α/plx with α from A,B,F,G (src/parameterizations.jl:15-19).
                                    * Astrometry, the O'Neil prior and HGCA only (no RV tables with this basis). */
@@ -158,16 +159,25 @@ int32_t octo_consts_default(octo_consts* out);
 
 int32_t octo_version(int32_t* major, int32_t* minor);
 
-/* Context = one HIP device + one stream + scratch. Not thread-safe: one ctx
- * per host thread (datasets may be shared read-only between contexts on the
- * same device). */
+/* Context = one HIP device + one stream + scratch + the row-partition cache. Not thread-safe: one ctx per host thread
+ * AND per stream of concurrent work — two evaluations through one context share its scratch, so they are ordered one after
+ * the other (if the caller switches streams between calls the library inserts the event wait itself; it never overlaps
+ * them). A dataset is immutable after octo_dataset_create and may be shared, without locking, by any number of contexts
+ * and host threads on the same device. */
 int32_t octo_ctx_create(octo_ctx** out, int32_t device_id);
 int32_t octo_ctx_destroy(octo_ctx* ctx);
 int32_t octo_consts_set(octo_ctx* ctx, const octo_consts* c);
+/* Batches of up to `max_walkers` parameter sets (default and maximum OCTO_SMALL_BATCH_MAX) take the fused small-batch
+ * launch: one kernel with the EPOCHS across the lanes and a wavefront/LDS tree reduction, inputs and outputs in mapped
+ * pinned memory — the latency path for samplers that evaluate one θ per call (src/logdensitymodel.jl:169-177). 0 sends
+ * every batch through the throughput kernels (lane = walker). Results agree to rounding, not bitwise (different summation order). */
+#define OCTO_SMALL_BATCH_MAX 32
+int32_t octo_ctx_set_small_batch(octo_ctx* ctx, int32_t max_walkers);
 const char* octo_last_error(const octo_ctx* ctx);
 
 /* Upload the observation tables (one-time). Observation likelihoods are summed
- * in the order given. */
+ * in the order given. OCTO_EINVAL for a non-finite epoch or measurement, an uncertainty that is not finite and > 0, or a
+ * correlation outside the reference's bound (relative-astrometry.jl:70-72). */
 int32_t octo_dataset_create(octo_ctx* ctx,
                             const octo_obs_desc* obs, int32_t n_obs,
                             const octo_planet_desc* planets, int32_t n_planets,
@@ -188,9 +198,15 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds,
                   const double* elems, const double* nuis, int64_t ld, int64_t W,
                   double* ll_out, double* g_elems, double* g_nuis);
 
-/* Same, DEVICE buffers already resident in HBM, enqueued on `hip_stream`
- * (NULL = the context's own stream). Asynchronous: pair with octo_sync (or
- * synchronise the stream yourself) before reading outputs. */
+/* `hip_stream` of every *_device entry point: a hipStream_t, handed to HIP as it is — so NULL is HIP's NULL (legacy
+ * default) stream, exactly what a framework that has no stream of its own selected reports as its current stream — or
+ * OCTO_STREAM_CTX for the context's own non-blocking stream (the one octo_sync waits for and every host-buffer entry
+ * point uses). The kernels are ordered like any other work on that stream: after what the caller enqueued before the
+ * call, before what it enqueues after it. */
+#define OCTO_STREAM_CTX ((void*)(intptr_t)-1)
+
+/* Same, DEVICE buffers already resident in HBM, enqueued on `hip_stream`. Asynchronous: synchronise that stream (or, for
+ * OCTO_STREAM_CTX, call octo_sync) before reading outputs. */
 int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* ds,
                          const double* d_elems, const double* d_nuis, int64_t ld, int64_t W,
                          double* d_ll_out, double* d_g_elems, double* d_g_nuis,
@@ -225,7 +241,9 @@ int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d
  *   order (src/variables.jl:1205-1369), UniformCircular angles and their UnitLengthPrior terms (:279-323),
  *   tp = θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω) (src/parameterizations.jl:6-69), then the likelihood above.
  * A model is: D priors (one per θ_t entry, in the reference's flattening order) and, for every kernel input (element
- * row of each planet, nuisance row of each observation), a SOURCE saying how it is built from the natural θ. */
+ * row of each planet, nuisance row of each observation), a SOURCE saying how it is built from the natural θ.
+ * Size limit: 1 <= D <= 64 and (4·D + 6·n_circular)·512 B of LDS per block must fit the device (160 KB on gfx950:
+ * i.e. 4·D + 6·n_circular <= 320: D = 64 with up to 10 UniformCircular variables); octo_model_create returns OCTO_EINVAL beyond it. */
 #define OCTO_PRIOR_UNIFORM     0   /* Uniform(p0, p1)                                                   */
 #define OCTO_PRIOR_LOGUNIFORM  1   /* LogUniform(p0, p1)                                                */
 #define OCTO_PRIOR_NORMAL      2   /* Normal(p0 = μ, p1 = σ)                                            */
@@ -257,7 +275,7 @@ int32_t octo_model_destroy(octo_model* m);
 /* theta_t[(d)*ld + w], d < D: unconstrained parameters. lp_out[W]; grad_out[(d)*ld + w] or NULL. HOST buffers. */
 int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, int64_t ld, int64_t W,
                            double* lp_out, double* grad_out);
-/* DEVICE buffers, asynchronous on hip_stream (NULL = the context's stream). */
+/* DEVICE buffers, asynchronous on hip_stream (see OCTO_STREAM_CTX). */
 int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_theta_t, int64_t ld, int64_t W,
                                   double* d_lp_out, double* d_grad_out, void* hip_stream);
 
@@ -267,6 +285,8 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
  * n-th evaluation (an event pair costs a few µs of stream time, so a timed region samples rather than brackets all). */
 int32_t octo_timing_enable(octo_ctx* ctx, int32_t every_n);
 int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int32_t reset);
+/* Median / min / max over the individual timed launches since the last reset (does not reset). */
+int32_t octo_timing_stats(octo_ctx* ctx, double* median_ms, double* min_ms, double* max_ms, int64_t* n_launches);
 
 /* Parallel-tempering swap step on device-resident log-likelihoods gathered from
  * all replicas (the one collective of the path; the gather itself is RCCL's

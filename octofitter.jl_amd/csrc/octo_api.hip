@@ -4,10 +4,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -22,6 +24,7 @@ using namespace octo;
 namespace {
 
 struct TaskTable {
+    uint64_t ds_serial = 0;          // the dataset this partition belongs to (octo_dataset::serial)
     int64_t key = 0;                 // > 0: target number of tasks of the plan; < 0: forced uniform rows-per-wave (OCTO_CHUNK)
     int n_tasks = 0;
     Task* d_tasks = nullptr;
@@ -45,7 +48,8 @@ struct octo_dataset {
     DevObs* d_obs = nullptr;
     std::vector<double*> d_bufs;
     octo_planet_desc planets[MAXP];
-    std::vector<TaskTable> tables;
+    uint64_t serial = 0;                 // process-unique id: the contexts key their task-table caches by it (the dataset itself
+                                         // is immutable after octo_dataset_create, so contexts may share it without locking)
 };
 
 struct octo_ofti {
@@ -58,7 +62,14 @@ struct octo_ofti {
 struct octo_ctx {
     int device = 0;
     int n_cus = 256;
-    hipStream_t stream = nullptr;
+    int64_t max_lds = 65536;                    // largest dynamic LDS allocation one block may ask for on this device
+    hipStream_t stream = nullptr;               // the context's own stream (OCTO_STREAM_CTX, and every host-buffer entry point)
+    // The scratch below is reused by every evaluation, so evaluations through one context must be ordered. They are when the
+    // caller keeps to one stream per context (the documented contract); if it does switch streams, the new stream is made to
+    // wait for the last evaluation enqueued on the old one (an event, no host synchronisation).
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    hipEvent_t ev_order = nullptr;
     octo_consts consts;
     std::string err;
     // scratch (device)
@@ -70,10 +81,22 @@ struct octo_ctx {
     double* d_extra = nullptr;                  // k_hgca output: ll and input-gradient of the non-epoch-loop terms
     int64_t cap_extra = 0;
     double* d_sctab = nullptr;                  // sin/cos grid of sincos_table, [SCT_N][2]
+    int32_t* d_counters = nullptr;              // k_small: finished-block counter per walker, [SMALL_W], zero between launches
+    uint64_t* h_flags = nullptr;                // mapped pinned [SMALL_W]: k_small's finishing block of walker w stores the call's
+    uint64_t flag_seq = 0;                      // sequence number here after its outputs; host-buffer calls spin on it
+    bool flag_request = false, flag_armed = false;
+    int64_t stage_ws_in = 0, stage_ws_out = 0;  // > 0 while octo_eval hands k_small its walker-major staging buffers
+    int small_w = SMALL_W;                      // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
     double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
     int64_t cap_in = 0, cap_out = 0;
     double *h_in = nullptr, *h_out = nullptr;   // pinned mirrors of d_in / d_out for SMALL batches: one transfer each way instead of
     int64_t cap_hin = 0, cap_hout = 0;          // one per array — what a single-chain sampler's per-gradient latency is made of
+    std::vector<void*> retired;                 // outgrown scratch buffers: kernels already enqueued may still use them, so they
+                                                // are freed at the next host-blocking point (octo_sync, the end of a host-buffer
+                                                // call, octo_ctx_destroy) instead of by a device-synchronising hipFree mid-stream
+    // row partitions ("task tables") of the datasets this context has evaluated, keyed by (dataset serial, plan key)
+    std::vector<TaskTable> tables;
+    std::map<uint32_t, int> occupancy;          // resident blocks per CU of each k_main variant (P, NUIS, KM) on THIS device
     // timing
     int timing_every = 0;                       // 0 = off, n = bracket every n-th evaluation's k_main with events
     int64_t timing_seq = 0;
@@ -81,9 +104,12 @@ struct octo_ctx {
     size_t ev_used = 0;
     double t_ms = 0.0;
     int64_t t_n = 0;
+    std::vector<float> t_samples;               // every timed launch since the last reset (median, spread)
 };
 
 namespace {
+
+std::atomic<uint64_t> g_dataset_serial{1};
 
 int fail(octo_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -110,16 +136,65 @@ DevConsts dev_consts(const octo_consts& c) {
 bool grow_pinned(double*& p, int64_t& cap, int64_t need) {
     if (need <= cap) return true;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-    if (hipHostMalloc((void**)&p, sizeof(double) * (size_t)(2 * need), hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+    if (hipHostMalloc((void**)&p, sizeof(double) * (size_t)(2 * need), hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) { p = nullptr; return false; }
     cap = 2 * need;
     return true;
+}
+
+// `hip_stream` of the *_device entry points: OCTO_STREAM_CTX = the context's own stream; anything else is handed to HIP as
+// it is, so NULL is HIP's NULL stream (the legacy default stream — what torch.cuda.current_stream().cuda_stream is when no
+// torch stream is active). Orders the scratch across a change of stream.
+int use_stream(octo_ctx* ctx, void* hip_stream, hipStream_t* out) {
+    hipStream_t st = hip_stream == OCTO_STREAM_CTX ? ctx->stream : (hipStream_t)hip_stream;
+    if (ctx->has_last && ctx->last_stream != st) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_order, ctx->last_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_order, 0));
+    }
+    ctx->last_stream = st; ctx->has_last = true;
+    *out = st;
+    return OCTO_OK;
+}
+
+// End of a small host-buffer call: if k_small was handed the completion flags, spin on them (its results are already in host
+// memory when a flag flips; ~3 µs less than a stream synchronisation), looking at the stream now and then so that a failed
+// launch cannot hang the caller; otherwise synchronise the stream.
+int wait_small(octo_ctx* ctx, hipStream_t st, int64_t W) {
+    if (ctx->flag_armed) {
+        ctx->flag_armed = false;
+        volatile uint64_t* f = ctx->h_flags;
+        const uint64_t seq = ctx->flag_seq;
+        uint32_t spins = 0;
+        for (int64_t w = 0; w < W; ++w) {
+            while (f[w] != seq) {
+                if ((++spins & 0x3fff) == 0) {
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q == hipSuccess) break;                 // the kernel has retired: the flag store is visible by now
+                    if (q != hipErrorNotReady) return fail(ctx, OCTO_EHIP, std::string("k_small: ") + hipGetErrorString(q));
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return OCTO_OK;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return OCTO_OK;
+}
+
+void free_retired(octo_ctx* ctx) {      // only after the streams that used them have been synchronised
+    for (void* p : ctx->retired) (void)hipFree(p);
+    ctx->retired.clear();
+}
+
+void free_table(TaskTable& t) {
+    (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw);
+    (void)hipFree(t.d_obs_range); (void)hipFree(t.d_obs_const_pre); (void)hipFree(t.d_obs_const_raw);
 }
 
 template <typename T>
 int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
     if (need <= cap) return OCTO_OK;
-    if (p) { HIPCHK(ctx, hipFree(p)); p = nullptr; cap = 0; }
-    const int64_t n = need + need / 8;
+    if (p) { ctx->retired.push_back((void*)p); p = nullptr; cap = 0; }
+    const int64_t n = need + need / 2;
     HIPCHK(ctx, hipMalloc((void**)&p, sizeof(T) * (size_t)n));
     cap = n;
     return OCTO_OK;
@@ -140,15 +215,17 @@ double row_cost(int kind) {
 // straddle tables and tables keep their order, so k_finish can sum each observation's partials contiguously and in a
 // fixed order. key > 0: about `key` tasks in total, shared between the tables in proportion to rows × row cost, each
 // table cut into EQUAL tasks (no ragged last task); key < 0: −key rows per wave everywhere (OCTO_CHUNK experiments).
-int get_tasks(octo_ctx* ctx, octo_dataset* ds, int64_t key, TaskTable** out) {
-    for (auto& t : ds->tables)
-        if (t.key == key) { *out = &t; return OCTO_OK; }
-    if (ds->tables.size() >= 32) {                            // many different batch sizes: start over
-        for (auto& t : ds->tables) { (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw);
-            (void)hipFree(t.d_obs_range); (void)hipFree(t.d_obs_const_pre); (void)hipFree(t.d_obs_const_raw); }
-        ds->tables.clear();
+int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out) {
+    // The cache belongs to the CONTEXT (one owner thread), not to the dataset, which stays immutable and can therefore be
+    // shared between contexts and host threads.
+    for (auto& t : ctx->tables)
+        if (t.ds_serial == ds->serial && t.key == key) { *out = &t; return OCTO_OK; }
+    if (ctx->tables.size() >= 48) {                           // many datasets / batch sizes: drop the oldest half. hipFree waits
+        for (size_t k = 0; k < 24; ++k) free_table(ctx->tables[k]);      // for the device, so no launched kernel still reads them
+        ctx->tables.erase(ctx->tables.begin(), ctx->tables.begin() + 24);
     }
     TaskTable tt;
+    tt.ds_serial = ds->serial;
     tt.key = key;
     std::vector<double> cpre, craw;
     double wsum = 0.0;
@@ -201,8 +278,12 @@ int get_tasks(octo_ctx* ctx, octo_dataset* ds, int64_t key, TaskTable** out) {
         HIPCHK(ctx, hipMemcpy(tt.d_const_pre, cpre.data(), sizeof(double) * tt.n_tasks, hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(tt.d_const_raw, craw.data(), sizeof(double) * tt.n_tasks, hipMemcpyHostToDevice));
     }
-    ds->tables.push_back(std::move(tt));
-    *out = &ds->tables.back();
+    if (tt.n_tasks > 65535) {      // grid.y limit; only reachable through the OCTO_CHUNK / OCTO_ROUNDS experiment knobs
+        free_table(tt);
+        return fail(ctx, OCTO_EINVAL, "row partition has more than 65535 tasks (OCTO_CHUNK / OCTO_ROUNDS too aggressive)");
+    }
+    ctx->tables.push_back(std::move(tt));
+    *out = &ctx->tables.back();
     return OCTO_OK;
 }
 
@@ -233,15 +314,72 @@ int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
     return std::max<int64_t>(1, rounds * capacity / cols);
 }
 
+bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
+    // (a marginalised-RV table keeps BOTH the forward and the gradient launch on the throughput kernels: the gradient needs
+    // their μ̂ pre-pass, and the value returned with a gradient must be bit-identical to the forward value)
+    return W <= ctx->small_w && ds->n_planets <= 2 && ds->n_hgca == 0 && !(ds->kind_mask & KM_MARG);
+}
+
+// Small batches: one fused launch, lane = epoch (octo_kernels.h: k_small). Eligible: W <= SMALL_W, at most two planets, no
+// HGCA table (k_hgca is its own launch) and no marginalised-RV table (its gradient needs the μ̂ pre-pass).
+template <int P, bool GRAD, bool NUIS, int KM>
+int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t st) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    static_assert(L::NACC <= WAVE, "k_small: lane k of the finishing wave owns running sum k");
+    // rows per block: enough blocks to spread one walker's epochs over the chip (about two blocks per CU in total), never
+    // less than one row per lane; the same partition for forward and gradient launches (bit-identical values).
+    // With the inputs in host memory every block starts with a PCIe read of its walker's elements (one or two 64-byte
+    // requests); a few hundred of those in flight is what the link sustains without queueing (measured: 448 blocks x 9
+    // scattered reads made W = 32 twice as slow as W = 1), so the block count is capped there.
+    int64_t total_blocks = ctx->stage_ws_in > 0 ? 160 : 2 * (int64_t)ctx->n_cus;
+    if (const char* ev = std::getenv("OCTO_SMALL_BLOCKS")) { const int v = std::atoi(ev); if (v > 0) total_blocks = v; }   // experiments
+    const int64_t target_tasks = std::max<int64_t>(1, total_blocks / a.W);
+    int64_t span = (ds->n_rows + target_tasks - 1) / target_tasks;
+    span = std::max<int64_t>(SMALL_TPB, (span + SMALL_TPB - 1) / SMALL_TPB * SMALL_TPB);
+    TaskTable* tt = nullptr;
+    int rc = get_tasks(ctx, ds, -(span / WPB), &tt);
+    if (rc) return rc;
+    a.tasks = tt->d_tasks; a.task_const = a.nuis ? tt->d_const_raw : tt->d_const_pre;
+    a.obs_range = tt->d_obs_range; a.obs_const = a.nuis ? tt->d_obs_const_raw : tt->d_obs_const_pre;
+    a.n_tasks = tt->n_tasks;
+    rc = grow(ctx, ctx->d_partials, ctx->cap_part, (int64_t)std::max(a.n_tasks, 1) * L::NACC * a.ldw);
+    if (rc) return rc;
+    a.partials = ctx->d_partials;
+    a.marg = nullptr; a.marg_out = nullptr; a.extra = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
+    if (timed) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            hipEvent_t x, y;
+            HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
+            ctx->ev_pool.emplace_back(x, y);
+        }
+        e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
+        HIPCHK(ctx, hipEventRecord(e0, st));
+    }
+    uint64_t* flags = nullptr;
+    if (ctx->flag_request) {      // a host-buffer call is waiting for these results: let it spin on per-walker flags
+        flags = ctx->h_flags; ctx->flag_seq += 1; ctx->flag_armed = true;
+    }
+    hipLaunchKernelGGL((k_small<P, GRAD, NUIS, KM>), dim3((unsigned)std::max(a.n_tasks, 1), (unsigned)a.W), dim3(SMALL_TPB), 0, st, a, ctx->d_counters,
+                       flags, ctx->flag_seq);
+    if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
+    HIPCHK(ctx, hipGetLastError());
+    return OCTO_OK;
+}
+
 template <int P, bool GRAD, bool NUIS, int KM>
 int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, hipStream_t st) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
-    octo_dataset* ds = const_cast<octo_dataset*>(cds);   // task-table cache only
+    const octo_dataset* ds = cds;
+    if constexpr (P <= 2) {
+        if (small_eligible(ctx, ds, a.W)) return launch_small<P, GRAD, NUIS, KM>(ctx, ds, a, st);
+    }
     // Occupancy of the GRADIENT variant, also for forward-only launches: both then use the same row partition, so the
     // forward value and the value returned with a gradient are the same sum in the same order — bit-identical, like the
-    // primal of a ForwardDiff dual.
-    static int blocks_per_cu = 0;                         // per (P, NUIS, KM)
+    // primal of a ForwardDiff dual. Cached per context (= per device) and variant.
+    int& blocks_per_cu = ctx->occupancy[(uint32_t)((P << 16) | ((NUIS ? 1 : 0) << 15) | KM)];
     if (blocks_per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM>, WAVE * WPB, (main_lds_bytes<P, true, NUIS, KM>())) != hipSuccess || nb < 1)
@@ -341,6 +479,7 @@ int drain_timing(octo_ctx* ctx) {
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[k].first, ctx->ev_pool[k].second));
         ctx->t_ms += ms;
         ctx->t_n += 1;
+        if (ctx->t_samples.size() < (1u << 20)) ctx->t_samples.push_back(ms);
     }
     ctx->ev_used = 0;
     return OCTO_OK;
@@ -380,9 +519,19 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     octo_consts_default(&ctx->consts);
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
+            ctx->n_cus = prop.multiProcessorCount;
+            // gfx950: 160 KB per CU, and one block may take all of it once the kernel's attribute has been raised
+            ctx->max_lds = std::max<int64_t>((int64_t)prop.sharedMemPerBlock, (int64_t)prop.maxSharedMemoryPerMultiProcessor);
+            if (ctx->max_lds <= 0) ctx->max_lds = 65536;
+        }
     }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return OCTO_EHIP;
+    }
+    if (hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return OCTO_EHIP;
     }
@@ -395,11 +544,24 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
         }
         if (hipMalloc((void**)&ctx->d_sctab, sizeof(double) * tab.size()) != hipSuccess ||
             hipMemcpy(ctx->d_sctab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipStreamDestroy(ctx->stream);
+            (void)hipStreamDestroy(ctx->stream); (void)hipEventDestroy(ctx->ev_order);
             delete ctx;
             return OCTO_ENOMEM;
         }
     }
+    if (hipMalloc((void**)&ctx->d_counters, sizeof(int32_t) * SMALL_W) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, sizeof(int32_t) * SMALL_W) != hipSuccess) {
+        (void)hipFree(ctx->d_sctab); (void)hipStreamDestroy(ctx->stream); (void)hipEventDestroy(ctx->ev_order);
+        delete ctx;
+        return OCTO_ENOMEM;
+    }
+    if (hipHostMalloc((void**)&ctx->h_flags, sizeof(uint64_t) * (SMALL_W + 32), hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sctab); (void)hipStreamDestroy(ctx->stream); (void)hipEventDestroy(ctx->ev_order);
+        delete ctx;
+        return OCTO_ENOMEM;
+    }
+    std::memset(ctx->h_flags, 0, sizeof(uint64_t) * (SMALL_W + 32));
+    if (const char* ev = std::getenv("OCTO_SMALL_W")) ctx->small_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     *out = ctx;
     return OCTO_OK;
 }
@@ -407,10 +569,14 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
 int32_t octo_ctx_destroy(octo_ctx* ctx) {
     if (!ctx) return OCTO_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    (void)hipDeviceSynchronize();      // evaluations may have been enqueued on caller-owned streams
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    free_retired(ctx);
+    for (auto& t : ctx->tables) free_table(t);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg); (void)hipFree(ctx->d_sctab); (void)hipFree(ctx->d_extra);
-    (void)hipHostFree(ctx->h_in); (void)hipHostFree(ctx->h_out);
+    (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg); (void)hipFree(ctx->d_sctab); (void)hipFree(ctx->d_extra); (void)hipFree(ctx->d_counters);
+    (void)hipHostFree(ctx->h_in); (void)hipHostFree(ctx->h_out); (void)hipHostFree(ctx->h_flags);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out);
     delete ctx;
     return OCTO_OK;
@@ -422,6 +588,17 @@ int32_t octo_consts_set(octo_ctx* ctx, const octo_consts* c) {
     for (int k = 0; k < 7; ++k)
         if (!(v[k] > 0.0) || !std::isfinite(v[k])) return fail(ctx, OCTO_EINVAL, "octo_consts_set: constants must be finite and positive");
     ctx->consts = *c;
+    return OCTO_OK;
+}
+
+#ifdef OCTO_SMALL_TRACE
+// development build only: cycle stamps of the last k_small launch's walker-0 finishing block (tools/small_trace.py)
+const uint64_t* octo_debug_small_trace(octo_ctx* ctx) { return ctx ? ctx->h_flags + 40 : nullptr; }
+#endif
+
+int32_t octo_ctx_set_small_batch(octo_ctx* ctx, int32_t max_walkers) {
+    if (!ctx || max_walkers < 0) return OCTO_EINVAL;
+    ctx->small_w = std::min<int>(max_walkers, SMALL_W);
     return OCTO_OK;
 }
 
@@ -440,6 +617,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
     octo_dataset* ds = new (std::nothrow) octo_dataset();
     if (!ds) return fail(ctx, OCTO_ENOMEM, "octo_dataset_create: host allocation failed");
     ds->device = ctx->device; ds->n_obs = n_obs; ds->n_planets = n_planets;
+    ds->serial = g_dataset_serial.fetch_add(1);
     for (int p = 0; p < n_planets; ++p) ds->planets[p] = planets[p];
     auto bail = [&](int code, const std::string& msg) { octo_dataset_destroy(ds); return fail(ctx, code, msg); };
     ds->h_obs.resize(n_obs); ds->h_rowconst_pre.resize(n_obs); ds->h_rowconst_raw.resize(n_obs);
@@ -463,6 +641,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
                 const int ax = (int)d.y1[r], ms = (int)d.y2[r];
                 if ((ax != OCTO_HGCA_RA && ax != OCTO_HGCA_DEC) || (ms != OCTO_HGCA_HIP && ms != OCTO_HGCA_GAIA))
                     return bail(OCTO_EINVAL, "octo_dataset_create: OCTO_HGCA rows need y1 in {RA, DEC}, y2 in {HIP, GAIA}");
+                if (!std::isfinite(d.epoch[r])) return bail(OCTO_EINVAL, "octo_dataset_create: OCTO_HGCA epochs must be finite");
                 raw[(size_t)r * ROW_STRIDE] = d.epoch[r]; raw[(size_t)r * ROW_STRIDE + 1] = ax; raw[(size_t)r * ROW_STRIDE + 2] = ms;
             }
             DevObs& h = ds->h_obs[o];
@@ -511,6 +690,11 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
             double* a = &raw[(size_t)r * ROW_STRIDE];
             double* b = &pre[(size_t)r * ROW_STRIDE];
             a[0] = b[0] = d.epoch[r]; a[1] = b[1] = d.y1[r];
+            // a non-finite value or σ <= 0 would be baked into 1/σ² and the log-constants and silently turn every walker into -Inf
+            if (!std::isfinite(d.epoch[r]) || !std::isfinite(d.y1[r]) || !(d.s1[r] > 0.0) || !std::isfinite(d.s1[r]) ||
+                (astrom && (!std::isfinite(d.y2[r]) || !(d.s2[r] > 0.0) || !std::isfinite(d.s2[r]))))
+                return bail(OCTO_EINVAL, "octo_dataset_create: table " + std::to_string(o) + " row " + std::to_string(r) +
+                                         ": epochs and measurements must be finite and uncertainties finite and > 0");
             if (astrom) {
                 const double s1 = d.s1[r], s2 = d.s2[r], c = d.cor ? d.cor[r] : 0.0;
                 if (d.cor && !(std::fabs(c) <= 1.0 - 1e-5))   // relative-astrometry.jl:70-72
@@ -562,8 +746,6 @@ int32_t octo_dataset_destroy(octo_dataset* ds) {
     if (!ds) return OCTO_OK;
     (void)hipSetDevice(ds->device);
     for (double* p : ds->d_bufs) (void)hipFree(p);
-    for (auto& t : ds->tables) { (void)hipFree(t.d_tasks); (void)hipFree(t.d_const_pre); (void)hipFree(t.d_const_raw);
-            (void)hipFree(t.d_obs_range); (void)hipFree(t.d_obs_const_pre); (void)hipFree(t.d_obs_const_raw); }
     (void)hipFree(ds->d_obs);
     delete ds;
     return OCTO_OK;
@@ -574,21 +756,23 @@ int64_t octo_dataset_n_rows(const octo_dataset* ds) { return ds ? ds->n_rows : -
 int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d_elems, const double* d_nuis,
                          int64_t ld, int64_t W, double* d_ll, double* d_g_elems, double* d_g_nuis, void* hip_stream) {
     if (!ctx || !cds || !d_elems || !d_ll) return fail(ctx, OCTO_EINVAL, "octo_eval_device: null argument");
-    if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_eval_device: need 0 <= W <= ld");
+    if (W < 0 || (ld < W && ctx->stage_ws_in == 0)) return fail(ctx, OCTO_EINVAL, "octo_eval_device: need 0 <= W <= ld");
     if (d_g_nuis && (!d_g_elems || !d_nuis)) return fail(ctx, OCTO_EINVAL, "octo_eval_device: g_nuis needs g_elems and nuis");
     if (d_g_elems && d_nuis && !d_g_nuis) return fail(ctx, OCTO_EINVAL, "octo_eval_device: nuis given with g_elems but no g_nuis");
     if (cds->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_eval_device: dataset lives on another device");
     if (W == 0) return OCTO_OK;
-    octo_dataset* ds = const_cast<octo_dataset*>(cds);   // task-table cache only
+    const octo_dataset* ds = cds;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
     if (ctx->timing_every > 0 && ctx->ev_used >= 4096) { int rc = drain_timing(ctx); if (rc) return rc; }
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     if (ldw > ctx->cap_w) {
         int64_t need = ldw;
         // both buffers share the walker capacity
-        if (ctx->d_wc) { HIPCHK(ctx, hipFree(ctx->d_wc)); ctx->d_wc = nullptr; }
-        if (ctx->d_valid) { HIPCHK(ctx, hipFree(ctx->d_valid)); ctx->d_valid = nullptr; }
+        if (ctx->d_wc) { ctx->retired.push_back(ctx->d_wc); ctx->d_wc = nullptr; }
+        if (ctx->d_valid) { ctx->retired.push_back(ctx->d_valid); ctx->d_valid = nullptr; }
+        need += need / 2;
         HIPCHK(ctx, hipMalloc((void**)&ctx->d_wc, sizeof(double) * (size_t)need * NWC * MAXP));
         HIPCHK(ctx, hipMalloc((void**)&ctx->d_valid, sizeof(int32_t) * (size_t)need * MAXP));
         ctx->cap_w = need;
@@ -599,6 +783,8 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     a.n_obs = ds->n_obs; a.n_planets = ds->n_planets;
     for (int p = 0; p < ds->n_planets; ++p) { a.orbit_kind[p] = ds->planets[p].orbit_kind; a.has_mass[p] = ds->planets[p].has_mass; }
     a.elems = d_elems; a.nuis = d_nuis; a.ld = ld; a.W = W;
+    a.ws_in = a.ws_out = 1;
+    if (ctx->stage_ws_in > 0) { a.ws_in = ctx->stage_ws_in; a.ws_out = ctx->stage_ws_out; }      // octo_eval's walker-major staging (k_small only)
     a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w; a.sctab = ctx->d_sctab;
     a.ll_out = d_ll; a.g_elems = d_g_elems; a.g_nuis = d_g_nuis;
     a.c = dev_consts(ctx->consts);
@@ -615,6 +801,7 @@ int32_t octo_sync(octo_ctx* ctx) {
     if (!ctx) return OCTO_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->has_last || ctx->last_stream == ctx->stream) free_retired(ctx);      // a caller-owned stream may still be running
     return OCTO_OK;
 }
 
@@ -628,11 +815,61 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
     const int64_t ldd = (W + 63) / 64 * 64;
     const int64_t n_in = (int64_t)(n_el + (nuis ? n_nu : 0)) * ldd;
     const int64_t n_out = (int64_t)(1 + (g_elems ? n_el : 0) + (g_nuis ? n_nu : 0)) * ldd;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
+    if (W <= ctx->small_w) {
+        // A handful of parameter sets (a sampler's one θ per call): no copy engine at all. The kernels read the inputs from, and
+        // write the results to, mapped pinned host memory.
+        if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
+            return fail(ctx, OCTO_ENOMEM, "octo_eval: pinned staging allocation failed");
+        double *m_in = nullptr, *m_out = nullptr;
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
+        if (small_eligible(ctx, ds, W)) {
+            // k_small: walker-major staging — [elems | nuis] of one walker contiguous (one PCIe read per block), and
+            // [ll | g_elems | g_nuis] likewise on the way back; completion through per-walker flags instead of a stream sync.
+            const int nn = nuis ? n_nu : 0, ne_o = g_elems ? n_el : 0, nn_o = g_nuis ? n_nu : 0;
+            const int64_t ws_in = n_el + nn, ws_out = 1 + ne_o + nn_o;
+            for (int64_t w = 0; w < W; ++w) {
+                double* dst = ctx->h_in + w * ws_in;
+                for (int r = 0; r < n_el; ++r) dst[r] = elems[(size_t)r * ld + w];
+                for (int r = 0; r < nn; ++r) dst[n_el + r] = nuis[(size_t)r * ld + w];
+            }
+            ctx->stage_ws_in = ws_in; ctx->stage_ws_out = ws_out;
+            ctx->flag_request = true; ctx->flag_armed = false;
+            int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + n_el : nullptr, 1, W, m_out, g_elems ? m_out + 1 : nullptr,
+                                       g_nuis ? m_out + 1 + ne_o : nullptr, st);
+            ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
+            if (rcz) return rcz;
+            rcz = wait_small(ctx, st, W);
+            if (rcz) return rcz;
+            for (int64_t w = 0; w < W; ++w) {
+                const double* src = ctx->h_out + w * ws_out;
+                ll_out[w] = src[0];
+                for (int r = 0; r < ne_o; ++r) g_elems[(size_t)r * ld + w] = src[1 + r];
+                for (int r = 0; r < nn_o; ++r) g_nuis[(size_t)r * ld + w] = src[1 + ne_o + r];
+            }
+            free_retired(ctx);
+            return OCTO_OK;
+        }
+        // datasets k_small does not take (HGCA, marginalised RV, > 2 planets): the throughput kernels on the same mapped buffers
+        for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
+        if (nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
+        const int64_t o_ge = ldd, o_gn = (int64_t)(1 + (g_elems ? n_el : 0)) * ldd;
+        int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + (int64_t)n_el * ldd : nullptr, ldd, W, m_out, g_elems ? m_out + o_ge : nullptr,
+                                   g_nuis ? m_out + o_gn : nullptr, st);
+        if (rcz) return rcz;
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        std::memcpy(ll_out, ctx->h_out, sizeof(double) * W);
+        if (g_elems) for (int r = 0; r < n_el; ++r) std::memcpy(g_elems + (size_t)r * ld, ctx->h_out + o_ge + (size_t)r * ldd, sizeof(double) * W);
+        if (g_nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(g_nuis + (size_t)r * ld, ctx->h_out + o_gn + (size_t)r * ldd, sizeof(double) * W);
+        free_retired(ctx);
+        return OCTO_OK;
+    }
     int rc = grow(ctx, ctx->d_in, ctx->cap_in, n_in);
     if (rc) return rc;
     rc = grow(ctx, ctx->d_out, ctx->cap_out, n_out);
     if (rc) return rc;
-    hipStream_t st = ctx->stream;
     double* d_nuis = nuis ? ctx->d_in + (int64_t)n_el * ldd : nullptr;
     double* d_ll = ctx->d_out;
     double* d_ge = g_elems ? ctx->d_out + ldd : nullptr;
@@ -651,6 +888,7 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
         std::memcpy(ll_out, ctx->h_out, sizeof(double) * W);
         if (g_elems) for (int r = 0; r < n_el; ++r) std::memcpy(g_elems + (size_t)r * ld, ctx->h_out + (d_ge - ctx->d_out) + (size_t)r * ldd, sizeof(double) * W);
         if (g_nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(g_nuis + (size_t)r * ld, ctx->h_out + (d_gn - ctx->d_out) + (size_t)r * ldd, sizeof(double) * W);
+        free_retired(ctx);
         return OCTO_OK;
     }
     HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, elems, sizeof(double) * ld, sizeof(double) * W, n_el,
@@ -668,6 +906,7 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
         HIPCHK(ctx, hipMemcpy2DAsync(g_nuis, sizeof(double) * ld, d_gn, sizeof(double) * ldd, sizeof(double) * W, n_nu,
                                      hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    free_retired(ctx);
     return OCTO_OK;
 }
 
@@ -680,7 +919,8 @@ int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int6
     if (rc) return rc;
     rc = grow(ctx, ctx->d_out, ctx->cap_out, 3 * n);
     if (rc) return rc;
-    hipStream_t st = ctx->stream;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, MA, sizeof(double) * n, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_in + n, e, sizeof(double) * n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_kepler, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx->d_in, ctx->d_in + n, n, ctx->d_out,
@@ -690,6 +930,7 @@ int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int6
     if (sinE_out) HIPCHK(ctx, hipMemcpyAsync(sinE_out, ctx->d_out + n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     if (cosE_out) HIPCHK(ctx, hipMemcpyAsync(cosE_out, ctx->d_out + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    free_retired(ctx);
     return OCTO_OK;
 }
 
@@ -707,7 +948,22 @@ int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int
     if (rc) return rc;
     if (avg_ms) *avg_ms = ctx->t_n > 0 ? ctx->t_ms / (double)ctx->t_n : 0.0;
     if (n_launches) *n_launches = ctx->t_n;
-    if (reset) { ctx->t_ms = 0.0; ctx->t_n = 0; }
+    if (reset) { ctx->t_ms = 0.0; ctx->t_n = 0; ctx->t_samples.clear(); }
+    return OCTO_OK;
+}
+
+int32_t octo_timing_stats(octo_ctx* ctx, double* median_ms, double* min_ms, double* max_ms, int64_t* n_launches) {
+    if (!ctx) return OCTO_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = drain_timing(ctx);
+    if (rc) return rc;
+    std::vector<float> v = ctx->t_samples;
+    std::sort(v.begin(), v.end());
+    const size_t n = v.size();
+    if (median_ms) *median_ms = n ? (n % 2 ? v[n / 2] : 0.5 * ((double)v[n / 2 - 1] + v[n / 2])) : 0.0;
+    if (min_ms) *min_ms = n ? v.front() : 0.0;
+    if (max_ms) *max_ms = n ? v.back() : 0.0;
+    if (n_launches) *n_launches = (int64_t)n;
     return OCTO_OK;
 }
 
@@ -728,6 +984,7 @@ struct octo_model {
     int64_t cap_w = 0;
     double *d_th = nullptr, *d_res = nullptr;   // staging for host buffers
     int64_t cap_th = 0, cap_res = 0;
+    int64_t lds_bytes = 0;     // dynamic LDS of k_model_fwd: (4·D + 6·n_circ) × 64 doubles
 };
 
 extern "C" {
@@ -786,6 +1043,15 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
         if (hipMalloc((void**)&m->d_circ, sizeof(int32_t) * slot.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
         if (hipMemcpy(m->d_circ, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
     }
+    // k_model_fwd shares x, dx, p, dp of every prior and 6 numbers per UniformCircular pair through LDS: 512 B each.
+    m->lds_bytes = (int64_t)sizeof(double) * (4 * D + 6 * m->n_circ) * WAVE;
+    if (m->lds_bytes > ctx->max_lds)
+        return bail(OCTO_EINVAL, "octo_model_create: the model needs more LDS per block than this device has ((4·D + 6·n_circular)·512 B)");
+    if (m->lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)k_model_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->lds_bytes > 64 * 1024) return bail(OCTO_EINVAL, "octo_model_create: cannot raise k_model_fwd's dynamic LDS limit for this model");
+    }
     *out = m;
     return OCTO_OK;
 }
@@ -806,14 +1072,16 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     if (m->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_model_logpost_device: model lives on another device");
     if (W == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     const int n_in = m->n_el + m->n_nu;
     const int64_t rows = (int64_t)n_in + (int64_t)n_in * m->D + 1 + m->D + 1 + n_in;
     if (ldw > m->cap_w) {
-        if (m->d_buf) { HIPCHK(ctx, hipFree(m->d_buf)); m->d_buf = nullptr; m->cap_w = 0; }
-        HIPCHK(ctx, hipMalloc((void**)&m->d_buf, sizeof(double) * (size_t)(rows * ldw)));
-        m->cap_w = ldw;
+        if (m->d_buf) { ctx->retired.push_back(m->d_buf); m->d_buf = nullptr; m->cap_w = 0; }
+        const int64_t cap = ldw + ldw / 2;
+        HIPCHK(ctx, hipMalloc((void**)&m->d_buf, sizeof(double) * (size_t)(rows * cap)));
+        m->cap_w = cap;
     }
     const int64_t L = m->cap_w;
     ModelArgs a;
@@ -838,7 +1106,7 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
         const int DBs = std::min(n_thr, 8), DB = std::max(DBs, std::min(m->D, 8));      // the priors are shared out over all DB waves
         a.src_waves = DBs; a.circ_slot = m->d_circ; a.n_circ = m->n_circ;
         hipLaunchKernelGGL(k_model_fwd, dim3((unsigned)((W + 63) / 64), (unsigned)((n_thr + DBs - 1) / DBs)), dim3(64, DB),
-                           sizeof(double) * (4 * m->D + 6 * m->n_circ) * WAVE, st, a);
+                           (size_t)m->lds_bytes, st, a);
     }
     HIPCHK(ctx, hipGetLastError());
     const bool grad = d_grad != nullptr;
@@ -856,12 +1124,28 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     if (W == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t ldd = (W + 63) / 64 * 64;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
+    const int64_t n_in = (int64_t)m->D * ldd, n_out = (int64_t)(grad_out ? m->D + 1 : 1) * ldd;
+    if (W <= ctx->small_w) {      // one θ_t per call (NUTS): mapped pinned buffers, no copy engine (see octo_eval)
+        if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
+            return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");
+        double *m_in = nullptr, *m_out = nullptr;
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
+        for (int r = 0; r < m->D; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, theta_t + (size_t)r * ld, sizeof(double) * W);
+        int rcz = octo_model_logpost_device(ctx, m, m_in, ldd, W, m_out, grad_out ? m_out + ldd : nullptr, st);
+        if (rcz) return rcz;
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        std::memcpy(lp_out, ctx->h_out, sizeof(double) * W);
+        if (grad_out) for (int r = 0; r < m->D; ++r) std::memcpy(grad_out + (size_t)r * ld, ctx->h_out + (size_t)(1 + r) * ldd, sizeof(double) * W);
+        free_retired(ctx);
+        return OCTO_OK;
+    }
     int rc = grow(ctx, m->d_th, m->cap_th, (int64_t)m->D * ldd);
     if (rc) return rc;
     rc = grow(ctx, m->d_res, m->cap_res, (int64_t)(m->D + 1) * ldd);
     if (rc) return rc;
-    hipStream_t st = ctx->stream;
-    const int64_t n_in = (int64_t)m->D * ldd, n_out = (int64_t)(grad_out ? m->D + 1 : 1) * ldd;
     if ((n_in + n_out) * (int64_t)sizeof(double) <= (1 << 18)) {      // small batch: one pinned transfer each way (see octo_eval)
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");
@@ -882,6 +1166,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     if (grad_out)
         HIPCHK(ctx, hipMemcpy2DAsync(grad_out, sizeof(double) * ld, m->d_res + ldd, sizeof(double) * ldd, sizeof(double) * W, m->D, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    free_retired(ctx);
     return OCTO_OK;
 }
 
@@ -903,6 +1188,12 @@ int32_t octo_ofti_create(octo_ctx* ctx, const double* epochs, const double* ra, 
     for (int64_t j = 0; j < n; ++j) {
         // inverse covariance of one epoch, parameterizations.jl:359-366
         const double sr = s_ra[j], sd = s_dec[j], rho = cor ? cor[j] : 0.0;
+        if (!std::isfinite(epochs[j]) || !std::isfinite(ra[j]) || !std::isfinite(dec[j]) || !(sr > 0.0) || !std::isfinite(sr) ||
+            !(sd > 0.0) || !std::isfinite(sd) || !(std::fabs(rho) < 1.0)) {
+            delete h;
+            return fail(ctx, OCTO_EINVAL, "octo_ofti_create: row " + std::to_string(j) + ": epochs and positions must be finite, "
+                                          "uncertainties finite and > 0, |cor| < 1");
+        }
         const double det = sr * sr * sd * sd * (1.0 - rho * rho);
         const double wrr = sd * sd / det, wdd = sr * sr / det, wrd = -rho * sr * sd / det;
         double* r = &rows[(size_t)j * ROW_STRIDE];
@@ -939,13 +1230,14 @@ int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d
     if (h->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_ofti_eval_device: handle lives on another device");
     if (W == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
     OftiArgs a;
     std::memset(&a, 0, sizeof(a));
     const int64_t cols = (W + WAVE - 1) / WAVE;
     int chunk = 32;
     {   // same sizing rule as the likelihood kernel: an exact number of rounds of resident blocks, equal tasks
-        static int blocks_per_cu = 0;
+        int& blocks_per_cu = ctx->occupancy[0xffff0001u];
         if (blocks_per_cu == 0) {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ofti_main, WAVE * WPB, sizeof(double) * (2 * SCT_N + OFTI_NACC * WAVE)) != hipSuccess || nb < 1) nb = 2;
@@ -984,7 +1276,8 @@ int32_t octo_ofti_eval(octo_ctx* ctx, const octo_ofti* h, const double* nl, int6
     if (rc) return rc;
     rc = grow(ctx, ctx->d_out, ctx->cap_out, 5 * ldd);
     if (rc) return rc;
-    hipStream_t st = ctx->stream;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
     HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, nl, sizeof(double) * ld, sizeof(double) * W, 5, hipMemcpyHostToDevice, st));
     rc = octo_ofti_eval_device(ctx, h, ctx->d_in, ldd, W, abfg_out ? ctx->d_out + ldd : nullptr, ctx->d_out, st);
     if (rc) return rc;
@@ -992,6 +1285,7 @@ int32_t octo_ofti_eval(octo_ctx* ctx, const octo_ofti* h, const double* nl, int6
     if (abfg_out)
         HIPCHK(ctx, hipMemcpy2DAsync(abfg_out, sizeof(double) * ld, ctx->d_out + ldd, sizeof(double) * ldd, sizeof(double) * W, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    free_retired(ctx);
     return OCTO_OK;
 }
 
@@ -1037,7 +1331,8 @@ extern "C" int32_t octo_pt_swap_device(octo_ctx* ctx, const double* d_ll_by_repl
     if (!ctx || !d_ll_by_replica || !d_beta || !d_slot2rep) return fail(ctx, OCTO_EINVAL, "octo_pt_swap_device: null argument");
     if (n_temps < 2 || n_chains < 1 || (parity != 0 && parity != 1)) return fail(ctx, OCTO_EINVAL, "octo_pt_swap_device: bad sizes");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
     const int n_pairs = (n_temps - parity) / 2;
     if (n_pairs == 0) return OCTO_OK;
     const int64_t n = n_chains * n_pairs;

@@ -55,6 +55,9 @@ struct EvalArgs {
     const double* elems;          // [P*9][ld]
     const double* nuis;           // [n_obs*3][ld] or null
     int64_t ld, W;
+    int64_t ws_in, ws_out;        // k_small only: walker stride of the inputs (elems, nuis) and of the outputs (ll, g_elems, g_nuis).
+                                  // 1 = the C ABI's SoA layout (walker fastest); the host-buffer path stages walker-major
+                                  // (ld = 1, ws = values per walker) so that one block's inputs are one contiguous PCIe read
     double* wc;                   // [P*NWC][ldw]
     int32_t* valid;               // [n_planets][ldw]
     double* partials;             // [n_tasks*NACC][ldw]
@@ -93,62 +96,111 @@ struct Layout {
     static constexpr int NACC = OFF_PL + P * PL_N;
 };
 
+template <int P, bool GRAD, bool NUIS, int KM>
+using AccArr = double[Layout<P, GRAD, NUIS, KM>::NACC];
+
 // ------------------------------------------------------------------------------------ k_setup
+// Orbit-constructor constants of one (walker, planet): everything the row loop and the finish need that depends on the walker
+// only. Shared by k_setup (stores them in `wc` for the big-batch kernels) and k_small (keeps them in registers).
+struct SetupOut {
+    double v[NWC];
+    double el[OCTO_N_EL];      // the element rows as read (the finish needs e, M, plx, mass and a ThieleInnesOrbit's A, B, F, G)
+    bool ok;
+};
+
+// sin/cos for the latency path: reduce to [−π, π] with a two-term 2π (exact for the |x| a sampler produces; beyond 1e5 the
+// library routine), then the half-angle polynomials — ~35 instructions instead of ocml's ~180 per angle.
+__device__ __forceinline__ void sincos_reduced(double x, double& s, double& c) {
+    if (fabs(x) < 1.0e5) {
+        const double k = rint(x * (1.0 / TWO_PI));
+        double r = fma(-k, 0x1.921fb54442d18p+2, x);      // 2π hi
+        r = fma(-k, 0x1.1a62633145c07p-52, r);            // 2π lo
+        sincos_halfangle(r, s, c);
+    } else {
+        sincos(x, &s, &c);
+    }
+}
+
+// √x from v_rsq_f64 + Newton (rsqrt_nr), with one correction step on the product: ≤ 1 ulp, 14 instructions (ocml: ~25).
+__device__ __forceinline__ double sqrt_fast(double x) {
+    const double y = rsqrt_nr(x);
+    const double s0 = x * y;
+    const double s1 = fma(fma(-s0, s0, x), 0.5 * y, s0);
+    return (x > 0.0 && x < 1.0e300) ? s1 : sqrt(x);       // 0, Inf, NaN, negatives: the library's edge handling
+}
+
+// FAST (k_small): reciprocal-multiply instead of IEEE division, rsqrt-based roots, polynomial sincos. At the clock a
+// mostly-idle GPU runs one short kernel at, every 100 serial FP64 instructions are about a microsecond of latency.
+template <bool FAST = false>
+__device__ __forceinline__ SetupOut setup_planet(const EvalArgs& a, int p, int64_t woff) {
+    SetupOut so;
+    auto fdiv = [](double x, double y) { return FAST ? x * rcp_nr<2>(y) : x / y; };
+    auto fsqrt = [](double x) { return FAST ? sqrt_fast(x) : sqrt(x); };
+    const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + woff;
+#pragma unroll
+    for (int k = 0; k < OCTO_N_EL; ++k) so.el[k] = el[(int64_t)k * a.ld];
+    const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
+    const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
+    const bool kep = a.orbit_kind[p] == OCTO_ORBIT_KEP;      // plain KepOrbit: no parallax, positions stay in AU (no astrometry tables)
+    const double e = el[OCTO_EL_E * a.ld], om = el[OCTO_EL_W * a.ld];
+    const double tp = el[OCTO_EL_TP * a.ld], Mt = el[OCTO_EL_M * a.ld];
+    double sma = el[OCTO_EL_A * a.ld];
+    double inc = radvel ? 0.0 : el[OCTO_EL_I * a.ld];
+    double Om = radvel ? 0.0 : el[OCTO_EL_O * a.ld];
+    const double plx = (radvel || kep) ? 1.0 : el[OCTO_EL_PLX * a.ld];
+    const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
+    bool ok = isfinite(sma) && isfinite(e) && isfinite(inc) && isfinite(om) && isfinite(Om) && isfinite(tp) &&
+              isfinite(Mt) && isfinite(plx) && isfinite(mass);
+    double T, A, B, F, G, si, ci, sw, cw, sO, cO;
+    if (ti) {
+        // ThieleInnesOrbit: rows a, i, ω, Ω carry A, B, F, G [mas]; a = α/plx   (src/parameterizations.jl:14-19)
+        A = sma; B = inc; F = om; G = Om;
+        const double u = 0.5 * (A * A + B * B + F * F + G * G), v = A * G - B * F;
+        sma = fdiv(fsqrt(u + fsqrt((u + v) * (u - v))), plx);
+        T = 1.0;
+        si = ci = sw = cw = sO = cO = 0.0;
+    } else {
+        // PlanetOrbits KepOrbit ctor invariants: i = rem(i, π, RoundDown), Ω = rem2pi(Ω, RoundDown)
+        inc = inc - PI * floor(inc / PI);
+        Om = Om - TWO_PI * floor(Om / TWO_PI);
+        if constexpr (FAST) { sincos_reduced(inc, si, ci); sincos_reduced(om, sw, cw); sincos_reduced(Om, sO, cO); }
+        else { sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO); }
+        if (radvel) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
+        // Thiele-Innes constants (parameterizations.jl:34-37) scaled to mas: T = a · cart2angle
+        T = (radvel || kep) ? 0.0 : sma * plx * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
+        A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
+        F = -cO * sw - sO * cw * ci; G = -sO * sw + cO * cw * ci;
+    }
+    ok = ok && (e >= 0.0) && (e < 1.0) && (sma > 0.0) && (Mt > 0.0) && (plx > 0.0);
+    const double P_d = a.c.k_yr * fsqrt(fdiv(sma * sma * sma, Mt));       // parameterizations.jl:62
+    const double ome2 = 1.0 - e * e;
+    const double beta = fsqrt(ome2);
+    // K = ((2π a)/P_yr)/√(1−e²) · au2m · sec2year · sin i
+    const double K = fdiv(fdiv(TWO_PI * sma, fdiv(P_d, a.c.yd)), beta) * a.c.au2m * a.c.sec2yr * si;   // 0 for a ThieleInnesOrbit (no RV tables there)
+    double* o = so.v;
+    o[WC_INVP] = fdiv(1.0, P_d); o[WC_TP] = tp; o[WC_E] = e; o[WC_BETA] = beta;
+    o[WC_EOB] = fdiv(e, beta);
+    o[WC_F32A] = pack_f32x2((float)e, (float)(1.0 - e));
+    o[WC_F32B] = pack_f32x2((float)fdiv(MK_K1N, 1.0 + e), 0.0f);
+    o[WC_CB] = T * B; o[WC_CG] = T * G; o[WC_CA] = T * A; o[WC_CF] = T * F;
+    o[WC_CGB] = T * G * beta; o[WC_CFB] = T * F * beta;
+    o[WC_CBE] = T * B * e; o[WC_CAE] = T * A * e;
+    o[WC_K] = K; o[WC_COSW] = cw; o[WC_SINW] = sw;
+    o[WC_MU] = fdiv(mass * a.c.mjup2msol, Mt); o[WC_A] = sma;
+    o[WC_SINI] = si; o[WC_COSI] = ci; o[WC_SINO] = sO; o[WC_COSO] = cO;
+    so.ok = ok;
+    return so;
+}
+
 __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.W) return;
-    bool ok = true;
-    {
-        const int p = blockIdx.y;                          // one thread per (walker, planet)
-        const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + w;
-        const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
-        const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
-        const double e = el[OCTO_EL_E * a.ld], om = el[OCTO_EL_W * a.ld];
-        const double tp = el[OCTO_EL_TP * a.ld], Mt = el[OCTO_EL_M * a.ld];
-        double sma = el[OCTO_EL_A * a.ld];
-        double inc = radvel ? 0.0 : el[OCTO_EL_I * a.ld];
-        double Om = radvel ? 0.0 : el[OCTO_EL_O * a.ld];
-        const double plx = radvel ? 1.0 : el[OCTO_EL_PLX * a.ld];
-        const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
-        ok = ok && isfinite(sma) && isfinite(e) && isfinite(inc) && isfinite(om) && isfinite(Om) && isfinite(tp) &&
-             isfinite(Mt) && isfinite(plx) && isfinite(mass);
-        double T, A, B, F, G, si, ci, sw, cw, sO, cO;
-        if (ti) {
-            // ThieleInnesOrbit: rows a, i, ω, Ω carry A, B, F, G [mas]; a = α/plx   (src/parameterizations.jl:14-19)
-            A = sma; B = inc; F = om; G = Om;
-            const double u = 0.5 * (A * A + B * B + F * F + G * G), v = A * G - B * F;
-            sma = sqrt(u + sqrt((u + v) * (u - v))) / plx;
-            T = 1.0;
-            si = ci = sw = cw = sO = cO = 0.0;
-        } else {
-            // PlanetOrbits KepOrbit ctor invariants: i = rem(i, π, RoundDown), Ω = rem2pi(Ω, RoundDown)
-            inc = inc - PI * floor(inc / PI);
-            Om = Om - TWO_PI * floor(Om / TWO_PI);
-            sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO);
-            if (radvel) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
-            // Thiele-Innes constants (parameterizations.jl:34-37) scaled to mas: T = a · cart2angle
-            T = radvel ? 0.0 : sma * plx * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
-            A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
-            F = -cO * sw - sO * cw * ci; G = -sO * sw + cO * cw * ci;
-        }
-        ok = ok && (e >= 0.0) && (e < 1.0) && (sma > 0.0) && (Mt > 0.0) && (plx > 0.0);
-        const double P_d = a.c.k_yr * sqrt(sma * sma * sma / Mt);       // parameterizations.jl:62
-        const double ome2 = 1.0 - e * e;
-        const double beta = sqrt(ome2);
-        // K = ((2π a)/P_yr)/√(1−e²) · au2m · sec2year · sin i
-        const double K = (TWO_PI * sma / (P_d / a.c.yd)) / beta * a.c.au2m * a.c.sec2yr * si;   // 0 for a ThieleInnesOrbit (no RV tables there)
-        double* o = a.wc + (int64_t)p * NWC * a.ldw + w;
-        o[WC_INVP * a.ldw] = 1.0 / P_d; o[WC_TP * a.ldw] = tp; o[WC_E * a.ldw] = e; o[WC_BETA * a.ldw] = beta;
-        o[WC_EOB * a.ldw] = e / beta;
-        o[WC_F32A * a.ldw] = pack_f32x2((float)e, (float)(1.0 - e));
-        o[WC_F32B * a.ldw] = pack_f32x2((float)(MK_K1N / (1.0 + e)), 0.0f);
-        o[WC_CB * a.ldw] = T * B; o[WC_CG * a.ldw] = T * G; o[WC_CA * a.ldw] = T * A; o[WC_CF * a.ldw] = T * F;
-        o[WC_CGB * a.ldw] = T * G * beta; o[WC_CFB * a.ldw] = T * F * beta;
-        o[WC_CBE * a.ldw] = T * B * e; o[WC_CAE * a.ldw] = T * A * e;
-        o[WC_K * a.ldw] = K; o[WC_COSW * a.ldw] = cw; o[WC_SINW * a.ldw] = sw;
-        o[WC_MU * a.ldw] = mass * a.c.mjup2msol / Mt; o[WC_A * a.ldw] = sma;
-        o[WC_SINI * a.ldw] = si; o[WC_COSI * a.ldw] = ci; o[WC_SINO * a.ldw] = sO; o[WC_COSO * a.ldw] = cO;
-    }
+    const int p = blockIdx.y;                          // one thread per (walker, planet)
+    const SetupOut so = setup_planet<false>(a, p, w);
+    bool ok = so.ok;
+    double* o = a.wc + (int64_t)p * NWC * a.ldw + w;
+#pragma unroll
+    for (int k = 0; k < NWC; ++k) o[(int64_t)k * a.ldw] = so.v[k];
     if (a.nuis && blockIdx.y == 0) {
         for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok = ok && isfinite(a.nuis[(int64_t)k * a.ld + w]);
     }
@@ -171,6 +223,310 @@ __global__ __launch_bounds__(256) void k_kepler(const double* __restrict__ MA, c
     E[i] = ok ? s.E : NAN;
     if (sE) sE[i] = ok ? s.sE : NAN;
     if (cE) cE[i] = ok ? s.cE : NAN;
+}
+
+// ------------------------------------------------------------------------------------ row bodies
+// One observation row for one walker: Kepler solve of every planet, projection, residual, density, and (GRAD) the reverse
+// sweep into the running sums. Written once and inlined into both mappings of the epoch loop:
+//   k_main   lane = walker: `pc`, the coefficients and nuisances are per-lane registers, the row record is wave-uniform (SGPRs);
+//   k_small  lane = epoch:  the row record is per-lane, everything that depends on the walker is wave-uniform.
+// TAB: sin/cos of the starter from the block's LDS table (k_main) or from the half-angle polynomials (k_small: no table fill).
+template <int P>
+struct AstromCoef {
+    double f[P];                    // coefficient of each planet's sky offset in the model (relative-astrometry.jl:117-138)
+    double jit, j2, ps, na, sn, cn; // θ_obs: jitter, jitter², platescale, northangle and its sin/cos (:170-172)
+    bool seppa, oneil;
+    int planet, has_cor;
+};
+
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ nuis, int64_t ld, int ob_kind, int ob_planet, int ob_has_cor,
+                                                     int obs_index, const PC (&pc)[P], int64_t wl) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    AstromCoef<P> c;
+    // 1 for the planet the table is attached to, +m/M for strictly-inner companions with a mass.
+    if constexpr (P == 1) {
+        c.f[0] = 1.0;
+    } else {
+        double a_this = 0.0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) a_this = (p == ob_planet) ? pc[p].a : a_this;
+#pragma unroll
+        for (int p = 0; p < P; ++p) c.f[p] = (p == ob_planet) ? 1.0 : ((pc[p].a < a_this) ? pc[p].mu : 0.0);
+    }
+    c.jit = 0.0; c.j2 = 0.0; c.ps = 1.0; c.na = 0.0; c.sn = 0.0; c.cn = 1.0;
+    if constexpr (NUIS) {
+        const double* nu = nuis + (int64_t)obs_index * OCTO_N_NUIS * ld + wl;
+        c.jit = nu[OCTO_NU_JITTER * ld]; c.ps = nu[OCTO_NU_PLATESCALE * ld];
+        c.na = nu[OCTO_NU_NORTHANGLE * ld];
+        sincos(c.na, &c.sn, &c.cn);
+        c.j2 = c.jit * c.jit;
+    }
+    c.seppa = (KM & KM_SEPPA) && (ob_kind == OCTO_ASTROM_SEPPA || ob_kind == OCTO_ONEIL_SEPPA);
+    c.oneil = L::HAS_ONEIL && (ob_kind == OCTO_ONEIL_RADEC || ob_kind == OCTO_ONEIL_SEPPA);
+    c.planet = ob_planet; c.has_cor = ob_has_cor;
+    return c;
+}
+
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB>
+__device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
+                                           const AstromCoef<P>& co, double t, double y1, double y2, double c3, double c4, double c5,
+                                           const SinCosTab& tab) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    const double (&f)[P] = co.f;
+    const double jit = co.jit, j2 = co.j2, ps = co.ps, na = co.na, sn = co.sn, cn = co.cn;
+    const bool seppa = co.seppa, oneil = co.oneil;
+    KSol s[P];
+    double rap[P], dep[P];      // each planet's own sky offset [mas]
+    double ra_m, dec_m;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        s[p] = kepler_solve<1, TAB>(t, pc[p], tab);
+        rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
+        dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
+    }
+    if constexpr (L::HAS_ONEIL) {
+        if (oneil) {
+            // M = meananom(sol) = E − e sin E; t = 3M(e + cos E) + 2(−2 + e² + e cos E) sin E   prior-observable.jl:129-133
+            double sE = 0.0, cE = 0.0, ee = 0.0, invD = 0.0, dtp = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const bool me = (P == 1) || (p == co.planet);
+                sE = me ? s[p].sE : sE; cE = me ? s[p].cE : cE; ee = me ? pc[p].e : ee; invD = me ? s[p].invD : invD; dtp = me ? s[p].dt : dtp;
+            }
+            double E = 0.0;                                  // E ∈ [−π, π], as the solver returns it (eccanom(sol))
+#pragma unroll
+            for (int p = 0; p < P; ++p) E = ((P == 1) || (p == co.planet)) ? s[p].E : E;
+            const double Mm = fma(-ee, sE, E);
+            const double c2 = fma(ee, ee + cE, -2.0);       // −2 + e² + e cos E
+            const double tt = fma(3.0 * Mm, ee + cE, 2.0 * c2 * sE);
+            acc[L::OFF_ONEIL] += fabs(tt);
+            if constexpr (GRAD) {
+                const double sg = tt < 0.0 ? -1.0 : 1.0;
+                const double D = fma(-ee, cE, 1.0);
+                const double tM = 3.0 * (ee + cE);                                        // ∂t/∂M
+                const double tE = fma(-3.0 * Mm, sE, 2.0 * fma(c2, cE, -(ee * sE * sE))) + tM * D;      // total ∂t/∂E (M = E − e sinE)
+                const double te = fma(2.0 * sE, 2.0 * ee + cE, 3.0 * Mm) - tM * sE;       // total ∂t/∂e at fixed E
+                const double Mb = sg * tE * invD;                                          // through E(M̄A, e)
+                acc[L::OFF_ONEIL + 1] += sg * te + Mb * sE;
+                acc[L::OFF_ONEIL + 2] += Mb;
+                acc[L::OFF_ONEIL + 3] = fma(Mb, dtp, acc[L::OFF_ONEIL + 3]);
+            }
+        }
+    }
+    if constexpr (P == 1) {
+        ra_m = rap[0]; dec_m = dep[0];
+    } else {
+        ra_m = 0.0; dec_m = 0.0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { ra_m = fma(f[p], rap[p], ra_m); dec_m = fma(f[p], dep[p], dec_m); }
+    }
+    // residuals
+    double r1, r2, irho = 1.0, u1 = 0.0, u2 = 0.0;
+    if (seppa) {
+        // relative-astrometry.jl:192-202
+        const double rho2 = fma(ra_m, ra_m, dec_m * dec_m);
+        irho = rsqrt_nr(rho2);                         // ρ = ρ²·(1/ρ) enters r2 through one explicit FMA below: a separate
+                                                       // product would be contracted differently by the forward-only and
+                                                       // the gradient instantiation, and their values must agree bitwise
+        const double pa = atan2_fast(ra_m, dec_m);
+        double dpa = (y1 + na) - pa + PI;
+        dpa = rem_2pi_trunc(dpa) - PI;                 // Julia `%`: truncated remainder
+        dpa = dpa < -PI ? dpa + TWO_PI : dpa;
+        r1 = dpa;
+        r2 = fma(-rho2, irho, y2 * ps);
+    } else {
+        // relative-astrometry.jl:210-215: the data are rotated by −northangle and scaled
+        if constexpr (NUIS) {
+            u1 = fma(y1, cn, y2 * sn);
+            u2 = fma(y2, cn, -(y1 * sn));
+            r1 = fma(ps, u1, -ra_m);
+            r2 = fma(ps, u2, -dec_m);
+        } else {
+            r1 = y1 - ra_m;
+            r2 = y2 - dec_m;
+        }
+    }
+    // density; g1, g2 = ∂ll/∂r1, ∂ll/∂r2
+    double g1, g2;
+    if constexpr (!NUIS) {
+        // precomputed Σ⁻¹ (the jitter == 0 branch, relative-astrometry.jl:218-219)
+        double a1, a2;
+        if constexpr (L::HAS_COR) { a1 = fma(c3, r1, c5 * r2); a2 = fma(c5, r1, c4 * r2); }
+        else { a1 = c3 * r1; a2 = c4 * r2; }
+        acc[L::OFF_S] = fma(r1, a1, fma(r2, a2, acc[L::OFF_S]));   // Σ rᵀΣ⁻¹r ; ll = const − ½Σ
+        g1 = -a1; g2 = -a2;
+    } else {
+        const double v1 = fma(c3, c3, j2), v2 = fma(c4, c4, j2);   // hypot(σ, jitter)², :234-235
+        const double v12 = v1 * v2;
+        const double iv12 = rcp_nr<2>(v12);                       // one reciprocal for 1/v1 and 1/v2
+        const double iv1 = iv12 * v2, iv2 = iv12 * v1;
+        double a1, a2;                                             // Σ⁻¹ r
+        if (L::HAS_COR && co.has_cor) {
+            const double cor = c5;
+            const double omc = 1.0 - cor * cor;
+            const double ic = rcp_nr<2>(omc);
+            const double is = rsqrt(v12);                          // 1/(σ1 σ2)
+            a1 = fma(r1, iv1, -(cor * r2 * is)) * ic;
+            a2 = fma(r2, iv2, -(cor * r1 * is)) * ic;
+            lp.mul(v12 * omc);
+        } else {
+            a1 = r1 * iv1; a2 = r2 * iv2;
+            lp.mul(v12);
+        }
+        // ll = −n·log2π − ½Σ(log|Σ| + rᵀΣ⁻¹r); the logs via lp. Explicit FMAs: the forward-only and the gradient
+        // instantiation must round this sum identically (the compiler would contract it differently around q1, q2)
+        acc[L::OFF_S] = fma(r1, a1, fma(r2, a2, acc[L::OFF_S]));
+        g1 = -a1; g2 = -a2;
+        if constexpr (GRAD) {
+            acc[L::OFF_NU + OCTO_NU_JITTER] += jit * fma(fma(r1, a1, -1.0), iv1, fma(r2, a2, -1.0) * iv2);
+            if (seppa) {
+                acc[L::OFF_NU + OCTO_NU_PLATESCALE] = fma(g2, y2, acc[L::OFF_NU + OCTO_NU_PLATESCALE]);
+                acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += g1;
+            } else {
+                acc[L::OFF_NU + OCTO_NU_PLATESCALE] += g1 * u1 + g2 * u2;
+                acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += ps * (g1 * u2 - g2 * u1);
+            }
+        }
+    }
+    if constexpr (GRAD) {
+        // adjoint of the model position
+        double rab, deb;
+        if (seppa) {
+            const double pab = -g1, rhob = -g2;
+            rab = (rhob * ra_m + pab * dec_m * irho) * irho;
+            deb = (rhob * dec_m - pab * ra_m * irho) * irho;
+        } else {
+            rab = -g1; deb = -g2;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double* g = &acc[L::OFF_PL + p * L::PL_N];
+            const double ra_f = (P == 1) ? rab : f[p] * rab, de_f = (P == 1) ? deb : f[p] * deb;
+            g[L::U1] = fma(s[p].cE, ra_f, g[L::U1]);
+            g[L::U2] = fma(s[p].sE, ra_f, g[L::U2]);
+            g[L::U3] = fma(s[p].cE, de_f, g[L::U3]);
+            g[L::U4] = fma(s[p].sE, de_f, g[L::U4]);
+            g[L::U5] += ra_f;
+            g[L::U6] += de_f;
+            if constexpr (P > 1)
+                g[L::GC] += (p == co.planet) ? 0.0 : ((f[p] != 0.0) ? fma(rab, rap[p], deb * dep[p]) : 0.0);
+            // Ē = r̄a·∂ra/∂E + d̄ec·∂dec/∂E ;  M̄ = Ē/(1 − e cos E)
+            const double dra = fma(pc[p].cGb, s[p].cE, -(pc[p].cB * s[p].sE));
+            const double dde = fma(pc[p].cFb, s[p].cE, -(pc[p].cA * s[p].sE));
+            const double Mb = fma(ra_f, dra, de_f * dde) * s[p].invD;
+            g[L::GE] = fma(Mb, s[p].sE, g[L::GE]);          // ∂E/∂e = sin E/(1 − e cos E); the rest of ē in k_finish
+            g[L::GM] += Mb;
+            g[L::GT] = fma(Mb, s[p].dt, g[L::GT]);
+        }
+    }
+}
+
+template <int P>
+struct RvCoef {
+    double gc[P];                   // coefficient of K_p·V_p in the RV model
+    double off, jit, j2, mu_hat, iA;
+    bool rel, marg;
+    int planet;
+};
+
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, int64_t ld, const double* __restrict__ margp, int64_t ldw,
+                                             int ob_kind, int ob_planet, int obs_index, const PC (&pc)[P], int64_t wl) {
+    RvCoef<P> c;
+    // RV_REL: +1 for this planet (rv-relative.jl:143), −m/M for strictly-inner massive companions (:148-156);
+    // absolute RV: −m/M for every planet (rv-absolute.jl:146-155).
+    c.rel = ob_kind == OCTO_RV_REL;
+    {
+        double a_this = 0.0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) a_this = (p == ob_planet) ? pc[p].a : a_this;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            c.gc[p] = c.rel ? ((p == ob_planet) ? 1.0 : ((pc[p].a < a_this) ? -pc[p].mu : 0.0)) : -pc[p].mu;
+    }
+    c.marg = (KM & KM_MARG) && ob_kind == OCTO_RV_ABS_MARG;
+    c.off = 0.0; c.jit = 0.0; c.j2 = 0.0;
+    if constexpr (NUIS) {
+        const double* nu = nuis + (int64_t)obs_index * OCTO_N_NUIS * ld + wl;
+        c.off = c.marg ? 0.0 : nu[OCTO_NU_RV_OFFSET * ld];
+        c.jit = nu[OCTO_NU_RV_JITTER * ld];
+        c.j2 = c.jit * c.jit;
+    }
+    c.mu_hat = 0.0; c.iA = 0.0;
+    if (GRAD && c.marg && margp) {
+        c.mu_hat = margp[((int64_t)obs_index * 2 + 0) * ldw + wl];
+        c.iA = 1.0 / margp[((int64_t)obs_index * 2 + 1) * ldw + wl];
+    }
+    c.planet = ob_planet;
+    return c;
+}
+
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB>
+__device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
+                                       const RvCoef<P>& co, double t, double rv, double c2, const SinCosTab& tab) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    const double (&gc)[P] = co.gc;
+    const bool rel = co.rel, marg = co.marg;
+    const double jit = co.jit, j2 = co.j2, mu_hat = co.mu_hat, iA = co.iA;
+    KSol s[P];
+    double V[P], cnu[P], snu[P];
+    double model = co.off;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
+        cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
+        snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
+        V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
+        model = fma(gc[p] * pc[p].K, V[p], model);
+    }
+    const double resid = rv - model;
+    double iv, var = 1.0;
+    if constexpr (NUIS) { var = fma(c2, c2, j2); iv = rcp_nr<2>(var); lp.mul(var); } else { iv = c2; }
+    double rvb;   // ∂ll/∂model
+    if (L::HAS_MARG && marg) {
+        // rv-absolute-margin.jl:171-180
+        if constexpr (L::HAS_MARG) {
+            acc[L::OFF_MARG + 0] += iv;
+            acc[L::OFF_MARG + 1] = fma(-2.0 * resid, iv, acc[L::OFF_MARG + 1]);
+            acc[L::OFF_MARG + 2] = fma(resid * resid, iv, acc[L::OFF_MARG + 2]);
+        }
+        const double dm = resid - mu_hat;
+        rvb = 2.0 * dm * iv;
+        if constexpr (GRAD && NUIS)
+            acc[L::OFF_NU + OCTO_NU_RV_JITTER] += 2.0 * jit * iv * (dm * dm * iv - 1.0 + iv * iA);
+    } else {
+        acc[L::OFF_S] = fma(resid * resid, iv, acc[L::OFF_S]);
+        rvb = resid * iv;
+        if constexpr (GRAD && NUIS) {
+            acc[L::OFF_NU + OCTO_NU_RV_OFFSET] += rvb;
+            acc[L::OFF_NU + OCTO_NU_RV_JITTER] += jit * iv * (resid * resid * iv - 1.0);
+        }
+    }
+    if constexpr (GRAD) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double* g = &acc[L::OFF_PL + p * L::PL_N];
+            g[L::GK] = fma(gc[p] * V[p], rvb, g[L::GK]);
+            const bool via_mu = rel ? (p != co.planet && gc[p] != 0.0) : true;
+            g[L::GC] += via_mu ? -(pc[p].K * V[p] * rvb) : 0.0;
+            const double Vb = gc[p] * pc[p].K * rvb;
+            g[L::GW] = fma(Vb, -fma(cnu[p] + pc[p].e, pc[p].sw, snu[p] * pc[p].cw), g[L::GW]);
+            // V(cos ν, sin ν, e) with cos ν = X/D, sin ν = Y/D, X = cE − e, Y = β sE, D = 1 − e cE
+            const double cb = Vb * pc[p].cw, sb = -Vb * pc[p].sw;
+            const double Xb = cb * s[p].invD, Yb = sb * s[p].invD;
+            const double Db = -fma(cb, cnu[p], sb * snu[p]) * s[p].invD;
+            const double cEb = fma(-pc[p].e, Db, Xb);
+            const double Eb = fma(pc[p].beta * Yb, s[p].cE, -(cEb * s[p].sE));
+            const double Mb = Eb * s[p].invD;
+            double eb = fma(Mb, s[p].sE, cb - Xb);
+            eb = fma(-(pc[p].eob * s[p].sE), Yb, eb);
+            eb = fma(-s[p].cE, Db, eb);
+            g[L::GE] += eb;
+            g[L::GM] += Mb;
+            g[L::GT] = fma(Mb, s[p].dt, g[L::GT]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ k_main
@@ -215,267 +571,21 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
 
     const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_RADEC ||
                            ob.kind == OCTO_ONEIL_SEPPA;
-    const bool oneil = L::HAS_ONEIL && (ob.kind == OCTO_ONEIL_RADEC || ob.kind == OCTO_ONEIL_SEPPA);
 
     if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
-        // coefficient of each planet's sky offset in the model (relative-astrometry.jl:117-138):
-        // 1 for the planet the table is attached to, +m/M for strictly-inner companions with a mass.
-        double f[P];
-        if constexpr (P == 1) {
-            f[0] = 1.0;
-        } else {
-            double a_this = 0.0;
-#pragma unroll
-            for (int p = 0; p < P; ++p) a_this = (p == ob.planet) ? pc[p].a : a_this;
-#pragma unroll
-            for (int p = 0; p < P; ++p) f[p] = (p == ob.planet) ? 1.0 : ((pc[p].a < a_this) ? pc[p].mu : 0.0);
-        }
-        double jit = 0.0, j2 = 0.0, ps = 1.0, na = 0.0, sn = 0.0, cn = 1.0;
-        if constexpr (NUIS) {
-            const double* nu = a.nuis + (int64_t)tk.obs * OCTO_N_NUIS * a.ld + wl;
-            jit = nu[OCTO_NU_JITTER * a.ld]; ps = nu[OCTO_NU_PLATESCALE * a.ld];
-            na = nu[OCTO_NU_NORTHANGLE * a.ld];
-            sincos(na, &sn, &cn);
-            j2 = jit * jit;
-        }
-        const bool seppa = (KM & KM_SEPPA) && (ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_SEPPA);
+        const AstromCoef<P> co = astrom_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, ob.kind, ob.planet, ob.has_cor, tk.obs, pc, wl);
         const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE;
         for (int j = 0; j < n_rows; ++j) {
             const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
-            const double t = rw[0], y1 = rw[1], y2 = rw[2], c3 = rw[3], c4 = rw[4], c5 = rw[5];
-            KSol s[P];
-            double rap[P], dep[P];      // each planet's own sky offset [mas]
-            double ra_m, dec_m;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                s[p] = kepler_solve<1, true>(t, pc[p], tab);
-                rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
-                dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
-            }
-            if constexpr (L::HAS_ONEIL) {
-                if (oneil) {
-                    // M = meananom(sol) = E − e sin E; t = 3M(e + cos E) + 2(−2 + e² + e cos E) sin E   prior-observable.jl:129-133
-                    double sE = 0.0, cE = 0.0, ee = 0.0, invD = 0.0, dtp = 0.0;
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        const bool me = (P == 1) || (p == ob.planet);
-                        sE = me ? s[p].sE : sE; cE = me ? s[p].cE : cE; ee = me ? pc[p].e : ee; invD = me ? s[p].invD : invD; dtp = me ? s[p].dt : dtp;
-                    }
-                    double E = 0.0;                                  // E ∈ [−π, π], as the solver returns it (eccanom(sol))
-#pragma unroll
-                    for (int p = 0; p < P; ++p) E = ((P == 1) || (p == ob.planet)) ? s[p].E : E;
-                    const double Mm = fma(-ee, sE, E);
-                    const double c2 = fma(ee, ee + cE, -2.0);       // −2 + e² + e cos E
-                    const double tt = fma(3.0 * Mm, ee + cE, 2.0 * c2 * sE);
-                    acc[L::OFF_ONEIL] += fabs(tt);
-                    if constexpr (GRAD) {
-                        const double sg = tt < 0.0 ? -1.0 : 1.0;
-                        const double D = fma(-ee, cE, 1.0);
-                        const double tM = 3.0 * (ee + cE);                                        // ∂t/∂M
-                        const double tE = fma(-3.0 * Mm, sE, 2.0 * fma(c2, cE, -(ee * sE * sE))) + tM * D;      // total ∂t/∂E (M = E − e sinE)
-                        const double te = fma(2.0 * sE, 2.0 * ee + cE, 3.0 * Mm) - tM * sE;       // total ∂t/∂e at fixed E
-                        const double Mb = sg * tE * invD;                                          // through E(M̄A, e)
-                        acc[L::OFF_ONEIL + 1] += sg * te + Mb * sE;
-                        acc[L::OFF_ONEIL + 2] += Mb;
-                        acc[L::OFF_ONEIL + 3] = fma(Mb, dtp, acc[L::OFF_ONEIL + 3]);
-                    }
-                }
-            }
-            if constexpr (P == 1) {
-                ra_m = rap[0]; dec_m = dep[0];
-            } else {
-                ra_m = 0.0; dec_m = 0.0;
-#pragma unroll
-                for (int p = 0; p < P; ++p) { ra_m = fma(f[p], rap[p], ra_m); dec_m = fma(f[p], dep[p], dec_m); }
-            }
-            // residuals
-            double r1, r2, irho = 1.0, u1 = 0.0, u2 = 0.0;
-            if (seppa) {
-                // relative-astrometry.jl:192-202
-                const double rho2 = fma(ra_m, ra_m, dec_m * dec_m);
-                irho = rsqrt_nr(rho2);                         // ρ = ρ²·(1/ρ) enters r2 through one explicit FMA below: a separate
-                                                               // product would be contracted differently by the forward-only and
-                                                               // the gradient instantiation, and their values must agree bitwise
-                const double pa = atan2_fast(ra_m, dec_m);
-                double dpa = (y1 + na) - pa + PI;
-                dpa = rem_2pi_trunc(dpa) - PI;                 // Julia `%`: truncated remainder
-                dpa = dpa < -PI ? dpa + TWO_PI : dpa;
-                r1 = dpa;
-                r2 = fma(-rho2, irho, y2 * ps);
-            } else {
-                // relative-astrometry.jl:210-215: the data are rotated by −northangle and scaled
-                if constexpr (NUIS) {
-                    u1 = fma(y1, cn, y2 * sn);
-                    u2 = fma(y2, cn, -(y1 * sn));
-                    r1 = fma(ps, u1, -ra_m);
-                    r2 = fma(ps, u2, -dec_m);
-                } else {
-                    r1 = y1 - ra_m;
-                    r2 = y2 - dec_m;
-                }
-            }
-            // density; g1, g2 = ∂ll/∂r1, ∂ll/∂r2
-            double g1, g2;
-            if constexpr (!NUIS) {
-                // precomputed Σ⁻¹ (the jitter == 0 branch, relative-astrometry.jl:218-219)
-                double a1, a2;
-                if constexpr (L::HAS_COR) { a1 = fma(c3, r1, c5 * r2); a2 = fma(c5, r1, c4 * r2); }
-                else { a1 = c3 * r1; a2 = c4 * r2; }
-                acc[L::OFF_S] = fma(r1, a1, fma(r2, a2, acc[L::OFF_S]));   // Σ rᵀΣ⁻¹r ; ll = const − ½Σ
-                g1 = -a1; g2 = -a2;
-            } else {
-                const double v1 = fma(c3, c3, j2), v2 = fma(c4, c4, j2);   // hypot(σ, jitter)², :234-235
-                const double v12 = v1 * v2;
-                const double iv12 = rcp_nr<2>(v12);                       // one reciprocal for 1/v1 and 1/v2
-                const double iv1 = iv12 * v2, iv2 = iv12 * v1;
-                double a1, a2;                                             // Σ⁻¹ r
-                if (L::HAS_COR && ob.has_cor) {
-                    const double cor = c5;
-                    const double omc = 1.0 - cor * cor;
-                    const double ic = rcp_nr<2>(omc);
-                    const double is = rsqrt(v12);                          // 1/(σ1 σ2)
-                    a1 = fma(r1, iv1, -(cor * r2 * is)) * ic;
-                    a2 = fma(r2, iv2, -(cor * r1 * is)) * ic;
-                    lp.mul(v12 * omc);
-                } else {
-                    a1 = r1 * iv1; a2 = r2 * iv2;
-                    lp.mul(v12);
-                }
-                // ll = −n·log2π − ½Σ(log|Σ| + rᵀΣ⁻¹r); the logs via lp. Explicit FMAs: the forward-only and the gradient
-                // instantiation must round this sum identically (the compiler would contract it differently around q1, q2)
-                acc[L::OFF_S] = fma(r1, a1, fma(r2, a2, acc[L::OFF_S]));
-                g1 = -a1; g2 = -a2;
-                if constexpr (GRAD) {
-                    acc[L::OFF_NU + OCTO_NU_JITTER] += jit * fma(fma(r1, a1, -1.0), iv1, fma(r2, a2, -1.0) * iv2);
-                    if (seppa) {
-                        acc[L::OFF_NU + OCTO_NU_PLATESCALE] = fma(g2, y2, acc[L::OFF_NU + OCTO_NU_PLATESCALE]);
-                        acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += g1;
-                    } else {
-                        acc[L::OFF_NU + OCTO_NU_PLATESCALE] += g1 * u1 + g2 * u2;
-                        acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += ps * (g1 * u2 - g2 * u1);
-                    }
-                }
-            }
-            if constexpr (GRAD) {
-                // adjoint of the model position
-                double rab, deb;
-                if (seppa) {
-                    const double pab = -g1, rhob = -g2;
-                    rab = (rhob * ra_m + pab * dec_m * irho) * irho;
-                    deb = (rhob * dec_m - pab * ra_m * irho) * irho;
-                } else {
-                    rab = -g1; deb = -g2;
-                }
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    double* g = &acc[L::OFF_PL + p * L::PL_N];
-                    const double ra_f = (P == 1) ? rab : f[p] * rab, de_f = (P == 1) ? deb : f[p] * deb;
-                    g[L::U1] = fma(s[p].cE, ra_f, g[L::U1]);
-                    g[L::U2] = fma(s[p].sE, ra_f, g[L::U2]);
-                    g[L::U3] = fma(s[p].cE, de_f, g[L::U3]);
-                    g[L::U4] = fma(s[p].sE, de_f, g[L::U4]);
-                    g[L::U5] += ra_f;
-                    g[L::U6] += de_f;
-                    if constexpr (P > 1)
-                        g[L::GC] += (p == ob.planet) ? 0.0 : ((f[p] != 0.0) ? fma(rab, rap[p], deb * dep[p]) : 0.0);
-                    // Ē = r̄a·∂ra/∂E + d̄ec·∂dec/∂E ;  M̄ = Ē/(1 − e cos E)
-                    const double dra = fma(pc[p].cGb, s[p].cE, -(pc[p].cB * s[p].sE));
-                    const double dde = fma(pc[p].cFb, s[p].cE, -(pc[p].cA * s[p].sE));
-                    const double Mb = fma(ra_f, dra, de_f * dde) * s[p].invD;
-                    g[L::GE] = fma(Mb, s[p].sE, g[L::GE]);          // ∂E/∂e = sin E/(1 − e cos E); the rest of ē in k_finish
-                    g[L::GM] += Mb;
-                    g[L::GT] = fma(Mb, s[p].dt, g[L::GT]);
-                }
-            }
+            astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab);
         }
     }
     if (L::HAS_RV && !is_astrom) {
-        // coefficient of K_p·V_p in the RV model: RV_REL: +1 for this planet (rv-relative.jl:143), −m/M for
-        // strictly-inner massive companions (:148-156); absolute RV: −m/M for every planet (rv-absolute.jl:146-155).
-        double gc[P];
-        const bool rel = ob.kind == OCTO_RV_REL;
-        {
-            double a_this = 0.0;
-#pragma unroll
-            for (int p = 0; p < P; ++p) a_this = (p == ob.planet) ? pc[p].a : a_this;
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-                gc[p] = rel ? ((p == ob.planet) ? 1.0 : ((pc[p].a < a_this) ? -pc[p].mu : 0.0)) : -pc[p].mu;
-        }
-        const bool marg = (KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG;
-        double off = 0.0, jit = 0.0, j2 = 0.0;
-        if constexpr (NUIS) {
-            const double* nu = a.nuis + (int64_t)tk.obs * OCTO_N_NUIS * a.ld + wl;
-            off = marg ? 0.0 : nu[OCTO_NU_RV_OFFSET * a.ld];
-            jit = nu[OCTO_NU_RV_JITTER * a.ld];
-            j2 = jit * jit;
-        }
-        double mu_hat = 0.0, iA = 0.0;
-        if (GRAD && marg && a.marg) {
-            mu_hat = a.marg[((int64_t)tk.obs * 2 + 0) * a.ldw + wl];
-            iA = 1.0 / a.marg[((int64_t)tk.obs * 2 + 1) * a.ldw + wl];
-        }
+        const RvCoef<P> co = rv_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, a.marg, a.ldw, ob.kind, ob.planet, tk.obs, pc, wl);
         const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE;
         for (int j = 0; j < n_rows; ++j) {
             const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
-            const double t = rw[0], rv = rw[1], c2 = rw[2];
-            KSol s[P];
-            double V[P], cnu[P], snu[P];
-            double model = off;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                s[p] = kepler_solve<2, true>(t, pc[p], tab);
-                cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
-                snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
-                V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
-                model = fma(gc[p] * pc[p].K, V[p], model);
-            }
-            const double resid = rv - model;
-            double iv, var = 1.0;
-            if constexpr (NUIS) { var = fma(c2, c2, j2); iv = rcp_nr<2>(var); lp.mul(var); } else { iv = c2; }
-            double rvb;   // ∂ll/∂model
-            if (marg) {
-                // rv-absolute-margin.jl:171-180
-                acc[L::OFF_MARG + 0] += iv;
-                acc[L::OFF_MARG + 1] = fma(-2.0 * resid, iv, acc[L::OFF_MARG + 1]);
-                acc[L::OFF_MARG + 2] = fma(resid * resid, iv, acc[L::OFF_MARG + 2]);
-                const double dm = resid - mu_hat;
-                rvb = 2.0 * dm * iv;
-                if constexpr (GRAD && NUIS)
-                    acc[L::OFF_NU + OCTO_NU_RV_JITTER] += 2.0 * jit * iv * (dm * dm * iv - 1.0 + iv * iA);
-            } else {
-                if constexpr (NUIS) acc[L::OFF_S] = fma(resid * resid, iv, acc[L::OFF_S]);
-                else acc[L::OFF_S] = fma(resid * resid, iv, acc[L::OFF_S]);
-                rvb = resid * iv;
-                if constexpr (GRAD && NUIS) {
-                    acc[L::OFF_NU + OCTO_NU_RV_OFFSET] += rvb;
-                    acc[L::OFF_NU + OCTO_NU_RV_JITTER] += jit * iv * (resid * resid * iv - 1.0);
-                }
-            }
-            if constexpr (GRAD) {
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    double* g = &acc[L::OFF_PL + p * L::PL_N];
-                    g[L::GK] = fma(gc[p] * V[p], rvb, g[L::GK]);
-                    const bool via_mu = rel ? (p != ob.planet && gc[p] != 0.0) : true;
-                    g[L::GC] += via_mu ? -(pc[p].K * V[p] * rvb) : 0.0;
-                    const double Vb = gc[p] * pc[p].K * rvb;
-                    g[L::GW] = fma(Vb, -fma(cnu[p] + pc[p].e, pc[p].sw, snu[p] * pc[p].cw), g[L::GW]);
-                    // V(cos ν, sin ν, e) with cos ν = X/D, sin ν = Y/D, X = cE − e, Y = β sE, D = 1 − e cE
-                    const double cb = Vb * pc[p].cw, sb = -Vb * pc[p].sw;
-                    const double Xb = cb * s[p].invD, Yb = sb * s[p].invD;
-                    const double Db = -fma(cb, cnu[p], sb * snu[p]) * s[p].invD;
-                    const double cEb = fma(-pc[p].e, Db, Xb);
-                    const double Eb = fma(pc[p].beta * Yb, s[p].cE, -(cEb * s[p].sE));
-                    const double Mb = Eb * s[p].invD;
-                    double eb = fma(Mb, s[p].sE, cb - Xb);
-                    eb = fma(-(pc[p].eob * s[p].sE), Yb, eb);
-                    eb = fma(-s[p].cE, Db, eb);
-                    g[L::GE] += eb;
-                    g[L::GM] += Mb;
-                    g[L::GT] = fma(Mb, s[p].dt, g[L::GT]);
-                }
-            }
+            rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], tab);
         }
     }
     if constexpr (NUIS) {
@@ -528,6 +638,160 @@ __global__ __launch_bounds__(256) void k_marg(EvalArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------ finish
+// The per-walker tail of an evaluation, shared by k_finish (big batches: sums arrive from the task partials) and k_small
+// (sums arrive from the block reduction): per-observation closed forms, then the map from the running sums to
+// ∂ll/∂(a, e, i, ω, Ω, tp, M, plx, mass).
+constexpr int NOBS_ACC = 11;             // S, 3 marg, 3 nuis, 4 O'Neil per observation
+
+struct FinPC { double sma, P_d, beta, si, ci, sO, cO, sw, cw; };
+
+template <int P, bool GRAD, bool NUIS, int KM>
+constexpr int oneil_slots() { return (Layout<P, GRAD, NUIS, KM>::HAS_ONEIL && GRAD) ? P * 6 : 1; }
+
+// v = {S, margA, margB, margC, nu0, nu1, nu2, on0..on3} summed over the observation's rows; returns its log-likelihood.
+// `sma[p]`: semi-major axis of each planet (derived for a ThieleInnesOrbit). Writes the observation's g_nuis rows if `write`.
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ double obs_finish(const DevObs* __restrict__ obs, int64_t ld, double* __restrict__ g_nuis,
+                                             const double* __restrict__ extra, int64_t ldw, double k_yr, int o, const double (&v)[NOBS_ACC],
+                                             double cst, const double (&sma_p)[P], const double (&e_p)[P], const double (&M_p)[P],
+                                             int64_t w /* offset of this walker in g_nuis / extra rows */, bool write,
+                                             double (&oneil_g)[oneil_slots<P, GRAD, NUIS, KM>()]) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    const int kind = obs[o].kind;
+    double llo;
+    if (L::HAS_MARG && kind == OCTO_RV_ABS_MARG) {
+        // ll = −Σ log(2π var) − (−B²/(4A) + C + log A)      rv-absolute-margin.jl:179-181
+        const double slog = NUIS ? v[0] : -cst;
+        llo = (obs[o].n > 0) ? -slog - (-v[2] * v[2] / (4.0 * v[1]) + v[3] + log(v[1])) : 0.0;
+    } else {
+        // NUIS: S = Σ(log|Σ| + q) [astrom] or Σ(log var + r²/var) [rv]; cst = −n·log2π·(1 or ½)
+        // !NUIS: S = Σ q, cst = Σ(−log2π·k − ½ log|Σ|)
+        llo = cst - 0.5 * v[0];
+    }
+    if constexpr (L::HAS_ONEIL) {
+        if ((kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && obs[o].n > 0) {
+            // ln_prior = 2 log(Σ|t_j| · ∛P / √(1−e²)), P = period/365.25   prior-observable.jl:96,136-139
+            const int ip = obs[o].planet;
+            double sma = sma_p[0], e = e_p[0], Mt = M_p[0];
+#pragma unroll
+            for (int p = 1; p < P; ++p) { sma = (p == ip) ? sma_p[p] : sma; e = (p == ip) ? e_p[p] : e; Mt = (p == ip) ? M_p[p] : Mt; }
+            const double Pyr = k_yr * sqrt(sma * sma * sma / Mt) / 365.25;
+            llo += 2.0 * log(v[7] * cbrt(Pyr) / sqrt(1.0 - e * e));
+            if constexpr (GRAD) {
+                const double f = 2.0 / v[7];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (p != ip) continue;
+                    oneil_g[p * 6 + 0] += f * v[8]; oneil_g[p * 6 + 1] += f * v[9]; oneil_g[p * 6 + 2] += f * v[10];
+                    oneil_g[p * 6 + 3] += 1.0 / sma; oneil_g[p * 6 + 4] += -1.0 / (3.0 * Mt); oneil_g[p * 6 + 5] += 2.0 * e / (1.0 - e * e);
+                }
+            }
+        }
+    }
+    if constexpr (L::N_NU > 0) {
+        if (write) {
+            double* gn = g_nuis + (int64_t)o * OCTO_N_NUIS * ld + w;
+            const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA;
+            gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : v[4];
+            gn[(int64_t)ld] = v[5];
+            gn[(int64_t)2 * ld] = astrom ? v[6] : 0.0;
+            if (kind == OCTO_HGCA) {      // ∂/∂(pmra, pmdec) from k_hgca
+                const double* x = extra + (int64_t)(1 + P * OCTO_N_EL + o * OCTO_N_NUIS) * ldw + w;
+                gn[0] = x[0]; gn[(int64_t)ld] = x[ldw]; gn[(int64_t)2 * ld] = 0.0;
+            }
+        }
+    }
+    return llo;
+}
+
+// Running sums of planet p -> its nine element adjoints, written to g_elems (zeros if !ok).
+template <int P, bool GRAD, bool NUIS, int KM, bool FAST = false>
+__device__ __forceinline__ void planet_finish(const double (&el)[OCTO_N_EL] /* the planet's element rows */, double* __restrict__ ge /* its g_elems rows, at this walker */,
+                                              int64_t ld, const double* __restrict__ extra_w /* k_hgca's rows at this walker, or null */,
+                                              int64_t ldw, const DevConsts& c, int orbit_kind, int has_mass, int p, const double* g,
+                                              const double* og /* this planet's 6 O'Neil terms or null */, const FinPC& fp, bool ok) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    auto fdiv = [](double x, double y) { return FAST ? x * rcp_nr<2>(y) : x / y; };      // FAST: k_small (see setup_planet)
+    const bool radvel = orbit_kind == OCTO_ORBIT_RADVEL;
+    const bool ti = orbit_kind == OCTO_ORBIT_THIELE_INNES;
+    const bool noplx = radvel || orbit_kind == OCTO_ORBIT_KEP;
+    const double e = el[OCTO_EL_E];
+    const double Mt = el[OCTO_EL_M];
+    const double plx = noplx ? 1.0 : el[OCTO_EL_PLX];
+    const double mass = has_mass ? el[OCTO_EL_MASS] : 0.0;
+    // per-walker constants the setup already derived: no second round of sincos/sqrt in this latency-bound code
+    const double sma = fp.sma;                 // the element itself, or α/plx of a ThieleInnesOrbit
+    const double P_d = fp.P_d, beta = fp.beta;
+    const double si = fp.si, ci = fp.ci, sO = fp.sO, cO = fp.cO, sw = fp.sw, cw = fp.cw;
+    const double kappa = c.mas_per_au_per_plx;
+    const double sm = plx * kappa, T = ti ? 1.0 : sma * sm;
+    // unit Thiele-Innes constants of a Campbell orbit, or the [mas] constants a ThieleInnesOrbit is parameterised by
+    const double A = ti ? el[OCTO_EL_TI_A] : cO * cw - sO * sw * ci, B = ti ? el[OCTO_EL_TI_B] : sO * cw + cO * sw * ci;
+    const double F = ti ? el[OCTO_EL_TI_F] : -cO * sw - sO * cw * ci, G = ti ? el[OCTO_EL_TI_G] : -sO * sw + cO * cw * ci;
+    double tiAb = 0, tiBb = 0, tiFb = 0, tiGb = 0;
+    double ab = 0, eb = g[L::GE], ib = 0, wb = 0, Ob = 0, tpb, Mb = 0, plxb = 0, massb = 0, Pb = 0;
+    double gM = g[L::GM], gT = g[L::GT];
+    if constexpr (L::HAS_ONEIL) {
+        eb += og[0] + og[5]; gM += og[1]; gT += og[2];
+        ab += og[3]; Mb += og[4];
+    }
+    if (!radvel) {
+        // adjoints of cB, cG, cA, cF (mas per unit X = cosE − e, Y = β sinE) from the running sums
+        const double gB = g[L::U1] - e * g[L::U5], gG = beta * g[L::U2];
+        const double gA = g[L::U3] - e * g[L::U6], gF = beta * g[L::U4];
+        // ē: −Σ X̄ − (e/β) Σ sinE·Ȳ, with X̄ = cB r̄a + cA d̄ec, Ȳ = cG r̄a + cF d̄ec
+        eb -= T * (B * g[L::U5] + A * g[L::U6]);
+        eb -= fdiv(e, beta) * T * (G * g[L::U2] + F * g[L::U4]);
+        const double Bb = T * gB, Gb = T * gG, Ab = T * gA, Fb = T * gF;
+        tiAb = gA; tiBb = gB; tiFb = gF; tiGb = gG;
+        const double Tb = ti ? 0.0 : B * gB + G * gG + A * gA + F * gF;
+        ab += Tb * sm; plxb += Tb * sma * kappa;
+        ib = Ab * (sO * sw * si) + Bb * (-cO * sw * si) + Fb * (sO * cw * si) + Gb * (-cO * cw * si);
+        wb = Ab * (-cO * sw - sO * cw * ci) + Bb * (-sO * sw + cO * cw * ci) + Fb * (-cO * cw + sO * sw * ci) + Gb * (-sO * cw - cO * sw * ci);
+        Ob = Ab * (-sO * cw - cO * sw * ci) + Bb * (cO * cw - sO * sw * ci) + Fb * (sO * sw - cO * cw * ci) + Gb * (-cO * sw - sO * cw * ci);
+    }
+    if constexpr (L::HAS_RV) {
+        const double sieff = radvel ? 1.0 : si;
+        const double Kc = TWO_PI * c.yd * c.au2m * c.sec2yr;      // K = Kc·a·sin i /(P_d·β)
+        const double K = fdiv(Kc * sma * sieff, P_d * beta);
+        const double Kb = g[L::GK];
+        ab += fdiv(Kb * K, sma);
+        if (!radvel) ib += fdiv(Kb * Kc * sma * ci, P_d * beta);
+        Pb += -fdiv(Kb * K, P_d);
+        eb += fdiv(Kb * K * e, beta * beta);
+        wb += g[L::GW];
+    }
+    // M = 2π (t − tp)/P_d
+    tpb = -fdiv(TWO_PI, P_d) * gM;
+    Pb += -fdiv(TWO_PI, P_d * P_d) * gT;
+    // P_d = k · a^{3/2} · M_tot^{−1/2}
+    ab += fdiv(Pb * 1.5 * P_d, sma);
+    Mb += fdiv(-0.5 * Pb * P_d, Mt);
+    if constexpr (L::PL_N > L::GC) {
+        const double mu = fdiv(mass * c.mjup2msol, Mt);
+        if (has_mass) { massb = fdiv(g[L::GC] * c.mjup2msol, Mt); Mb += fdiv(-g[L::GC] * mu, Mt); }
+    }
+    double out[OCTO_N_EL] = {ab, eb, radvel ? 0.0 : ib, wb, radvel ? 0.0 : Ob, tpb, Mb, noplx ? 0.0 : plxb, massb};
+    if (ti) {
+        // a = α/plx, α² = u + √(u² − v²), u = (A²+B²+F²+G²)/2, v = AG − BF  (src/parameterizations.jl:15-18): push ā back
+        const double u = 0.5 * (A * A + B * B + F * F + G * G), v = A * G - B * F;
+        const double sq = sqrt((u + v) * (u - v)), alpha = sma * plx;
+        const double alphab = ab / plx;
+        const double ub = alphab * (1.0 + u / sq) / (2.0 * alpha), vb = -alphab * (v / sq) / (2.0 * alpha);
+        out[OCTO_EL_TI_A] = tiAb + ub * A + vb * G;
+        out[OCTO_EL_TI_B] = tiBb + ub * B - vb * F;
+        out[OCTO_EL_TI_F] = tiFb + ub * F - vb * B;
+        out[OCTO_EL_TI_G] = tiGb + ub * G + vb * A;
+        out[OCTO_EL_PLX] = -ab * sma / plx;
+    }
+#pragma unroll
+    for (int k = 0; k < OCTO_N_EL; ++k) {
+        const double x = extra_w ? extra_w[(int64_t)(1 + p * OCTO_N_EL + k) * ldw] : 0.0;
+        ge[(int64_t)k * ld] = ok ? out[k] + x : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------ k_finish
 // block = 64 walkers × FIN_G task groups: group g sums tasks g, g+FIN_G, … of each observation (more loads in
 // flight than one thread per walker), groups are combined through LDS in a fixed order, group 0 finishes.
@@ -535,7 +799,6 @@ template <int P, bool GRAD, bool NUIS, int KM>
 __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
     constexpr int NPL = P * L::PL_N;
-    constexpr int NOBS_ACC = 11;             // S, 3 marg, 3 nuis, 4 O'Neil per observation
     constexpr int LDS_ROWS = NOBS_ACC > L::PL_N ? NOBS_ACC : L::PL_N;
     static_assert(LDS_ROWS <= 12, "k_finish LDS scratch is sized for 12 rows");
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -548,9 +811,16 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     for (int k = 0; k < NPL; ++k) gp[k] = 0.0;
     // LDS scratch: [max(NOBS_ACC, PL_N)][FIN_G][64], reused per observation and per planet (two barriers each)
     double ll = 0.0;
-    double oneil_g[L::HAS_ONEIL && GRAD ? P * 6 : 1];     // per planet: ΔGE, ΔGM, ΔGT, Δā, ΔM̄tot, Δē from O'Neil terms
+    double oneil_g[oneil_slots<P, GRAD, NUIS, KM>()];     // per planet: ΔGE, ΔGM, ΔGT, Δā, ΔM̄tot, Δē from O'Neil terms
 #pragma unroll
-    for (int k = 0; k < (L::HAS_ONEIL && GRAD ? P * 6 : 1); ++k) oneil_g[k] = 0.0;
+    for (int k = 0; k < oneil_slots<P, GRAD, NUIS, KM>(); ++k) oneil_g[k] = 0.0;
+    double sma_p[P], e_p[P], M_p[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        sma_p[p] = L::HAS_ONEIL ? a.wc[((int64_t)p * NWC + WC_A) * a.ldw + wl] : 0.0;
+        e_p[p] = L::HAS_ONEIL ? a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wl] : 0.0;
+        M_p[p] = L::HAS_ONEIL ? a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wl] : 1.0;
+    }
     int t = 0;
     for (int o = 0; o < a.n_obs; ++o) {
         double S = 0.0, mA = 0.0, mB = 0.0, mC = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0, cst = 0.0;
@@ -589,7 +859,6 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
         lo[7 * FIN_G * WAVE] = on0; lo[8 * FIN_G * WAVE] = on1; lo[9 * FIN_G * WAVE] = on2; lo[10 * FIN_G * WAVE] = on3;
         __syncthreads();
         if (grp == 0) {
-            const int kind = a.obs[o].kind;
             double v[NOBS_ACC];
 #pragma unroll
             for (int k = 0; k < NOBS_ACC; ++k) {
@@ -598,46 +867,8 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                 for (int g = 0; g < FIN_G; ++g) x += lds[(k * FIN_G + g) * WAVE + lane];
                 v[k] = x;
             }
-            double llo;
-            if (L::HAS_MARG && kind == OCTO_RV_ABS_MARG) {
-                // ll = −Σ log(2π var) − (−B²/(4A) + C + log A)      rv-absolute-margin.jl:179-181
-                const double slog = NUIS ? v[0] : -cst;
-                llo = (a.obs[o].n > 0) ? -slog - (-v[2] * v[2] / (4.0 * v[1]) + v[3] + log(v[1])) : 0.0;
-            } else {
-                // NUIS: S = Σ(log|Σ| + q) [astrom] or Σ(log var + r²/var) [rv]; cst = −n·log2π·(1 or ½)
-                // !NUIS: S = Σ q, cst = Σ(−log2π·k − ½ log|Σ|)
-                llo = cst - 0.5 * v[0];
-            }
-            if constexpr (L::HAS_ONEIL) {
-                if ((kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && a.obs[o].n > 0) {
-                    // ln_prior = 2 log(Σ|t_j| · ∛P / √(1−e²)), P = period/365.25   prior-observable.jl:96,136-139
-                    const int ip = a.obs[o].planet;
-                    const double* el = a.elems + (int64_t)ip * OCTO_N_EL * a.ld + wl;
-                    const double sma = a.wc[((int64_t)ip * NWC + WC_A) * a.ldw + wl];      // derived for a ThieleInnesOrbit
-                    const double e = el[OCTO_EL_E * a.ld], Mt = el[OCTO_EL_M * a.ld];
-                    const double Pyr = a.c.k_yr * sqrt(sma * sma * sma / Mt) / 365.25;
-                    llo += 2.0 * log(v[7] * cbrt(Pyr) / sqrt(1.0 - e * e));
-                    if constexpr (GRAD) {
-                        const double f = 2.0 / v[7];
-                        oneil_g[ip * 6 + 0] += f * v[8]; oneil_g[ip * 6 + 1] += f * v[9]; oneil_g[ip * 6 + 2] += f * v[10];
-                        oneil_g[ip * 6 + 3] += 1.0 / sma; oneil_g[ip * 6 + 4] += -1.0 / (3.0 * Mt); oneil_g[ip * 6 + 5] += 2.0 * e / (1.0 - e * e);
-                    }
-                }
-            }
-            ll += llo;                   // observations are summed in the order given (system.jl:93,186)
-            if constexpr (L::N_NU > 0) {
-                if (w < a.W) {
-                    double* gn = a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w;
-                    const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA;
-                    gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : v[4];
-                    gn[(int64_t)a.ld] = v[5];
-                    gn[(int64_t)2 * a.ld] = astrom ? v[6] : 0.0;
-                    if (kind == OCTO_HGCA) {      // ∂/∂(pmra, pmdec) from k_hgca
-                        const double* x = a.extra + (int64_t)(1 + P * OCTO_N_EL + o * OCTO_N_NUIS) * a.ldw + w;
-                        gn[0] = x[0]; gn[(int64_t)a.ld] = x[a.ldw]; gn[(int64_t)2 * a.ld] = 0.0;
-                    }
-                }
-            }
+            // observations are summed in the order given (system.jl:93,186)
+            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, a.g_nuis, a.extra, a.ldw, a.c.k_yr, o, v, cst, sma_p, e_p, M_p, w, w < a.W, oneil_g);
         }
         __syncthreads();
     }
@@ -671,90 +902,257 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + w;
-            double* ge = a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w;
-            const double* g = &gp[p * L::PL_N];
-            const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
-            const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
-            const double e = el[OCTO_EL_E * a.ld];
-            const double Mt = el[OCTO_EL_M * a.ld];
-            const double plx = radvel ? 1.0 : el[OCTO_EL_PLX * a.ld];
-            const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
-            // per-walker constants k_setup already derived: no second round of sincos/sqrt in this latency-bound kernel
             const double* wc = a.wc + (int64_t)p * NWC * a.ldw + w;
-            const double sma = wc[WC_A * a.ldw];                 // the element itself, or α/plx of a ThieleInnesOrbit
-            const double P_d = 1.0 / wc[WC_INVP * a.ldw];
-            const double beta = wc[WC_BETA * a.ldw];
-            const double si = wc[WC_SINI * a.ldw], ci = wc[WC_COSI * a.ldw], sO = wc[WC_SINO * a.ldw], cO = wc[WC_COSO * a.ldw];
-            const double sw = wc[WC_SINW * a.ldw], cw = wc[WC_COSW * a.ldw];
-            const double kappa = a.c.mas_per_au_per_plx;
-            const double sm = plx * kappa, T = ti ? 1.0 : sma * sm;
-            // unit Thiele-Innes constants of a Campbell orbit, or the [mas] constants a ThieleInnesOrbit is parameterised by
-            const double A = ti ? el[OCTO_EL_TI_A * a.ld] : cO * cw - sO * sw * ci, B = ti ? el[OCTO_EL_TI_B * a.ld] : sO * cw + cO * sw * ci;
-            const double F = ti ? el[OCTO_EL_TI_F * a.ld] : -cO * sw - sO * cw * ci, G = ti ? el[OCTO_EL_TI_G * a.ld] : -sO * sw + cO * cw * ci;
-            double tiAb = 0, tiBb = 0, tiFb = 0, tiGb = 0;
-            double ab = 0, eb = g[L::GE], ib = 0, wb = 0, Ob = 0, tpb, Mb = 0, plxb = 0, massb = 0, Pb = 0;
-            double gM = g[L::GM], gT = g[L::GT];
-            if constexpr (L::HAS_ONEIL) {
-                eb += oneil_g[p * 6 + 0] + oneil_g[p * 6 + 5]; gM += oneil_g[p * 6 + 1]; gT += oneil_g[p * 6 + 2];
-                ab += oneil_g[p * 6 + 3]; Mb += oneil_g[p * 6 + 4];
-            }
-            if (!radvel) {
-                // adjoints of cB, cG, cA, cF (mas per unit X = cosE − e, Y = β sinE) from the running sums
-                const double gB = g[L::U1] - e * g[L::U5], gG = beta * g[L::U2];
-                const double gA = g[L::U3] - e * g[L::U6], gF = beta * g[L::U4];
-                // ē: −Σ X̄ − (e/β) Σ sinE·Ȳ, with X̄ = cB r̄a + cA d̄ec, Ȳ = cG r̄a + cF d̄ec
-                eb -= T * (B * g[L::U5] + A * g[L::U6]);
-                eb -= (e / beta) * T * (G * g[L::U2] + F * g[L::U4]);
-                const double Bb = T * gB, Gb = T * gG, Ab = T * gA, Fb = T * gF;
-                tiAb = gA; tiBb = gB; tiFb = gF; tiGb = gG;
-                const double Tb = ti ? 0.0 : B * gB + G * gG + A * gA + F * gF;
-                ab += Tb * sm; plxb += Tb * sma * kappa;
-                ib = Ab * (sO * sw * si) + Bb * (-cO * sw * si) + Fb * (sO * cw * si) + Gb * (-cO * cw * si);
-                wb = Ab * (-cO * sw - sO * cw * ci) + Bb * (-sO * sw + cO * cw * ci) + Fb * (-cO * cw + sO * sw * ci) + Gb * (-sO * cw - cO * sw * ci);
-                Ob = Ab * (-sO * cw - cO * sw * ci) + Bb * (cO * cw - sO * sw * ci) + Fb * (sO * sw - cO * cw * ci) + Gb * (-cO * sw - sO * cw * ci);
-            }
-            if constexpr (L::HAS_RV) {
-                const double sieff = radvel ? 1.0 : si;
-                const double Kc = TWO_PI * a.c.yd * a.c.au2m * a.c.sec2yr;      // K = Kc·a·sin i /(P_d·β)
-                const double K = Kc * sma * sieff / (P_d * beta);
-                const double Kb = g[L::GK];
-                ab += Kb * K / sma;
-                if (!radvel) ib += Kb * Kc * sma * ci / (P_d * beta);
-                Pb += -Kb * K / P_d;
-                eb += Kb * K * e / (beta * beta);
-                wb += g[L::GW];
-            }
-            // M = 2π (t − tp)/P_d
-            tpb = -(TWO_PI / P_d) * gM;
-            Pb += -(TWO_PI / (P_d * P_d)) * gT;
-            // P_d = k · a^{3/2} · M_tot^{−1/2}
-            ab += Pb * 1.5 * P_d / sma;
-            Mb += -0.5 * Pb * P_d / Mt;
-            if constexpr (L::PL_N > L::GC) {
-                const double mu = mass * a.c.mjup2msol / Mt;
-                if (a.has_mass[p]) { massb = g[L::GC] * a.c.mjup2msol / Mt; Mb += -g[L::GC] * mu / Mt; }
-            }
-            double out[OCTO_N_EL] = {ab, eb, radvel ? 0.0 : ib, wb, radvel ? 0.0 : Ob, tpb, Mb, radvel ? 0.0 : plxb, massb};
-            if (ti) {
-                // a = α/plx, α² = u + √(u² − v²), u = (A²+B²+F²+G²)/2, v = AG − BF  (src/parameterizations.jl:15-18): push ā back
-                const double u = 0.5 * (A * A + B * B + F * F + G * G), v = A * G - B * F;
-                const double sq = sqrt((u + v) * (u - v)), alpha = sma * plx;
-                const double alphab = ab / plx;
-                const double ub = alphab * (1.0 + u / sq) / (2.0 * alpha), vb = -alphab * (v / sq) / (2.0 * alpha);
-                out[OCTO_EL_TI_A] = tiAb + ub * A + vb * G;
-                out[OCTO_EL_TI_B] = tiBb + ub * B - vb * F;
-                out[OCTO_EL_TI_F] = tiFb + ub * F - vb * B;
-                out[OCTO_EL_TI_G] = tiGb + ub * G + vb * A;
-                out[OCTO_EL_PLX] = -ab * sma / plx;
-            }
+            FinPC fp;
+            fp.sma = wc[WC_A * a.ldw]; fp.P_d = 1.0 / wc[WC_INVP * a.ldw]; fp.beta = wc[WC_BETA * a.ldw];
+            fp.si = wc[WC_SINI * a.ldw]; fp.ci = wc[WC_COSI * a.ldw]; fp.sO = wc[WC_SINO * a.ldw]; fp.cO = wc[WC_COSO * a.ldw];
+            fp.sw = wc[WC_SINW * a.ldw]; fp.cw = wc[WC_COSW * a.ldw];
+            double elv[OCTO_N_EL];
 #pragma unroll
-            for (int k = 0; k < OCTO_N_EL; ++k) {
-                const double x = a.extra ? a.extra[(int64_t)(1 + p * OCTO_N_EL + k) * a.ldw + w] : 0.0;
-                ge[(int64_t)k * a.ld] = ok ? out[k] + x : 0.0;
-            }
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + w];
+            planet_finish<P, GRAD, NUIS, KM>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
+                                             a.orbit_kind[p], a.has_mass[p], p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------ k_small
+// Small batches (W <= SMALL_W walkers: one parameter set per call from NUTS / Pigeons' explorers, src/logdensitymodel.jl:169-177):
+// the whole evaluation in ONE launch, mapped the other way round — grid = (row tasks, walkers), lane = EPOCH.
+//   * every block derives its walker's orbit constants itself (setup_planet: wave-uniform, no k_setup launch, no `wc` round trip);
+//   * its 256 lanes stride over the task's rows with per-lane row records (coalesced 64-byte records), same row bodies as k_main;
+//   * the running sums are reduced across the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic), across the block's
+//     four waves through LDS, in a fixed order — bit-reproducible run to run;
+//   * with more than one task per walker, blocks publish their partial with device-scope (write-through) atomic stores and
+//     bump a per-walker counter; the block that sees the last count sums the partials IN TASK ORDER (so the result does not
+//     depend on which block that is) and runs the finish — no k_finish launch;
+//   * inputs and outputs may live in pinned host memory (octo_eval maps its staging buffers), so a call is one launch + one
+//     stream synchronisation, with no copy engine involved.
+constexpr int SMALL_W = OCTO_SMALL_BATCH_MAX;
+constexpr int SMALL_TPB = 256;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return x + __hiloint2double(hi2, lo2);
+}
+
+// Sum over the 64 lanes of a wave, returned in every lane (wave-uniform). Inclusive scan within each row of 16 lanes by
+// row_shr:1,2,4,8 (lanes without a source add 0), then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3:
+// lane 63 holds the total; a fixed tree, so the rounding is the same every run.
+__device__ __forceinline__ double wave_sum(double x) {
+    x = dpp_add<0x111, 0xf>(x);
+    x = dpp_add<0x112, 0xf>(x);
+    x = dpp_add<0x114, 0xf>(x);
+    x = dpp_add<0x118, 0xf>(x);
+    x = dpp_add<0x142, 0xa>(x);
+    x = dpp_add<0x143, 0xc>(x);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double lane_value(double x, int src_lane) {      // src_lane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void pc_from_setup(PC& pc, const double (&v)[NWC]) {
+    pc.invP = v[WC_INVP]; pc.tp = v[WC_TP]; pc.e = v[WC_E]; pc.beta = v[WC_BETA]; pc.eob = v[WC_EOB];
+    pc.cB = v[WC_CB]; pc.cG = v[WC_CG]; pc.cA = v[WC_CA]; pc.cF = v[WC_CF]; pc.K = v[WC_K]; pc.cw = v[WC_COSW]; pc.sw = v[WC_SINW];
+    pc.mu = v[WC_MU]; pc.a = v[WC_A]; pc.cGb = v[WC_CGB]; pc.cFb = v[WC_CFB]; pc.cBe = v[WC_CBE]; pc.cAe = v[WC_CAE];
+    const float2 fa = *reinterpret_cast<const float2*>(&v[WC_F32A]);
+    const float2 fb = *reinterpret_cast<const float2*>(&v[WC_F32B]);
+    pc.ef = fa.x; pc.omef = fa.y; pc.k1f = fb.x;
+}
+
+template <int P, bool GRAD, bool NUIS, int KM>
+__global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, int32_t* __restrict__ counters, uint64_t* done_flags, uint64_t seq) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    constexpr int NACC = L::NACC;
+    constexpr int NW = SMALL_TPB / WAVE;
+    __shared__ double red[NW][NACC];
+    __shared__ double tot[NACC];
+    __shared__ int last_flag;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef OCTO_SMALL_TRACE
+    unsigned long long tr[8]; int ntr = 0;
+#define TRACE_POINT() tr[ntr++] = __builtin_readcyclecounter()
+#else
+#define TRACE_POINT()
+#endif
+    TRACE_POINT();
+    const int64_t w = blockIdx.y;                       // this block's walker (wave-uniform)
+    const int64_t wi = w * a.ws_in, wo = w * a.ws_out;  // its offset in the input and the output rows
+    const int task = blockIdx.x;
+    const bool has_task = task < a.n_tasks;
+
+    // ---- orbit constants of this walker (what k_setup would have written to `wc`)
+    PC pc[P];
+    FinPC fp[P];
+    double elv[P][OCTO_N_EL];
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const SetupOut so = setup_planet<true>(a, p, wi);
+        pc_from_setup(pc[p], so.v);
+#pragma unroll
+        for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = so.el[k];
+        fp[p].sma = so.v[WC_A]; fp[p].P_d = 1.0 / so.v[WC_INVP]; fp[p].beta = so.v[WC_BETA];
+        fp[p].si = so.v[WC_SINI]; fp[p].ci = so.v[WC_COSI]; fp[p].sO = so.v[WC_SINO]; fp[p].cO = so.v[WC_COSO];
+        fp[p].sw = so.v[WC_SINW]; fp[p].cw = so.v[WC_COSW];
+        ok = ok && so.ok;
+    }
+
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    TRACE_POINT();      // setup done
+    if (has_task) {
+        const Task tk = a.tasks[task];
+        const DevObs ob = a.obs[tk.obs];
+        LogProd lp;
+        int my_rows = 0;
+        const SinCosTab notab{nullptr, 0.0};
+        const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_RADEC ||
+                               ob.kind == OCTO_ONEIL_SEPPA;
+        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)tk.row0 * ROW_STRIDE;
+        if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
+            const AstromCoef<P> co = astrom_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, ob.kind, ob.planet, ob.has_cor, tk.obs, pc, wi);
+            for (int r = threadIdx.x; r < tk.nrows; r += SMALL_TPB) {
+                const double* __restrict__ rw = rows + (int64_t)r * ROW_STRIDE;
+                astrom_row<P, GRAD, NUIS, KM, false>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], notab);
+                ++my_rows;
+            }
+        }
+        if (L::HAS_RV && !is_astrom) {
+            const RvCoef<P> co = rv_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, nullptr, a.ldw, ob.kind, ob.planet, tk.obs, pc, wi);
+            for (int r = threadIdx.x; r < tk.nrows; r += SMALL_TPB) {
+                const double* __restrict__ rw = rows + (int64_t)r * ROW_STRIDE;
+                rv_row<P, GRAD, NUIS, KM, false>(acc, lp, pc, co, rw[0], rw[1], rw[2], notab);
+                ++my_rows;
+            }
+        }
+        if constexpr (NUIS) {
+            double lg = lp.log_value();      // a lane without rows: log(1) = 0
+            if ((KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG) lg = fma((double)my_rows, LOG2PI, lg);
+            acc[L::OFF_S] += lg;
+        }
+    }
+    TRACE_POINT();      // rows done
+    // ---- lanes -> wave (DPP), waves -> block (LDS), fixed order
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const double sum = wave_sum(acc[k]);
+        if (lane == 0) red[wv][k] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double x = red[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) x += red[q][threadIdx.x];
+        tot[threadIdx.x] = x;
+    }
+    __syncthreads();
+    TRACE_POINT();      // block reduction done
+    const int n_tasks = a.n_tasks;
+    const bool multi = n_tasks > 1;
+    if (multi) {
+        // publish this block's partial; device-scope atomic stores are written through, so no L2 write-back fence is needed
+        if (threadIdx.x < NACC)
+            __hip_atomic_store(a.partials + ((int64_t)w * n_tasks + task) * NACC + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above have completed (s_waitcnt vmcnt(0))
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(&counters[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = (old == n_tasks - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    // ---- finish (the single / last block). All 256 threads gather the task partials — thread (slot, k) sums tasks slot,
+    // slot + NTS, … of running sum k, plain loads (the acquire fence above made them coherent), several in flight — then wave 0
+    // combines the slots in order: lane k owns running sum k. The order is fixed, whichever block got here.
+    TRACE_POINT();      // last block known
+    constexpr int NTS = SMALL_TPB / WAVE;      // independent of NACC: the forward-only and the gradient launch sum in the same order
+    __shared__ double psum[NTS * NACC];
+    const int slot = lane < NACC ? wv : NTS, kcol = lane < NACC ? lane : 0;
+    if constexpr (NUIS) {      // every nuisance finite (k_setup's check)
+        bool fin = true;
+        for (int k = lane; k < a.n_obs * OCTO_N_NUIS; k += WAVE) fin = fin && isfinite(a.nuis[(int64_t)k * a.ld + wi]);
+        ok = ok && __all(fin);
+    }
+    double gp_acc = 0.0, ll = 0.0;
+    double oneil_g[oneil_slots<P, GRAD, NUIS, KM>()];
+#pragma unroll
+    for (int k = 0; k < oneil_slots<P, GRAD, NUIS, KM>(); ++k) oneil_g[k] = 0.0;
+    double sma_p[P], e_p[P], M_p[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { sma_p[p] = fp[p].sma; e_p[p] = elv[p][OCTO_EL_E]; M_p[p] = elv[p][OCTO_EL_M]; }
+    for (int o = 0; o < a.n_obs; ++o) {
+        const int t0 = a.obs_range[2 * o], t1 = a.obs_range[2 * o + 1];
+        if (slot < NTS) {
+            double s = 0.0;
+            if (multi) {
+                const double* __restrict__ pp = a.partials + (int64_t)w * n_tasks * NACC + kcol;      // [walker][task][NACC]
+#pragma unroll 8
+                for (int t = t0 + slot; t < t1; t += NTS) s += pp[(int64_t)t * NACC];
+            } else if (slot == 0 && t1 > t0) {
+                s = tot[kcol];
+            }
+            psum[slot * NACC + kcol] = s;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            double sum = 0.0;
+            if (lane < NACC) {
+#pragma unroll
+                for (int q = 0; q < NTS; ++q) sum += psum[q * NACC + lane];
+            }
+            gp_acc += sum;
+            double v[NOBS_ACC];
+#pragma unroll
+            for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
+            v[0] = lane_value(sum, L::OFF_S);
+            if constexpr (L::HAS_MARG) { v[1] = lane_value(sum, L::OFF_MARG); v[2] = lane_value(sum, L::OFF_MARG + 1); v[3] = lane_value(sum, L::OFF_MARG + 2); }
+            if constexpr (L::N_NU > 0) { v[4] = lane_value(sum, L::OFF_NU); v[5] = lane_value(sum, L::OFF_NU + 1); v[6] = lane_value(sum, L::OFF_NU + 2); }
+            if constexpr (L::HAS_ONEIL) {
+                v[7] = lane_value(sum, L::OFF_ONEIL);
+                if constexpr (GRAD) { v[8] = lane_value(sum, L::OFF_ONEIL + 1); v[9] = lane_value(sum, L::OFF_ONEIL + 2); v[10] = lane_value(sum, L::OFF_ONEIL + 3); }
+            }
+            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, a.g_nuis, nullptr, a.ldw, a.c.k_yr, o, v, a.obs_const[o], sma_p, e_p, M_p, wo, lane == 0, oneil_g);
+        }
+        __syncthreads();
+    }
+    if (wv != 0) return;
+    TRACE_POINT();      // observations finished
+    double gp[P * L::PL_N > 0 ? P * L::PL_N : 1];
+#pragma unroll
+    for (int k = 0; k < P * L::PL_N; ++k) gp[k] = lane_value(gp_acc, L::OFF_PL + k);
+    if (multi && lane == 0) __hip_atomic_store(&counters[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    ok = ok && isfinite(ll);
+    if (lane != 0) return;
+    a.ll_out[wo] = ok ? ll : -INFINITY;
+    if constexpr (GRAD) {
+        if (!ok && L::N_NU > 0) {
+            for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + wo] = 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            planet_finish<P, GRAD, NUIS, KM, true>(elv[p], a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p],
+                                             p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp[p], ok);
+    }
+    TRACE_POINT();      // outputs stored
+    // host-buffer calls: this walker's results are in (mapped, coherent) host memory — release them to the host, which spins
+    // on the flag instead of paying a stream synchronisation
+    if (done_flags) __hip_atomic_store(done_flags + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef OCTO_SMALL_TRACE
+    TRACE_POINT();
+    if (done_flags && w == 0) for (int k = 0; k < ntr; ++k) done_flags[40 + k] = tr[k];      // h_flags has room behind the SMALL_W flags
+#endif
 }
 
 // ==================================================================================== OFTI

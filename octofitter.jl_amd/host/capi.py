@@ -28,6 +28,7 @@ NU_JITTER, NU_PLATESCALE, NU_NORTHANGLE = 0, 1, 2
 NU_RV_OFFSET, NU_RV_JITTER = 0, 1
 
 c_double_p = C.POINTER(C.c_double)
+STREAM_CTX = C.c_void_p(-1)      # OCTO_STREAM_CTX: the context's own stream (NULL = HIP's NULL stream, e.g. torch's default stream)
 
 
 class OctoConsts(C.Structure):
@@ -125,6 +126,7 @@ _SIGS = {
     "octo_ctx_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32]),
     "octo_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "octo_consts_set": (C.c_int32, [C.c_void_p, C.POINTER(OctoConsts)]),
+    "octo_ctx_set_small_batch": (C.c_int32, [C.c_void_p, C.c_int32]),
     "octo_last_error": (C.c_char_p, [C.c_void_p]),
     "octo_dataset_create": (C.c_int32, [C.c_void_p, C.POINTER(OctoObsDesc), C.c_int32,
                                         C.POINTER(OctoPlanetDesc), C.c_int32, C.POINTER(C.c_void_p)]),
@@ -148,6 +150,7 @@ _SIGS = {
     "octo_model_logpost_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "octo_timing_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "octo_timing_read": (C.c_int32, [C.c_void_p, c_double_p, C.POINTER(C.c_int64), C.c_int32]),
+    "octo_timing_stats": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
     "octo_pt_swap_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                         C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
 }

@@ -267,8 +267,10 @@ class BatchedLnLike:
 
     # -- evaluation: device-resident torch tensors (plumbing for bench / sharded drivers) -------------
     def ln_like_device(self, elems_t, nuis_t=None, grad=False, out=None, stream=None):
-        """elems_t: torch float64 CUDA tensor [P*9, W] (contiguous). Enqueues on torch's current stream
-        unless `stream` (a raw hipStream_t integer) is given. Returns torch tensors; asynchronous."""
+        """elems_t: torch float64 CUDA tensor [P*9, W] (contiguous). Enqueues on torch's CURRENT stream — its raw handle is
+        handed to the C ABI as it is (0 = HIP's NULL stream when no torch stream is active), so the kernels are ordered
+        after the torch ops that produced the inputs and before the ones that consume the outputs — unless `stream`
+        (a raw hipStream_t integer, or capi.STREAM_CTX for the context's own stream) is given. Asynchronous."""
         import torch
         assert elems_t.is_cuda and elems_t.dtype == torch.float64 and elems_t.is_contiguous()
         W = elems_t.shape[1]
@@ -280,10 +282,12 @@ class BatchedLnLike:
             ll, g_el, g_nu = out
         if stream is None:
             stream = torch.cuda.current_stream(elems_t.device).cuda_stream
+        if not isinstance(stream, C.c_void_p):
+            stream = C.c_void_p(stream)
         self._check(self.lib.octo_eval_device(
             self._ctx, self._ds, elems_t.data_ptr(), nuis_t.data_ptr() if nuis_t is not None else None, W, W,
             ll.data_ptr(), g_el.data_ptr() if g_el is not None else None, g_nu.data_ptr() if g_nu is not None else None,
-            C.c_void_p(stream)), "octo_eval_device")
+            stream), "octo_eval_device")
         return (ll, g_el, g_nu) if grad else ll
 
     def sync(self):
@@ -291,6 +295,12 @@ class BatchedLnLike:
 
     def timing_enable(self, on=True):
         self._check(self.lib.octo_timing_enable(self._ctx, int(on)), "octo_timing_enable")
+
+    def timing_stats(self):
+        """(median_ms, min_ms, max_ms, n) over the individual timed launches since the last reset."""
+        med, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.octo_timing_stats(self._ctx, C.byref(med), C.byref(lo), C.byref(hi), C.byref(n)), "octo_timing_stats")
+        return med.value, lo.value, hi.value, n.value
 
     def timing_read(self, reset=True):
         ms = C.c_double()

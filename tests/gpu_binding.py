@@ -12,7 +12,7 @@ capi = pkg.capi
 
 
 class GpuPath:
-    def __init__(self, obs_tables, planets, device=0, consts=None):
+    def __init__(self, obs_tables, planets, device=0, consts=None, small_batch=None):
         self.lib = capi.load_library()
         self.ctx = C.c_void_p()
         st = self.lib.octo_ctx_create(C.byref(self.ctx), device)
@@ -20,6 +20,8 @@ class GpuPath:
             raise capi.OctoError(st, "octo_ctx_create")
         if consts is not None:
             self._chk(self.lib.octo_consts_set(self.ctx, C.byref(consts)))
+        if small_batch is not None:      # 0: force the throughput kernels (lane = walker) also for tiny batches
+            self._chk(self.lib.octo_ctx_set_small_batch(self.ctx, int(small_batch)))
         obs_arr, keep = capi.pack_obs(obs_tables)
         pl_arr = capi.pack_planets(planets)
         self.ds = C.c_void_p()
@@ -54,6 +56,6 @@ class GpuPath:
         self.close()
 
 
-def gpu_eval(obs_tables, planets, elems, nuis=None, grad=True, consts=None):
-    with GpuPath(obs_tables, planets, consts=consts) as g:
+def gpu_eval(obs_tables, planets, elems, nuis=None, grad=True, consts=None, small_batch=None):
+    with GpuPath(obs_tables, planets, consts=consts, small_batch=small_batch) as g:
         return g.eval(elems, nuis, grad)

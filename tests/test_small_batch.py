@@ -1,0 +1,130 @@
+"""
+GPU parity of the small-batch path (-m gpu): octo_eval with W <= 32 takes the fused single-launch kernel k_small — epochs across
+the 64 lanes, DPP/LDS tree reduction, last-block finish, inputs/outputs in mapped pinned memory (what a sampler that evaluates
+ONE θ per call pays: src/logdensitymodel.jl:169-177, src/likelihoods/system.jl:257-269). Checked against the oracle at
+W ∈ {1, 2, 31, 32, 33} (33 is the first size on the throughput kernels) and against the throughput kernels on the same inputs
+(same math, different summation order: equal to rounding, not bitwise).
+"""
+import numpy as np
+import pytest
+
+import synth
+from conftest import case_tables, rel_err
+from test_gpu_parity import _cmp_oracle, _gpu
+from test_oracle import grad_ok
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(obs, planets, elems, nuis):
+    gb = _gpu()
+    small = gb.gpu_eval(obs, planets, elems, nuis, grad=True)
+    small_f = gb.gpu_eval(obs, planets, elems, nuis, grad=False)
+    big = gb.gpu_eval(obs, planets, elems, nuis, grad=True, small_batch=0)
+    assert np.array_equal(small[0], small_f[0]), "forward-only and gradient launches disagree"
+    return small, big
+
+
+def _close(small, big, tol=2e-12):
+    ll, g, gn = small
+    ll_b, g_b, gn_b = big
+    fin = np.isfinite(ll_b)
+    assert np.array_equal(np.isfinite(ll), fin)
+    assert np.all(np.abs(ll[fin] - ll_b[fin]) <= tol * np.maximum(1.0, np.abs(ll_b[fin])))
+    sc = np.maximum(np.abs(g_b).max(axis=1, keepdims=True), 1e-300)
+    assert np.all(np.abs(g - g_b) <= 1e-10 * sc), np.max(np.abs(g - g_b) / sc)
+    if gn is not None:
+        sc = np.maximum(np.abs(gn_b).max(axis=1, keepdims=True), 1e-300)
+        assert np.all(np.abs(gn - gn_b) <= 1e-10 * sc)
+
+
+@pytest.mark.parametrize("n_walkers", [1, 2, 31, 32, 33])
+@pytest.mark.parametrize("n_epochs", [1, 50, 300, 10_000])
+def test_astrometry_small_batches_vs_oracle(oracle, n_epochs, n_walkers):
+    cfg = synth.config_astrom(n_epochs=n_epochs, n_walkers=n_walkers, seed=7000 + n_epochs + n_walkers)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    small, big = _both(obs, planets, cfg["elems"], None)
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, cfg["elems"], None, grad=True, active=synth.active_mask(1, 1, mass=False, nuis=False))
+    _cmp_oracle(f"small {n_epochs}x{n_walkers}", small[0], small[1], None, ll_o, g_o, None)
+    _close(small, big)
+    # bit-reproducible run to run (fixed reduction tree, partials summed in task order whichever block finishes last)
+    again = _gpu().gpu_eval(obs, planets, cfg["elems"], None, grad=True)
+    assert np.array_equal(small[0], again[0]) and np.array_equal(small[1], again[1])
+
+
+@pytest.mark.parametrize("n_walkers", [1, 5, 32])
+def test_all_kinds_two_planets_small_batches(oracle, n_walkers):
+    """Two planets, every epoch-loop kind (RA/Dec with cor, sep/PA, relative RV, absolute RV; nuisances) — the forward value of a
+    dataset with a marginalised-RV table also takes k_small, its gradient needs the μ̂ pre-pass and stays on the throughput path."""
+    cfg = synth.config_two_planet(n_astrom=300, n_rv=280, n_walkers=n_walkers, seed=5)
+    a, r = cfg["astrom"], cfg["rv"]
+    rng = np.random.default_rng(9)
+    n = len(a["epoch"])
+    pa = np.arctan2(a["ra"], a["dec"]); sep = np.hypot(a["ra"], a["dec"])
+    obs = [
+        dict(kind=0, planet=1, epoch=a["epoch"], y1=a["ra"], y2=a["dec"], s1=a["σ_ra"], s2=a["σ_dec"], cor=rng.uniform(-0.7, 0.7, n)),
+        dict(kind=1, planet=1, epoch=a["epoch"] + 0.5, y1=pa, y2=sep, s1=np.full(n, 0.02), s2=a["σ_ra"], cor=None),
+        dict(kind=0, planet=0, epoch=a["epoch"][:50], y1=a["ra"][:50] * 0.2, y2=a["dec"][:50] * 0.2, s1=a["σ_ra"][:50], s2=a["σ_dec"][:50], cor=None),
+        dict(kind=4, planet=1, epoch=r["epoch"], y1=r["rv"] * 30, y2=None, s1=r["σ_rv"] * 10, s2=None, cor=None),
+        dict(kind=2, planet=-1, epoch=r["epoch"], y1=r["rv"], y2=None, s1=r["σ_rv"], s2=None, cor=None),
+    ]
+    planets = [dict(orbit_kind=0, has_mass=True), dict(orbit_kind=0, has_mass=True)]
+    W = n_walkers
+    nuis = np.zeros((len(obs) * 3, W))
+    for o in range(3):
+        nuis[o * 3 + 0] = rng.uniform(0, 5, W); nuis[o * 3 + 1] = rng.normal(1, 0.01, W); nuis[o * 3 + 2] = rng.normal(0, 0.01, W)
+    nuis[0, : W // 2] = 0.0
+    for o in range(3, 5):
+        nuis[o * 3 + 0] = rng.normal(10, 3, W); nuis[o * 3 + 1] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+    elems = cfg["elems"].copy()
+    elems[9 + 0, : W // 3] = elems[0, : W // 3] * 0.5      # "outer" planet inside the "inner" one for some walkers
+    for nz in (nuis, None):
+        small, big = _both(obs, planets, elems, nz)
+        ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, elems, nz, grad=True)
+        _cmp_oracle("all kinds small", small[0], small[1], small[2], ll_o, g_o, gn_o, ll_rtol=1e-11, g_rtol=1e-8)
+        _close(small, big, tol=1e-11)
+    # marginalised RV: forward through k_small, value equal to the throughput path
+    obs_m = obs + [dict(kind=3, planet=-1, epoch=r["epoch"][::2], y1=r["rv"][::2] + 3.0, y2=None, s1=r["σ_rv"][::2] * 1.5, s2=None, cor=None)]
+    nuis_m = np.concatenate([nuis, np.stack([np.zeros(W), np.exp(rng.uniform(np.log(0.1), np.log(10), W)), np.zeros(W)])])
+    gb = _gpu()
+    ll_s, _, _ = gb.gpu_eval(obs_m, planets, elems, nuis_m, grad=False)
+    ll_b, _, _ = gb.gpu_eval(obs_m, planets, elems, nuis_m, grad=False, small_batch=0)
+    ll_g, _, _ = gb.gpu_eval(obs_m, planets, elems, nuis_m, grad=True)
+    ll_o, _, _ = oracle.oracle_eval(obs_m, planets, elems, nuis_m, grad=False)
+    assert np.all(rel_err(ll_s, ll_o, 1.0) < 1e-9) and np.all(rel_err(ll_s, ll_b, 1.0) < 1e-9) and np.all(rel_err(ll_g, ll_o, 1.0) < 1e-9)
+
+
+def test_golden_vectors_small_and_throughput_paths(golden):
+    """Every committed 50/60-digit fixture through BOTH kernel families (the fixtures hold 1-16 walkers, so the default route is
+    k_small; small_batch=0 forces k_setup/k_main/k_finish)."""
+    gb = _gpu()
+    for case in golden["cases"]:
+        obs, planets, elems, nuis = case_tables(case)
+        has_marg = any(ob["kind"] == "RV_ABS_MARG" for ob in case["obs"])
+        for sb in (None, 0):
+            ll, g_el, g_nu = gb.gpu_eval(obs, planets, elems, nuis, grad=True, small_batch=sb)
+            err = rel_err(ll, np.asarray(case["ll"]), 1.0)
+            assert np.all(err < (1e-9 if has_marg else 1e-12)), (case["name"], sb, "ll", err.max())
+            rtol, cancel = (1e-9, 1e-10) if (has_marg or case["name"] == "F7_kepler_edges") else (1e-9, 1e-13)
+            ok, worst = grad_ok(g_el, case["g_elems"], case["s_elems"], rtol=rtol, cancel=cancel)
+            assert ok, (case["name"], sb, "g_elems", worst)
+            if nuis is not None:
+                ok, worst = grad_ok(g_nu, case["g_nuis"], case["s_nuis"], rtol=rtol, cancel=cancel)
+                assert ok, (case["name"], sb, "g_nuis", worst)
+
+
+def test_invalid_walkers_small_batch():
+    gb = _gpu()
+    cfg = synth.config_astrom(n_epochs=700, n_walkers=8, seed=3)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    el = cfg["elems"].copy()
+    ref, gref, _ = gb.gpu_eval(obs, planets, el, None, grad=True)
+    bad = el.copy()
+    bad[1, 0] = 1.0; bad[1, 1] = -0.1; bad[0, 2] = -3.0; bad[6, 3] = 0.0; bad[5, 4] = np.nan; bad[1, 5] = 1e30; bad[3, 6] = np.inf
+    ll, g, _ = gb.gpu_eval(obs, planets, bad, None, grad=True)
+    assert np.all(np.isneginf(ll[:7])) and np.all(g[:, :7] == 0.0)
+    assert ll[7] == ref[7] and np.array_equal(g[:, 7], gref[:, 7])      # a neighbour's garbage does not leak

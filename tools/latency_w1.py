@@ -1,6 +1,9 @@
-"""Latency of ONE parameter set through the host-buffer entry point (what a single-chain sampler pays per gradient):
-octo_eval with W = 1, for a 50-epoch and a 1e4-epoch table. Development aid."""
-import sys, time
+"""Latency of small batches through the host-buffer entry points (what a single-chain sampler pays per gradient, and Pigeons'
+32 replicas per sweep): octo_eval at W ∈ {1, 32} for a 50-epoch and a 1e4-epoch table, and octo_model_logpost for one θ_t
+(the whole ∇ℓπcallback, src/logdensitymodel.jl:169-177). The C calls are timed with prebuilt ctypes arguments, so the number is the
+call itself (+ ~1 µs of ctypes dispatch), not NumPy wrapper overhead. `small_batch=0` rows: the same call forced onto the
+throughput kernels (3 launches + staging copies), i.e. the round-1 path.   python tools/latency_w1.py"""
+import ctypes as C, json, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
@@ -8,24 +11,39 @@ import numpy as np
 from __graft_entry__ import load_package
 import synth
 pkg = load_package()
-for E in (50, 10000):
-    cfg = synth.config_astrom(n_epochs=E, n_walkers=1, cfg=3)
-    obs, planet = synth.to_mirror(pkg, cfg)
-    fn = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
-    el = np.ascontiguousarray(cfg["elems"])
-    for grad in (False, True):
-        for _ in range(200): fn.ln_like_arrays(el, None, grad=grad)
-        t0 = time.perf_counter(); n = 2000
-        for _ in range(n): fn.ln_like_arrays(el, None, grad=grad)
-        dt = (time.perf_counter() - t0) / n
-        print(f"E={E:6d} W=1 grad={grad}: {dt*1e6:7.1f} us per call (Python + ctypes + H2D + 3 kernels + D2H + sync)", flush=True)
-    fn.close()
+capi = pkg.capi
+out = {}
 
-# the whole callback for one θ_t: what AdvancedHMC's leapfrog calls (model.∇ℓπcallback, src/logdensitymodel.jl:169-177)
-import json
+
+def time_call(f, n=3000, warm=300):
+    for _ in range(warm): f()
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(n // 5): f()
+        best = min(best, (time.perf_counter() - t0) / (n // 5))
+    return best * 1e6
+
+
+for E in (50, 10000):
+    for W in (1, 32):
+        cfg = synth.config_astrom(n_epochs=E, n_walkers=W, cfg=3)
+        obs, planet = synth.to_mirror(pkg, cfg)
+        fn = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
+        el = np.ascontiguousarray(cfg["elems"]); ll = np.empty(W); g = np.empty_like(el)
+        for sb in (None, 0):
+            fn._check(fn.lib.octo_ctx_set_small_batch(fn._ctx, 32 if sb is None else 0), "set")
+            for grad in (False, True):
+                args = (fn._ctx, fn._ds, capi._dptr(el), None, W, W, capi._dptr(ll), capi._dptr(g) if grad else None, None)
+                us = time_call(lambda: fn.lib.octo_eval(*args))
+                key = f"octo_eval E={E} W={W} grad={int(grad)} {'small-batch kernel' if sb is None else 'throughput kernels'}"
+                out[key] = us
+                print(f"{key:78s} {us:7.1f} us", flush=True)
+        fn.close()
+
 case = json.loads((ROOT / "tests" / "golden" / "model.json").read_text())["cases"][0]
 o = case["obs"][0]
-for E in (8, 10000):
+for E in (8, 50, 10000):
     if E == 8:
         table = dict(epoch=o["epoch"], ra=o["y1"], dec=o["y2"], σ_ra=o["s1"], σ_dec=o["s2"], cor=o["cor"])
     else:
@@ -36,9 +54,15 @@ for E in (8, 10000):
                                            Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
     model = pkg.LogDensityModel(pkg.System(name="T", companions=[b], observations=[],
                                 variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))))
-    th = np.asarray(case["theta_t"])[:, 0].copy()
-    for _ in range(200): model.logdensity_and_gradient(th)
-    t0 = time.perf_counter(); n = 2000
-    for _ in range(n): model.logdensity_and_gradient(th)
-    print(f"E={E:6d} D=11 one theta_t, log-posterior + gradient: {(time.perf_counter() - t0) / n * 1e6:7.1f} us per call", flush=True)
+    fn = model.ln_like
+    th = np.ascontiguousarray(np.asarray(case["theta_t"])[:, :1]); lp = np.empty(1); g = np.empty_like(th)
+    for sb in (None, 0):
+        fn._check(fn.lib.octo_ctx_set_small_batch(fn._ctx, 32 if sb is None else 0), "set")
+        args = (fn._ctx, model._m, capi._dptr(th), 1, 1, capi._dptr(lp), capi._dptr(g))
+        us = time_call(lambda: fn.lib.octo_model_logpost(*args))
+        key = f"octo_model_logpost D=11 E={E} one theta_t, value+gradient {'small-batch kernel' if sb is None else 'throughput kernels'}"
+        out[key] = us
+        print(f"{key:78s} {us:7.1f} us", flush=True)
     model.close()
+Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
+(ROOT / "gpurun_out" / "latency_w1.json").write_text(json.dumps(out, indent=1))

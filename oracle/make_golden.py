@@ -293,6 +293,36 @@ def model_cases():
     print("wrote", p, p.stat().st_size, "bytes")
 
 
+def config1_case():
+    """tests/golden/config1.json — BASELINE config 1 as SURVEY.md §8(d) defines it: the D = 11 model of
+    test/integration/sampling.jl:29-64 (same priors and derived tp as model_cases (1)) on 50 RA/Dec epochs t_j = 50000 + 17·j,
+    σ = 10 mas (truth orbit of examples/ofti_rejection_sampling.jl:26-35 + seeded N(0, 10²) noise), ONE parameter set per call:
+    log-posterior and its 11 partials at 60 digits, for 4 θ_t (each evaluated as its own W = 1 call by the tests)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import synth
+    rng = np.random.default_rng(20260929 + 1)
+    P = lambda kind, p0=0.0, p1=0.0, lo=None, hi=None: dict(kind=kind, p0=p0, p1=p1, lo=lo, hi=hi)
+    S = lambda kind, i0=0, i1=0, flags=0, value=0.0: dict(kind=kind, i0=i0, i1=i1, flags=flags, value=value)
+    N01 = P(2, 0.0, 1.0)
+    t = 50000.0 + 17.0 * np.arange(50)
+    ra, dec = synth.truth_radec(t)
+    ra = ra + rng.normal(0, 10.0, 50); dec = dec + rng.normal(0, 10.0, 50)
+    obs = [astrom(0, t, ra, dec, [10.0] * 50, [10.0] * 50)]
+    priors = [P(3, 1.2, 0.1, 0.1, None), P(3, 50.0, 0.02, 0.1, None), P(0, 0.0, 100.0), P(0, 0.0, 0.99), P(4)] + [N01] * 6
+    esrc = [S(1, 2), S(1, 3), S(1, 4), S(2, 5, 6, 1, 2 * np.pi), S(2, 7, 8, 1, 2 * np.pi), S(3, 9, 10, 1, 50000.0), S(1, 0), S(1, 1), S(0)]
+    W = 4
+    th = rng.normal(0, 1, (11, W))
+    th[2] = rng.normal(-2.2, 0.3, W)          # a = 100·logistic(·) ~ 7-14 AU
+    th[0] = np.log(rng.normal(1.2, 0.05, W) - 0.1); th[1] = np.log(rng.normal(50.0, 0.02, W) - 0.1)
+    res = [mpo.model_logpost_and_grad(C, [VIS], obs, priors, esrc, None, list(th[:, w])) for w in range(W)]
+    case = dict(name="config1_D11_50_epochs", planets=[VIS], obs=obs, priors=priors, esrc=esrc, nsrc=None, theta_t=th.tolist(),
+                lp=[fl(r[0]) for r in res], grad=np.array([[fl(v) for v in r[1]] for r in res]).T.tolist())
+    print(f"  config1: lp={case['lp']}", flush=True)
+    p = ROOT / "tests" / "golden" / "config1.json"
+    p.write_text(json.dumps(dict(consts=C, cases=[case], generator="oracle/make_golden.py config1_case (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 def hgca_table(hg, N_ave, factor=1.0):
     """Rows and catalogue numbers of an HGCAInstantaneousObs built from a catalogue row (src/likelihoods/hgca.jl:80-145),
     in the C-ABI form (include/octofitter_hip.h: OCTO_HGCA)."""
@@ -410,7 +440,7 @@ def ti_cases():
 
 if __name__ == "__main__":
     sys.path.insert(0, str(ROOT / "oracle"))
-    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only") if f in sys.argv]
+    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only") if f in sys.argv]
     if not only:
         main()
     if not only or "--ofti-only" in only:
@@ -421,3 +451,5 @@ if __name__ == "__main__":
         hgca_cases()
     if not only or "--ti-only" in only:
         ti_cases()
+    if not only or "--config1-only" in only:
+        config1_case()

@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import oracle_binding as ob, gpu_binding as gb, synth
 
-for E, W in ((1000, 1_000_000), (100_000, 20_000)):
+for E, W in ((1000, 1_000_000), (100_000, 20_000)):      # tests/test_sweeps_gpu.py runs the first shape under pytest -m gpu
     cfg = synth.config_astrom(n_epochs=E, n_walkers=W, cfg=3, seed=123)
     t = cfg["table"]
     obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]

@@ -2,7 +2,8 @@
 Thiele-Innes, radial-velocity-only), random subsets of every observation kind incl. the O'Neil wrapper and HGCA, with and
 without the nuisance block, random table and batch sizes (ragged tiles). Run on a GPU box:
     python tests/stress_parity.py [n_systems] [seed]
-Prints the worst errors; exits non-zero if a case breaks the bars of tests/test_gpu_parity.py. Not collected by pytest."""
+Prints the worst errors; exits non-zero if a case breaks the bars of tests/test_gpu_parity.py. tests/test_sweeps_gpu.py runs a
+fixed-seed slice of the same sweep under pytest -m gpu."""
 import sys
 from pathlib import Path
 import numpy as np
@@ -81,6 +82,40 @@ def random_system(rng, invalid=True):
     return obs, planets, elems, (nuis if use_nuis else None)
 
 
+def check_system(sysm):
+    """GPU vs oracle for one random system: returns (ok, e_ll, e_grad, loose) with the bars of tests/test_gpu_parity.py."""
+    obs, planets, elems, nuis = sysm
+    ll, g, gn = gb.gpu_eval(obs, planets, elems, nuis, grad=True)
+    llf, _, _ = gb.gpu_eval(obs, planets, elems, nuis, grad=False)
+    ll_o, g_o, gn_o = ob.oracle_eval(obs, planets, elems, nuis, grad=True, n_threads=0)
+    ok = np.isfinite(ll_o)
+    same = np.array_equal(ll, llf) and np.array_equal(np.isfinite(ll), ok) and np.all(np.isneginf(ll[~ok])) and np.all(g[:, ~ok] == 0.0)
+    e_ll = np.max(np.abs(ll[ok] - ll_o[ok]) / np.maximum(1, np.abs(ll_o[ok]))) if ok.any() else 0.0
+    G = np.concatenate([g] + ([gn] if gn is not None else [])); Go = np.concatenate([g_o] + ([gn_o] if gn_o is not None else []))
+    # per-input scale, floored: an input the likelihood does not depend on has a true gradient of 0 ± rounding noise
+    scale = np.maximum(np.abs(Go[:, ok]).max(axis=1, keepdims=True), 1e-10 * np.abs(Go[:, ok]).max()) if ok.any() else 1.0
+    e_g = np.max(np.abs(G[:, ok] - Go[:, ok]) / np.maximum(scale, 1e-300)) if ok.any() else 0.0
+    marg = any(o["kind"] == 3 for o in obs)
+    ti = any(p["orbit_kind"] == 2 for p in planets)
+    # marginalised RV: cancellation in the reference's formula (rv-absolute-margin.jl:181). Thiele-Innes: a = α/plx with
+    # α² = u + √((u+v)(u−v)) loses digits in u − v near face-on orbits, in the reference's arithmetic as in ours.
+    lim_ll, lim_g = (1e-9, 1e-8) if marg else ((1e-10, 1e-7) if ti else (1e-12, 1e-9))
+    return bool(same and e_ll < lim_ll and e_g < lim_g), float(e_ll), float(e_g), bool(marg or ti)
+
+
+def draw_system(rng, invalid=True):
+    sysm = None
+    while sysm is None:
+        sysm = random_system(rng, invalid=invalid)
+    return sysm
+
+
+def describe(sysm):
+    obs, planets, elems, nuis = sysm
+    return (f"P={len(planets)} bases={[p['orbit_kind'] for p in planets]} kinds={[o['kind'] for o in obs]} "
+            f"rows={[len(o['epoch']) for o in obs]} W={elems.shape[1]} nuis={nuis is not None}")
+
+
 def main():
     global SCALE
     SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -89,30 +124,13 @@ def main():
     worst_ll = worst_g = 0.0
     bad = 0
     for k in range(n_sys):
-        sysm = None
-        while sysm is None:
-            sysm = random_system(rng)
-        obs, planets, elems, nuis = sysm
-        print(f"{k:3d} P={len(planets)} bases={[p['orbit_kind'] for p in planets]} kinds={[o['kind'] for o in obs]} rows={[len(o['epoch']) for o in obs]} W={elems.shape[1]} nuis={nuis is not None}: ", end="", flush=True)
-        ll, g, gn = gb.gpu_eval(obs, planets, elems, nuis, grad=True)
-        llf, _, _ = gb.gpu_eval(obs, planets, elems, nuis, grad=False)
-        ll_o, g_o, gn_o = ob.oracle_eval(obs, planets, elems, nuis, grad=True, n_threads=0)
-        ok = np.isfinite(ll_o)
-        same = np.array_equal(ll, llf) and np.array_equal(np.isfinite(ll), ok) and np.all(np.isneginf(ll[~ok])) and np.all(g[:, ~ok] == 0.0)
-        e_ll = np.max(np.abs(ll[ok] - ll_o[ok]) / np.maximum(1, np.abs(ll_o[ok]))) if ok.any() else 0.0
-        G = np.concatenate([g] + ([gn] if gn is not None else [])); Go = np.concatenate([g_o] + ([gn_o] if gn_o is not None else []))
-        # per-input scale, floored: an input the likelihood does not depend on has a true gradient of 0 ± rounding noise
-        scale = np.maximum(np.abs(Go[:, ok]).max(axis=1, keepdims=True), 1e-10 * np.abs(Go[:, ok]).max()) if ok.any() else 1.0
-        e_g = np.max(np.abs(G[:, ok] - Go[:, ok]) / np.maximum(scale, 1e-300)) if ok.any() else 0.0
-        marg = any(o["kind"] == 3 for o in obs)
-        ti = any(p["orbit_kind"] == 2 for p in planets)
-        # marginalised RV: cancellation in the reference's formula (rv-absolute-margin.jl:181). Thiele-Innes: a = α/plx with
-        # α² = u + √((u+v)(u−v)) loses digits in u − v near face-on orbits, in the reference's arithmetic as in ours.
-        lim_ll, lim_g = (1e-9, 1e-8) if marg else ((1e-10, 1e-7) if ti else (1e-12, 1e-9))
-        flag = "" if (same and e_ll < lim_ll and e_g < lim_g) else "   <-- FAIL"
-        bad += bool(flag)
-        worst_ll, worst_g = max(worst_ll, e_ll if not (marg or ti) else 0), max(worst_g, e_g if not (marg or ti) else 0)
-        print(f"ll {e_ll:.1e} grad/scale {e_g:.1e}{flag}", flush=True)
+        sysm = draw_system(rng)
+        print(f"{k:3d} {describe(sysm)}: ", end="", flush=True)
+        good, e_ll, e_g, loose = check_system(sysm)
+        bad += not good
+        if not loose:
+            worst_ll, worst_g = max(worst_ll, e_ll), max(worst_g, e_g)
+        print(f"ll {e_ll:.1e} grad/scale {e_g:.1e}{'' if good else '   <-- FAIL'}", flush=True)
     print(f"worst (no marginalised RV, no Thiele-Innes): ll {worst_ll:.2e} grad {worst_g:.2e}; failures {bad}")
     sys.exit(1 if bad else 0)
 

@@ -1,0 +1,161 @@
+"""
+BASELINE.json's configurations that round 1 measured only in bench.py, now under -m gpu at their FULL sizes:
+
+  config 1  D = 11 model of test/integration/sampling.jl:29-64 on 50 RA/Dec epochs t_j = 50000 + 17 j, ONE θ_t per call
+            (SURVEY.md §8d): log-posterior + gradient against the 60-digit fixture tests/golden/config1.json.
+  config 4  2 planets, 2500 RA/Dec + 2500 absolute-RV epochs × 4096 walkers with nuisances (kernel k_main<2, true, true, ·>,
+            one-round planner branch): determinism, forward == gradient value, a 24-walker oracle sample.
+  config 5  per-GPU shape of the tempered run, 8 temperatures × 1024 walkers × 1e4 epochs: TemperedSwap (world = 1) around
+            ln_like_device for several steps; log-likelihoods against the oracle on a seeded sample, slot2rep against the NumPy
+            restatement of the swap (ext/OctofitterPigeonsExt/OctofitterPigeonsExt.jl:115-126 is the reference's exchange step).
+  streams   the torch-facing wrappers run on torch's CURRENT stream: torch op -> logpost/ln_like -> torch op with no
+            device-wide synchronisation in between (the NULL stream handle used to mean "context stream").
+"""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import rel_err
+from test_gpu_parity import _cmp_oracle, _gpu, _pt_swap_reference
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _tables(case):
+    from conftest import KIND_IDS
+    obs = [dict(kind=KIND_IDS[o["kind"]], planet=o["planet"], **{k: (None if o[k] is None else np.asarray(o[k], dtype=np.float64))
+                                                                  for k in ("epoch", "y1", "y2", "s1", "s2", "cor")}) for o in case["obs"]]
+    return obs, case["planets"]
+
+
+def test_config1_one_theta_per_call(pkg, oracle):
+    case = json.loads((ROOT / "tests" / "golden" / "config1.json").read_text())["cases"][0]
+    o = case["obs"][0]
+    assert len(o["epoch"]) == 50 and o["epoch"][1] - o["epoch"][0] == 17.0
+    table = dict(epoch=o["epoch"], ra=o["y1"], dec=o["y2"], σ_ra=o["s1"], σ_dec=o["s2"])
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromLikelihood(table, name="astrom")],
+                   variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                           Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+    model = pkg.LogDensityModel(pkg.System(name="cfg1", companions=[b], observations=[],
+                                variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))))
+    assert model.D == 11
+    th = np.asarray(case["theta_t"])
+    for w in range(th.shape[1]):                      # one θ_t per call, as NUTS does (src/logdensitymodel.jl:169-177)
+        lp, g = model.logdensity_and_gradient(th[:, w])
+        assert abs(lp - case["lp"][w]) <= 1e-12 * abs(case["lp"][w]), (w, lp, case["lp"][w])
+        gref = np.asarray(case["grad"])[:, w]
+        assert np.all(np.abs(g - gref) <= 1e-9 * np.abs(gref) + 1e-10 * np.abs(gref).max()), (w, np.max(np.abs(g - gref) / np.abs(gref).max()))
+        assert model.ℓπcallback(th[:, w]) == lp
+    # the same four θ_t as one batch, and forced onto the throughput kernels
+    lp_b, g_b = model.logdensity_and_gradient(th)
+    assert np.all(rel_err(lp_b, np.asarray(case["lp"]), 1.0) < 1e-12)
+    fn = model.ln_like
+    fn._check(fn.lib.octo_ctx_set_small_batch(fn._ctx, 0), "octo_ctx_set_small_batch")
+    lp_t, g_t = model.logdensity_and_gradient(th)
+    assert np.all(rel_err(lp_t, lp_b, 1.0) < 1e-13) and np.all(np.abs(g_t - g_b) <= 1e-11 * np.abs(g_b).max(axis=1, keepdims=True))
+    obs, planets = _tables(case)
+    lp_o, g_o = oracle.oracle_model_logpost(obs, planets, model._c_priors, model._c_esrc, None, th)
+    assert np.all(np.abs(lp_b - lp_o) <= 1e-12 * np.abs(lp_o))
+    model.close()
+
+
+def test_config4_full_size(oracle):
+    gb = _gpu()
+    c4 = synth.config_two_planet()                    # 2500 + 2500 rows × 4096 walkers, rng 20260929+4
+    a, r = c4["astrom"], c4["rv"]
+    assert len(a["epoch"]) == 2500 and len(r["epoch"]) == 2500 and c4["n_walkers"] == 4096
+    # evaluation order of make_ln_like: planet observations planet by planet, then system observations (system.jl:229-235)
+    obs = [dict(kind=0, planet=1, epoch=a["epoch"], y1=a["ra"], y2=a["dec"], s1=a["σ_ra"], s2=a["σ_dec"], cor=None),
+           dict(kind=2, planet=-1, epoch=r["epoch"], y1=r["rv"], y2=None, s1=r["σ_rv"], s2=None, cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=True), dict(orbit_kind=0, has_mass=True)]
+    path = gb.GpuPath(obs, planets)
+    ll, g, gn = path.eval(c4["elems"], c4["nuis"], grad=True)
+    ll2, g2, gn2 = path.eval(c4["elems"], c4["nuis"], grad=True)
+    llf, _, _ = path.eval(c4["elems"], c4["nuis"], grad=False)
+    path.close()
+    assert np.array_equal(ll, ll2) and np.array_equal(g, g2) and np.array_equal(gn, gn2), "not deterministic"
+    assert np.array_equal(ll, llf), "forward-only and gradient launches disagree"
+    assert np.all(np.isfinite(ll))
+    idx = np.random.default_rng(4).choice(4096, 24, replace=False)
+    ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, c4["elems"][:, idx], c4["nuis"][:, idx], grad=True, n_threads=0)
+    _cmp_oracle("config 4 sample", ll[idx], g[:, idx], gn[:, idx], ll_o, g_o, gn_o)
+    # without the nuisance block (the jitter == 0 / precomputed Σ⁻¹ path of the same two-planet kernel family)
+    ll0, g0, _ = gb.gpu_eval(obs, planets, c4["elems"], None, grad=True)
+    ll0_o, g0_o, _ = oracle.oracle_eval(obs, planets, c4["elems"][:, idx], None, grad=True, n_threads=0)
+    _cmp_oracle("config 4 sample, no nuisances", ll0[idx], g0[:, idx], None, ll0_o, g0_o, None)
+
+
+def test_config5_per_gpu_shape(pkg, oracle):
+    import torch
+    from octofitter_jl_amd.host.tempering import TemperedSwap
+    n_temps, chains, E = 8, 1024, 10_000
+    W = n_temps * chains
+    cfg = synth.config_astrom(n_epochs=E, n_walkers=W, cfg=2, seed=20260929 + 5)
+    obs_m, planet = synth.to_mirror(pkg, cfg)
+    fn = pkg.make_ln_like(pkg.System(name="cfg5", companions=[planet]), cfg["theta_example"])
+    dev = torch.device("cuda", 0)
+    elems = torch.tensor(cfg["elems"], device=dev)
+    pt = TemperedSwap(fn, n_temps_total=n_temps, n_chains=chains, rank=0, world=1, device=dev, seed=20260929)
+    ll_t = torch.empty(W, dtype=torch.float64, device=dev)
+    ref = pt.slot2rep.cpu().numpy().copy()
+    acc_ref = np.zeros(n_temps, dtype=np.int32)
+    beta = pt.beta.cpu().numpy()
+    for step in range(4):
+        fn.ln_like_device(elems, None, grad=False, out=(ll_t, None, None))
+        s2r = pt.swap_step(ll_t, step)
+        torch.cuda.synchronize()
+        ll = ll_t.cpu().numpy()
+        ref, a = _pt_swap_reference(ll.reshape(n_temps, chains), beta, ref, step % 2, 20260929, step)
+        acc_ref += a
+        assert np.array_equal(s2r.cpu().numpy(), ref), f"slot2rep differs from the restatement at step {step}"
+        # a different state for the next step: the explorer moved (here: a seeded perturbation of tp)
+        elems[5] += 3.0 * torch.tensor(np.random.default_rng(step).normal(size=W), device=dev)
+    assert np.array_equal(pt.accepted.cpu().numpy(), acc_ref) and acc_ref.sum() > 0
+    assert np.all(np.sort(ref, axis=1) == np.arange(n_temps))
+    # β of every local walker follows the permutation
+    b_loc = pt.local_betas().cpu().numpy().reshape(n_temps, chains)
+    rep2slot = np.argsort(ref, axis=1)
+    assert np.array_equal(b_loc, beta[rep2slot].T)
+    # the log-likelihoods that fed the last swap, against the oracle on a seeded sample of walkers at the full epoch count
+    idx = np.random.default_rng(5).choice(W, 16, replace=False)
+    el_last = elems.cpu().numpy()
+    el_last[5] -= 3.0 * np.random.default_rng(3).normal(size=W)      # undo the perturbation applied after the last evaluation
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    ll_o, _, _ = oracle.oracle_eval(obs, [dict(orbit_kind=0, has_mass=False)], el_last[:, idx], None, grad=False, n_threads=0)
+    assert np.all(rel_err(ll[idx], ll_o, 1.0) < 1e-12)
+    fn.close()
+
+
+def test_torch_stream_ordering(pkg, oracle):
+    """torch op -> device entry point -> torch op on torch's current stream with NO device-wide synchronisation: the results
+    are right only if the kernels really run on that stream (default stream, then a side stream)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = synth.config_astrom(n_epochs=400, n_walkers=3000, seed=77)
+    obs_m, planet = synth.to_mirror(pkg, cfg)
+    fn = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
+    ll_ref = fn.ln_like_arrays(cfg["elems"], None)
+    base = torch.tensor(cfg["elems"], device=dev)
+    big = torch.randn(4096, 4096, device=dev)
+    for stream in (None, torch.cuda.Stream(device=dev)):
+        ctxm = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream())
+        with ctxm:
+            for rep in range(3):
+                for _ in range(4):
+                    big = big @ big * 1e-3              # keep the stream busy: the producer below finishes late
+                el = base * 0.0
+                el += base                              # producer: elems only exist once these torch ops have run
+                ll, g, _ = fn.ln_like_device(el, None, grad=True)
+                total = (ll * 2.0).sum()                # consumer on the same stream, no synchronize in between
+                el.zero_()                              # and a later overwrite of the INPUT must not race the kernels
+                got = total.item()
+                assert abs(got - 2.0 * ll_ref.sum()) <= 1e-9 * abs(ll_ref.sum()), (stream, rep, got, 2.0 * ll_ref.sum())
+    fn.close()

@@ -81,3 +81,27 @@ def test_gpu_ofti_large_batch_and_edges(pkg, oracle, ofti_golden):
     solver.close()
     one = pkg.ofti_linear_solve(*_cols(case), case["sigma_abfg"], e[0], a[0], tp[0], M[0], plx[0])
     assert one["log_marginal_likelihood"].shape == (1,) and one["log_marginal_likelihood"][0] == lm[0]
+
+
+@pytest.mark.gpu
+def test_gpu_ofti_invalid_walkers_do_not_disturb_neighbours(pkg, ofti_golden):
+    """k_ofti_main reads the starter's sin/cos from the LDS table with an UNCLAMPED index (octo_device.h: sincos_table): a walker
+    with e >= 1 or non-finite elements may index anywhere. It must come back as -Inf / NaN and leave the other lanes of its
+    wave bit-identical to a clean run (the same guarantee test_invalid_walkers checks for k_main)."""
+    case = ofti_golden[1]
+    rng = np.random.default_rng(12)
+    W = 200
+    M = np.abs(rng.normal(1.2, 0.1, W)) + 0.1; plx = rng.normal(50.0, 0.5, W)
+    e = rng.uniform(0, 0.95, W); a = np.exp(rng.uniform(0, np.log(60.0), W))
+    tp = 50000.0 + rng.uniform(0, 1, W) * np.sqrt(a ** 3 / M) * 365.2568983840419
+    solver = pkg.OftiLinearSolver(*_cols(case), case["sigma_abfg"])
+    clean = solver(e, a, tp, M, plx)
+    eb, ab, tb, Mb = e.copy(), a.copy(), tp.copy(), M.copy()
+    bad = [3, 64, 65, 127, 130, 131, 199]
+    eb[3] = 1e30; eb[64] = np.nan; eb[65] = np.inf; eb[127] = -np.inf; eb[130] = 1.0; ab[131] = np.nan; tb[199] = np.nan
+    res = solver(eb, ab, tb, Mb, plx)
+    solver.close()
+    lm, lm0 = res["log_marginal_likelihood"], clean["log_marginal_likelihood"]
+    assert np.all(np.isneginf(lm[bad])) and all(np.all(np.isnan(res[q][bad])) for q in "ABFG")
+    good = np.setdiff1d(np.arange(W), bad)
+    assert np.array_equal(lm[good], lm0[good]) and all(np.array_equal(res[q][good], clean[q][good]) for q in "ABFG")

@@ -2,42 +2,59 @@
 """
 bench.py — throughput of the epoch-loop likelihood hot path on MI355X.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                          python -m torch.distributed.run --nproc-per-node N)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the hot path (k_setup -> k_main -> k_finish through octo_eval_device) over one
-batch of synthetic input that is already resident in HBM: BASELINE.json config 3 — 1 planet, 1e4 RA/Dec
-epochs x 1e4 prior-drawn walkers, forward log-likelihood + reverse gradient w.r.t. the orbital elements.
-Metric: epoch-likelihood evaluations per second = walkers x rows x steps / wall time, whole job.
-Multi-GPU: walkers are independent -> each rank owns its own 1e4 walkers (weak scaling), the dataset is
-replicated, and there is NO collective on the data path (the only collective of the path is the
-parallel-tempering swap step, exercised with --workload pt).
+A "step" is ONE pass of the hot path (k_setup -> k_main -> k_finish through octo_eval_device) over one batch of synthetic
+input that is already resident in HBM: BASELINE.json config 3 — 1 planet, 1e4 RA/Dec epochs x 1e4 prior-drawn walkers,
+forward log-likelihood + reverse gradient w.r.t. the orbital elements. Metric: epoch-likelihood evaluations per second =
+walkers x rows x steps / wall time, whole job. Multi-GPU: walkers are independent -> each rank owns its own 1e4 walkers
+(weak scaling), the dataset is replicated, and there is NO collective on the data path (the only collective of the path is
+the parallel-tempering swap step, exercised with --workload pt).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      HBM bound as contracted by north_star: achieved = algorithmic bytes per launch
-                (40 B per RA/Dec row per walker + 136 B per walker) / average duration of the
-                dominant kernel k_main measured with HIP events on its launch stream.
+Timed region: W warm-up steps, then an untimed spin-up until the device has been busy for >= 0.3 s (clocks ramped, so that a
+20-step run measures the same thing as a 200-step run), barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over
+ranks. Beside the wall-clock value the line carries the median per-step time from HIP events on the launch stream.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline      the bound that BINDS the dominant kernel k_main: FP64 vector issue. achieved = FP64 flops per evaluation (from
+                the committed PMC instruction counts of exactly this kernel source, profiles/pmc_traffic.json) x evaluations per
+                launch / the kernel's average duration measured live with HIP events on its launch stream; peak = 78.6 TFLOP/s
+                (MI355X FP64 vector). `hbm`: the real HBM rate (PMC FETCH/WRITE bytes per launch / the same live duration)
+                against 8 TB/s — 1-2 % — and, clearly named, the north_star's ALGORITHMIC streaming figure (40 B per row per
+                walker), which exceeds the HBM peak because rows are served to 64 lanes from the scalar cache.
+  pcie_inclusive the same batch through octo_eval with HOST buffers (H2D of elems, D2H of ll and gradient inside the timed
+                region): SURVEY.md §8(d)'s definition of the metric; never `value`.
+  parity        max relative error of ll and gradient on 8 walkers of the batch just timed, against the oracle.
   cpu_baseline  the CPU restatement (oracle/, kind "port") timed on this host's cores on a bounded sample.
+  config1       BASELINE config 1 (D = 11 model, 50 epochs, one θ per call): µs per call of octo_model_logpost (value +
+                gradient) next to the single-thread CPU restatement's µs per call.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
 import numpy as np
 
-TIMED_EVERY = 8   # k_main is bracketed with HIP events on every 8th step of the timed region (an event pair costs ~µs of stream time)
+TIMED_EVERY = 4   # k_main is bracketed with HIP events on every 4th step of the timed region (an event pair costs ~µs of stream time)
+SPINUP_SECONDS = 0.3
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VECTOR_PEAK_TFLOPS = 78.6
 BYTES_PER_ROW = 40.0          # epoch, ra, dec, σ_ra, σ_dec  (SURVEY.md §8d)
 BYTES_PER_WALKER = 64.0 + 72.0  # read 8 elements, write ll + 8 adjoints
 
@@ -51,6 +68,7 @@ def parse():
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default 10000; 8192 = 8 temperatures x 1024 for --workload pt)")
     ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti", "logpost"], default="grad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive, parity and config-1 legs (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for single-GPU dry runs")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device index (dry runs of the N>1 path on one GPU)")
@@ -58,6 +76,22 @@ def parse():
     if args.walkers is None:      # BASELINE config 5: 64 temperatures x 1024 walkers over 8 GPUs = 8 x 1024 per GPU
         args.walkers = 8192 if args.workload == "pt" else 10_000
     return args
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run this same command line under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def kernel_source_hash():
+    from __graft_entry__ import kernel_source_hash as h
+    return h()
 
 
 def cpu_baseline(cfg, obs_tables, planets, seconds):
@@ -85,17 +119,72 @@ def cpu_baseline(cfg, obs_tables, planets, seconds):
                       f"(gcc -O3 -march=native, OpenMP over walkers, 8 forward-mode partials per dual), {dt:.1f} s"}
 
 
+def parity_sample(fn, cfg, ll_dev, g_dev, n=8):
+    """ll and gradient of n walkers of the batch just timed against the oracle (the checker)."""
+    import oracle_binding as ob
+    import synth
+    idx = np.random.default_rng(0).choice(cfg["n_walkers"], n, replace=False)
+    ll_o, g_o, _ = ob.oracle_eval(fn.obs_tables, fn.planet_desc, cfg["elems"][:, idx], None, grad=True,
+                                  active=synth.active_mask(1, 1, mass=False, nuis=False))
+    e_ll = float(np.max(np.abs(ll_dev[idx] - ll_o) / np.maximum(1.0, np.abs(ll_o))))
+    sc = np.maximum(np.abs(g_o[:8]).max(axis=1, keepdims=True), 1e-300)
+    e_g = float(np.max(np.abs(g_dev[:8, idx] - g_o[:8]) / sc))
+    return {"max_rel_err_ll": e_ll, "max_rel_err_grad": e_g, "walkers_checked": int(n), "against": "oracle/liboctooracle.so (CPU restatement)",
+            "tolerance": 1e-8, "ok": bool(e_ll < 1e-8 and e_g < 1e-8)}
+
+
+def config1_latency(pkg, dev_index):
+    """BASELINE config 1 / SURVEY §8(d): D = 11 model, 50 RA/Dec epochs, ONE θ_t per call — what NUTS pays per gradient."""
+    import ctypes as C
+    import oracle_binding as ob
+    case = json.loads((ROOT / "tests" / "golden" / "config1.json").read_text())["cases"][0]
+    o = case["obs"][0]
+    table = dict(epoch=o["epoch"], ra=o["y1"], dec=o["y2"], σ_ra=o["s1"], σ_dec=o["s2"])
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromLikelihood(table, name="astrom")],
+                   variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                           Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+    model = pkg.LogDensityModel(pkg.System(name="cfg1", companions=[b], observations=[],
+                                variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))),
+                                device=dev_index)
+    capi = pkg.capi
+    fn = model.ln_like
+    th = np.ascontiguousarray(np.asarray(case["theta_t"])[:, :1]); lp = np.empty(1); g = np.empty_like(th)
+    args = (fn._ctx, model._m, capi._dptr(th), 1, 1, capi._dptr(lp), capi._dptr(g))
+    for _ in range(300):
+        fn.lib.octo_model_logpost(*args)
+    n = 2000
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn.lib.octo_model_logpost(*args)
+    gpu_us = (time.perf_counter() - t0) / n * 1e6
+    ok = abs(lp[0] - case["lp"][0]) <= 1e-10 * abs(case["lp"][0])
+    obs = [dict(kind=0, planet=0, epoch=np.asarray(o["epoch"]), y1=np.asarray(o["y1"]), y2=np.asarray(o["y2"]), s1=np.asarray(o["s1"]),
+                s2=np.asarray(o["s2"]), cor=None)]
+    for _ in range(20):
+        ob.oracle_model_logpost(obs, case["planets"], model._c_priors, model._c_esrc, None, th)
+    m = 300
+    t0 = time.perf_counter()
+    for _ in range(m):
+        ob.oracle_model_logpost(obs, case["planets"], model._c_priors, model._c_esrc, None, th)
+    cpu_us = (time.perf_counter() - t0) / m * 1e6
+    model.close()
+    return {"workload": "config1: D=11 model (test/integration/sampling.jl:29-64), 50 RA/Dec epochs, one theta_t per call, value + gradient",
+            "gpu_us_per_call": gpu_us, "gpu_entry": "octo_model_logpost (host buffers, blocking)", "gpu_matches_fixture": bool(ok),
+            "cpu_us_per_call": cpu_us, "cpu_entry": "oracle/ octo_oracle_model_logpost, 1 thread, forward-mode duals (includes ~10 us of ctypes marshalling)"}
+
+
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes on this driver
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = local_rank if args.device is None else args.device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -111,6 +200,47 @@ def main():
     pkg = load_package()
     capi = pkg.capi
 
+    def timed_loop(step_fn, on_timed_start=None):
+        """warm-up, spin-up, barrier + sync, K steps (per-step events on the launch stream), sync + barrier; max over ranks."""
+        for i in range(args.warmup):
+            step_fn(i)
+        torch.cuda.synchronize()
+        t_spin = time.perf_counter()
+        n_spin = 0
+        while time.perf_counter() - t_spin < SPINUP_SECONDS:
+            for _ in range(8):
+                step_fn(args.warmup + n_spin); n_spin += 1
+            torch.cuda.synchronize()
+        if on_timed_start is not None:
+            on_timed_start()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(args.steps):
+            step_fn(args.warmup + n_spin + i)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, per_step, n_spin
+
+    def base_line(metric, value, dt, per_step, n_spin, workload, extra_cfg=None):
+        cfgd = {"workload": workload}
+        cfgd.update(extra_cfg or {})
+        return {"metric": metric, "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median_events": float(np.median(per_step)),
+                "ms_per_step_min_events": float(per_step.min()), "spinup_steps_untimed": n_spin,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfgd}
+
     grad = args.workload in ("grad", "two_planet")
     if args.workload == "ofti":
         # SURVEY §8(f3): batched ofti_linear_solve (src/parameterizations.jl:318-405), forward marginal likelihood
@@ -119,19 +249,10 @@ def main():
         solver = pkg.OftiLinearSolver(t["epoch"], t["ra"], t["dec"], t["σ_ra"], t["σ_dec"], None, 1000.0, device=dev_index)
         el = cfg0["elems"]
         nl = torch.tensor(np.stack([el[1], el[0], el[5], el[6], el[7]]), device=dev)
-        for _ in range(args.warmup):
-            solver.eval_device(nl)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            solver.eval_device(nl)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt, per_step, n_spin = timed_loop(lambda i: solver.eval_device(nl))
         if rank == 0:
-            print(json.dumps({"metric": "OFTI marginal-likelihood epoch evals/sec (fwd)", "value": args.epochs * args.walkers * args.steps / dt,
-                              "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": f"ofti_linear_solve: {args.epochs} RA/Dec epochs x {args.walkers} walkers, forward"}}))
+            print(json.dumps(base_line("OFTI marginal-likelihood epoch evals/sec (fwd)", args.epochs * args.walkers * args.steps * world / dt, dt, per_step, n_spin,
+                                       f"ofti_linear_solve: {args.epochs} RA/Dec epochs x {args.walkers} walkers, forward")))
         solver.close()
         return
     if args.workload == "logpost":
@@ -146,20 +267,11 @@ def main():
                                                                               plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1)))
         model = pkg.LogDensityModel(sysm, device=dev_index)
         θt = torch.tensor(model.link(model.sample_priors(np.random.default_rng(20260929 + 7), args.walkers)), device=dev)
-        for _ in range(args.warmup):
-            model.logpost_device(θt, grad=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.logpost_device(θt, grad=True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt, per_step, n_spin = timed_loop(lambda i: model.logpost_device(θt, grad=True))
         if rank == 0:
-            print(json.dumps({"metric": "epoch-likelihood evals/sec, full log-posterior + gradient w.r.t. theta_t (D=11)",
-                              "value": args.epochs * args.walkers * args.steps / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
-                              "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": f"LogDensityModel D={model.D}: {args.epochs} RA/Dec epochs x {args.walkers} walkers, theta_t resident in HBM"}}))
+            print(json.dumps(base_line("epoch-likelihood evals/sec, full log-posterior + gradient w.r.t. theta_t (D=11)",
+                                       args.epochs * args.walkers * args.steps * world / dt, dt, per_step, n_spin,
+                                       f"LogDensityModel D={model.D}: {args.epochs} RA/Dec epochs x {args.walkers} walkers, theta_t resident in HBM")))
         model.close()
         return
     if args.workload == "two_planet":
@@ -195,16 +307,19 @@ def main():
            torch.empty_like(nuis) if (grad and nuis is not None) else None)
 
     pt = None
+    parallelism = f"walkers sharded x{world}, dataset replicated, no data-path collective"
     if args.workload == "pt":
-        # config 5: temperatures sharded over ranks; every step = fwd+grad-free explorer evaluation, RCCL
-        # all_gather of the per-replica log-likelihoods, deterministic neighbour swap of β labels.
+        # config 5: temperatures sharded over ranks; every step = fwd+grad-free explorer evaluation, all-gather of the
+        # per-replica log-likelihoods (RCCL; nothing to gather on one rank), deterministic neighbour swap of β labels.
         from octofitter_jl_amd.host.tempering import TemperedSwap
         n_temps_total = 8 * world
         chains = W // 8
         pt = TemperedSwap(fn, n_temps_total=n_temps_total, n_chains=chains, rank=rank, world=world, device=dev, seed=20260929)
         grad = False
         out = (out[0], None, None)
-        workload = f"config5: {n_temps_total} temperatures x {chains} walkers x {n_rows} epochs, sharded by temperature, RCCL all_gather swap"
+        workload = (f"config5: {n_temps_total} temperatures x {chains} walkers x {n_rows} epochs, sharded by temperature, "
+                    + ("RCCL all_gather of log-likelihoods + swap kernel" if world > 1 else "swap kernel (single rank: no collective ran)"))
+        parallelism = f"temperatures sharded x{world}, dataset replicated, one all_gather per swap step" if world > 1 else "single rank"
 
     def run_step(i):
         if grad:
@@ -214,69 +329,90 @@ def main():
         if pt is not None:
             pt.swap_step(out[0], i)
 
-    for i in range(args.warmup):
-        run_step(i)
-    torch.cuda.synchronize()
-    fn.timing_enable(TIMED_EVERY)      # HIP events around k_main of every TIMED_EVERY-th step of the timed region
-    fn.timing_read(reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    kern_ms, kern_n = fn.timing_read(reset=True)
+    fn.timing_enable(TIMED_EVERY)      # HIP events around k_main of every TIMED_EVERY-th evaluation, on its launch stream
+    dt, per_step, n_spin = timed_loop(run_step, on_timed_start=lambda: fn.timing_read(reset=True))
+    kern_med, kern_min, kern_max, kern_n = fn.timing_stats()
+    kern_ms, _ = fn.timing_read(reset=True)
     fn.timing_enable(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
     evals = float(W) * n_rows * args.steps * world
     value = evals / dt
-    res = {
-        "metric": "epoch-likelihood evals/sec (fwd+grad), 1e4 epochs x 1e4 walkers" if args.workload == "grad" else f"epoch-likelihood evals/sec ({args.workload})",
-        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload, "walkers_per_gpu": W, "rows": n_rows, "parallelism": f"walkers sharded x{world}, dataset replicated, no data-path collective"},
-    }
+    metric = "epoch-likelihood evals/sec (fwd+grad), 1e4 epochs x 1e4 walkers" if args.workload == "grad" else f"epoch-likelihood evals/sec ({args.workload})"
+    res = base_line(metric, value, dt, per_step, n_spin, workload, {"walkers_per_gpu": W, "rows": n_rows, "parallelism": parallelism})
     if rank == 0:
-        ach = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-        traffic, flops_per_eval, issue = None, None, None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists() and args.workload == "grad" and (n_rows, W) == (10_000, 10_000):
-            try:      # PMC figures are per launch of exactly this workload; measured off-line (separate --pmc passes)
-                j = json.loads(pmc.read_text())
-                traffic, flops_per_eval = j.get("hbm_bytes_per_launch"), j.get("fp64_flops_per_eval")
-                issue = j.get("issue_model")
-            except Exception:
-                traffic = None
-        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": (ach / HBM_PEAK_GBPS) if ach else None, "traffic": traffic,
-                           "kernel": "k_main", "kernel_avg_ms": kern_ms, "kernel_launches_timed": kern_n,
-                           "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "note": "algorithmic bytes (SURVEY 8d) over the live k_main duration, as north_star contracts; rows are "
-                                   "reused across 64 lanes from the scalar cache, so real HBM traffic is `traffic` bytes per launch "
-                                   "and frac may exceed 1. The kernel's true bound is FP64 VALU issue (see `valu`, DESIGN.md)"}
-        if flops_per_eval and kern_ms > 0:
-            tf = flops_per_eval * float(W) * n_rows / (kern_ms * 1e-3) / 1e12
-            res["roofline"]["valu"] = {"bound": "fp64_vector", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
-                                       "fp64_flops_per_eval": flops_per_eval,
-                                       "note": "FP64 flops only (FMA = 2); VALU issue slots are ~100 % busy at the sustained ~2.1 GHz clock"}
+        is_cfg3 = args.workload == "grad" and (n_rows, W) == (10_000, 10_000)
+        pmc, pmc_ok, pmc_note = None, False, None
+        pmc_path = ROOT / "profiles" / "pmc_traffic.json"
+        if is_cfg3 and pmc_path.exists():
+            try:      # PMC figures are per launch of exactly this kernel and workload; measured off-line (separate --pmc passes)
+                pmc = json.loads(pmc_path.read_text())
+                pmc_ok = pmc.get("kernel_source_sha256") == kernel_source_hash()
+                if not pmc_ok:
+                    pmc_note = ("profiles/pmc_traffic.json was collected for a DIFFERENT kernel source (sha256 mismatch): counter-derived "
+                                "fields withheld; re-run tools/profile_round.sh + tools/make_pmc_json.py")
+                    print("bench.py: " + pmc_note, file=sys.stderr, flush=True)
+            except Exception as ex:
+                pmc, pmc_note = None, f"profiles/pmc_traffic.json unreadable: {ex}"
+        kernel_s = kern_ms * 1e-3 if kern_ms > 0 else None
+        alg_gbps = bytes_per_launch / kernel_s / 1e9 if kernel_s else None
+        roof = {"bound": "fp64_vector", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "kernel": "k_main", "kernel_avg_ms": kern_ms, "kernel_median_ms": kern_med, "kernel_min_ms": kern_min, "kernel_max_ms": kern_max,
+                "kernel_launches_timed": kern_n,
+                "note": "k_main is bound by FP64 VALU issue, not by HBM: rows reach the 64 lanes of a wave through the scalar cache, so the "
+                        "compulsory HBM traffic is ~0.02 B per evaluation. achieved = counter-derived FP64 flops per evaluation (FMA = 2) x "
+                        "evaluations per launch / live HIP-event duration of k_main on its launch stream."}
+        if pmc is not None and pmc_ok and kernel_s:
+            flops_per_eval = pmc["fp64_flops_per_eval"]
+            tf = flops_per_eval * float(W) * n_rows / kernel_s / 1e12
+            traffic = pmc["hbm_bytes_per_launch"]
+            roof.update({"achieved": tf, "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "fp64_flops_per_eval": flops_per_eval,
+                         "valu_instructions_per_row_per_wave": pmc.get("valu_instructions_per_row_per_wave"),
+                         "pmc_source": pmc.get("source"), "pmc_kernel_source_sha256": pmc.get("kernel_source_sha256")})
+            issue = pmc.get("issue_model")
             if issue:
                 # time the chip needs just to ISSUE this kernel's VALU instructions (measured mix x measured cost per class)
                 t_issue = issue["ns_per_row_per_wave"] * 1e-6 * n_rows * ((W + 63) // 64) / issue["simds"]
-                res["roofline"]["valu"].update({"issue_bound_ms": t_issue, "issue_frac": t_issue / kern_ms})
-        if not args.no_cpu_baseline and cfg is not None and world == 1 and args.workload in ("grad",):
+                roof.update({"issue_bound_ms": t_issue, "issue_frac": t_issue / kern_ms})
+            roof["hbm"] = {"bound": "hbm", "achieved": traffic / kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": traffic / kernel_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                           "what": "real HBM bytes per launch (PMC FETCH_SIZE x2 on gfx950 + WRITE_SIZE) / live kernel duration"}
+        elif pmc_note:
+            roof["note"] = pmc_note + " | " + roof["note"]
+        roof["north_star_algorithmic_hbm"] = {
+            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_stream_GBps": alg_gbps,
+            "frac_of_hbm_peak": (alg_gbps / HBM_PEAK_GBPS) if alg_gbps else None,
+            "what": "SURVEY.md 8(d) streaming definition (every walker re-reads every 40-byte row) over the live kernel duration, as "
+                    "north_star words the claim; NOT a bandwidth measurement — it exceeds the 8 TB/s peak because the rows are reused "
+                    "by 64 lanes from the scalar cache"}
+        res["roofline"] = roof
+        if not args.no_extras and cfg is not None and world == 1 and args.workload == "grad":
+            # ---- parity of the batch just timed
+            try:
+                res["parity"] = parity_sample(fn, cfg, out[0].cpu().numpy(), out[1].cpu().numpy())
+                res["max_rel_err"] = max(res["parity"]["max_rel_err_ll"], res["parity"]["max_rel_err_grad"])
+            except Exception as ex:
+                res["parity"] = {"ok": None, "error": str(ex)}
+            # ---- the same batch through octo_eval, host buffers, H2D + D2H inside the timed call
+            el_h = np.ascontiguousarray(elems_h); ll_h = np.empty(W); g_h = np.empty_like(el_h)
+            a_ = (fn._ctx, fn._ds, capi._dptr(el_h), None, W, W, capi._dptr(ll_h), capi._dptr(g_h), None)
+            for _ in range(5):
+                fn.lib.octo_eval(*a_)
+            ts = []
+            for _ in range(25):
+                t1 = time.perf_counter(); fn.lib.octo_eval(*a_); ts.append(time.perf_counter() - t1)
+            med = float(np.median(ts))
+            res["pcie_inclusive"] = {"value": W * n_rows / med, "unit": "evals/s", "ms_per_call_median": med * 1e3, "calls": len(ts),
+                                     "what": "octo_eval with host buffers: H2D of elems and D2H of ll + gradient inside the call (SURVEY 8d definition); median of 25"}
+        if not args.no_cpu_baseline and cfg is not None and world == 1 and args.workload == "grad":
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg, fn.obs_tables, fn.planet_desc, args.cpu_seconds)
             except Exception as ex:  # the checker is optional for the measurement itself
                 res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex}"}
+        if not args.no_extras and world == 1 and args.workload == "grad":
+            try:
+                res["config1"] = config1_latency(pkg, dev_index)
+            except Exception as ex:
+                res["config1"] = {"error": str(ex)}
         print(json.dumps(res), flush=True)
     fn.close()
     if world > 1:

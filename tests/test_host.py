@@ -130,3 +130,13 @@ def test_hgca_constructor(pkg):
     t = o._c_table(-1)
     assert t["kind"] == pkg.capi.HGCA and t["planet"] == -1 and len(t["extra"]) == pkg.capi.HGCA_N_EXTRA
     assert b.name == "b"
+
+
+def test_pmc_json_matches_the_kernel_sources():
+    """bench.py derives roofline.achieved from instruction counts measured off-line (profiles/pmc_traffic.json); they are only
+    valid for the kernel they were collected on. The JSON records the sha256 of the kernel sources + compiler flags."""
+    import json
+    from __graft_entry__ import kernel_source_hash, ROOT
+    j = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+    assert j.get("kernel_source_sha256") == kernel_source_hash(), \
+        "kernel sources changed since the PMC passes: re-run `bash tools/profile_round.sh <tag>` on the GPU box and copy gpurun_out/<tag>_pmc_traffic.json to profiles/pmc_traffic.json"

@@ -3,12 +3,12 @@
 # command, then PMC passes (each in its own run, never combined with trace domains other than --kernel-trace).
 # Usage: bash tools/profile_round.sh <tag>     -> gpurun_out/<tag>/..., summary in gpurun_out/<tag>_rocprof_summary.txt
 set -u
-tag=${1:-r1_v3}
+tag=${1:-r2_v0}
 ROOT=$PWD
 out=$ROOT/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="python $ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline"
+B="python $ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extras"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $out/stats -o k -- python $ROOT/bench.py > $out/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $out/pmc_fetch -o k -- $B > $out/b_fetch.log 2>&1
@@ -17,4 +17,5 @@ rocprofv3 --kernel-trace --stats --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VA
 rocprofv3 --kernel-trace --stats --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d $out/pmc_sq -o k -- $B > $out/b_sq.log 2>&1
 cd $ROOT
 python profiles/summarize_rocpd.py gpurun_out/$tag gpurun_out/$tag > /dev/null
+python tools/make_pmc_json.py gpurun_out/$tag gpurun_out/${tag}_pmc_traffic.json > /dev/null
 tail -1 $out/bench_under_rocprof.log | cut -c1-600

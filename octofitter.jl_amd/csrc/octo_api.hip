@@ -1,113 +1,11 @@
 // octo_api.hip — C ABI of include/octofitter_hip.h over the HIP runtime (gfx950 only).
 // Host logic only: uploads, task tables, scratch, kernel dispatch, timing. No CPU compute path:
 // every entry point that evaluates fails with OCTO_ENODEV / OCTO_EHIP when no device is usable.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "octo_kernels.h"
-#include "octo_model.h"
-#include "octo_hgca.h"
-#include "octofitter_hip.h"
+#include "octo_host.h"
 
 using namespace octo;
 
-namespace {
-
-struct TaskTable {
-    uint64_t ds_serial = 0;          // the dataset this partition belongs to (octo_dataset::serial)
-    int64_t key = 0;                 // > 0: target number of tasks of the plan; < 0: forced uniform rows-per-wave (OCTO_CHUNK)
-    int n_tasks = 0;
-    Task* d_tasks = nullptr;
-    double* d_const_pre = nullptr;   // per-task constants for the no-nuisance path
-    double* d_const_raw = nullptr;   // per-task constants for the nuisance path
-    int32_t* d_obs_range = nullptr;  // [n_obs][2] task range of each observation
-    double* d_obs_const_pre = nullptr, *d_obs_const_raw = nullptr;   // [n_obs] Σ of the task constants, in task order
-    std::vector<Task> h_tasks;
-};
-
-}  // namespace
-
-struct octo_dataset {
-    int device = 0;
-    int n_obs = 0, n_planets = 0;
-    int kind_mask = 0;
-    int64_t n_rows = 0;
-    int n_hgca = 0;                      // OCTO_HGCA tables: evaluated by k_hgca, not by the epoch-loop kernel
-    std::vector<DevObs> h_obs;
-    std::vector<std::vector<double>> h_rowconst_pre, h_rowconst_raw;   // per obs, per row
-    DevObs* d_obs = nullptr;
-    std::vector<double*> d_bufs;
-    octo_planet_desc planets[MAXP];
-    uint64_t serial = 0;                 // process-unique id: the contexts key their task-table caches by it (the dataset itself
-                                         // is immutable after octo_dataset_create, so contexts may share it without locking)
-};
-
-struct octo_ofti {
-    int device = 0;
-    int64_t n = 0;
-    double* d_rows = nullptr;
-    double lambda = 0, data_quad = 0, log_det_data_cov = 0, log_det_prior_inv = 0, n_log2pi = 0;
-};
-
-struct octo_ctx {
-    int device = 0;
-    int n_cus = 256;
-    int64_t max_lds = 65536;                    // largest dynamic LDS allocation one block may ask for on this device
-    hipStream_t stream = nullptr;               // the context's own stream (OCTO_STREAM_CTX, and every host-buffer entry point)
-    // The scratch below is reused by every evaluation, so evaluations through one context must be ordered. They are when the
-    // caller keeps to one stream per context (the documented contract); if it does switch streams, the new stream is made to
-    // wait for the last evaluation enqueued on the old one (an event, no host synchronisation).
-    hipStream_t last_stream = nullptr;
-    bool has_last = false;
-    hipEvent_t ev_order = nullptr;
-    octo_consts consts;
-    std::string err;
-    // scratch (device)
-    int64_t cap_w = 0, cap_part = 0, cap_io = 0, cap_marg = 0;
-    double* d_wc = nullptr;
-    int32_t* d_valid = nullptr;
-    double* d_partials = nullptr;
-    double* d_marg = nullptr;
-    double* d_extra = nullptr;                  // k_hgca output: ll and input-gradient of the non-epoch-loop terms
-    int64_t cap_extra = 0;
-    double* d_sctab = nullptr;                  // sin/cos grid of sincos_table, [SCT_N][2]
-    int32_t* d_counters = nullptr;              // k_small: finished-block counter per walker, [SMALL_W], zero between launches
-    uint64_t* h_flags = nullptr;                // mapped pinned [SMALL_W]: k_small's finishing block of walker w stores the call's
-    uint64_t flag_seq = 0;                      // sequence number here after its outputs; host-buffer calls spin on it
-    bool flag_request = false, flag_armed = false;
-    int64_t stage_ws_in = 0, stage_ws_out = 0;  // > 0 while octo_eval hands k_small its walker-major staging buffers
-    int small_w = SMALL_W;                      // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
-    double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
-    int64_t cap_in = 0, cap_out = 0;
-    double *h_in = nullptr, *h_out = nullptr;   // pinned mirrors of d_in / d_out for SMALL batches: one transfer each way instead of
-    int64_t cap_hin = 0, cap_hout = 0;          // one per array — what a single-chain sampler's per-gradient latency is made of
-    std::vector<void*> retired;                 // outgrown scratch buffers: kernels already enqueued may still use them, so they
-                                                // are freed at the next host-blocking point (octo_sync, the end of a host-buffer
-                                                // call, octo_ctx_destroy) instead of by a device-synchronising hipFree mid-stream
-    // row partitions ("task tables") of the datasets this context has evaluated, keyed by (dataset serial, plan key)
-    std::vector<TaskTable> tables;
-    std::map<uint32_t, int> occupancy;          // resident blocks per CU of each k_main variant (P, NUIS, KM) on THIS device
-    // timing
-    int timing_every = 0;                       // 0 = off, n = bracket every n-th evaluation's k_main with events
-    int64_t timing_seq = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    size_t ev_used = 0;
-    double t_ms = 0.0;
-    int64_t t_n = 0;
-    std::vector<float> t_samples;               // every timed launch since the last reset (median, spread)
-};
-
-namespace {
+namespace octo {
 
 std::atomic<uint64_t> g_dataset_serial{1};
 
@@ -116,13 +14,6 @@ int fail(octo_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
-#define HIPCHK(ctx, call)                                                                          \
-    do {                                                                                           \
-        hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? OCTO_ENOMEM : OCTO_EHIP,                  \
-                        std::string(#call) + ": " + hipGetErrorString(e_));                        \
-    } while (0)
 
 DevConsts dev_consts(const octo_consts& c) {
     DevConsts d;
@@ -190,15 +81,6 @@ void free_table(TaskTable& t) {
     (void)hipFree(t.d_obs_range); (void)hipFree(t.d_obs_const_pre); (void)hipFree(t.d_obs_const_raw);
 }
 
-template <typename T>
-int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
-    if (need <= cap) return OCTO_OK;
-    if (p) { ctx->retired.push_back((void*)p); p = nullptr; cap = 0; }
-    const int64_t n = need + need / 2;
-    HIPCHK(ctx, hipMalloc((void**)&p, sizeof(T) * (size_t)n));
-    cap = n;
-    return OCTO_OK;
-}
 
 // Relative cost of one row of a table (VALU instructions per row, from the ISA of the mixed-kind kernels): used only to
 // balance block durations across tables of different kinds.
@@ -322,156 +204,6 @@ bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
 
 // Small batches: one fused launch, lane = epoch (octo_kernels.h: k_small). Eligible: W <= SMALL_W, at most two planets, no
 // HGCA table (k_hgca is its own launch) and no marginalised-RV table (its gradient needs the μ̂ pre-pass).
-template <int P, bool GRAD, bool NUIS, int KM>
-int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t st) {
-    using L = Layout<P, GRAD, NUIS, KM>;
-    static_assert(L::NACC <= WAVE, "k_small: lane k of the finishing wave owns running sum k");
-    // rows per block: enough blocks to spread one walker's epochs over the chip (about two blocks per CU in total), never
-    // less than one row per lane; the same partition for forward and gradient launches (bit-identical values).
-    // With the inputs in host memory every block starts with a PCIe read of its walker's elements (one or two 64-byte
-    // requests); a few hundred of those in flight is what the link sustains without queueing (measured: 448 blocks x 9
-    // scattered reads made W = 32 twice as slow as W = 1), so the block count is capped there.
-    int64_t total_blocks = ctx->stage_ws_in > 0 ? 160 : 2 * (int64_t)ctx->n_cus;
-    if (const char* ev = std::getenv("OCTO_SMALL_BLOCKS")) { const int v = std::atoi(ev); if (v > 0) total_blocks = v; }   // experiments
-    const int64_t target_tasks = std::max<int64_t>(1, total_blocks / a.W);
-    int64_t span = (ds->n_rows + target_tasks - 1) / target_tasks;
-    span = std::max<int64_t>(SMALL_TPB, (span + SMALL_TPB - 1) / SMALL_TPB * SMALL_TPB);
-    TaskTable* tt = nullptr;
-    int rc = get_tasks(ctx, ds, -(span / WPB), &tt);
-    if (rc) return rc;
-    a.tasks = tt->d_tasks; a.task_const = a.nuis ? tt->d_const_raw : tt->d_const_pre;
-    a.obs_range = tt->d_obs_range; a.obs_const = a.nuis ? tt->d_obs_const_raw : tt->d_obs_const_pre;
-    a.n_tasks = tt->n_tasks;
-    rc = grow(ctx, ctx->d_partials, ctx->cap_part, (int64_t)std::max(a.n_tasks, 1) * L::NACC * a.ldw);
-    if (rc) return rc;
-    a.partials = ctx->d_partials;
-    a.marg = nullptr; a.marg_out = nullptr; a.extra = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
-    if (timed) {
-        if (ctx->ev_used == ctx->ev_pool.size()) {
-            hipEvent_t x, y;
-            HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
-            ctx->ev_pool.emplace_back(x, y);
-        }
-        e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
-        HIPCHK(ctx, hipEventRecord(e0, st));
-    }
-    uint64_t* flags = nullptr;
-    if (ctx->flag_request) {      // a host-buffer call is waiting for these results: let it spin on per-walker flags
-        flags = ctx->h_flags; ctx->flag_seq += 1; ctx->flag_armed = true;
-    }
-    hipLaunchKernelGGL((k_small<P, GRAD, NUIS, KM>), dim3((unsigned)std::max(a.n_tasks, 1), (unsigned)a.W), dim3(SMALL_TPB), 0, st, a, ctx->d_counters,
-                       flags, ctx->flag_seq);
-    if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
-    HIPCHK(ctx, hipGetLastError());
-    return OCTO_OK;
-}
-
-template <int P, bool GRAD, bool NUIS, int KM>
-int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, hipStream_t st) {
-    using L = Layout<P, GRAD, NUIS, KM>;
-    const int64_t cols = (a.W + WAVE - 1) / WAVE;
-    const octo_dataset* ds = cds;
-    if constexpr (P <= 2) {
-        if (small_eligible(ctx, ds, a.W)) return launch_small<P, GRAD, NUIS, KM>(ctx, ds, a, st);
-    }
-    // Occupancy of the GRADIENT variant, also for forward-only launches: both then use the same row partition, so the
-    // forward value and the value returned with a gradient are the same sum in the same order — bit-identical, like the
-    // primal of a ForwardDiff dual. Cached per context (= per device) and variant.
-    int& blocks_per_cu = ctx->occupancy[(uint32_t)((P << 16) | ((NUIS ? 1 : 0) << 15) | KM)];
-    if (blocks_per_cu == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM>, WAVE * WPB, (main_lds_bytes<P, true, NUIS, KM>())) != hipSuccess || nb < 1)
-            nb = 2;
-        blocks_per_cu = nb;
-    }
-    TaskTable* tt = nullptr;
-    int rc0 = get_tasks(ctx, ds, plan_key(a.W, ds->n_rows, blocks_per_cu, ctx->n_cus), &tt);
-    if (rc0) return rc0;
-    const Task* tt_tasks = tt->h_tasks.data();
-    a.tasks = tt->d_tasks; a.task_const = a.nuis ? tt->d_const_raw : tt->d_const_pre;
-    a.obs_range = tt->d_obs_range; a.obs_const = a.nuis ? tt->d_obs_const_raw : tt->d_obs_const_pre;
-    a.n_tasks = tt->n_tasks;
-    const int64_t need = (int64_t)a.n_tasks * L::NACC * a.ldw;
-    int rc = grow(ctx, ctx->d_partials, ctx->cap_part, need);
-    if (rc) return rc;
-    a.partials = ctx->d_partials;
-    const dim3 gsetup((unsigned)((a.W + 255) / 256));
-    hipLaunchKernelGGL(k_setup, dim3(gsetup.x, (unsigned)a.n_planets), dim3(256), 0, st, a);
-    if (a.n_tasks > 0) {
-        if (GRAD && L::HAS_MARG && (ds->kind_mask & KM_MARG)) {
-            // marginalised RV: forward pre-pass over those tables' tasks for μ̂ and A, then the gradient pass
-            using L0 = Layout<P, false, NUIS, KM>;
-            static_assert(L0::NACC <= L::NACC, "forward partials fit in the gradient buffer");
-            rc = grow(ctx, ctx->d_marg, ctx->cap_marg, (int64_t)a.n_obs * 2 * a.ldw);
-            if (rc) return rc;
-            a.marg = nullptr; a.marg_out = ctx->d_marg;
-            for (int t0 = 0; t0 < a.n_tasks;) {
-                const int o = tt_tasks[t0].obs;
-                int t1 = t0;
-                while (t1 < a.n_tasks && tt_tasks[t1].obs == o) ++t1;
-                if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) {
-                    a.task0 = t0;
-                    hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)(t1 - t0)), dim3(WAVE * WPB),
-                                       (main_lds_bytes<P, false, NUIS, KM>()), st, a);
-                }
-                t0 = t1;
-            }
-            a.task0 = 0;
-            hipLaunchKernelGGL((k_marg<P, NUIS, KM>), gsetup, dim3(256), 0, st, a);
-            a.marg = ctx->d_marg;
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
-        if (timed) {
-            if (ctx->ev_used == ctx->ev_pool.size()) {
-                hipEvent_t x, y;
-                HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
-                ctx->ev_pool.emplace_back(x, y);
-            }
-            e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
-            HIPCHK(ctx, hipEventRecord(e0, st));
-        }
-        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
-                           (main_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
-        if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
-    }
-    a.extra = nullptr;
-    if (ds->n_hgca > 0) {
-        if constexpr (NUIS) {
-            const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
-            rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
-            if (rc) return rc;
-            a.extra = ctx->d_extra;
-            hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)cols, (unsigned)n_dir), dim3(WAVE), 0, st, a);
-        } else {
-            return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
-        }
-    }
-    hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * FIN_G),
-                       sizeof(double) * 12 * FIN_G * WAVE, st, a);
-    HIPCHK(ctx, hipGetLastError());
-    return OCTO_OK;
-}
-
-template <int P, int KM>
-int dispatch2(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
-    if (grad) return nuis ? launch_all<P, true, true, KM>(ctx, ds, a, st) : launch_all<P, true, false, KM>(ctx, ds, a, st);
-    return nuis ? launch_all<P, false, true, KM>(ctx, ds, a, st) : launch_all<P, false, false, KM>(ctx, ds, a, st);
-}
-
-template <int P>
-int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, hipStream_t st) {
-    const int km = ds->kind_mask;
-    if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR>(ctx, ds, a, grad, nuis, st);
-    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL>(ctx, ds, a, grad, nuis, st);
-    if ((km & (KM_MARG | KM_ONEIL)) == 0) return dispatch2<P, KM_ALL & ~KM_MARG & ~KM_ONEIL>(ctx, ds, a, grad, nuis, st);
-    return dispatch2<P, KM_ALL>(ctx, ds, a, grad, nuis, st);
-}
-
 int drain_timing(octo_ctx* ctx) {
     for (size_t k = 0; k < ctx->ev_used; ++k) {
         float ms = 0.f;
@@ -485,7 +217,7 @@ int drain_timing(octo_ctx* ctx) {
     return OCTO_OK;
 }
 
-}  // namespace
+}  // namespace octo
 
 extern "C" {
 
@@ -753,18 +485,10 @@ int32_t octo_dataset_destroy(octo_dataset* ds) {
 
 int64_t octo_dataset_n_rows(const octo_dataset* ds) { return ds ? ds->n_rows : -1; }
 
-int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d_elems, const double* d_nuis,
-                         int64_t ld, int64_t W, double* d_ll, double* d_g_elems, double* d_g_nuis, void* hip_stream) {
-    if (!ctx || !cds || !d_elems || !d_ll) return fail(ctx, OCTO_EINVAL, "octo_eval_device: null argument");
-    if (W < 0 || (ld < W && ctx->stage_ws_in == 0)) return fail(ctx, OCTO_EINVAL, "octo_eval_device: need 0 <= W <= ld");
-    if (d_g_nuis && (!d_g_elems || !d_nuis)) return fail(ctx, OCTO_EINVAL, "octo_eval_device: g_nuis needs g_elems and nuis");
-    if (d_g_elems && d_nuis && !d_g_nuis) return fail(ctx, OCTO_EINVAL, "octo_eval_device: nuis given with g_elems but no g_nuis");
-    if (cds->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_eval_device: dataset lives on another device");
-    if (W == 0) return OCTO_OK;
-    const octo_dataset* ds = cds;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st;
-    { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
+// The evaluation behind octo_eval_device and octo_model_logpost_device. `sm` non-null: the fused small-batch launch with the
+// standard parameterisation inside (θ_t in, log-posterior out; d_elems / outputs unused), `grad` / `nuis` given by the caller.
+static int eval_impl(octo_ctx* ctx, const octo_dataset* ds, const double* d_elems, const double* d_nuis, int64_t ld, int64_t W,
+                     double* d_ll, double* d_g_elems, double* d_g_nuis, hipStream_t st, const SmallModel* sm, bool grad, bool nuis) {
     if (ctx->timing_every > 0 && ctx->ev_used >= 4096) { int rc = drain_timing(ctx); if (rc) return rc; }
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     if (ldw > ctx->cap_w) {
@@ -788,13 +512,26 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d
     a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w; a.sctab = ctx->d_sctab;
     a.ll_out = d_ll; a.g_elems = d_g_elems; a.g_nuis = d_g_nuis;
     a.c = dev_consts(ctx->consts);
-    const bool grad = d_g_elems != nullptr, nuis = d_nuis != nullptr;
     switch (ds->n_planets) {
-        case 1: return dispatch1<1>(ctx, ds, a, grad, nuis, st);
-        case 2: return dispatch1<2>(ctx, ds, a, grad, nuis, st);
-        case 3: return dispatch1<3>(ctx, ds, a, grad, nuis, st);
-        default: return dispatch1<4>(ctx, ds, a, grad, nuis, st);
+        case 1: return dispatch1<1>(ctx, ds, a, grad, nuis, sm, st);
+        case 2: return dispatch1<2>(ctx, ds, a, grad, nuis, sm, st);
+        case 3: return dispatch1<3>(ctx, ds, a, grad, nuis, sm, st);
+        default: return dispatch1<4>(ctx, ds, a, grad, nuis, sm, st);
     }
+}
+
+int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d_elems, const double* d_nuis,
+                         int64_t ld, int64_t W, double* d_ll, double* d_g_elems, double* d_g_nuis, void* hip_stream) {
+    if (!ctx || !cds || !d_elems || !d_ll) return fail(ctx, OCTO_EINVAL, "octo_eval_device: null argument");
+    if (W < 0 || (ld < W && ctx->stage_ws_in == 0)) return fail(ctx, OCTO_EINVAL, "octo_eval_device: need 0 <= W <= ld");
+    if (d_g_nuis && (!d_g_elems || !d_nuis)) return fail(ctx, OCTO_EINVAL, "octo_eval_device: g_nuis needs g_elems and nuis");
+    if (d_g_elems && d_nuis && !d_g_nuis) return fail(ctx, OCTO_EINVAL, "octo_eval_device: nuis given with g_elems but no g_nuis");
+    if (cds->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_eval_device: dataset lives on another device");
+    if (W == 0) return OCTO_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st;
+    { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
+    return eval_impl(ctx, cds, d_elems, d_nuis, ld, W, d_ll, d_g_elems, d_g_nuis, st, nullptr, d_g_elems != nullptr, d_nuis != nullptr);
 }
 
 int32_t octo_sync(octo_ctx* ctx) {
@@ -1068,12 +805,23 @@ int32_t octo_model_destroy(octo_model* m) {
 int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_theta_t, int64_t ld, int64_t W, double* d_lp,
                                   double* d_grad, void* hip_stream) {
     if (!ctx || !m || !d_theta_t || !d_lp) return fail(ctx, OCTO_EINVAL, "octo_model_logpost_device: null argument");
-    if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_model_logpost_device: need 0 <= W <= ld");
+    if (W < 0 || (ld < W && ctx->stage_ws_in == 0)) return fail(ctx, OCTO_EINVAL, "octo_model_logpost_device: need 0 <= W <= ld");
     if (m->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_model_logpost_device: model lives on another device");
     if (W == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st;
     { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
+    if (small_eligible(ctx, m->ds, W)) {
+        // one launch: θ_t -> priors, elements, likelihood, ∇θ_t inside k_small<MODEL> (octo_small.h)
+        SmallModel sm;
+        std::memset(&sm, 0, sizeof(sm));
+        sm.priors = m->d_priors; sm.esrc = m->d_esrc; sm.nsrc = m->d_nsrc; sm.D = m->D;
+        sm.theta_t = d_theta_t; sm.lp_out = d_lp; sm.grad_out = d_grad;
+        if (ctx->stage_ws_in > 0) { sm.ld_t = 1; sm.ws_t = ctx->stage_ws_in; sm.ld_o = 1; sm.ws_o = ctx->stage_ws_out; }      // walker-major staging
+        else { sm.ld_t = ld; sm.ws_t = 1; sm.ld_o = ld; sm.ws_o = 1; }
+        sm.k_yr = ctx->consts.kepler_year_to_julian_day; sm.yd = ctx->consts.year2day_julian;
+        return eval_impl(ctx, m->ds, nullptr, nullptr, 1, W, nullptr, nullptr, nullptr, st, &sm, d_grad != nullptr, m->has_nuis);
+    }
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     const int n_in = m->n_el + m->n_nu;
     const int64_t rows = (int64_t)n_in + (int64_t)n_in * m->D + 1 + m->D + 1 + n_in;
@@ -1110,8 +858,8 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     }
     HIPCHK(ctx, hipGetLastError());
     const bool grad = d_grad != nullptr;
-    int rc = octo_eval_device(ctx, m->ds, a.elems, m->has_nuis ? a.nuis : nullptr, L, W, d_ll, grad ? d_gel : nullptr,
-                              (grad && m->has_nuis) ? d_gnu : nullptr, st);
+    int rc = eval_impl(ctx, m->ds, a.elems, m->has_nuis ? a.nuis : nullptr, L, W, d_ll, grad ? d_gel : nullptr,
+                       (grad && m->has_nuis) ? d_gnu : nullptr, st, nullptr, grad, m->has_nuis);
     if (rc) return rc;
     hipLaunchKernelGGL(k_model_bwd, dim3((unsigned)((W + 255) / 256), (unsigned)(d_grad ? m->D : 1)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
@@ -1133,6 +881,25 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
         double *m_in = nullptr, *m_out = nullptr;
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
+        if (small_eligible(ctx, m->ds, W)) {
+            // the fused launch: θ_t of one walker contiguous on the way in, [lp | ∇θ_t] on the way out, completion by flag
+            const int64_t D = m->D, ws_o = grad_out ? D + 1 : 1;
+            for (int64_t w = 0; w < W; ++w)
+                for (int r = 0; r < D; ++r) ctx->h_in[w * D + r] = theta_t[(size_t)r * ld + w];
+            ctx->stage_ws_in = D; ctx->stage_ws_out = ws_o;
+            ctx->flag_request = true; ctx->flag_armed = false;
+            int rcz = octo_model_logpost_device(ctx, m, m_in, 1, W, m_out, grad_out ? m_out + 1 : nullptr, st);
+            ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
+            if (rcz) return rcz;
+            rcz = wait_small(ctx, st, W);
+            if (rcz) return rcz;
+            for (int64_t w = 0; w < W; ++w) {
+                lp_out[w] = ctx->h_out[w * ws_o];
+                if (grad_out) for (int r = 0; r < D; ++r) grad_out[(size_t)r * ld + w] = ctx->h_out[w * ws_o + 1 + r];
+            }
+            free_retired(ctx);
+            return OCTO_OK;
+        }
         for (int r = 0; r < m->D; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, theta_t + (size_t)r * ld, sizeof(double) * W);
         int rcz = octo_model_logpost_device(ctx, m, m_in, ldd, W, m_out, grad_out ? m_out + ldd : nullptr, st);
         if (rcz) return rcz;

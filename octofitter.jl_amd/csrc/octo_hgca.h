@@ -41,7 +41,7 @@ __device__ __forceinline__ Dual<1> hgca_logpdf2(const Dual<1>& r1, const Dual<1>
 
 // grid = (walker tiles of 64, P·9 + n_obs·3 input directions), block = 64
 template <int P>
-__global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
+static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
     using D = Dual<1>;
     const int64_t w = (int64_t)blockIdx.x * WAVE + threadIdx.x;
     const int64_t wl = w < a.W ? w : a.W - 1;

@@ -1,0 +1,149 @@
+// octo_host.h — host-side internals shared by the translation units of the library: the opaque handle structs, the scratch /
+// row-partition helpers and the declaration of the per-planet-count dispatch. The kernel templates are instantiated in
+// octo_inst_p{1..4}.hip (one translation unit per planet count, so that they compile in parallel); octo_api.hip holds the
+// C ABI and every non-template helper.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "octo_kernels.h"
+#include "octo_model.h"
+#include "octo_hgca.h"
+#include "octo_small.h"
+#include "octofitter_hip.h"
+
+namespace octo {
+
+struct TaskTable {
+    uint64_t ds_serial = 0;          // the dataset this partition belongs to (octo_dataset::serial)
+    int64_t key = 0;                 // > 0: target number of tasks of the plan; < 0: forced uniform rows-per-wave (OCTO_CHUNK)
+    int n_tasks = 0;
+    Task* d_tasks = nullptr;
+    double* d_const_pre = nullptr;   // per-task constants for the no-nuisance path
+    double* d_const_raw = nullptr;   // per-task constants for the nuisance path
+    int32_t* d_obs_range = nullptr;  // [n_obs][2] task range of each observation
+    double* d_obs_const_pre = nullptr, *d_obs_const_raw = nullptr;   // [n_obs] Σ of the task constants, in task order
+    std::vector<Task> h_tasks;
+};
+
+
+}  // namespace octo
+
+using namespace octo;      // host translation units only: the handle structs below hold kernel-side types
+
+struct octo_dataset {
+    int device = 0;
+    int n_obs = 0, n_planets = 0;
+    int kind_mask = 0;
+    int64_t n_rows = 0;
+    int n_hgca = 0;                      // OCTO_HGCA tables: evaluated by k_hgca, not by the epoch-loop kernel
+    std::vector<DevObs> h_obs;
+    std::vector<std::vector<double>> h_rowconst_pre, h_rowconst_raw;   // per obs, per row
+    DevObs* d_obs = nullptr;
+    std::vector<double*> d_bufs;
+    octo_planet_desc planets[MAXP];
+    uint64_t serial = 0;                 // process-unique id: the contexts key their task-table caches by it (the dataset itself
+                                         // is immutable after octo_dataset_create, so contexts may share it without locking)
+};
+
+struct octo_ofti {
+    int device = 0;
+    int64_t n = 0;
+    double* d_rows = nullptr;
+    double lambda = 0, data_quad = 0, log_det_data_cov = 0, log_det_prior_inv = 0, n_log2pi = 0;
+};
+
+struct octo_ctx {
+    int device = 0;
+    int n_cus = 256;
+    int64_t max_lds = 65536;                    // largest dynamic LDS allocation one block may ask for on this device
+    hipStream_t stream = nullptr;               // the context's own stream (OCTO_STREAM_CTX, and every host-buffer entry point)
+    // The scratch below is reused by every evaluation, so evaluations through one context must be ordered. They are when the
+    // caller keeps to one stream per context (the documented contract); if it does switch streams, the new stream is made to
+    // wait for the last evaluation enqueued on the old one (an event, no host synchronisation).
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    hipEvent_t ev_order = nullptr;
+    octo_consts consts;
+    std::string err;
+    // scratch (device)
+    int64_t cap_w = 0, cap_part = 0, cap_io = 0, cap_marg = 0;
+    double* d_wc = nullptr;
+    int32_t* d_valid = nullptr;
+    double* d_partials = nullptr;
+    double* d_marg = nullptr;
+    double* d_extra = nullptr;                  // k_hgca output: ll and input-gradient of the non-epoch-loop terms
+    int64_t cap_extra = 0;
+    double* d_sctab = nullptr;                  // sin/cos grid of sincos_table, [SCT_N][2]
+    int32_t* d_counters = nullptr;              // k_small: finished-block counter per walker, [SMALL_W], zero between launches
+    uint64_t* h_flags = nullptr;                // mapped pinned [SMALL_W]: k_small's finishing block of walker w stores the call's
+    uint64_t flag_seq = 0;                      // sequence number here after its outputs; host-buffer calls spin on it
+    bool flag_request = false, flag_armed = false;
+    int64_t stage_ws_in = 0, stage_ws_out = 0;  // > 0 while octo_eval hands k_small its walker-major staging buffers
+    int small_w = SMALL_W;                      // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
+    double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
+    int64_t cap_in = 0, cap_out = 0;
+    double *h_in = nullptr, *h_out = nullptr;   // pinned mirrors of d_in / d_out for SMALL batches: one transfer each way instead of
+    int64_t cap_hin = 0, cap_hout = 0;          // one per array — what a single-chain sampler's per-gradient latency is made of
+    std::vector<void*> retired;                 // outgrown scratch buffers: kernels already enqueued may still use them, so they
+                                                // are freed at the next host-blocking point (octo_sync, the end of a host-buffer
+                                                // call, octo_ctx_destroy) instead of by a device-synchronising hipFree mid-stream
+    // row partitions ("task tables") of the datasets this context has evaluated, keyed by (dataset serial, plan key)
+    std::vector<octo::TaskTable> tables;
+    std::map<uint32_t, int> occupancy;          // resident blocks per CU of each k_main variant (P, NUIS, KM) on THIS device
+    // timing
+    int timing_every = 0;                       // 0 = off, n = bracket every n-th evaluation's k_main with events
+    int64_t timing_seq = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double t_ms = 0.0;
+    int64_t t_n = 0;
+    std::vector<float> t_samples;               // every timed launch since the last reset (median, spread)
+};
+
+
+namespace octo {
+
+int fail(octo_ctx* ctx, int code, const std::string& msg);
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? OCTO_ENOMEM : OCTO_EHIP,                  \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+template <typename T>
+int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
+    if (need <= cap) return OCTO_OK;
+    if (p) { ctx->retired.push_back((void*)p); p = nullptr; cap = 0; }
+    const int64_t n = need + need / 2;
+    HIPCHK(ctx, hipMalloc((void**)&p, sizeof(T) * (size_t)n));
+    cap = n;
+    return OCTO_OK;
+}
+
+int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out);
+int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus);
+bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);
+
+// Launch of one evaluation for a dataset with P planets (octo_launch.h; instantiated in octo_inst_p<P>.hip).
+template <int P>
+int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st);
+extern template int dispatch1<1>(octo_ctx*, const octo_dataset*, EvalArgs&, bool, bool, const SmallModel*, hipStream_t);
+extern template int dispatch1<2>(octo_ctx*, const octo_dataset*, EvalArgs&, bool, bool, const SmallModel*, hipStream_t);
+extern template int dispatch1<3>(octo_ctx*, const octo_dataset*, EvalArgs&, bool, bool, const SmallModel*, hipStream_t);
+extern template int dispatch1<4>(octo_ctx*, const octo_dataset*, EvalArgs&, bool, bool, const SmallModel*, hipStream_t);
+
+}  // namespace octo

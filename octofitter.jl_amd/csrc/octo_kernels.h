@@ -132,23 +132,22 @@ __device__ __forceinline__ double sqrt_fast(double x) {
 // FAST (k_small): reciprocal-multiply instead of IEEE division, rsqrt-based roots, polynomial sincos. At the clock a
 // mostly-idle GPU runs one short kernel at, every 100 serial FP64 instructions are about a microsecond of latency.
 template <bool FAST = false>
-__device__ __forceinline__ SetupOut setup_planet(const EvalArgs& a, int p, int64_t woff) {
+__device__ __forceinline__ SetupOut setup_planet_vals(const double (&elv)[OCTO_N_EL], const DevConsts& cst, int orbit_kind, int has_mass) {
     SetupOut so;
     auto fdiv = [](double x, double y) { return FAST ? x * rcp_nr<2>(y) : x / y; };
     auto fsqrt = [](double x) { return FAST ? sqrt_fast(x) : sqrt(x); };
-    const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + woff;
 #pragma unroll
-    for (int k = 0; k < OCTO_N_EL; ++k) so.el[k] = el[(int64_t)k * a.ld];
-    const bool radvel = a.orbit_kind[p] == OCTO_ORBIT_RADVEL;
-    const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
-    const bool kep = a.orbit_kind[p] == OCTO_ORBIT_KEP;      // plain KepOrbit: no parallax, positions stay in AU (no astrometry tables)
-    const double e = el[OCTO_EL_E * a.ld], om = el[OCTO_EL_W * a.ld];
-    const double tp = el[OCTO_EL_TP * a.ld], Mt = el[OCTO_EL_M * a.ld];
-    double sma = el[OCTO_EL_A * a.ld];
-    double inc = radvel ? 0.0 : el[OCTO_EL_I * a.ld];
-    double Om = radvel ? 0.0 : el[OCTO_EL_O * a.ld];
-    const double plx = (radvel || kep) ? 1.0 : el[OCTO_EL_PLX * a.ld];
-    const double mass = a.has_mass[p] ? el[OCTO_EL_MASS * a.ld] : 0.0;
+    for (int k = 0; k < OCTO_N_EL; ++k) so.el[k] = elv[k];
+    const bool radvel = orbit_kind == OCTO_ORBIT_RADVEL;
+    const bool ti = orbit_kind == OCTO_ORBIT_THIELE_INNES;
+    const bool kep = orbit_kind == OCTO_ORBIT_KEP;      // plain KepOrbit: no parallax, positions stay in AU (no astrometry tables)
+    const double e = elv[OCTO_EL_E], om = elv[OCTO_EL_W];
+    const double tp = elv[OCTO_EL_TP], Mt = elv[OCTO_EL_M];
+    double sma = elv[OCTO_EL_A];
+    double inc = radvel ? 0.0 : elv[OCTO_EL_I];
+    double Om = radvel ? 0.0 : elv[OCTO_EL_O];
+    const double plx = (radvel || kep) ? 1.0 : elv[OCTO_EL_PLX];
+    const double mass = has_mass ? elv[OCTO_EL_MASS] : 0.0;
     bool ok = isfinite(sma) && isfinite(e) && isfinite(inc) && isfinite(om) && isfinite(Om) && isfinite(tp) &&
               isfinite(Mt) && isfinite(plx) && isfinite(mass);
     double T, A, B, F, G, si, ci, sw, cw, sO, cO;
@@ -167,16 +166,16 @@ __device__ __forceinline__ SetupOut setup_planet(const EvalArgs& a, int p, int64
         else { sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO); }
         if (radvel) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
         // Thiele-Innes constants (parameterizations.jl:34-37) scaled to mas: T = a · cart2angle
-        T = (radvel || kep) ? 0.0 : sma * plx * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
+        T = (radvel || kep) ? 0.0 : sma * plx * cst.mas_per_au_per_plx;   // parameterizations.jl:215-216
         A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
         F = -cO * sw - sO * cw * ci; G = -sO * sw + cO * cw * ci;
     }
     ok = ok && (e >= 0.0) && (e < 1.0) && (sma > 0.0) && (Mt > 0.0) && (plx > 0.0);
-    const double P_d = a.c.k_yr * fsqrt(fdiv(sma * sma * sma, Mt));       // parameterizations.jl:62
+    const double P_d = cst.k_yr * fsqrt(fdiv(sma * sma * sma, Mt));       // parameterizations.jl:62
     const double ome2 = 1.0 - e * e;
     const double beta = fsqrt(ome2);
     // K = ((2π a)/P_yr)/√(1−e²) · au2m · sec2year · sin i
-    const double K = fdiv(fdiv(TWO_PI * sma, fdiv(P_d, a.c.yd)), beta) * a.c.au2m * a.c.sec2yr * si;   // 0 for a ThieleInnesOrbit (no RV tables there)
+    const double K = fdiv(fdiv(TWO_PI * sma, fdiv(P_d, cst.yd)), beta) * cst.au2m * cst.sec2yr * si;   // 0 for a ThieleInnesOrbit (no RV tables there)
     double* o = so.v;
     o[WC_INVP] = fdiv(1.0, P_d); o[WC_TP] = tp; o[WC_E] = e; o[WC_BETA] = beta;
     o[WC_EOB] = fdiv(e, beta);
@@ -186,13 +185,22 @@ __device__ __forceinline__ SetupOut setup_planet(const EvalArgs& a, int p, int64
     o[WC_CGB] = T * G * beta; o[WC_CFB] = T * F * beta;
     o[WC_CBE] = T * B * e; o[WC_CAE] = T * A * e;
     o[WC_K] = K; o[WC_COSW] = cw; o[WC_SINW] = sw;
-    o[WC_MU] = fdiv(mass * a.c.mjup2msol, Mt); o[WC_A] = sma;
+    o[WC_MU] = fdiv(mass * cst.mjup2msol, Mt); o[WC_A] = sma;
     o[WC_SINI] = si; o[WC_COSI] = ci; o[WC_SINO] = sO; o[WC_COSO] = cO;
     so.ok = ok;
     return so;
 }
 
-__global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
+template <bool FAST = false>
+__device__ __forceinline__ SetupOut setup_planet(const EvalArgs& a, int p, int64_t woff) {
+    const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + woff;
+    double elv[OCTO_N_EL];
+#pragma unroll
+    for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = el[(int64_t)k * a.ld];
+    return setup_planet_vals<FAST>(elv, a.c, a.orbit_kind[p], a.has_mass[p]);
+}
+
+static __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.W) return;
     const int p = blockIdx.y;                          // one thread per (walker, planet)
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
 // ------------------------------------------------------------------------------------ k_kepler
 // Batched PlanetOrbits.kepler_solver(MA, e) (call site src/parameterizations.jl:340) through the same device
 // routine k_main uses; exported as octo_kepler_solve so tests can check the solver itself.
-__global__ __launch_bounds__(256) void k_kepler(const double* __restrict__ MA, const double* __restrict__ ecc, int64_t n,
+static __global__ __launch_bounds__(256) void k_kepler(const double* __restrict__ MA, const double* __restrict__ ecc, int64_t n,
                                                  double* E, double* sE, double* cE) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -240,8 +248,7 @@ struct AstromCoef {
 };
 
 template <int P, bool GRAD, bool NUIS, int KM>
-__device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ nuis, int64_t ld, int ob_kind, int ob_planet, int ob_has_cor,
-                                                     int obs_index, const PC (&pc)[P], int64_t wl) {
+__device__ __forceinline__ AstromCoef<P> astrom_coef_vals(double jit, double ps, double na, int ob_kind, int ob_planet, int ob_has_cor, const PC (&pc)[P]) {
     using L = Layout<P, GRAD, NUIS, KM>;
     AstromCoef<P> c;
     // 1 for the planet the table is attached to, +m/M for strictly-inner companions with a mass.
@@ -256,9 +263,7 @@ __device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ 
     }
     c.jit = 0.0; c.j2 = 0.0; c.ps = 1.0; c.na = 0.0; c.sn = 0.0; c.cn = 1.0;
     if constexpr (NUIS) {
-        const double* nu = nuis + (int64_t)obs_index * OCTO_N_NUIS * ld + wl;
-        c.jit = nu[OCTO_NU_JITTER * ld]; c.ps = nu[OCTO_NU_PLATESCALE * ld];
-        c.na = nu[OCTO_NU_NORTHANGLE * ld];
+        c.jit = jit; c.ps = ps; c.na = na;
         sincos(c.na, &c.sn, &c.cn);
         c.j2 = c.jit * c.jit;
     }
@@ -266,6 +271,17 @@ __device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ 
     c.oneil = L::HAS_ONEIL && (ob_kind == OCTO_ONEIL_RADEC || ob_kind == OCTO_ONEIL_SEPPA);
     c.planet = ob_planet; c.has_cor = ob_has_cor;
     return c;
+}
+
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ nuis, int64_t ld, int ob_kind, int ob_planet, int ob_has_cor,
+                                                     int obs_index, const PC (&pc)[P], int64_t wl) {
+    double jit = 0.0, ps = 1.0, na = 0.0;
+    if constexpr (NUIS) {
+        const double* nu = nuis + (int64_t)obs_index * OCTO_N_NUIS * ld + wl;
+        jit = nu[OCTO_NU_JITTER * ld]; ps = nu[OCTO_NU_PLATESCALE * ld]; na = nu[OCTO_NU_NORTHANGLE * ld];
+    }
+    return astrom_coef_vals<P, GRAD, NUIS, KM>(jit, ps, na, ob_kind, ob_planet, ob_has_cor, pc);
 }
 
 template <int P, bool GRAD, bool NUIS, int KM, bool TAB>
@@ -431,12 +447,12 @@ struct RvCoef {
 };
 
 template <int P, bool GRAD, bool NUIS, int KM>
-__device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, int64_t ld, const double* __restrict__ margp, int64_t ldw,
-                                             int ob_kind, int ob_planet, int obs_index, const PC (&pc)[P], int64_t wl) {
+__device__ __forceinline__ RvCoef<P> rv_coef_vals(double off, double jit, const double* __restrict__ margp, int64_t ldw,
+                                                  int ob_kind, int ob_planet, int obs_index, const PC (&pc)[P], int64_t wl) {
     RvCoef<P> c;
     // RV_REL: +1 for this planet (rv-relative.jl:143), −m/M for strictly-inner massive companions (:148-156);
     // absolute RV: −m/M for every planet (rv-absolute.jl:146-155).
-    c.rel = ob_kind == OCTO_RV_REL;
+    c.rel = (KM & KM_RVREL) && ob_kind == OCTO_RV_REL;
     {
         double a_this = 0.0;
 #pragma unroll
@@ -448,9 +464,8 @@ __device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, in
     c.marg = (KM & KM_MARG) && ob_kind == OCTO_RV_ABS_MARG;
     c.off = 0.0; c.jit = 0.0; c.j2 = 0.0;
     if constexpr (NUIS) {
-        const double* nu = nuis + (int64_t)obs_index * OCTO_N_NUIS * ld + wl;
-        c.off = c.marg ? 0.0 : nu[OCTO_NU_RV_OFFSET * ld];
-        c.jit = nu[OCTO_NU_RV_JITTER * ld];
+        c.off = c.marg ? 0.0 : off;
+        c.jit = jit;
         c.j2 = c.jit * c.jit;
     }
     c.mu_hat = 0.0; c.iA = 0.0;
@@ -460,6 +475,17 @@ __device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, in
     }
     c.planet = ob_planet;
     return c;
+}
+
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, int64_t ld, const double* __restrict__ margp, int64_t ldw,
+                                             int ob_kind, int ob_planet, int obs_index, const PC (&pc)[P], int64_t wl) {
+    double off = 0.0, jit = 0.0;
+    if constexpr (NUIS) {
+        const double* nu = nuis + (int64_t)obs_index * OCTO_N_NUIS * ld + wl;
+        off = nu[OCTO_NU_RV_OFFSET * ld]; jit = nu[OCTO_NU_RV_JITTER * ld];
+    }
+    return rv_coef_vals<P, GRAD, NUIS, KM>(off, jit, margp, ldw, ob_kind, ob_planet, obs_index, pc, wl);
 }
 
 template <int P, bool GRAD, bool NUIS, int KM, bool TAB>
@@ -534,7 +560,7 @@ template <int P, bool GRAD, bool NUIS, int KM>
 constexpr size_t main_lds_bytes() { return sizeof(double) * (2 * SCT_N + Layout<P, GRAD, NUIS, KM>::NACC * WAVE); }
 
 template <int P, bool GRAD, bool NUIS, int KM>
-__global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
+static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -619,7 +645,7 @@ __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
 // ------------------------------------------------------------------------------------ k_marg
 // Pre-pass for marginalised-RV tables when a gradient is requested: μ̂ = −B/(2A) and A per walker.
 template <int P, bool NUIS, int KM>
-__global__ __launch_bounds__(256) void k_marg(EvalArgs a) {
+static __global__ __launch_bounds__(256) void k_marg(EvalArgs a) {
     using L = Layout<P, false, NUIS, KM>;
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.W) return;
@@ -652,10 +678,10 @@ constexpr int oneil_slots() { return (Layout<P, GRAD, NUIS, KM>::HAS_ONEIL && GR
 // v = {S, margA, margB, margC, nu0, nu1, nu2, on0..on3} summed over the observation's rows; returns its log-likelihood.
 // `sma[p]`: semi-major axis of each planet (derived for a ThieleInnesOrbit). Writes the observation's g_nuis rows if `write`.
 template <int P, bool GRAD, bool NUIS, int KM>
-__device__ __forceinline__ double obs_finish(const DevObs* __restrict__ obs, int64_t ld, double* __restrict__ g_nuis,
-                                             const double* __restrict__ extra, int64_t ldw, double k_yr, int o, const double (&v)[NOBS_ACC],
-                                             double cst, const double (&sma_p)[P], const double (&e_p)[P], const double (&M_p)[P],
-                                             int64_t w /* offset of this walker in g_nuis / extra rows */, bool write,
+__device__ __forceinline__ double obs_finish(const DevObs* __restrict__ obs, int64_t ld, double* __restrict__ gn /* this observation's g_nuis rows at this walker */,
+                                             const double* __restrict__ extra_w /* k_hgca's rows at this walker, or null */, int64_t ldw, double k_yr,
+                                             int o, const double (&v)[NOBS_ACC],
+                                             double cst, const double (&sma_p)[P], const double (&e_p)[P], const double (&M_p)[P], bool write,
                                              double (&oneil_g)[oneil_slots<P, GRAD, NUIS, KM>()]) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const int kind = obs[o].kind;
@@ -691,13 +717,12 @@ __device__ __forceinline__ double obs_finish(const DevObs* __restrict__ obs, int
     }
     if constexpr (L::N_NU > 0) {
         if (write) {
-            double* gn = g_nuis + (int64_t)o * OCTO_N_NUIS * ld + w;
             const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA;
             gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : v[4];
             gn[(int64_t)ld] = v[5];
             gn[(int64_t)2 * ld] = astrom ? v[6] : 0.0;
             if (kind == OCTO_HGCA) {      // ∂/∂(pmra, pmdec) from k_hgca
-                const double* x = extra + (int64_t)(1 + P * OCTO_N_EL + o * OCTO_N_NUIS) * ldw + w;
+                const double* x = extra_w + (int64_t)(1 + P * OCTO_N_EL + o * OCTO_N_NUIS) * ldw;
                 gn[0] = x[0]; gn[(int64_t)ld] = x[ldw]; gn[(int64_t)2 * ld] = 0.0;
             }
         }
@@ -796,7 +821,7 @@ __device__ __forceinline__ void planet_finish(const double (&el)[OCTO_N_EL] /* t
 // block = 64 walkers × FIN_G task groups: group g sums tasks g, g+FIN_G, … of each observation (more loads in
 // flight than one thread per walker), groups are combined through LDS in a fixed order, group 0 finishes.
 template <int P, bool GRAD, bool NUIS, int KM>
-__global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
+static __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
     constexpr int NPL = P * L::PL_N;
     constexpr int LDS_ROWS = NOBS_ACC > L::PL_N ? NOBS_ACC : L::PL_N;
@@ -868,7 +893,8 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
                 v[k] = x;
             }
             // observations are summed in the order given (system.jl:93,186)
-            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, a.g_nuis, a.extra, a.ldw, a.c.k_yr, o, v, cst, sma_p, e_p, M_p, w, w < a.W, oneil_g);
+            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + w : nullptr,
+                                                a.ldw, a.c.k_yr, o, v, cst, sma_p, e_p, M_p, w < a.W, oneil_g);
         }
         __syncthreads();
     }
@@ -916,245 +942,6 @@ __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------ k_small
-// Small batches (W <= SMALL_W walkers: one parameter set per call from NUTS / Pigeons' explorers, src/logdensitymodel.jl:169-177):
-// the whole evaluation in ONE launch, mapped the other way round — grid = (row tasks, walkers), lane = EPOCH.
-//   * every block derives its walker's orbit constants itself (setup_planet: wave-uniform, no k_setup launch, no `wc` round trip);
-//   * its 256 lanes stride over the task's rows with per-lane row records (coalesced 64-byte records), same row bodies as k_main;
-//   * the running sums are reduced across the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic), across the block's
-//     four waves through LDS, in a fixed order — bit-reproducible run to run;
-//   * with more than one task per walker, blocks publish their partial with device-scope (write-through) atomic stores and
-//     bump a per-walker counter; the block that sees the last count sums the partials IN TASK ORDER (so the result does not
-//     depend on which block that is) and runs the finish — no k_finish launch;
-//   * inputs and outputs may live in pinned host memory (octo_eval maps its staging buffers), so a call is one launch + one
-//     stream synchronisation, with no copy engine involved.
-constexpr int SMALL_W = OCTO_SMALL_BATCH_MAX;
-constexpr int SMALL_TPB = 256;
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double x) {
-    const int lo = __double2loint(x), hi = __double2hiint(x);
-    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-    return x + __hiloint2double(hi2, lo2);
-}
-
-// Sum over the 64 lanes of a wave, returned in every lane (wave-uniform). Inclusive scan within each row of 16 lanes by
-// row_shr:1,2,4,8 (lanes without a source add 0), then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3:
-// lane 63 holds the total; a fixed tree, so the rounding is the same every run.
-__device__ __forceinline__ double wave_sum(double x) {
-    x = dpp_add<0x111, 0xf>(x);
-    x = dpp_add<0x112, 0xf>(x);
-    x = dpp_add<0x114, 0xf>(x);
-    x = dpp_add<0x118, 0xf>(x);
-    x = dpp_add<0x142, 0xa>(x);
-    x = dpp_add<0x143, 0xc>(x);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double lane_value(double x, int src_lane) {      // src_lane wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ void pc_from_setup(PC& pc, const double (&v)[NWC]) {
-    pc.invP = v[WC_INVP]; pc.tp = v[WC_TP]; pc.e = v[WC_E]; pc.beta = v[WC_BETA]; pc.eob = v[WC_EOB];
-    pc.cB = v[WC_CB]; pc.cG = v[WC_CG]; pc.cA = v[WC_CA]; pc.cF = v[WC_CF]; pc.K = v[WC_K]; pc.cw = v[WC_COSW]; pc.sw = v[WC_SINW];
-    pc.mu = v[WC_MU]; pc.a = v[WC_A]; pc.cGb = v[WC_CGB]; pc.cFb = v[WC_CFB]; pc.cBe = v[WC_CBE]; pc.cAe = v[WC_CAE];
-    const float2 fa = *reinterpret_cast<const float2*>(&v[WC_F32A]);
-    const float2 fb = *reinterpret_cast<const float2*>(&v[WC_F32B]);
-    pc.ef = fa.x; pc.omef = fa.y; pc.k1f = fb.x;
-}
-
-template <int P, bool GRAD, bool NUIS, int KM>
-__global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, int32_t* __restrict__ counters, uint64_t* done_flags, uint64_t seq) {
-    using L = Layout<P, GRAD, NUIS, KM>;
-    constexpr int NACC = L::NACC;
-    constexpr int NW = SMALL_TPB / WAVE;
-    __shared__ double red[NW][NACC];
-    __shared__ double tot[NACC];
-    __shared__ int last_flag;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef OCTO_SMALL_TRACE
-    unsigned long long tr[8]; int ntr = 0;
-#define TRACE_POINT() tr[ntr++] = __builtin_readcyclecounter()
-#else
-#define TRACE_POINT()
-#endif
-    TRACE_POINT();
-    const int64_t w = blockIdx.y;                       // this block's walker (wave-uniform)
-    const int64_t wi = w * a.ws_in, wo = w * a.ws_out;  // its offset in the input and the output rows
-    const int task = blockIdx.x;
-    const bool has_task = task < a.n_tasks;
-
-    // ---- orbit constants of this walker (what k_setup would have written to `wc`)
-    PC pc[P];
-    FinPC fp[P];
-    double elv[P][OCTO_N_EL];
-    bool ok = true;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const SetupOut so = setup_planet<true>(a, p, wi);
-        pc_from_setup(pc[p], so.v);
-#pragma unroll
-        for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = so.el[k];
-        fp[p].sma = so.v[WC_A]; fp[p].P_d = 1.0 / so.v[WC_INVP]; fp[p].beta = so.v[WC_BETA];
-        fp[p].si = so.v[WC_SINI]; fp[p].ci = so.v[WC_COSI]; fp[p].sO = so.v[WC_SINO]; fp[p].cO = so.v[WC_COSO];
-        fp[p].sw = so.v[WC_SINW]; fp[p].cw = so.v[WC_COSW];
-        ok = ok && so.ok;
-    }
-
-    double acc[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-    TRACE_POINT();      // setup done
-    if (has_task) {
-        const Task tk = a.tasks[task];
-        const DevObs ob = a.obs[tk.obs];
-        LogProd lp;
-        int my_rows = 0;
-        const SinCosTab notab{nullptr, 0.0};
-        const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_RADEC ||
-                               ob.kind == OCTO_ONEIL_SEPPA;
-        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)tk.row0 * ROW_STRIDE;
-        if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
-            const AstromCoef<P> co = astrom_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, ob.kind, ob.planet, ob.has_cor, tk.obs, pc, wi);
-            for (int r = threadIdx.x; r < tk.nrows; r += SMALL_TPB) {
-                const double* __restrict__ rw = rows + (int64_t)r * ROW_STRIDE;
-                astrom_row<P, GRAD, NUIS, KM, false>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], notab);
-                ++my_rows;
-            }
-        }
-        if (L::HAS_RV && !is_astrom) {
-            const RvCoef<P> co = rv_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, nullptr, a.ldw, ob.kind, ob.planet, tk.obs, pc, wi);
-            for (int r = threadIdx.x; r < tk.nrows; r += SMALL_TPB) {
-                const double* __restrict__ rw = rows + (int64_t)r * ROW_STRIDE;
-                rv_row<P, GRAD, NUIS, KM, false>(acc, lp, pc, co, rw[0], rw[1], rw[2], notab);
-                ++my_rows;
-            }
-        }
-        if constexpr (NUIS) {
-            double lg = lp.log_value();      // a lane without rows: log(1) = 0
-            if ((KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG) lg = fma((double)my_rows, LOG2PI, lg);
-            acc[L::OFF_S] += lg;
-        }
-    }
-    TRACE_POINT();      // rows done
-    // ---- lanes -> wave (DPP), waves -> block (LDS), fixed order
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-        const double sum = wave_sum(acc[k]);
-        if (lane == 0) red[wv][k] = sum;
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-        double x = red[0][threadIdx.x];
-#pragma unroll
-        for (int q = 1; q < NW; ++q) x += red[q][threadIdx.x];
-        tot[threadIdx.x] = x;
-    }
-    __syncthreads();
-    TRACE_POINT();      // block reduction done
-    const int n_tasks = a.n_tasks;
-    const bool multi = n_tasks > 1;
-    if (multi) {
-        // publish this block's partial; device-scope atomic stores are written through, so no L2 write-back fence is needed
-        if (threadIdx.x < NACC)
-            __hip_atomic_store(a.partials + ((int64_t)w * n_tasks + task) * NACC + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above have completed (s_waitcnt vmcnt(0))
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int old = __hip_atomic_fetch_add(&counters[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_flag = (old == n_tasks - 1) ? 1 : 0;
-        }
-        __syncthreads();
-        if (!last_flag) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    // ---- finish (the single / last block). All 256 threads gather the task partials — thread (slot, k) sums tasks slot,
-    // slot + NTS, … of running sum k, plain loads (the acquire fence above made them coherent), several in flight — then wave 0
-    // combines the slots in order: lane k owns running sum k. The order is fixed, whichever block got here.
-    TRACE_POINT();      // last block known
-    constexpr int NTS = SMALL_TPB / WAVE;      // independent of NACC: the forward-only and the gradient launch sum in the same order
-    __shared__ double psum[NTS * NACC];
-    const int slot = lane < NACC ? wv : NTS, kcol = lane < NACC ? lane : 0;
-    if constexpr (NUIS) {      // every nuisance finite (k_setup's check)
-        bool fin = true;
-        for (int k = lane; k < a.n_obs * OCTO_N_NUIS; k += WAVE) fin = fin && isfinite(a.nuis[(int64_t)k * a.ld + wi]);
-        ok = ok && __all(fin);
-    }
-    double gp_acc = 0.0, ll = 0.0;
-    double oneil_g[oneil_slots<P, GRAD, NUIS, KM>()];
-#pragma unroll
-    for (int k = 0; k < oneil_slots<P, GRAD, NUIS, KM>(); ++k) oneil_g[k] = 0.0;
-    double sma_p[P], e_p[P], M_p[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) { sma_p[p] = fp[p].sma; e_p[p] = elv[p][OCTO_EL_E]; M_p[p] = elv[p][OCTO_EL_M]; }
-    for (int o = 0; o < a.n_obs; ++o) {
-        const int t0 = a.obs_range[2 * o], t1 = a.obs_range[2 * o + 1];
-        if (slot < NTS) {
-            double s = 0.0;
-            if (multi) {
-                const double* __restrict__ pp = a.partials + (int64_t)w * n_tasks * NACC + kcol;      // [walker][task][NACC]
-#pragma unroll 8
-                for (int t = t0 + slot; t < t1; t += NTS) s += pp[(int64_t)t * NACC];
-            } else if (slot == 0 && t1 > t0) {
-                s = tot[kcol];
-            }
-            psum[slot * NACC + kcol] = s;
-        }
-        __syncthreads();
-        if (wv == 0) {
-            double sum = 0.0;
-            if (lane < NACC) {
-#pragma unroll
-                for (int q = 0; q < NTS; ++q) sum += psum[q * NACC + lane];
-            }
-            gp_acc += sum;
-            double v[NOBS_ACC];
-#pragma unroll
-            for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
-            v[0] = lane_value(sum, L::OFF_S);
-            if constexpr (L::HAS_MARG) { v[1] = lane_value(sum, L::OFF_MARG); v[2] = lane_value(sum, L::OFF_MARG + 1); v[3] = lane_value(sum, L::OFF_MARG + 2); }
-            if constexpr (L::N_NU > 0) { v[4] = lane_value(sum, L::OFF_NU); v[5] = lane_value(sum, L::OFF_NU + 1); v[6] = lane_value(sum, L::OFF_NU + 2); }
-            if constexpr (L::HAS_ONEIL) {
-                v[7] = lane_value(sum, L::OFF_ONEIL);
-                if constexpr (GRAD) { v[8] = lane_value(sum, L::OFF_ONEIL + 1); v[9] = lane_value(sum, L::OFF_ONEIL + 2); v[10] = lane_value(sum, L::OFF_ONEIL + 3); }
-            }
-            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, a.g_nuis, nullptr, a.ldw, a.c.k_yr, o, v, a.obs_const[o], sma_p, e_p, M_p, wo, lane == 0, oneil_g);
-        }
-        __syncthreads();
-    }
-    if (wv != 0) return;
-    TRACE_POINT();      // observations finished
-    double gp[P * L::PL_N > 0 ? P * L::PL_N : 1];
-#pragma unroll
-    for (int k = 0; k < P * L::PL_N; ++k) gp[k] = lane_value(gp_acc, L::OFF_PL + k);
-    if (multi && lane == 0) __hip_atomic_store(&counters[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-    ok = ok && isfinite(ll);
-    if (lane != 0) return;
-    a.ll_out[wo] = ok ? ll : -INFINITY;
-    if constexpr (GRAD) {
-        if (!ok && L::N_NU > 0) {
-            for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + wo] = 0.0;
-        }
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-            planet_finish<P, GRAD, NUIS, KM, true>(elv[p], a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p],
-                                             p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp[p], ok);
-    }
-    TRACE_POINT();      // outputs stored
-    // host-buffer calls: this walker's results are in (mapped, coherent) host memory — release them to the host, which spins
-    // on the flag instead of paying a stream synchronisation
-    if (done_flags) __hip_atomic_store(done_flags + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef OCTO_SMALL_TRACE
-    TRACE_POINT();
-    if (done_flags && w == 0) for (int k = 0; k < ntr; ++k) done_flags[40 + k] = tr[k];      // h_flags has room behind the SMALL_W flags
-#endif
-}
-
 // ==================================================================================== OFTI
 // ofti_linear_solve(epochs, ra, dec, σ_ra, σ_dec, cor, σ_ABFG, e, a, tp, M, plx) — src/parameterizations.jl:318-405:
 // for fixed (e, a, tp, M) the sky position is linear in the Thiele-Innes constants (A, B, F, G); they are
@@ -1173,7 +960,7 @@ struct OftiArgs {
     double k_yr, lambda /* 1/σ_ABFG² */, data_quad, log_det_data_cov, log_det_prior_inv, n_log2pi;
 };
 
-__global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
+static __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1235,7 +1022,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
     }
 }
 
-__global__ __launch_bounds__(64) void k_ofti_finish(OftiArgs a) {
+static __global__ __launch_bounds__(64) void k_ofti_finish(OftiArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.W) return;
     double v[OFTI_NACC];

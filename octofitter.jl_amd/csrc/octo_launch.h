@@ -1,0 +1,166 @@
+// octo_launch.h — the launch templates of one evaluation: planner, k_setup / k_main / k_finish (+ k_marg, k_hgca) for big batches,
+// k_small for small ones, and the choice of the compiled kind set. Included only by octo_inst_p{1..4}.hip.
+#pragma once
+#include "octo_host.h"
+
+namespace octo {
+
+template <int P, bool GRAD, bool NUIS, int KM, bool MODEL>
+int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const SmallModel* smp, hipStream_t st) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    static_assert(L::NACC <= WAVE, "k_small: lane k of the finishing wave owns running sum k");
+    // rows per block: enough blocks to spread one walker's epochs over the chip (about two blocks per CU in total), never
+    // less than one row per lane; the same partition for forward and gradient launches (bit-identical values).
+    // With the inputs in host memory every block starts with a PCIe read of its walker's elements (one or two 64-byte
+    // requests); a few hundred of those in flight is what the link sustains without queueing (measured: 448 blocks x 9
+    // scattered reads made W = 32 twice as slow as W = 1), so the block count is capped there.
+    int64_t total_blocks = ctx->stage_ws_in > 0 ? 160 : 2 * (int64_t)ctx->n_cus;
+    if (const char* ev = std::getenv("OCTO_SMALL_BLOCKS")) { const int v = std::atoi(ev); if (v > 0) total_blocks = v; }   // experiments
+    const int64_t target_tasks = std::max<int64_t>(1, total_blocks / a.W);
+    int64_t span = (ds->n_rows + target_tasks - 1) / target_tasks;
+    span = std::max<int64_t>(SMALL_TPB, (span + SMALL_TPB - 1) / SMALL_TPB * SMALL_TPB);
+    TaskTable* tt = nullptr;
+    int rc = get_tasks(ctx, ds, -(span / WPB), &tt);
+    if (rc) return rc;
+    a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;
+    a.obs_range = tt->d_obs_range; a.obs_const = NUIS ? tt->d_obs_const_raw : tt->d_obs_const_pre;
+    a.n_tasks = tt->n_tasks;
+    rc = grow(ctx, ctx->d_partials, ctx->cap_part, (int64_t)std::max(a.n_tasks, 1) * L::NACC * a.ldw);
+    if (rc) return rc;
+    a.partials = ctx->d_partials;
+    a.marg = nullptr; a.marg_out = nullptr; a.extra = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
+    if (timed) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            hipEvent_t x, y;
+            HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
+            ctx->ev_pool.emplace_back(x, y);
+        }
+        e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
+        HIPCHK(ctx, hipEventRecord(e0, st));
+    }
+    uint64_t* flags = nullptr;
+    if (ctx->flag_request) {      // a host-buffer call is waiting for these results: let it spin on per-walker flags
+        flags = ctx->h_flags; ctx->flag_seq += 1; ctx->flag_armed = true;
+    }
+    SmallModel sm;
+    std::memset(&sm, 0, sizeof(sm));
+    if (MODEL) sm = *smp;
+    hipLaunchKernelGGL((k_small<P, GRAD, NUIS, KM, MODEL>), dim3((unsigned)std::max(a.n_tasks, 1), (unsigned)a.W), dim3(SMALL_TPB), 0, st, a, sm,
+                       ctx->d_counters, flags, ctx->flag_seq);
+    if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
+    HIPCHK(ctx, hipGetLastError());
+    return OCTO_OK;
+}
+
+template <int P, bool GRAD, bool NUIS, int KM>
+int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallModel* sm, hipStream_t st) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    const int64_t cols = (a.W + WAVE - 1) / WAVE;
+    const octo_dataset* ds = cds;
+    if constexpr (P <= 2) {
+        if (sm) return launch_small<P, GRAD, NUIS, KM, true>(ctx, ds, a, sm, st);      // the caller checked small_eligible
+        if (small_eligible(ctx, ds, a.W)) return launch_small<P, GRAD, NUIS, KM, false>(ctx, ds, a, nullptr, st);
+    }
+    if (sm) return fail(ctx, OCTO_EINVAL, "internal: fused model launch requested for an ineligible dataset");
+    // Occupancy of the GRADIENT variant, also for forward-only launches: both then use the same row partition, so the
+    // forward value and the value returned with a gradient are the same sum in the same order — bit-identical, like the
+    // primal of a ForwardDiff dual. Cached per context (= per device) and variant.
+    int& blocks_per_cu = ctx->occupancy[(uint32_t)((P << 16) | ((NUIS ? 1 : 0) << 15) | KM)];
+    if (blocks_per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM>, WAVE * WPB, (main_lds_bytes<P, true, NUIS, KM>())) != hipSuccess || nb < 1)
+            nb = 2;
+        blocks_per_cu = nb;
+    }
+    TaskTable* tt = nullptr;
+    int rc0 = get_tasks(ctx, ds, plan_key(a.W, ds->n_rows, blocks_per_cu, ctx->n_cus), &tt);
+    if (rc0) return rc0;
+    const Task* tt_tasks = tt->h_tasks.data();
+    a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;
+    a.obs_range = tt->d_obs_range; a.obs_const = NUIS ? tt->d_obs_const_raw : tt->d_obs_const_pre;
+    a.n_tasks = tt->n_tasks;
+    const int64_t need = (int64_t)a.n_tasks * L::NACC * a.ldw;
+    int rc = grow(ctx, ctx->d_partials, ctx->cap_part, need);
+    if (rc) return rc;
+    a.partials = ctx->d_partials;
+    const dim3 gsetup((unsigned)((a.W + 255) / 256));
+    hipLaunchKernelGGL(k_setup, dim3(gsetup.x, (unsigned)a.n_planets), dim3(256), 0, st, a);
+    if (a.n_tasks > 0) {
+        if (GRAD && L::HAS_MARG && (ds->kind_mask & KM_MARG)) {
+            // marginalised RV: forward pre-pass over those tables' tasks for μ̂ and A, then the gradient pass
+            using L0 = Layout<P, false, NUIS, KM>;
+            static_assert(L0::NACC <= L::NACC, "forward partials fit in the gradient buffer");
+            rc = grow(ctx, ctx->d_marg, ctx->cap_marg, (int64_t)a.n_obs * 2 * a.ldw);
+            if (rc) return rc;
+            a.marg = nullptr; a.marg_out = ctx->d_marg;
+            for (int t0 = 0; t0 < a.n_tasks;) {
+                const int o = tt_tasks[t0].obs;
+                int t1 = t0;
+                while (t1 < a.n_tasks && tt_tasks[t1].obs == o) ++t1;
+                if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) {
+                    a.task0 = t0;
+                    hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)(t1 - t0)), dim3(WAVE * WPB),
+                                       (main_lds_bytes<P, false, NUIS, KM>()), st, a);
+                }
+                t0 = t1;
+            }
+            a.task0 = 0;
+            hipLaunchKernelGGL((k_marg<P, NUIS, KM>), gsetup, dim3(256), 0, st, a);
+            a.marg = ctx->d_marg;
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
+        if (timed) {
+            if (ctx->ev_used == ctx->ev_pool.size()) {
+                hipEvent_t x, y;
+                HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
+                ctx->ev_pool.emplace_back(x, y);
+            }
+            e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
+            HIPCHK(ctx, hipEventRecord(e0, st));
+        }
+        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                           (main_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+        if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
+    }
+    a.extra = nullptr;
+    if (ds->n_hgca > 0) {
+        if constexpr (NUIS) {
+            const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
+            rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
+            if (rc) return rc;
+            a.extra = ctx->d_extra;
+            hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)cols, (unsigned)n_dir), dim3(WAVE), 0, st, a);
+        } else {
+            return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
+        }
+    }
+    hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * FIN_G),
+                       sizeof(double) * 12 * FIN_G * WAVE, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return OCTO_OK;
+}
+
+template <int P, int KM>
+int dispatch2(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st) {
+    if (grad) return nuis ? launch_all<P, true, true, KM>(ctx, ds, a, sm, st) : launch_all<P, true, false, KM>(ctx, ds, a, sm, st);
+    return nuis ? launch_all<P, false, true, KM>(ctx, ds, a, sm, st) : launch_all<P, false, false, KM>(ctx, ds, a, sm, st);
+}
+
+template <int P>
+int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st) {
+    // The smallest compiled kind set that covers the dataset: registers and occupancy are not paid for code it never runs.
+    const int km = ds->kind_mask;
+    if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, grad, nuis, sm, st);
+    if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, grad, nuis, sm, st);
+    if ((km & ~(KM_RADEC | KM_RVABS)) == 0) return dispatch2<P, KM_RADEC | KM_RVABS>(ctx, ds, a, grad, nuis, sm, st);      // BASELINE config 4
+    if ((km & ~(KM_RADEC | KM_RVREL)) == 0) return dispatch2<P, KM_RADEC | KM_RVREL>(ctx, ds, a, grad, nuis, sm, st);      // imaging + planet RV
+    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR>(ctx, ds, a, grad, nuis, sm, st);
+    if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL>(ctx, ds, a, grad, nuis, sm, st);
+    if ((km & (KM_MARG | KM_ONEIL)) == 0) return dispatch2<P, KM_ALL & ~KM_MARG & ~KM_ONEIL>(ctx, ds, a, grad, nuis, sm, st);
+    return dispatch2<P, KM_ALL>(ctx, ds, a, grad, nuis, sm, st);
+}
+
+}  // namespace octo

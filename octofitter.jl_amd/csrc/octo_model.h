@@ -151,7 +151,7 @@ __device__ __forceinline__ Dual<N> tperi(const Dual<N>& th, double theta_epoch, 
 // coalesced Jacobian rows, D× the parallelism of a thread-per-walker layout. The diagonal part — invlink and
 // logpdf_with_trans of every prior — is computed once per walker by the block's waves (prior k by wave k mod DB) and
 // shared through LDS: x[k], dx/dθ_t[k], p[k], dp/dθ_t[k].
-__global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
+static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     constexpr int N = MODEL_NPART;      // partials carried per thread
     extern __shared__ __attribute__((aligned(16))) double lds[];      // [4][D][64]
     const int lane = threadIdx.x;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
 }
 
 // grid = (walker tiles of 256, D): thread (w, d) produces grad[d][w] = ∂(prior)/∂θ_t[d] + Σ_k J[k][d]·ḡ[k].
-__global__ __launch_bounds__(256) void k_model_bwd(ModelArgs a) {
+static __global__ __launch_bounds__(256) void k_model_bwd(ModelArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int d = blockIdx.y;
     if (w >= a.W) return;

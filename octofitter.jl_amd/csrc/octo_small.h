@@ -1,0 +1,400 @@
+// octo_small.h — k_small: the SMALL-BATCH mapping of the path (W <= OCTO_SMALL_BATCH_MAX parameter sets per call — what NUTS, the
+// slice sampler and Pigeons' explorers do: one θ per ℓπcallback / ∇ℓπcallback, src/logdensitymodel.jl:110-177).
+// The whole evaluation is ONE launch, mapped the other way round from k_main — grid = (row tasks, walkers), lane = EPOCH:
+//   * every block derives its walker's orbit constants itself (setup_planet_vals: wave-uniform; no k_setup launch, no `wc` round trip);
+//   * its 256 lanes stride over the task's rows with per-lane row records, through the same row bodies as k_main;
+//   * the running sums are reduced across the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic), across the block's
+//     four waves through LDS, in a fixed order — bit-reproducible run to run;
+//   * with more than one task per walker, blocks publish their partial with device-scope (write-through) atomic stores and
+//     bump a per-walker counter; the block that sees the last count sums the partials IN TASK ORDER (so the result does not
+//     depend on which block that is) and runs the finish — no k_finish launch;
+//   * inputs and outputs may live in mapped pinned host memory and completion is signalled through per-walker flags there,
+//     so a host-buffer call is one launch and no copy engine, no stream synchronisation.
+// MODEL = true fuses the standard parameterisation (octo_model.h) into the same launch: θ_t in, log-posterior and
+// ∇θ_t out. There the 64 lanes of a wave carry the D <= 64 PARTIALS: lane d applies prior d (invlink, logpdf_with_trans) and then
+// pushes ∂/∂θ_t[d] through the derived variables as a one-partial dual, so the whole Jacobian of (elements, nuisances) w.r.t.
+// θ_t is one SIMD evaluation of the chain; the finishing wave forms ∇θ_t[d] = ∂prior/∂θ_t[d] + Σ_k J[k][d]·ḡ[k] in lane d.
+#pragma once
+#include "octo_model.h"
+
+namespace octo {
+
+constexpr int SMALL_W = OCTO_SMALL_BATCH_MAX;
+constexpr int SMALL_TPB = 256;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return x + __hiloint2double(hi2, lo2);
+}
+
+// Sum over the 64 lanes of a wave, returned in every lane (wave-uniform). Inclusive scan within each row of 16 lanes by
+// row_shr:1,2,4,8 (lanes without a source add 0), then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3:
+// lane 63 holds the total; a fixed tree, so the rounding is the same every run.
+__device__ __forceinline__ double wave_sum(double x) {
+    x = dpp_add<0x111, 0xf>(x);
+    x = dpp_add<0x112, 0xf>(x);
+    x = dpp_add<0x114, 0xf>(x);
+    x = dpp_add<0x118, 0xf>(x);
+    x = dpp_add<0x142, 0xa>(x);
+    x = dpp_add<0x143, 0xc>(x);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double lane_value(double x, int src_lane) {      // src_lane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void pc_from_setup(PC& pc, const double (&v)[NWC]) {
+    pc.invP = v[WC_INVP]; pc.tp = v[WC_TP]; pc.e = v[WC_E]; pc.beta = v[WC_BETA]; pc.eob = v[WC_EOB];
+    pc.cB = v[WC_CB]; pc.cG = v[WC_CG]; pc.cA = v[WC_CA]; pc.cF = v[WC_CF]; pc.K = v[WC_K]; pc.cw = v[WC_COSW]; pc.sw = v[WC_SINW];
+    pc.mu = v[WC_MU]; pc.a = v[WC_A]; pc.cGb = v[WC_CGB]; pc.cFb = v[WC_CFB]; pc.cBe = v[WC_CBE]; pc.cAe = v[WC_CAE];
+    const float2 fa = *reinterpret_cast<const float2*>(&v[WC_F32A]);
+    const float2 fb = *reinterpret_cast<const float2*>(&v[WC_F32B]);
+    pc.ef = fa.x; pc.omef = fa.y; pc.k1f = fb.x;
+}
+
+// ---- standard parameterisation, lane = partial -------------------------------------------------------------------------
+// This lane's own prior: natural value x[lane], dx/dθ_t[lane]. Other θ are fetched from their lanes.
+struct LaneTheta {
+    double xv, xd;
+    int lane;
+};
+
+__device__ __forceinline__ Dual<1> nat_theta(const LaneTheta& T, int k) {      // natural θ[k] with this lane's partial (k wave-uniform)
+    Dual<1> r;
+    r.v = lane_value(T.xv, k);
+    r.d[0] = (k == T.lane) ? T.xd : 0.0;
+    return r;
+}
+
+// OCTO_SRC_CONST / _THETA / _CIRCULAR (variables.jl:279-299). A UniformCircular source that carries its UnitLengthPrior term
+// (OCTO_SRC_FLAG_UNITLEN, variables.jl:309-323) adds it to `ul` when `count_ul`.
+__device__ __forceinline__ Dual<1> src_angle(const octo_source& sc, const LaneTheta& T, Dual<1>& ul, bool count_ul) {
+    const Dual<1> cx = nat_theta(T, sc.i0), cy = nat_theta(T, sc.i1);
+    if (count_ul && (sc.flags & OCTO_SRC_FLAG_UNITLEN)) ul = ul + unit_length(cx, cy);
+    return datan2(cy, cx);
+}
+
+__device__ __forceinline__ Dual<1> src_plain(const octo_source& sc, const LaneTheta& T, Dual<1>& ul, bool count_ul) {
+    if (sc.kind == OCTO_SRC_CONST) return dconst<1>(sc.value);
+    if (sc.kind == OCTO_SRC_THETA) return nat_theta(T, sc.i0);
+    return src_angle(sc, T, ul, count_ul) * (sc.value / TWO_PI);               // atan(y, x) / 2π * domain, variables.jl:284
+}
+
+// default nuisance source of row k of an observation when the model gives none (jitter 0, platescale 1, northangle 0 / offset 0)
+__device__ __forceinline__ octo_source default_nuis_source(int obs_kind, int r) {
+    octo_source sc;
+    sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
+    sc.value = ((obs_kind <= OCTO_ASTROM_SEPPA || obs_kind == OCTO_ONEIL_RADEC || obs_kind == OCTO_ONEIL_SEPPA) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+    return sc;
+}
+
+struct SmallModel {       // the part of ModelArgs k_small<MODEL> reads
+    const octo_prior* priors;
+    const octo_source* esrc;
+    const octo_source* nsrc;       // or null = defaults
+    const double* theta_t;         // [W][D] walker-major (ld = 1) or [D][ld]
+    int64_t ld_t, ws_t;            // θ_t[d * ld_t + w * ws_t]
+    double* lp_out; double* grad_out; int64_t ld_o, ws_o;      // lp_out[w * ws_o], grad_out[d * ld_o + w * ws_o]
+    int32_t D, pad;
+    double k_yr, yd;
+};
+
+template <int P, bool GRAD, bool NUIS, int KM, bool MODEL>
+static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallModel sm, int32_t* __restrict__ counters, uint64_t* done_flags, uint64_t seq) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    constexpr int NACC = L::NACC;
+    constexpr int NW = SMALL_TPB / WAVE;
+    __shared__ double red[NW][NACC];
+    __shared__ double tot[NACC];
+    __shared__ int last_flag;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef OCTO_SMALL_TRACE
+    unsigned long long tr[8]; int ntr = 0;
+#define TRACE_POINT() tr[ntr++] = __builtin_readcyclecounter()
+#else
+#define TRACE_POINT()
+#endif
+    TRACE_POINT();
+    const int64_t w = blockIdx.y;                       // this block's walker (wave-uniform)
+    const int64_t wi = w * a.ws_in, wo = w * a.ws_out;  // its offset in the input and the output rows
+    const int task = blockIdx.x;
+    const bool has_task = task < a.n_tasks;
+
+    // ---- (MODEL) θ_t -> natural θ, priors, elements as one-partial duals: lane d carries ∂/∂θ_t[d]
+    LaneTheta T{0.0, 0.0, lane};
+    Dual<1> elD[P][OCTO_N_EL];
+    Dual<1> ul = dconst<1>(0.0);                        // Σ UnitLengthPrior terms (value and this lane's partial)
+    double lpp = 0.0, glp = 0.0;                        // Σ logpdf_with_trans in declaration order, and ∂/∂θ_t[lane]
+    bool healed = false, finite_in = true;
+    if constexpr (MODEL) {
+        const int D = sm.D;
+        const int dl = lane < D ? lane : D - 1;
+        const double y = sm.theta_t[(int64_t)dl * sm.ld_t + w * sm.ws_t];
+        finite_in = __all(isfinite(y));                                              // logdensitymodel.jl:120-124
+        Dual<1> xk, pk;
+        prior_apply(sm.priors[dl], dvar<1>(y, 0), xk, pk);
+        T.xv = xk.v; T.xd = xk.d[0];
+        for (int k = 0; k < D; ++k) {                                                // in declaration order, healing as the reference
+            const double pv = lane_value(pk.v, k);                                   // does (variables.jl:1229-1236)
+            if (!healed) {
+                if (!isfinite(pv)) { lpp = -1.7976931348623157e308; healed = true; }
+                else lpp += pv;
+            }
+        }
+        glp = (healed || lane >= D) ? 0.0 : pk.d[0];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) {
+                const octo_source sc = sm.esrc[p * OCTO_N_EL + k];
+                elD[p][k] = (sc.kind == OCTO_SRC_TPERI) ? dconst<1>(0.0) : src_plain(sc, T, ul, true);
+            }
+            const octo_source sc = sm.esrc[p * OCTO_N_EL + OCTO_EL_TP];
+            if (sc.kind == OCTO_SRC_TPERI)      // tp = θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω | plx, A, B, F, G), parameterizations.jl:6-69
+                elD[p][OCTO_EL_TP] = tperi(src_angle(sc, T, ul, true), sc.value, elD[p][OCTO_EL_M], elD[p][OCTO_EL_E], elD[p][OCTO_EL_A], elD[p][OCTO_EL_I],
+                                           elD[p][OCTO_EL_W], elD[p][OCTO_EL_O], sm.k_yr, sm.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &elD[p][OCTO_EL_PLX]);
+        }
+    }
+
+    // ---- orbit constants of this walker (what k_setup would have written to `wc`)
+    PC pc[P];
+    FinPC fp[P];
+    double elv[P][OCTO_N_EL];
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if constexpr (MODEL) {
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = elD[p][k].v;
+        } else {
+            const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + wi;
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = el[(int64_t)k * a.ld];
+        }
+        const SetupOut so = setup_planet_vals<true>(elv[p], a.c, a.orbit_kind[p], a.has_mass[p]);
+        pc_from_setup(pc[p], so.v);
+        fp[p].sma = so.v[WC_A]; fp[p].P_d = 1.0 / so.v[WC_INVP]; fp[p].beta = so.v[WC_BETA];
+        fp[p].si = so.v[WC_SINI]; fp[p].ci = so.v[WC_COSI]; fp[p].sO = so.v[WC_SINO]; fp[p].cO = so.v[WC_COSO];
+        fp[p].sw = so.v[WC_SINW]; fp[p].cw = so.v[WC_COSW];
+        ok = ok && so.ok;
+    }
+    // nuisance rows of observation o: from memory, or (MODEL) from their sources
+    auto nuis_of = [&](int o, int obs_kind, double (&nu)[OCTO_N_NUIS], Dual<1>* nuD, bool count_ul) {
+        if constexpr (MODEL) {
+#pragma unroll
+            for (int r = 0; r < OCTO_N_NUIS; ++r) {
+                const octo_source sc = sm.nsrc ? sm.nsrc[o * OCTO_N_NUIS + r] : default_nuis_source(obs_kind, r);
+                const Dual<1> v = src_plain(sc, T, ul, count_ul);
+                nu[r] = v.v;
+                if (nuD) nuD[r] = v;
+            }
+        } else {
+            const double* p = a.nuis + (int64_t)o * OCTO_N_NUIS * a.ld + wi;
+#pragma unroll
+            for (int r = 0; r < OCTO_N_NUIS; ++r) nu[r] = p[(int64_t)r * a.ld];
+        }
+    };
+
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    TRACE_POINT();      // setup done
+    if (has_task) {
+        const Task tk = a.tasks[task];
+        const DevObs ob = a.obs[tk.obs];
+        LogProd lp;
+        int my_rows = 0;
+        const SinCosTab notab{nullptr, 0.0};
+        const bool is_astrom = ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || ob.kind == OCTO_ONEIL_RADEC ||
+                               ob.kind == OCTO_ONEIL_SEPPA;
+        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)tk.row0 * ROW_STRIDE;
+        double nu[OCTO_N_NUIS] = {0.0, 0.0, 0.0};
+        if constexpr (NUIS) nuis_of(tk.obs, ob.kind, nu, nullptr, false);
+        if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
+            const AstromCoef<P> co = astrom_coef_vals<P, GRAD, NUIS, KM>(nu[OCTO_NU_JITTER], nu[OCTO_NU_PLATESCALE], nu[OCTO_NU_NORTHANGLE], ob.kind, ob.planet, ob.has_cor, pc);
+            for (int r = threadIdx.x; r < tk.nrows; r += SMALL_TPB) {
+                const double* __restrict__ rw = rows + (int64_t)r * ROW_STRIDE;
+                astrom_row<P, GRAD, NUIS, KM, false>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], notab);
+                ++my_rows;
+            }
+        }
+        if (L::HAS_RV && !is_astrom) {
+            const RvCoef<P> co = rv_coef_vals<P, GRAD, NUIS, KM>(nu[OCTO_NU_RV_OFFSET], nu[OCTO_NU_RV_JITTER], nullptr, a.ldw, ob.kind, ob.planet, tk.obs, pc, 0);
+            for (int r = threadIdx.x; r < tk.nrows; r += SMALL_TPB) {
+                const double* __restrict__ rw = rows + (int64_t)r * ROW_STRIDE;
+                rv_row<P, GRAD, NUIS, KM, false>(acc, lp, pc, co, rw[0], rw[1], rw[2], notab);
+                ++my_rows;
+            }
+        }
+        if constexpr (NUIS) {
+            double lg = lp.log_value();      // a lane without rows: log(1) = 0
+            if ((KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG) lg = fma((double)my_rows, LOG2PI, lg);
+            acc[L::OFF_S] += lg;
+        }
+    }
+    TRACE_POINT();      // rows done
+    // ---- lanes -> wave (DPP), waves -> block (LDS), fixed order
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const double sum = wave_sum(acc[k]);
+        if (lane == 0) red[wv][k] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double x = red[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) x += red[q][threadIdx.x];
+        tot[threadIdx.x] = x;
+    }
+    __syncthreads();
+    TRACE_POINT();      // block reduction done
+    const int n_tasks = a.n_tasks;
+    const bool multi = n_tasks > 1;
+    if (multi) {
+        // publish this block's partial; device-scope atomic stores are written through, so no L2 write-back fence is needed
+        if (threadIdx.x < NACC)
+            __hip_atomic_store(a.partials + ((int64_t)w * n_tasks + task) * NACC + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above have completed (s_waitcnt vmcnt(0))
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(&counters[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = (old == n_tasks - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    // ---- finish (the single / last block). All 256 threads gather the task partials — thread (slot, k) sums tasks slot,
+    // slot + NTS, … of running sum k, plain loads (the acquire fence above made them coherent), several in flight — then wave 0
+    // combines the slots in order: lane k owns running sum k. The order is fixed, whichever block got here.
+    TRACE_POINT();      // last block known
+    constexpr int NTS = SMALL_TPB / WAVE;      // independent of NACC: the forward-only and the gradient launch sum in the same order
+    __shared__ double psum[NTS * NACC];
+    const int slot = lane < NACC ? wv : NTS, kcol = lane < NACC ? lane : 0;
+    if constexpr (NUIS && !MODEL) {      // every nuisance finite (k_setup's check)
+        bool fin = true;
+        for (int k = lane; k < a.n_obs * OCTO_N_NUIS; k += WAVE) fin = fin && isfinite(a.nuis[(int64_t)k * a.ld + wi]);
+        ok = ok && __all(fin);
+    }
+    double gp_acc = 0.0, ll = 0.0;
+    double gth = 0.0;                          // MODEL: Σ_k J[k][lane]·ḡ[k], this lane's share of ∇θ_t
+    double oneil_g[oneil_slots<P, GRAD, NUIS, KM>()];
+#pragma unroll
+    for (int k = 0; k < oneil_slots<P, GRAD, NUIS, KM>(); ++k) oneil_g[k] = 0.0;
+    double sma_p[P], e_p[P], M_p[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { sma_p[p] = fp[p].sma; e_p[p] = elv[p][OCTO_EL_E]; M_p[p] = elv[p][OCTO_EL_M]; }
+    for (int o = 0; o < a.n_obs; ++o) {
+        const int t0 = a.obs_range[2 * o], t1 = a.obs_range[2 * o + 1];
+        if (slot < NTS) {
+            double s = 0.0;
+            if (multi) {
+                const double* __restrict__ pp = a.partials + (int64_t)w * n_tasks * NACC + kcol;      // [walker][task][NACC]
+#pragma unroll 8
+                for (int t = t0 + slot; t < t1; t += NTS) s += pp[(int64_t)t * NACC];
+            } else if (slot == 0 && t1 > t0) {
+                s = tot[kcol];
+            }
+            psum[slot * NACC + kcol] = s;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            double sum = 0.0;
+            if (lane < NACC) {
+#pragma unroll
+                for (int q = 0; q < NTS; ++q) sum += psum[q * NACC + lane];
+            }
+            gp_acc += sum;
+            double v[NOBS_ACC];
+#pragma unroll
+            for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
+            v[0] = lane_value(sum, L::OFF_S);
+            if constexpr (L::HAS_MARG) { v[1] = lane_value(sum, L::OFF_MARG); v[2] = lane_value(sum, L::OFF_MARG + 1); v[3] = lane_value(sum, L::OFF_MARG + 2); }
+            if constexpr (L::N_NU > 0) { v[4] = lane_value(sum, L::OFF_NU); v[5] = lane_value(sum, L::OFF_NU + 1); v[6] = lane_value(sum, L::OFF_NU + 2); }
+            if constexpr (L::HAS_ONEIL) {
+                v[7] = lane_value(sum, L::OFF_ONEIL);
+                if constexpr (GRAD) { v[8] = lane_value(sum, L::OFF_ONEIL + 1); v[9] = lane_value(sum, L::OFF_ONEIL + 2); v[10] = lane_value(sum, L::OFF_ONEIL + 3); }
+            }
+            if constexpr (MODEL) {
+                // the observation's nuisances once more, now with their partials (and their UnitLengthPrior terms, counted here
+                // exactly once per walker), and ḡ_nuis kept in registers for this lane's chain-rule sum
+                double nu[OCTO_N_NUIS];
+                Dual<1> nuD[OCTO_N_NUIS];
+                const int kind = a.obs[o].kind;
+                nuis_of(o, kind, nu, nuD, true);
+                bool fin = true;
+#pragma unroll
+                for (int r = 0; r < OCTO_N_NUIS; ++r) fin = fin && isfinite(nu[r]);
+                ok = ok && fin;
+                double gn3[OCTO_N_NUIS] = {0.0, 0.0, 0.0};
+                ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, 1, gn3, nullptr, a.ldw, a.c.k_yr, o, v, a.obs_const[o], sma_p, e_p, M_p, true, oneil_g);
+                if constexpr (L::N_NU > 0) {
+#pragma unroll
+                    for (int r = 0; r < OCTO_N_NUIS; ++r) gth = fma(nuD[r].d[0], gn3[r], gth);
+                }
+            } else {
+                ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + wo : nullptr, nullptr, a.ldw, a.c.k_yr,
+                                                    o, v, a.obs_const[o], sma_p, e_p, M_p, lane == 0, oneil_g);
+            }
+        }
+        __syncthreads();
+    }
+    if (wv != 0) return;
+    TRACE_POINT();      // observations finished
+    double gp[P * L::PL_N > 0 ? P * L::PL_N : 1];
+#pragma unroll
+    for (int k = 0; k < P * L::PL_N; ++k) gp[k] = lane_value(gp_acc, L::OFF_PL + k);
+    if (multi && lane == 0) __hip_atomic_store(&counters[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    ok = ok && isfinite(ll);
+    if constexpr (MODEL) {
+        // ℓπcallback: non-finite θ_t -> -Inf; non-finite prior -> returned without the likelihood (logdensitymodel.jl:120-133);
+        // the UnitLengthPrior terms are likelihood terms of the reference (variables.jl:309-323): part of ll, never healed
+        const double llk = ok ? ll + ul.v : -INFINITY;
+        const double lpr = finite_in ? lpp : -INFINITY;
+        double lp = isfinite(lpr) ? lpr + llk : lpr;
+        if (isnan(lp)) lp = -INFINITY;
+        const bool fin = isfinite(lp);
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double gel[OCTO_N_EL];
+                planet_finish<P, GRAD, NUIS, KM, true>(elv[p], gel, 1, nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p], p, &gp[p * L::PL_N],
+                                                       L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp[p], ok);
+#pragma unroll
+                for (int k = 0; k < OCTO_N_EL; ++k) gth = fma(elD[p][k].d[0], gel[k], gth);
+            }
+            if (lane < sm.D) sm.grad_out[(int64_t)lane * sm.ld_o + w * sm.ws_o] = fin ? glp + ul.d[0] + gth : 0.0;
+        }
+        if (lane == 0) sm.lp_out[w * sm.ws_o] = lp;
+    } else {
+        if (lane == 0) {
+            a.ll_out[wo] = ok ? ll : -INFINITY;
+            if constexpr (GRAD) {
+                if (!ok && L::N_NU > 0) {
+                    for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + wo] = 0.0;
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    planet_finish<P, GRAD, NUIS, KM, true>(elv[p], a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p],
+                                                           p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp[p], ok);
+            }
+        }
+    }
+    TRACE_POINT();      // outputs stored
+    // host-buffer calls: this walker's results are in (mapped, coherent) host memory — release them to the host, which spins
+    // on the flag instead of paying a stream synchronisation. (All the wave's stores precede lane 0's release in program order.)
+    if (done_flags && lane == 0) __hip_atomic_store(done_flags + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef OCTO_SMALL_TRACE
+    TRACE_POINT();
+    if (done_flags && w == 0 && lane == 0) for (int k = 0; k < ntr; ++k) done_flags[40 + k] = tr[k];      // h_flags has room behind the SMALL_W flags
+#endif
+}
+
+}  // namespace octo

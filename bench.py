@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--epochs", type=int, default=10_000)
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default 10000; 8192 = 8 temperatures x 1024 for --workload pt)")
     ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti", "logpost"], default="grad")
+    ap.add_argument("--pt-comm", choices=["c_abi", "torch"], default="c_abi",
+                    help="--workload pt: all-gather inside the library (octo_pt_step_device, RCCL bound by the C ABI) or through torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive, parity and config-1 legs (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -314,11 +316,14 @@ def main():
         from octofitter_jl_amd.host.tempering import TemperedSwap
         n_temps_total = 8 * world
         chains = W // 8
-        pt = TemperedSwap(fn, n_temps_total=n_temps_total, n_chains=chains, rank=rank, world=world, device=dev, seed=20260929)
+        pt = TemperedSwap(fn, n_temps_total=n_temps_total, n_chains=chains, rank=rank, world=world, device=dev, seed=20260929, comm=args.pt_comm)
+        if args.pt_comm == "c_abi":
+            pt.create_comm()
         grad = False
         out = (out[0], None, None)
         workload = (f"config5: {n_temps_total} temperatures x {chains} walkers x {n_rows} epochs, sharded by temperature, "
-                    + ("RCCL all_gather of log-likelihoods + swap kernel" if world > 1 else "swap kernel (single rank: no collective ran)"))
+                    + ((f"ncclAllGather of log-likelihoods ({'octo_pt_step_device, C ABI' if args.pt_comm == 'c_abi' else 'torch.distributed'}) + swap kernel")
+                       if world > 1 else "swap kernel (single rank: no collective ran)"))
         parallelism = f"temperatures sharded x{world}, dataset replicated, one all_gather per swap step" if world > 1 else "single rank"
 
     def run_step(i):

@@ -198,6 +198,22 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds,
                   const double* elems, const double* nuis, int64_t ld, int64_t W,
                   double* ll_out, double* g_elems, double* g_nuis);
 
+/* The same call in two halves, for one host thread that drives several devices: octo_eval_begin enqueues the
+ * copies and kernels on the context's stream and returns; octo_eval_end waits for them and finishes the copy-out. One
+ * begin may be outstanding per context; the host buffers must stay valid and untouched until the matching end. */
+int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds,
+                        const double* elems, const double* nuis, int64_t ld, int64_t W,
+                        double* ll_out, double* g_elems, double* g_nuis);
+int32_t octo_eval_end(octo_ctx* ctx);
+
+/* One host batch over n_dev devices from ONE host thread: walkers are split contiguously and evenly (device i gets
+ * [i·W/n, (i+1)·W/n) up to rounding), every device's work is enqueued before any is waited for, and the outputs land in
+ * the caller's arrays at the walkers' own columns. ctxs[i] and datasets[i] live on device i (the dataset is replicated:
+ * create it once per context from the same tables). No communication: walkers are independent (system.jl:206-241). */
+int32_t octo_eval_multi(octo_ctx* const* ctxs, const octo_dataset* const* datasets, int32_t n_dev,
+                        const double* elems, const double* nuis, int64_t ld, int64_t W,
+                        double* ll_out, double* g_elems, double* g_nuis);
+
 /* `hip_stream` of every *_device entry point: a hipStream_t, handed to HIP as it is — so NULL is HIP's NULL (legacy
  * default) stream, exactly what a framework that has no stream of its own selected reports as its current stream — or
  * OCTO_STREAM_CTX for the context's own non-blocking stream (the one octo_sync waits for and every host-buffer entry
@@ -303,6 +319,24 @@ int32_t octo_pt_swap_device(octo_ctx* ctx, const double* d_ll_by_replica, const 
                             int32_t* d_slot2rep, int32_t n_temps, int64_t n_chains,
                             int32_t parity, uint64_t seed, uint64_t step,
                             int32_t* d_accepted, void* hip_stream);
+
+/* ---- Parallel tempering across processes (BASELINE config 5): one process per GPU, temperatures (replicas) split
+ * contiguously over the ranks, ONE collective per swap step — an all-gather of the per-replica log-likelihoods over RCCL —
+ * followed by the deterministic swap kernel above on every rank (same seed, same step: every rank derives the same
+ * permutation, so nothing else is exchanged). Stands in for Pigeons' communication step reached through
+ * ext/OctofitterPigeonsExt/OctofitterPigeonsExt.jl:76-128 (docs/src/parallel-sampling.md:64-80).
+ *   octo_comm_unique_id   rank 0 makes the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other ranks by
+ *                         whatever the host has (MPI, a file, a socket);
+ *   octo_comm_create      every rank joins (ncclCommInitRank) with its context's device; world = 1 needs no id and no RCCL;
+ *   octo_pt_step_device   d_ll_local [n_temps/world][n_chains] -> all-gather into d_ll_all [n_temps][n_chains] (rank order
+ *                         = replica order, so the layout is the one octo_pt_swap_device reads) -> swap, all on hip_stream.
+ * RCCL (librccl.so.1) is bound at run time, preferring a copy the process already maps. */
+int32_t octo_comm_unique_id(uint8_t* out128);
+int32_t octo_comm_create(octo_ctx* ctx, const uint8_t* unique_id128, int32_t rank, int32_t world);
+int32_t octo_comm_destroy(octo_ctx* ctx);
+int32_t octo_pt_step_device(octo_ctx* ctx, const double* d_ll_local, double* d_ll_all /* [n_temps][n_chains]; unused when world = 1 */,
+                            const double* d_beta, int32_t* d_slot2rep, int32_t n_temps, int64_t n_chains,
+                            int32_t parity, uint64_t seed, uint64_t step, int32_t* d_accepted, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -301,6 +301,7 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
 int32_t octo_ctx_destroy(octo_ctx* ctx) {
     if (!ctx) return OCTO_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->comm) (void)octo_comm_destroy(ctx);
     (void)hipDeviceSynchronize();      // evaluations may have been enqueued on caller-owned streams
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
@@ -542,10 +543,11 @@ int32_t octo_sync(octo_ctx* ctx) {
     return OCTO_OK;
 }
 
-int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, const double* nuis, int64_t ld, int64_t W,
-                  double* ll_out, double* g_elems, double* g_nuis) {
+int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* elems, const double* nuis, int64_t ld, int64_t W,
+                        double* ll_out, double* g_elems, double* g_nuis) {
     if (!ctx || !ds || !elems || !ll_out) return fail(ctx, OCTO_EINVAL, "octo_eval: null argument");
     if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_eval: need 0 <= W <= ld");
+    if (ctx->pending.active) return fail(ctx, OCTO_EINVAL, "octo_eval_begin: the previous octo_eval_begin of this context has not been ended");
     if (W == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int n_el = ds->n_planets * OCTO_N_EL, n_nu = ds->n_obs * OCTO_N_NUIS;
@@ -554,6 +556,10 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
     const int64_t n_out = (int64_t)(1 + (g_elems ? n_el : 0) + (g_nuis ? n_nu : 0)) * ldd;
     hipStream_t st;
     { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
+    octo_ctx::Pending& pd = ctx->pending;
+    pd = octo_ctx::Pending();
+    pd.W = W; pd.ld = ld; pd.ldd = ldd; pd.ll = ll_out; pd.g_elems = g_elems; pd.g_nuis = g_nuis;
+    pd.n_el_out = g_elems ? n_el : 0; pd.n_nu_out = g_nuis ? n_nu : 0;
     if (W <= ctx->small_w) {
         // A handful of parameter sets (a sampler's one θ per call): no copy engine at all. The kernels read the inputs from, and
         // write the results to, mapped pinned host memory.
@@ -562,45 +568,35 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
         double *m_in = nullptr, *m_out = nullptr;
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
+        pd.staged = true;
         if (small_eligible(ctx, ds, W)) {
             // k_small: walker-major staging — [elems | nuis] of one walker contiguous (one PCIe read per block), and
             // [ll | g_elems | g_nuis] likewise on the way back; completion through per-walker flags instead of a stream sync.
-            const int nn = nuis ? n_nu : 0, ne_o = g_elems ? n_el : 0, nn_o = g_nuis ? n_nu : 0;
-            const int64_t ws_in = n_el + nn, ws_out = 1 + ne_o + nn_o;
+            const int nn = nuis ? n_nu : 0;
+            const int64_t ws_in = n_el + nn, ws_out = 1 + pd.n_el_out + pd.n_nu_out;
             for (int64_t w = 0; w < W; ++w) {
                 double* dst = ctx->h_in + w * ws_in;
                 for (int r = 0; r < n_el; ++r) dst[r] = elems[(size_t)r * ld + w];
                 for (int r = 0; r < nn; ++r) dst[n_el + r] = nuis[(size_t)r * ld + w];
             }
+            pd.walker_major = true; pd.ws_out = ws_out;
             ctx->stage_ws_in = ws_in; ctx->stage_ws_out = ws_out;
             ctx->flag_request = true; ctx->flag_armed = false;
             int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + n_el : nullptr, 1, W, m_out, g_elems ? m_out + 1 : nullptr,
-                                       g_nuis ? m_out + 1 + ne_o : nullptr, st);
+                                       g_nuis ? m_out + 1 + pd.n_el_out : nullptr, st);
             ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
             if (rcz) return rcz;
-            rcz = wait_small(ctx, st, W);
-            if (rcz) return rcz;
-            for (int64_t w = 0; w < W; ++w) {
-                const double* src = ctx->h_out + w * ws_out;
-                ll_out[w] = src[0];
-                for (int r = 0; r < ne_o; ++r) g_elems[(size_t)r * ld + w] = src[1 + r];
-                for (int r = 0; r < nn_o; ++r) g_nuis[(size_t)r * ld + w] = src[1 + ne_o + r];
-            }
-            free_retired(ctx);
+            pd.active = true;
             return OCTO_OK;
         }
         // datasets k_small does not take (HGCA, marginalised RV, > 2 planets): the throughput kernels on the same mapped buffers
         for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
         if (nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
-        const int64_t o_ge = ldd, o_gn = (int64_t)(1 + (g_elems ? n_el : 0)) * ldd;
-        int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + (int64_t)n_el * ldd : nullptr, ldd, W, m_out, g_elems ? m_out + o_ge : nullptr,
-                                   g_nuis ? m_out + o_gn : nullptr, st);
+        pd.o_ge = ldd; pd.o_gn = (int64_t)(1 + pd.n_el_out) * ldd;
+        int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + (int64_t)n_el * ldd : nullptr, ldd, W, m_out, g_elems ? m_out + pd.o_ge : nullptr,
+                                   g_nuis ? m_out + pd.o_gn : nullptr, st);
         if (rcz) return rcz;
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        std::memcpy(ll_out, ctx->h_out, sizeof(double) * W);
-        if (g_elems) for (int r = 0; r < n_el; ++r) std::memcpy(g_elems + (size_t)r * ld, ctx->h_out + o_ge + (size_t)r * ldd, sizeof(double) * W);
-        if (g_nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(g_nuis + (size_t)r * ld, ctx->h_out + o_gn + (size_t)r * ldd, sizeof(double) * W);
-        free_retired(ctx);
+        pd.active = true;
         return OCTO_OK;
     }
     int rc = grow(ctx, ctx->d_in, ctx->cap_in, n_in);
@@ -611,23 +607,6 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
     double* d_ll = ctx->d_out;
     double* d_ge = g_elems ? ctx->d_out + ldd : nullptr;
     double* d_gn = g_nuis ? ctx->d_out + (int64_t)(1 + (g_elems ? n_el : 0)) * ldd : nullptr;
-    const bool small = (n_in + n_out) * (int64_t)sizeof(double) <= (1 << 18);     // <= 256 KB in total: latency, not bandwidth
-    if (small) {
-        if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
-            return fail(ctx, OCTO_ENOMEM, "octo_eval: pinned staging allocation failed");
-        for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
-        if (nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, ctx->h_in, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, st));
-        rc = octo_eval_device(ctx, ds, ctx->d_in, d_nuis, ldd, W, d_ll, d_ge, d_gn, st);
-        if (rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        std::memcpy(ll_out, ctx->h_out, sizeof(double) * W);
-        if (g_elems) for (int r = 0; r < n_el; ++r) std::memcpy(g_elems + (size_t)r * ld, ctx->h_out + (d_ge - ctx->d_out) + (size_t)r * ldd, sizeof(double) * W);
-        if (g_nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(g_nuis + (size_t)r * ld, ctx->h_out + (d_gn - ctx->d_out) + (size_t)r * ldd, sizeof(double) * W);
-        free_retired(ctx);
-        return OCTO_OK;
-    }
     HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, elems, sizeof(double) * ld, sizeof(double) * W, n_el,
                                  hipMemcpyHostToDevice, st));
     if (nuis)
@@ -642,9 +621,47 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
     if (g_nuis)
         HIPCHK(ctx, hipMemcpy2DAsync(g_nuis, sizeof(double) * ld, d_gn, sizeof(double) * ldd, sizeof(double) * W, n_nu,
                                      hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    pd.active = true;
+    return OCTO_OK;
+}
+
+int32_t octo_eval_end(octo_ctx* ctx) {
+    if (!ctx) return OCTO_EINVAL;
+    octo_ctx::Pending& pd = ctx->pending;
+    if (!pd.active) return OCTO_OK;
+    pd.active = false;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (!pd.staged) {
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        free_retired(ctx);
+        return OCTO_OK;
+    }
+    const int64_t W = pd.W, ld = pd.ld, ldd = pd.ldd;
+    if (pd.walker_major) {
+        int rcz = wait_small(ctx, st, W);
+        if (rcz) return rcz;
+        for (int64_t w = 0; w < W; ++w) {
+            const double* src = ctx->h_out + w * pd.ws_out;
+            pd.ll[w] = src[0];
+            for (int r = 0; r < pd.n_el_out; ++r) pd.g_elems[(size_t)r * ld + w] = src[1 + r];
+            for (int r = 0; r < pd.n_nu_out; ++r) pd.g_nuis[(size_t)r * ld + w] = src[1 + pd.n_el_out + r];
+        }
+    } else {
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        std::memcpy(pd.ll, ctx->h_out, sizeof(double) * W);
+        for (int r = 0; r < pd.n_el_out; ++r) std::memcpy(pd.g_elems + (size_t)r * ld, ctx->h_out + pd.o_ge + (size_t)r * ldd, sizeof(double) * W);
+        for (int r = 0; r < pd.n_nu_out; ++r) std::memcpy(pd.g_nuis + (size_t)r * ld, ctx->h_out + pd.o_gn + (size_t)r * ldd, sizeof(double) * W);
+    }
     free_retired(ctx);
     return OCTO_OK;
+}
+
+int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, const double* nuis, int64_t ld, int64_t W,
+                  double* ll_out, double* g_elems, double* g_nuis) {
+    const int rc = octo_eval_begin(ctx, ds, elems, nuis, ld, W, ll_out, g_elems, g_nuis);
+    if (rc) { if (ctx) ctx->pending.active = false; return rc; }
+    return octo_eval_end(ctx);
 }
 
 int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n, double* E_out, double* sinE_out,

@@ -90,6 +90,16 @@ struct octo_ctx {
     uint64_t flag_seq = 0;                      // sequence number here after its outputs; host-buffer calls spin on it
     bool flag_request = false, flag_armed = false;
     int64_t stage_ws_in = 0, stage_ws_out = 0;  // > 0 while octo_eval hands k_small its walker-major staging buffers
+    // octo_eval_begin .. octo_eval_end: what is still to be waited for and copied out
+    struct Pending {
+        bool active = false, staged = false, walker_major = false;
+        int64_t W = 0, ld = 0, ldd = 0, ws_out = 0, o_ge = 0, o_gn = 0;
+        int n_el_out = 0, n_nu_out = 0;
+        double *ll = nullptr, *g_elems = nullptr, *g_nuis = nullptr;
+    } pending;
+    // parallel tempering over RCCL (octo_comm.hip)
+    void* comm = nullptr;                       // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
     int small_w = SMALL_W;                      // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
     double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
     int64_t cap_in = 0, cap_out = 0;

@@ -134,6 +134,16 @@ _SIGS = {
     "octo_dataset_n_rows": (C.c_int64, [C.c_void_p]),
     "octo_eval": (C.c_int32, [C.c_void_p, C.c_void_p, c_double_p, c_double_p, C.c_int64, C.c_int64,
                               c_double_p, c_double_p, c_double_p]),
+    "octo_eval_begin": (C.c_int32, [C.c_void_p, C.c_void_p, c_double_p, c_double_p, C.c_int64, C.c_int64,
+                                    c_double_p, c_double_p, c_double_p]),
+    "octo_eval_end": (C.c_int32, [C.c_void_p]),
+    "octo_eval_multi": (C.c_int32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, c_double_p, c_double_p, C.c_int64, C.c_int64,
+                                    c_double_p, c_double_p, c_double_p]),
+    "octo_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
+    "octo_comm_create": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
+    "octo_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "octo_pt_step_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                        C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "octo_eval_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "octo_sync": (C.c_int32, [C.c_void_p]),

@@ -72,6 +72,22 @@ def _worker(rank, world, port, tmp):
                 for r in range(pt.lo, pt.hi):
                     slot = int((s2r[c] == r).nonzero()[0])
                     assert b[r - pt.lo, c] == pt.beta[slot]
+        # the same host function with an INJECTED gather (what octo_pt_step_device does inside the library on a GPU box)
+        calls = []
+
+        def gather(local, out):
+            calls.append(local.numel())
+            dist.all_gather_into_tensor(out, local)
+            return out
+        pt2 = pkg.TemperedSwap(None, n_temps_total=n_temps, n_chains=n_chains, rank=rank, world=world, device="cpu",
+                               seed=99, swap_impl=_numpy_swap, gather=gather)
+        gen2 = torch.Generator().manual_seed(7)
+        for step in range(6):
+            ll_all = torch.randn(n_temps, n_chains, generator=gen2, dtype=torch.float64) * 3
+            s2r = pt2.swap_step(ll_all[pt2.lo:pt2.hi].reshape(-1).contiguous(), step)
+            assert torch.equal(s2r, history[step]), "injected gather and torch.distributed gather disagree"
+        assert calls == [(n_temps // world) * n_chains] * 6
+        assert pt2.comm == "torch" and pkg.TemperedSwap(None, 8, 5, device="cpu", swap_impl=_numpy_swap).comm == "torch"
         # every rank computed the same permutation history
         flat = torch.stack(history).to(torch.int64)
         gathered = [torch.empty_like(flat) for _ in range(world)]

@@ -1,0 +1,152 @@
+"""
+Multi-device entry points of the C ABI (-m gpu):
+  * octo_eval_multi — one host batch split over several contexts from one host thread (run here with two contexts on device 0, and
+    over every visible device when there is more than one);
+  * octo_comm_* / octo_pt_step_device — the tempering swap step with the all-gather inside the library (RCCL bound at run time).
+    On a one-GPU box RCCL is exercised with a one-rank communicator (dlopen, ncclCommInitRank, ncclAllGather all run); the
+    two-rank test spawns one process per GPU and is skipped when fewer than two are visible.
+"""
+import ctypes as C
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import synth
+from test_gpu_parity import _gpu, _pt_swap_reference
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_eval_multi_splits_a_host_batch(pkg, oracle):
+    gb = _gpu()
+    capi = pkg.capi
+    lib = capi.load_library()
+    cfg = synth.config_astrom(n_epochs=300, n_walkers=1001, seed=31)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    ref = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=True)
+    n_vis = _device_count()
+    for devices in ([0, 0], [0, 0, 0], list(range(n_vis)) if n_vis > 1 else [0]):
+        paths = [gb.GpuPath(obs, planets, device=d) for d in devices]
+        n = len(paths)
+        ctxs = (C.c_void_p * n)(*[p.ctx for p in paths]); dss = (C.c_void_p * n)(*[p.ds for p in paths])
+        el = np.ascontiguousarray(cfg["elems"]); W = el.shape[1]
+        ll = np.full(W, np.nan); g = np.full_like(el, np.nan)
+        st = lib.octo_eval_multi(ctxs, dss, n, capi._dptr(el), None, W, W, capi._dptr(ll), capi._dptr(g), None)
+        assert st == 0, (st, lib.octo_last_error(paths[0].ctx))
+        # walkers are independent and every slice is >= 64 walkers: the same kernels on the same inputs, so bit-identical
+        assert np.array_equal(ll, ref[0]) and np.array_equal(g, ref[1]), devices
+        # a batch smaller than the number of devices, and a forward-only call
+        ll3 = np.full(2, np.nan)
+        el3 = np.ascontiguousarray(el[:, :2])
+        assert lib.octo_eval_multi(ctxs, dss, n, capi._dptr(el3), None, 2, 2, capi._dptr(ll3), None, None) == 0
+        assert np.all(np.abs(ll3 - ref[0][:2]) <= 1e-12 * np.abs(ref[0][:2]))
+        for p in paths:
+            p.close()
+
+
+def test_eval_begin_end_overlap_two_contexts(pkg):
+    """octo_eval_begin on two contexts, then octo_eval_end on both: the two halves the multi-device split is made of."""
+    gb = _gpu()
+    capi = pkg.capi
+    lib = capi.load_library()
+    cfg = synth.config_astrom(n_epochs=200, n_walkers=640, seed=32)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    ref = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=True)
+    a, b = gb.GpuPath(obs, planets), gb.GpuPath(obs, planets)
+    el = np.ascontiguousarray(cfg["elems"]); W = el.shape[1]
+    outs = [(np.full(W, np.nan), np.full_like(el, np.nan)) for _ in range(2)]
+    for p, (ll, g) in zip((a, b), outs):
+        assert lib.octo_eval_begin(p.ctx, p.ds, capi._dptr(el), None, W, W, capi._dptr(ll), capi._dptr(g), None) == 0
+    assert lib.octo_eval_begin(a.ctx, a.ds, capi._dptr(el), None, W, W, capi._dptr(outs[0][0]), None, None) == capi.OCTO_EINVAL   # one outstanding begin per context
+    for p in (a, b):
+        assert lib.octo_eval_end(p.ctx) == 0
+    for ll, g in outs:
+        assert np.array_equal(ll, ref[0]) and np.array_equal(g, ref[1])
+    a.close(); b.close()
+
+
+def test_pt_step_with_rccl_one_rank(pkg):
+    """The library's own RCCL path end to end on one GPU: octo_comm_unique_id -> octo_comm_create (one-rank communicator) ->
+    octo_pt_step_device (ncclAllGather + swap kernel on torch's current stream) against the NumPy restatement."""
+    import torch
+    from octofitter_jl_amd.host.tempering import TemperedSwap
+    cfg = synth.config_astrom(n_epochs=50, n_walkers=64, seed=33)
+    obs_m, planet = synth.to_mirror(pkg, cfg)
+    fn = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
+    dev = torch.device("cuda", 0)
+    n_temps, chains = 8, 41
+    pt = TemperedSwap(fn, n_temps_total=n_temps, n_chains=chains, rank=0, world=1, device=dev, seed=7)
+    assert pt.comm == "c_abi"
+    pt.create_comm(force_rccl=True)
+    rng = np.random.default_rng(3)
+    ref = pt.slot2rep.cpu().numpy().copy(); acc = np.zeros(n_temps, dtype=np.int32)
+    beta = pt.beta.cpu().numpy()
+    for step in range(5):
+        ll = rng.normal(-50, 4, (n_temps, chains))
+        s2r = pt.swap_step(torch.tensor(ll.reshape(-1), device=dev), step)
+        torch.cuda.synchronize()
+        ref, a = _pt_swap_reference(ll, beta, ref, step % 2, 7, step); acc += a
+        assert np.array_equal(s2r.cpu().numpy(), ref), step
+        assert np.array_equal(pt._ll_all.cpu().numpy(), ll.reshape(-1)), "the gathered buffer is the local one on a single rank"
+    assert np.array_equal(pt.accepted.cpu().numpy(), acc) and acc.sum() > 0
+    assert fn.lib.octo_comm_destroy(fn._ctx) == 0
+    fn.close()
+
+
+def _rank_main(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from octofitter_jl_amd.host.tempering import TemperedSwap
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # only carries the 128-byte id and the final comparison
+    try:
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        cfg = synth.config_astrom(n_epochs=400, n_walkers=4 * 64, seed=34)      # every rank draws the same 8 x 64 replicas, owns half
+        obs_m, planet = synth.to_mirror(pkg, cfg)
+        fn = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"], device=rank)
+        n_temps, chains = 4 * world, 64
+        full = synth.config_astrom(n_epochs=400, n_walkers=n_temps * chains, seed=35)["elems"]
+        pt = TemperedSwap(fn, n_temps_total=n_temps, n_chains=chains, rank=rank, world=world, device=dev, seed=11)
+        pt.create_comm()
+        el = torch.tensor(np.ascontiguousarray(full[:, pt.lo * chains: pt.hi * chains]), device=dev)
+        hist = []
+        for step in range(4):
+            ll = fn.ln_like_device(el, None, grad=False)
+            hist.append(pt.swap_step(ll, step).clone())
+            el[5] += 2.0
+        torch.cuda.synchronize()
+        flat = torch.stack(hist).to(torch.int64).cpu()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], x) for x in gathered), "ranks derived different permutations"
+        assert int(pt.accepted.sum()) > 0
+        fn.lib.octo_comm_destroy(fn._ctx); fn.close()
+        Path(tmp, f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif("_device_count() < 2", reason="needs two GPUs: one process per GPU over RCCL")
+def test_pt_step_two_ranks_over_rccl(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()

@@ -1,67 +1,226 @@
-# OctofitterHIP.jl — the reference-side binding of include/octofitter_hip.h: pure `ccall`, no CUDA.jl/AMDGPU.jl.
+# OctofitterHIP.jl — the reference-side binding of include/octofitter_hip.h: pure `ccall`, no CUDA.jl / AMDGPU.jl.
 #
-# NOT EXECUTED IN THE BUILD CONTAINER (Julia is not installed there). Every behaviour it relies on is
-# exercised through the same shared library from Python (tests/, ctypes) — see INTEGRATION.md.
+# NOT EXECUTED IN THE BUILD CONTAINER (Julia is not installed there). What can be checked without Julia is checked:
+# tests/test_abi.py compares every struct mirrored below with the header (field order, types, sizes through a compiled C
+# program) and requires a `ccall` for every symbol the header declares. Every behaviour the shim relies on is exercised through
+# the same shared library from Python (tests/, ctypes) — see INTEGRATION.md.
 #
-# What it adds next to an existing `Octofitter.LogDensityModel` (src/logdensitymodel.jl) — nothing in the
-# reference is modified:
+# Nothing in the reference is modified. Three ways in, from least to most of the callback on the device:
 #
-#   g = OctofitterHIP.GPUBatchedLikelihood(model)        # walks model.system, uploads the tables once
-#   ll      = ln_like_batch(g, Θ)                        # Θ :: Vector of arr2nt NamedTuples (or a D×W matrix of θ_t)
-#   ll, ∇   = ln_post_and_grad_batch(g, Θ_t)             # log-posterior and gradient w.r.t. θ_t, D×W
-#   g(system, θ_nt)                                      # drop-in for the closure make_ln_like returns (W = 1)
+#  (1) UNCHANGED SAMPLERS, ANY MODEL      model = Octofitter.LogDensityModel(OctofitterHIP.accelerate(system))
+#      `accelerate` returns the same System with every eligible observation wrapped in a `HIPObs` (the pattern of the reference's
+#      own ObsPriorAstromONeil2019 wrapper, src/likelihoods/prior-observable.jl:56-76). The reference then builds its callbacks as
+#      always (priors, Derived code, arr2nt, ForwardDiff — src/logdensitymodel.jl:25-250) and `octofit`, `octofit_pigeons`,
+#      `octofit_rejection`, … run unchanged (src/sampling.jl:412-423 calls LogDensityProblems.logdensity_and_gradient at :252-256).
+#      Inside, `ln_like(::HIPObs, ctx)` (the plug-in interface, src/variables.jl:94-102) evaluates ALL wrapped tables in one
+#      octo_eval call on the VALUES of the resolved elements and, when they are ForwardDiff.Dual numbers, returns a Dual whose
+#      partials are Σ_k ḡ_k · partials(input_k) (SURVEY.md §8b). The wrapped tables expose no `table.epoch`, so the reference
+#      solves no Kepler equation on the CPU (src/likelihoods/system.jl:35-54, :131-134).
 #
-# Eligibility follows SURVEY.md §8(b): tables the kernels implement go to the device; epoch-free prior-like
-# terms (UnitLengthPrior, UserLikelihood, PlanetOrderPrior, ...) are evaluated on the host and added; any other
-# epoch-bearing observation (full HGCA line fit, GP RV, images, ...) makes the model ineligible and the constructor throws, so
-# callers keep using model.ℓπcallback.
+#  (2) THE WHOLE CALLBACK ON THE DEVICE    hm = OctofitterHIP.HIPLogDensityModel(model)
+#      for models made of the standard blocks (Uniform/LogUniform/Normal/truncated Normal/Sine priors, UniformCircular,
+#      θ_at_epoch_to_tperi): ℓπcallback / ∇ℓπcallback become ONE kernel launch per θ_t (octo_model_logpost), and batches of θ_t
+#      (guess_starting_position's 5e5 prior draws, octofit_rejection's draws, Pigeons' replicas) one launch per batch.
+#      `hm` implements LogDensityProblems.{dimension, capabilities, logdensity, logdensity_and_gradient} and carries the fields
+#      the reference's drivers read (D, ℓπcallback, ∇ℓπcallback, system, link, invlink, arr2nt, sample_priors, starting_points).
+#
+#  (3) BATCHES OF STRUCTURED θ             g = OctofitterHIP.GPUBatchedLikelihood(model); ln_like_batch(g, Θ)
 module OctofitterHIP
 
-using Octofitter, PlanetOrbits, ForwardDiff
-using Octofitter: PlanetRelAstromObs, System, Planet, normalizename, likelihoodname
+using Octofitter, PlanetOrbits, ForwardDiff, LogDensityProblems, Random, Distributions
+using Octofitter: PlanetRelAstromObs, System, Planet, AbstractObs, Priors, Derived, normalizename, likelihoodname
 
 const LIB = get(ENV, "OCTOFITTER_HIP_LIB", "liboctofitter_hip.so")
 
-const OCTO_OK = Int32(0)
+# ---------------------------------------------------------------------------------------------------- constants of the header
+const OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
 const ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
 const ONEIL_RADEC, ONEIL_SEPPA, HGCA = Int32(5), Int32(6), Int32(7)
-const ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES = Int32(0), Int32(1), Int32(2)
+const ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES, ORBIT_KEP = Int32(0), Int32(1), Int32(2), Int32(3)
+const PRIOR_UNIFORM, PRIOR_LOGUNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_SINE = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
+const SRC_CONST, SRC_THETA, SRC_CIRCULAR, SRC_TPERI = Int32(0), Int32(1), Int32(2), Int32(3)
+const SRC_FLAG_UNITLEN, SRC_FLAG_TI = Int32(1), Int32(2)
+const STREAM_CTX = Ptr{Cvoid}(typemax(UInt))       # OCTO_STREAM_CTX = (void*)-1: the context's own stream
 const N_EL, N_NUIS = 9, 3
 const EL_KEYS = (:a, :e, :i, :ω, :Ω, :tp, :M, :plx, :mass)
 const EL_KEYS_TI = (:A, :e, :B, :F, :G, :tp, :M, :plx, :mass)     # ThieleInnesOrbit: constants [mas] in the rows of a, i, ω, Ω
 
+# ---------------------------------------------------------------------------------------------------- structs of the header
 struct OctoConsts            # mirrors `octo_consts`
-    kepler_year_to_julian_day::Float64; year2day_julian::Float64; au2m::Float64; sec2year_julian::Float64
-    pc2au::Float64; rad2as::Float64; mjup2msol::Float64
+    kepler_year_to_julian_day::Float64
+    year2day_julian::Float64
+    au2m::Float64
+    sec2year_julian::Float64
+    pc2au::Float64
+    rad2as::Float64
+    mjup2msol::Float64
 end
 struct OctoObsDesc           # mirrors `octo_obs_desc`
-    kind::Int32; planet::Int32; n_epochs::Int64
-    epoch::Ptr{Float64}; y1::Ptr{Float64}; y2::Ptr{Float64}; s1::Ptr{Float64}; s2::Ptr{Float64}; cor::Ptr{Float64}
-    extra::Ptr{Float64}; n_extra::Int64
+    kind::Int32
+    planet::Int32
+    n_epochs::Int64
+    epoch::Ptr{Float64}
+    y1::Ptr{Float64}
+    y2::Ptr{Float64}
+    s1::Ptr{Float64}
+    s2::Ptr{Float64}
+    cor::Ptr{Float64}
+    extra::Ptr{Float64}
+    n_extra::Int64
 end
 struct OctoPlanetDesc        # mirrors `octo_planet_desc`
-    orbit_kind::Int32; has_mass::Int32
+    orbit_kind::Int32
+    has_mass::Int32
+end
+struct OctoPrior             # mirrors `octo_prior`
+    kind::Int32
+    pad::Int32
+    p0::Float64
+    p1::Float64
+    lo::Float64
+    hi::Float64
+end
+struct OctoSource            # mirrors `octo_source`
+    kind::Int32
+    i0::Int32
+    i1::Int32
+    flags::Int32
+    value::Float64
 end
 
+# ---------------------------------------------------------------------------------------------------- one ccall per exported symbol
 check(ctx, st, what) = st == OCTO_OK ? nothing :
     error("$what failed with status $st: " * unsafe_string(ccall((:octo_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
 
-mutable struct GPUBatchedLikelihood{TModel}
-    model::TModel
-    ctx::Ptr{Cvoid}
-    ds::Ptr{Cvoid}
-    n_planets::Int
-    obs_entries::Vector{Any}          # (obs, i_planet or 0, θ_obs key) in evaluation order
-    host_terms::Vector{Any}           # epoch-free observations evaluated in Julia
-    has_mass::Vector{Bool}
-    columns::Vector{Vector{Float64}}  # keeps the uploaded host columns alive during octo_dataset_create
+octo_version() = (a = Ref{Int32}(0); b = Ref{Int32}(0); ccall((:octo_version, LIB), Int32, (Ref{Int32}, Ref{Int32}), a, b); (a[], b[]))
+octo_consts_default() = (c = Ref{OctoConsts}(); ccall((:octo_consts_default, LIB), Int32, (Ref{OctoConsts},), c); c[])
+function octo_ctx_create(device::Integer)
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    st = ccall((:octo_ctx_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32), ctx, device)
+    st == OCTO_OK || error("octo_ctx_create failed with status $st (no usable MI355X?)")
+    return ctx[]
+end
+octo_ctx_destroy(ctx) = ccall((:octo_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), ctx)
+octo_consts_set(ctx, c::OctoConsts) = check(ctx, ccall((:octo_consts_set, LIB), Int32, (Ptr{Cvoid}, Ref{OctoConsts}), ctx, c), "octo_consts_set")
+octo_ctx_set_small_batch(ctx, n::Integer) = check(ctx, ccall((:octo_ctx_set_small_batch, LIB), Int32, (Ptr{Cvoid}, Int32), ctx, n), "octo_ctx_set_small_batch")
+function octo_dataset_create(ctx, descs::Vector{OctoObsDesc}, planets::Vector{OctoPlanetDesc})
+    ds = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx, ccall((:octo_dataset_create, LIB), Int32, (Ptr{Cvoid}, Ptr{OctoObsDesc}, Int32, Ptr{OctoPlanetDesc}, Int32, Ref{Ptr{Cvoid}}),
+                     ctx, descs, length(descs), planets, length(planets), ds), "octo_dataset_create")
+    return ds[]
+end
+octo_dataset_destroy(ds) = ccall((:octo_dataset_destroy, LIB), Int32, (Ptr{Cvoid},), ds)
+octo_dataset_n_rows(ds) = ccall((:octo_dataset_n_rows, LIB), Int64, (Ptr{Cvoid},), ds)
+octo_sync(ctx) = check(ctx, ccall((:octo_sync, LIB), Int32, (Ptr{Cvoid},), ctx), "octo_sync")
+
+"Host buffers, blocking. `Xt`: W×inputs (walker index fastest); `G`: same shape or nothing (forward only)."
+function octo_eval!(ctx, ds, Xt::Matrix{Float64}, n_el::Int, ll::Vector{Float64}, G::Union{Nothing,Matrix{Float64}})
+    W = size(Xt, 1); n_nu = size(Xt, 2) - n_el
+    pel = pointer(Xt); pnu = n_nu > 0 ? pointer(Xt, n_el * W + 1) : Ptr{Float64}(C_NULL)
+    gel = G === nothing ? Ptr{Float64}(C_NULL) : pointer(G)
+    gnu = (G === nothing || n_nu == 0) ? Ptr{Float64}(C_NULL) : pointer(G, n_el * W + 1)
+    GC.@preserve Xt ll G check(ctx, ccall((:octo_eval, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx, ds, pel, pnu, W, W, ll, gel, gnu), "octo_eval")
+    return ll
+end
+"The same call in two halves (one host thread, several devices): enqueue / wait. The arrays must stay rooted until `octo_eval_end`."
+octo_eval_begin(ctx, ds, pel, pnu, ld, W, pll, pgel, pgnu) = check(ctx, ccall((:octo_eval_begin, LIB), Int32,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx, ds, pel, pnu, ld, W, pll, pgel, pgnu), "octo_eval_begin")
+octo_eval_end(ctx) = check(ctx, ccall((:octo_eval_end, LIB), Int32, (Ptr{Cvoid},), ctx), "octo_eval_end")
+"One host batch over several devices: ctxs[i], dss[i] live on device i (dataset replicated)."
+octo_eval_multi(ctxs::Vector{Ptr{Cvoid}}, dss::Vector{Ptr{Cvoid}}, pel, pnu, ld, W, pll, pgel, pgnu) = check(ctxs[1], ccall((:octo_eval_multi, LIB), Int32,
+    (Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+    ctxs, dss, length(ctxs), pel, pnu, ld, W, pll, pgel, pgnu), "octo_eval_multi")
+"Device-resident buffers (raw device pointers, e.g. from a HIP allocation the host owns), asynchronous on `stream`."
+octo_eval_device(ctx, ds, d_el, d_nu, ld, W, d_ll, d_gel, d_gnu, stream=STREAM_CTX) = check(ctx, ccall((:octo_eval_device, LIB), Int32,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+    ctx, ds, d_el, d_nu, ld, W, d_ll, d_gel, d_gnu, stream), "octo_eval_device")
+
+"Batched PlanetOrbits.kepler_solver(MA, e) (src/parameterizations.jl:340) on the device."
+function octo_kepler_solve(ctx, MA::Vector{Float64}, e::Vector{Float64})
+    n = length(MA); E = similar(MA); sE = similar(MA); cE = similar(MA)
+    check(ctx, ccall((:octo_kepler_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                     ctx, MA, e, n, E, sE, cE), "octo_kepler_solve")
+    return E, sE, cE
 end
 
+# OFTI marginal likelihood (src/parameterizations.jl:318-405)
+function octo_ofti_create(ctx, epochs, ra, dec, σ_ra, σ_dec, cor, σ_ABFG)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    c = cor === nothing ? Ptr{Float64}(C_NULL) : pointer(cor)
+    GC.@preserve cor check(ctx, ccall((:octo_ofti_create, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ref{Ptr{Cvoid}}),
+        ctx, epochs, ra, dec, σ_ra, σ_dec, c, length(epochs), σ_ABFG, h), "octo_ofti_create")
+    return h[]
+end
+octo_ofti_destroy(h) = ccall((:octo_ofti_destroy, LIB), Int32, (Ptr{Cvoid},), h)
+"nl: W×5 columns e, a, tp, M, plx. Returns (ABFG W×4, log_marginal_likelihood W)."
+function octo_ofti_eval(ctx, h, nl::Matrix{Float64})
+    W = size(nl, 1); abfg = Matrix{Float64}(undef, W, 4); lm = Vector{Float64}(undef, W)
+    check(ctx, ccall((:octo_ofti_eval, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}),
+                     ctx, h, nl, W, W, abfg, lm), "octo_ofti_eval")
+    return abfg, lm
+end
+octo_ofti_eval_device(ctx, h, d_nl, ld, W, d_abfg, d_lm, stream=STREAM_CTX) = check(ctx, ccall((:octo_ofti_eval_device, LIB), Int32,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), ctx, h, d_nl, ld, W, d_abfg, d_lm, stream), "octo_ofti_eval_device")
+
+# standard parameterisation on the device
+function octo_model_create(ctx, ds, priors::Vector{OctoPrior}, esrc::Vector{OctoSource}, nsrc::Union{Nothing,Vector{OctoSource}})
+    m = Ref{Ptr{Cvoid}}(C_NULL)
+    pn = nsrc === nothing ? Ptr{OctoSource}(C_NULL) : pointer(nsrc)
+    GC.@preserve nsrc check(ctx, ccall((:octo_model_create, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{OctoPrior}, Int32, Ptr{OctoSource}, Ptr{OctoSource}, Ref{Ptr{Cvoid}}),
+        ctx, ds, priors, length(priors), esrc, pn, m), "octo_model_create")
+    return m[]
+end
+octo_model_destroy(m) = ccall((:octo_model_destroy, LIB), Int32, (Ptr{Cvoid},), m)
+"Θt: W×D (walker index fastest). Returns lp (and fills G, W×D, when given)."
+function octo_model_logpost!(ctx, m, Θt::Matrix{Float64}, lp::Vector{Float64}, G::Union{Nothing,Matrix{Float64}})
+    W = size(Θt, 1)
+    pg = G === nothing ? Ptr{Float64}(C_NULL) : pointer(G)
+    GC.@preserve G check(ctx, ccall((:octo_model_logpost, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}),
+                                    ctx, m, Θt, W, W, lp, pg), "octo_model_logpost")
+    return lp
+end
+octo_model_logpost_device(ctx, m, d_θt, ld, W, d_lp, d_grad, stream=STREAM_CTX) = check(ctx, ccall((:octo_model_logpost_device, LIB), Int32,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), ctx, m, d_θt, ld, W, d_lp, d_grad, stream), "octo_model_logpost_device")
+
+# measurement hooks
+octo_timing_enable(ctx, every_n::Integer) = ccall((:octo_timing_enable, LIB), Int32, (Ptr{Cvoid}, Int32), ctx, every_n)
+function octo_timing_read(ctx; reset::Bool=true)
+    ms = Ref{Float64}(0); n = Ref{Int64}(0)
+    ccall((:octo_timing_read, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Int64}, Int32), ctx, ms, n, reset)
+    return ms[], n[]
+end
+function octo_timing_stats(ctx)
+    med = Ref{Float64}(0); lo = Ref{Float64}(0); hi = Ref{Float64}(0); n = Ref{Int64}(0)
+    ccall((:octo_timing_stats, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ref{Int64}), ctx, med, lo, hi, n)
+    return med[], lo[], hi[], n[]
+end
+
+# parallel tempering (BASELINE config 5): one process per GPU, one all-gather per swap step inside the library
+"Rank 0: the 128-byte RCCL rendezvous id; hand it to the other ranks (MPI.Bcast!, a file, …)."
+octo_comm_unique_id() = (id = zeros(UInt8, 128); st = ccall((:octo_comm_unique_id, LIB), Int32, (Ptr{UInt8},), id); st == OCTO_OK || error("octo_comm_unique_id: status $st"); id)
+octo_comm_create(ctx, id::Union{Nothing,Vector{UInt8}}, rank::Integer, world::Integer) = check(ctx, ccall((:octo_comm_create, LIB), Int32,
+    (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), ctx, id === nothing ? Ptr{UInt8}(C_NULL) : pointer(id), rank, world), "octo_comm_create")
+octo_comm_destroy(ctx) = ccall((:octo_comm_destroy, LIB), Int32, (Ptr{Cvoid},), ctx)
+"ncclAllGather of the local replicas' log-likelihoods + deterministic neighbour swap of β labels, on `stream` (device pointers)."
+octo_pt_step_device(ctx, d_ll_local, d_ll_all, d_beta, d_slot2rep, n_temps, n_chains, parity, seed, step, d_accepted, stream=STREAM_CTX) =
+    check(ctx, ccall((:octo_pt_step_device, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Int32, Int64, Int32, UInt64, UInt64, Ptr{Int32}, Ptr{Cvoid}),
+        ctx, d_ll_local, d_ll_all, d_beta, d_slot2rep, n_temps, n_chains, parity, seed, step, d_accepted, stream), "octo_pt_step_device")
+octo_pt_swap_device(ctx, d_ll_by_replica, d_beta, d_slot2rep, n_temps, n_chains, parity, seed, step, d_accepted, stream=STREAM_CTX) =
+    check(ctx, ccall((:octo_pt_swap_device, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Int32, Int64, Int32, UInt64, UInt64, Ptr{Int32}, Ptr{Cvoid}),
+        ctx, d_ll_by_replica, d_beta, d_slot2rep, n_temps, n_chains, parity, seed, step, d_accepted, stream), "octo_pt_swap_device")
+
+# ---------------------------------------------------------------------------------------------------- tables -> octo_obs_desc
 _f64(x) = collect(Float64, vec(x))
 
+"(kind, 0-based planet or -1, [epoch, y1, y2, s1, s2, cor, extra]) of an observation the kernels implement, or nothing."
 function _table(obs, i_planet)
     t = obs.table
-    z = Ptr{Float64}(C_NULL)
     if obs isa PlanetRelAstromObs
         if hasproperty(t, :pa) && hasproperty(t, :sep)      # relative-astrometry.jl:53
             cols = (_f64(t.epoch), _f64(t.pa), _f64(t.sep), _f64(t.σ_pa), _f64(t.σ_sep)); kind = ASTROM_SEPPA
@@ -69,7 +228,7 @@ function _table(obs, i_planet)
             cols = (_f64(t.epoch), _f64(t.ra), _f64(t.dec), _f64(t.σ_ra), _f64(t.σ_dec)); kind = ASTROM_RADEC
         end
         cor = hasproperty(t, :cor) ? _f64(t.cor) : Float64[]
-        return kind, Int32(i_planet - 1), [cols..., cor]
+        return kind, Int32(i_planet - 1), [cols..., cor, Float64[]]
     end
     T = nameof(typeof(obs))
     if T === :ObsPriorAstromONeil2019 && obs.wrapped_like isa PlanetRelAstromObs      # prior-observable.jl:56-76
@@ -89,83 +248,60 @@ function _table(obs, i_planet)
     kind === nothing && return nothing
     # GP / trend branches are Julia closures: not on the device path (rv-absolute.jl:205-315)
     (hasproperty(obs, :gaussian_process) && !isnothing(obs.gaussian_process)) && return nothing
-    return kind, Int32(kind == RV_REL ? i_planet - 1 : -1), [_f64(t.epoch), _f64(t.rv), Float64[], _f64(t.σ_rv), Float64[], Float64[]]
+    return kind, Int32(kind == RV_REL ? i_planet - 1 : -1), [_f64(t.epoch), _f64(t.rv), Float64[], _f64(t.σ_rv), Float64[], Float64[], Float64[]]
 end
 
 _has_epochs(obs) = hasproperty(obs, :table) && hasproperty(obs.table, :epoch)     # system.jl:39,48
 
-function GPUBatchedLikelihood(model; device::Integer=0)
-    system = model.system
-    θ0 = model.arr2nt(model.sample_priors(Octofitter.Random.default_rng()))
-    entries = Any[]; host_terms = Any[]; descs = OctoObsDesc[]; columns = Vector{Float64}[]
-    add! = function (obs, ip, ctxkind)
-        if !_has_epochs(obs)
-            push!(host_terms, (obs, ip, ctxkind)); return
-        end
-        tb = _table(obs, ip)
-        tb === nothing && error("observation $(likelihoodname(obs)) is not on the HIP path; keep using model.ℓπcallback")
-        kind, planet, cols = tb
-        append!(columns, cols)
-        p(c) = isempty(c) ? Ptr{Float64}(C_NULL) : pointer(c)
-        ex = length(cols) >= 7 ? cols[7] : Float64[]
-        push!(descs, OctoObsDesc(kind, planet, length(cols[1]), p(cols[1]), p(cols[2]), p(cols[3]), p(cols[4]), p(cols[5]), p(cols[6]), p(ex), length(ex)))
-        push!(entries, (obs, ip, normalizename(likelihoodname(obs))))
-    end
-    # evaluation order of the generated closure: planet observations planet by planet, then system ones (system.jl:229-235)
-    for (ip, pl) in enumerate(system.planets), obs in pl.observations
-        add!(obs, ip, :planet)
-    end
-    for obs in system.observations
-        add!(obs, 0, :system)
-    end
-    planets = OctoPlanetDesc[]
-    has_mass = Bool[]
-    for (ip, pl) in enumerate(system.planets)
-        OT = Octofitter.orbittype(pl)
-        ok = OT <: Visual{<:KepOrbit} ? ORBIT_VISUAL_KEP : OT <: RadialVelocityOrbit ? ORBIT_RADVEL : OT <: ThieleInnesOrbit ? ORBIT_THIELE_INNES :
-             error("orbit type $OT is not on the HIP path")
-        hm = hasproperty(θ0.planets[ip], :mass)                 # relative-astrometry.jl:122
-        push!(planets, OctoPlanetDesc(ok, hm)); push!(has_mass, hm)
-    end
-    ctx = Ref{Ptr{Cvoid}}(C_NULL)
-    st = ccall((:octo_ctx_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32), ctx, device)
-    st == OCTO_OK || error("octo_ctx_create failed with status $st (no usable MI355X?)")
-    consts = OctoConsts(PlanetOrbits.kepler_year_to_julian_day_conversion_factor, PlanetOrbits.year2day_julian,
-                        PlanetOrbits.au2m, PlanetOrbits.sec2year_julian, PlanetOrbits.pc2au, PlanetOrbits.rad2as, Octofitter.mjup2msol)
-    check(ctx[], ccall((:octo_consts_set, LIB), Int32, (Ptr{Cvoid}, Ref{OctoConsts}), ctx[], consts), "octo_consts_set")
-    ds = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve columns begin
-        check(ctx[], ccall((:octo_dataset_create, LIB), Int32,
-                           (Ptr{Cvoid}, Ptr{OctoObsDesc}, Int32, Ptr{OctoPlanetDesc}, Int32, Ref{Ptr{Cvoid}}),
-                           ctx[], descs, length(descs), planets, length(planets), ds), "octo_dataset_create")
-    end
-    g = GPUBatchedLikelihood(model, ctx[], ds[], length(planets), entries, host_terms, has_mass, columns)
-    finalizer(g) do x
-        ccall((:octo_dataset_destroy, LIB), Int32, (Ptr{Cvoid},), x.ds)
-        ccall((:octo_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), x.ctx)
-    end
-    return g
+function _orbit_kind(pl)
+    OT = Octofitter.orbittype(pl)
+    OT <: Visual{<:KepOrbit} ? ORBIT_VISUAL_KEP : OT <: RadialVelocityOrbit ? ORBIT_RADVEL : OT <: ThieleInnesOrbit ? ORBIT_THIELE_INNES :
+    OT <: KepOrbit ? ORBIT_KEP : error("orbit type $OT is not on the HIP path")
 end
 
-# ---- θ (nested NamedTuple from arr2nt) -> the kernel's inputs --------------------------------------------------
-"Resolved orbital elements and nuisances of ONE parameter set, in C-ABI order; generic in the number type."
-function kernel_inputs(g::GPUBatchedLikelihood, θ)
+_consts() = OctoConsts(PlanetOrbits.kepler_year_to_julian_day_conversion_factor, PlanetOrbits.year2day_julian,
+                       PlanetOrbits.au2m, PlanetOrbits.sec2year_julian, PlanetOrbits.pc2au, PlanetOrbits.rad2as, Octofitter.mjup2msol)
+
+"Context + dataset for a list of (obs, i_planet or 0) in evaluation order. Returns (ctx, ds, entries, columns)."
+function _upload(system, eligible, θ0; device::Integer=0)
+    entries = Any[]; descs = OctoObsDesc[]; columns = Vector{Float64}[]
+    p(c) = isempty(c) ? Ptr{Float64}(C_NULL) : pointer(c)
+    for (obs, ip) in eligible
+        kind, planet, cols = _table(obs, ip)
+        append!(columns, cols)
+        push!(descs, OctoObsDesc(kind, planet, length(cols[1]), p(cols[1]), p(cols[2]), p(cols[3]), p(cols[4]), p(cols[5]), p(cols[6]), p(cols[7]), length(cols[7])))
+        push!(entries, (obs, ip, normalizename(likelihoodname(obs))))
+    end
+    planets = OctoPlanetDesc[]
+    for (ip, pl) in enumerate(system.planets)
+        push!(planets, OctoPlanetDesc(_orbit_kind(pl), hasproperty(θ0.planets[ip], :mass)))                 # relative-astrometry.jl:122
+    end
+    ctx = octo_ctx_create(device)
+    octo_consts_set(ctx, _consts())
+    ds = GC.@preserve columns octo_dataset_create(ctx, descs, planets)
+    return ctx, ds, entries, columns
+end
+
+"Resolved orbital elements and nuisances of ONE parameter set, in C-ABI order; generic in the number type (Float64 or Dual)."
+function kernel_inputs(system, entries, θ)
     T = Octofitter._system_number_type(θ)
-    x = Vector{T}(undef, g.n_planets * N_EL + length(g.obs_entries) * N_NUIS)
-    for ip in 1:g.n_planets
+    nP = length(system.planets)
+    x = Vector{T}(undef, nP * N_EL + length(entries) * N_NUIS)
+    for ip in 1:nP
         θp = merge(θ, θ.planets[ip])                                    # system.jl:117
-        keys = Octofitter.orbittype(g.model.system.planets[ip]) <: ThieleInnesOrbit ? EL_KEYS_TI : EL_KEYS
+        keys = Octofitter.orbittype(system.planets[ip]) <: ThieleInnesOrbit ? EL_KEYS_TI : EL_KEYS
         for (k, key) in enumerate(keys)
             x[(ip-1)*N_EL+k] = hasproperty(θp, key) ? getproperty(θp, key) : zero(T)
         end
     end
-    o0 = g.n_planets * N_EL
-    for (io, (obs, ip, key)) in enumerate(g.obs_entries)
+    o0 = nP * N_EL
+    for (io, (obs, ip, key)) in enumerate(entries)
         src = ip > 0 ? θ.planets[ip].observations : θ.observations
         θobs = hasproperty(src, key) ? getproperty(src, key) : (;)
-        if nameof(typeof(obs)) === :HGCAInstantaneousObs                  # θ_system.pmra / .pmdec, hgca.jl:266-267
+        T1 = nameof(typeof(obs))
+        if T1 === :HGCAInstantaneousObs                                   # θ_system.pmra / .pmdec, hgca.jl:266-267
             x[o0+(io-1)*N_NUIS+1] = θ.pmra; x[o0+(io-1)*N_NUIS+2] = θ.pmdec; x[o0+(io-1)*N_NUIS+3] = zero(T)
-        elseif obs isa PlanetRelAstromObs || nameof(typeof(obs)) === :ObsPriorAstromONeil2019   # relative-astrometry.jl:170-172
+        elseif obs isa PlanetRelAstromObs || T1 === :ObsPriorAstromONeil2019   # relative-astrometry.jl:170-172
             x[o0+(io-1)*N_NUIS+1] = hasproperty(θobs, :jitter) ? θobs.jitter : zero(T)
             x[o0+(io-1)*N_NUIS+2] = hasproperty(θobs, :platescale) ? θobs.platescale : one(T)
             x[o0+(io-1)*N_NUIS+3] = hasproperty(θobs, :northangle) ? θobs.northangle : zero(T)
@@ -178,46 +314,188 @@ function kernel_inputs(g::GPUBatchedLikelihood, θ)
     return x
 end
 
+# ==================================================================================================== (1) accelerate(system)
+"State shared by the HIPObs wrappers of one system: context, dataset and the staging arrays of the W = 1 call."
+mutable struct HIPShared
+    ctx::Ptr{Cvoid}
+    ds::Ptr{Cvoid}
+    system::Any                       # the accelerated System (set after construction)
+    entries::Vector{Any}              # (wrapped obs, i_planet or 0, θ_obs key) in evaluation order
+    columns::Vector{Vector{Float64}}
+    n_el::Int
+    lock::ReentrantLock               # ℓπcallback is called from many Julia threads (initialization.jl:33-48); one ctx = one caller at a time
+    Xt::Matrix{Float64}               # 1 × inputs
+    G::Matrix{Float64}
+    ll::Vector{Float64}
+end
+
+"""
+    HIPObs(obs, shared, leader)
+
+Wrapper of an observation whose `ln_like` runs on the device. The `leader` (first wrapped observation in the evaluation order of
+src/likelihoods/system.jl:229-235) evaluates ALL wrapped observations in one call; the others contribute zero. It keeps the wrapped
+observation's `priors` / `derived` (so the model's variables are unchanged) and its name, but exposes no `table`, so the reference
+gathers no epochs for it and pre-solves nothing on the CPU.
+"""
+struct HIPObs{TObs<:AbstractObs} <: AbstractObs
+    wrapped_like::TObs
+    priors::Priors
+    derived::Union{Derived,Nothing}
+    shared::HIPShared
+    leader::Bool
+end
+Octofitter.likelihoodname(obs::HIPObs) = likelihoodname(obs.wrapped_like)
+Octofitter._isprior(::HIPObs) = false
+Octofitter.likeobj_from_epoch_subset(obs::HIPObs, inds) = Octofitter.likeobj_from_epoch_subset(obs.wrapped_like, inds)   # cross-validation falls back to the CPU
+
+_eligible(obs) = _has_epochs(obs) && _table(obs, 1) !== nothing
+
+"""
+    accelerate(system::System; device=0) -> System
+
+The same model with every observation the kernels implement wrapped in `HIPObs`. Epoch-free terms (UnitLengthPrior, UserLikelihood,
+PlanetOrderPrior, …) stay as they are and run in Julia. Any OTHER epoch-bearing observation (full HGCA line fit, Hipparcos/Gaia
+IAD, GP RV, images, …) also stays in Julia and the reference keeps solving the orbits for its epochs — the two mix freely because
+each `ln_like` method is independent (src/variables.jl:94-102).
+"""
+function accelerate(system::System; device::Integer=0, verbosity::Integer=1)
+    arr2nt = Octofitter.make_arr2nt(system)
+    θ0 = arr2nt(Octofitter.make_prior_sampler(system)(Random.default_rng()))
+    eligible = Any[]
+    for (ip, pl) in enumerate(system.planets), obs in pl.observations
+        _eligible(obs) && push!(eligible, (obs, ip))
+    end
+    for obs in system.observations
+        _eligible(obs) && push!(eligible, (obs, 0))
+    end
+    isempty(eligible) && (verbosity >= 1 && @info "OctofitterHIP: no observation of this system is on the HIP path"; return system)
+    ctx, ds, entries, columns = _upload(system, eligible, θ0; device)
+    n_in = length(system.planets) * N_EL + length(entries) * N_NUIS
+    shared = HIPShared(ctx, ds, nothing, entries, columns, length(system.planets) * N_EL, ReentrantLock(),
+                       Matrix{Float64}(undef, 1, n_in), Matrix{Float64}(undef, 1, n_in), Vector{Float64}(undef, 1))
+    finalizer(shared) do s
+        octo_dataset_destroy(s.ds); octo_ctx_destroy(s.ctx)
+    end
+    first_seen = Ref(false)
+    wrap(obs) = _eligible(obs) ? (l = !first_seen[]; first_seen[] = true; HIPObs(obs, obs.priors, obs.derived, shared, l)) : obs
+    planets = map(system.planets) do pl
+        obs2 = map(wrap, pl.observations)
+        Planet{Octofitter.orbittype(pl),typeof(pl.priors),typeof(pl.derived),typeof(obs2)}(pl.priors, pl.derived, obs2, pl.name)
+    end
+    sysobs = map(wrap, system.observations)
+    sys2 = System(system.priors, system.derived, sysobs, planets, system.name)
+    shared.system = sys2
+    verbosity >= 1 && @info "OctofitterHIP: $(length(entries)) observation table(s), $(octo_dataset_n_rows(ds)) epochs on the device"
+    return sys2
+end
+
+_value(x::Real) = Float64(x)
+_value(x::ForwardDiff.Dual) = Float64(ForwardDiff.value(x))
+
+"ll and (when the inputs carry partials) its Dual: partials(ll) = Σ_k ∂ll/∂input_k · partials(input_k)."
+function _ln_like_all(sh::HIPShared, θ_system)
+    x = kernel_inputs(sh.system, sh.entries, θ_system)
+    T = eltype(x)
+    lock(sh.lock) do
+        @inbounds for k in eachindex(x)
+            sh.Xt[1, k] = _value(x[k])
+        end
+        if T <: ForwardDiff.Dual
+            octo_eval!(sh.ctx, sh.ds, sh.Xt, sh.n_el, sh.ll, sh.G)
+            ll = sh.ll[1]
+            isfinite(ll) || return T(ll)                                  # -Inf: zero partials (logdensitymodel.jl:120-124)
+            p = zero(ForwardDiff.partials(x[1]))
+            @inbounds for k in eachindex(x)
+                p += sh.G[1, k] * ForwardDiff.partials(x[k])
+            end
+            return T(ll, p)
+        else
+            octo_eval!(sh.ctx, sh.ds, sh.Xt, sh.n_el, sh.ll, nothing)
+            return T(sh.ll[1])
+        end
+    end
+end
+
+# The plug-in interface of the reference (src/variables.jl:94-102): one method per context type.
+function Octofitter.ln_like(obs::HIPObs, ctx::Octofitter.PlanetObservationContext)
+    obs.leader || return zero(Octofitter._system_number_type(ctx.θ_system))
+    return _ln_like_all(obs.shared, ctx.θ_system)
+end
+function Octofitter.ln_like(obs::HIPObs, ctx::Octofitter.SystemObservationContext)
+    obs.leader || return zero(Octofitter._system_number_type(ctx.θ_system))
+    return _ln_like_all(obs.shared, ctx.θ_system)
+end
+# posterior-predictive simulation and plotting use the wrapped observation on the CPU
+Octofitter.generate_from_params(obs::HIPObs, args...; kwargs...) = Octofitter.generate_from_params(obs.wrapped_like, args...; kwargs...)
+
+# ==================================================================================================== (3) batches of structured θ
+mutable struct GPUBatchedLikelihood{TModel}
+    model::TModel
+    ctx::Ptr{Cvoid}
+    ds::Ptr{Cvoid}
+    n_planets::Int
+    obs_entries::Vector{Any}          # (obs, i_planet or 0, θ_obs key) in evaluation order
+    host_terms::Vector{Any}           # epoch-free observations evaluated in Julia
+    columns::Vector{Vector{Float64}}  # keeps the uploaded host columns alive
+end
+
+function GPUBatchedLikelihood(model; device::Integer=0)
+    system = model.system
+    θ0 = model.arr2nt(model.sample_priors(Random.default_rng()))
+    eligible = Any[]; host_terms = Any[]
+    add! = function (obs, ip, ctxkind)
+        obs isa HIPObs && (obs = obs.wrapped_like)
+        if !_has_epochs(obs)
+            push!(host_terms, (obs, ip, ctxkind)); return
+        end
+        _table(obs, max(ip, 1)) === nothing && error("observation $(likelihoodname(obs)) is not on the HIP path; keep using model.ℓπcallback")
+        push!(eligible, (obs, ip))
+    end
+    # evaluation order of the generated closure: planet observations planet by planet, then system ones (system.jl:229-235)
+    for (ip, pl) in enumerate(system.planets), obs in pl.observations
+        add!(obs, ip, :planet)
+    end
+    for obs in system.observations
+        add!(obs, 0, :system)
+    end
+    ctx, ds, entries, columns = _upload(system, eligible, θ0; device)
+    g = GPUBatchedLikelihood(model, ctx, ds, length(system.planets), entries, host_terms, columns)
+    finalizer(g) do x
+        octo_dataset_destroy(x.ds); octo_ctx_destroy(x.ctx)
+    end
+    return g
+end
+
+kernel_inputs(g::GPUBatchedLikelihood, θ) = kernel_inputs(g.model.system, g.obs_entries, θ)
+
 "Host-side (epoch-free) likelihood terms, summed exactly as the reference does."
 function host_ll(g::GPUBatchedLikelihood, θ)
     ll = zero(Octofitter._system_number_type(θ))
+    sysm = g.model.system
     for (obs, ip, kind) in g.host_terms
         key = normalizename(likelihoodname(obs))
+        orbits = ntuple(i -> Octofitter.orbittype(sysm.planets[i])(; merge(θ, θ.planets[i])...), g.n_planets)
         if kind === :planet
             src = θ.planets[ip].observations
             θobs = hasproperty(src, key) ? getproperty(src, key) : (;)
-            orbits = ntuple(i -> Octofitter.orbittype(g.model.system.planets[i])(; merge(θ, θ.planets[i])...), g.n_planets)
             ll += Octofitter.ln_like(obs, Octofitter.PlanetObservationContext(θ, θ.planets[ip], θobs, orbits, ntuple(_ -> (), g.n_planets), ip, -1))
         else
             θobs = hasproperty(θ.observations, key) ? getproperty(θ.observations, key) : (;)
-            orbits = ntuple(i -> Octofitter.orbittype(g.model.system.planets[i])(; merge(θ, θ.planets[i])...), g.n_planets)
             ll += Octofitter.ln_like(obs, Octofitter.SystemObservationContext(θ, θobs, orbits, ntuple(_ -> (), g.n_planets), -1))
         end
     end
     return ll
 end
 
-# ---- raw batched call ---------------------------------------------------------------------------------------------
-"X :: (n_planets*9 + n_obs*3) × W, column per walker. Returns ll[W] and, if grad, ∂ll/∂X of the same shape."
+"X :: inputs × W, column per walker. Returns ll[W] and, if grad, ∂ll/∂X of the same shape."
 function eval_inputs(g::GPUBatchedLikelihood, X::Matrix{Float64}; grad::Bool=false)
-    n_el = g.n_planets * N_EL
-    W = size(X, 2)
     Xt = permutedims(X)                                  # [W, inputs]: walker index fastest, as the C ABI wants
-    ll = Vector{Float64}(undef, W)
-    G = grad ? similar(Xt) : Xt
-    n_nu = size(X, 1) - n_el
-    pel, pnu = pointer(Xt), n_nu > 0 ? pointer(Xt, n_el * W + 1) : Ptr{Float64}(C_NULL)
-    gel = grad ? pointer(G) : Ptr{Float64}(C_NULL)
-    gnu = grad && n_nu > 0 ? pointer(G, n_el * W + 1) : Ptr{Float64}(C_NULL)
-    GC.@preserve Xt ll G begin
-        check(g.ctx, ccall((:octo_eval, LIB), Int32,
-                           (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                           g.ctx, g.ds, pel, pnu, W, W, ll, gel, gnu), "octo_eval")
-    end
+    ll = Vector{Float64}(undef, size(X, 2))
+    G = grad ? similar(Xt) : nothing
+    octo_eval!(g.ctx, g.ds, Xt, g.n_planets * N_EL, ll, G)
     return grad ? (ll, permutedims(G)) : ll
 end
 
-# ---- the callable surface -----------------------------------------------------------------------------------------
 "ln_like for a batch of structured parameter sets (what `make_ln_like(system, θ)(system, θ)` returns, W at a time)."
 function ln_like_batch(g::GPUBatchedLikelihood, Θ::AbstractVector)
     X = reduce(hcat, (Float64.(kernel_inputs(g, θ)) for θ in Θ))
@@ -229,35 +507,199 @@ end
 "Drop-in for the closure returned by make_ln_like (src/likelihoods/system.jl:206): one θ at a time."
 (g::GPUBatchedLikelihood)(system, θ) = ln_like_batch(g, [θ])[1]
 
-"""
-log-posterior and its gradient w.r.t. the unconstrained θ_t for a D×W batch — the batched sibling of
-`model.∇ℓπcallback` (src/logdensitymodel.jl:169-177). The kernel returns ḡ = ∂ll/∂(elements, nuisances); the
-cheap per-walker map θ_t -> (elements, nuisances) and the prior are differentiated on the host with ForwardDiff
-(no epoch loop), and ∇θ_t = Jᵀ ḡ + ∇θ_t(ln prior + host terms).
-"""
-function ln_post_and_grad_batch(g::GPUBatchedLikelihood, Θt::AbstractMatrix{<:Real}, ln_prior_transformed)
-    m = g.model
-    D, W = size(Θt)
-    tonat(θt) = m.arr2nt(m.invlink(θt))
-    X = Matrix{Float64}(undef, g.n_planets * N_EL + length(g.obs_entries) * N_NUIS, W)
-    Js = Vector{Matrix{Float64}}(undef, W)
-    lp = Vector{Float64}(undef, W); ∇lp = Matrix{Float64}(undef, D, W)
-    for w in 1:W
-        θt = collect(Θt[:, w])
-        res = ForwardDiff.jacobian(t -> kernel_inputs(g, tonat(t)), θt)
-        Js[w] = res
-        X[:, w] = Float64.(kernel_inputs(g, tonat(θt)))
-        host(t) = ln_prior_transformed(m.invlink(t), true) + host_ll(g, tonat(t))
-        lp[w] = host(θt); ∇lp[:, w] = ForwardDiff.gradient(host, θt)
+"Batched `pointwise_like` column (src/cross-validation.jl:34-46): the log-likelihood of every posterior sample, one device call."
+pointwise_like_batch(g::GPUBatchedLikelihood, sample_nts::AbstractVector) = ln_like_batch(g, sample_nts)
+
+# ==================================================================================================== (2) HIPLogDensityModel
+function _octo_prior(d::Distribution)
+    d isa Uniform && return OctoPrior(PRIOR_UNIFORM, 0, minimum(d), maximum(d), -Inf, Inf)
+    d isa LogUniform && return OctoPrior(PRIOR_LOGUNIFORM, 0, minimum(d), maximum(d), -Inf, Inf)
+    d isa Normal && return OctoPrior(PRIOR_NORMAL, 0, mean(d), std(d), -Inf, Inf)
+    if d isa Truncated && d.untruncated isa Normal
+        lo = d.lower === nothing ? -Inf : Float64(d.lower); hi = d.upper === nothing ? Inf : Float64(d.upper)
+        return OctoPrior(PRIOR_TRUNCNORMAL, 0, mean(d.untruncated), std(d.untruncated), lo, hi)
     end
-    ll, G = eval_inputs(g, X; grad=true)
-    ∇ = similar(∇lp)
-    for w in 1:W
-        ∇[:, w] = Js[w]' * G[:, w] .+ ∇lp[:, w]
-        isfinite(lp[w]) || (ll[w] = 0.0; ∇[:, w] .= 0.0)           # logdensitymodel.jl:130-133
-    end
-    return lp .+ ll, ∇
+    nameof(typeof(d)) === :Sine && return OctoPrior(PRIOR_SINE, 0, 0.0, 0.0, -Inf, Inf)     # Octofitter.Sine, src/distributions.jl:14-39
+    return nothing
 end
 
-export GPUBatchedLikelihood, ln_like_batch, ln_post_and_grad_batch
+"All priors in the reference's flattening order (src/variables.jl:1205-1347): system, system observations, then per planet its own and its observations'."
+function _flat_priors(system)
+    ds = Distribution[]
+    append!(ds, values(system.priors.priors))
+    for obs in system.observations
+        hasproperty(obs, :priors) && append!(ds, values(obs.priors.priors))
+    end
+    for pl in system.planets
+        append!(ds, values(pl.priors.priors))
+        for obs in pl.observations
+            hasproperty(obs, :priors) && append!(ds, values(obs.priors.priors))
+        end
+    end
+    return ds
+end
+
+"""
+How is kernel input k built from the natural θ? Found NUMERICALLY, not from the user's expressions: the Jacobian of
+`kernel_inputs ∘ arr2nt` at a few prior draws tells which θ an input depends on, and the candidate closed forms (identity,
+constant, atan(y, x)/2π·domain, θ_at_epoch_to_tperi) are checked against its values. Anything else: `nothing` (not a standard model).
+"""
+function _classify_sources(model, g::GPUBatchedLikelihood; n_probe::Int=4)
+    D = model.D
+    rng = Random.Xoshiro(20260929)
+    θs = [model.sample_priors(rng) for _ in 1:n_probe]
+    f(θ) = kernel_inputs(g, model.arr2nt(θ))
+    vals = [Float64.(f(θ)) for θ in θs]
+    jacs = [ForwardDiff.jacobian(f, collect(Float64, θ)) for θ in θs]
+    n_in = length(vals[1]); n_el = g.n_planets * N_EL
+    src = Vector{Union{Nothing,OctoSource}}(nothing, n_in)
+    used_pairs = Set{Tuple{Int,Int}}()
+    dep(k) = findall(d -> any(abs(J[k, d]) > 0 for J in jacs), 1:D)
+    for k in 1:n_in
+        deps = dep(k)
+        if isempty(deps)
+            all(v -> v[k] == vals[1][k], vals) || return nothing
+            src[k] = OctoSource(SRC_CONST, 0, 0, 0, vals[1][k])
+        elseif length(deps) == 1 && all(i -> vals[i][k] == θs[i][deps[1]], 1:n_probe)
+            src[k] = OctoSource(SRC_THETA, deps[1] - 1, 0, 0, 0.0)
+        elseif length(deps) == 2
+            ix, iy = deps                                               # UniformCircular: (x, y) are declared in this order, variables.jl:290-293
+            ang(i) = atan(θs[i][iy], θs[i][ix])
+            dom = vals[1][k] / ang(1) * 2π
+            all(i -> isapprox(vals[i][k], ang(i) / 2π * dom; rtol=1e-12, atol=1e-14), 1:n_probe) || return nothing
+            flag = (ix, iy) in used_pairs ? Int32(0) : SRC_FLAG_UNITLEN
+            push!(used_pairs, (ix, iy))
+            src[k] = OctoSource(SRC_CIRCULAR, ix - 1, iy - 1, flag, dom)
+        end
+    end
+    # what is left must be tp = θ_at_epoch_to_tperi(θ, epoch; …) of a planet whose other elements are already classified
+    for k in 1:n_in
+        src[k] === nothing || continue
+        (k <= n_el && (k - 1) % N_EL + 1 == 6) || return nothing
+        ip = (k - 1) ÷ N_EL + 1
+        ti = Octofitter.orbittype(model.system.planets[ip]) <: ThieleInnesOrbit
+        others = Set(Iterators.flatten(dep(j) for j in (ip-1)*N_EL+1:ip*N_EL if j != k))
+        pair = sort(setdiff(dep(k), others))
+        length(pair) == 2 || return nothing
+        ix, iy = pair
+        # epoch = tp + MA/n·year2day with MA, n from the planet's elements at θ = atan(y, x): the same for every probe
+        function epoch_of(i)
+            el = vals[i][(ip-1)*N_EL+1:ip*N_EL]; θang = atan(θs[i][iy], θs[i][ix])
+            nt = ti ? (; plx=el[8], M=el[7], e=el[2], A=el[1], B=el[3], F=el[4], G=el[5]) : (; M=el[7], e=el[2], a=el[1], i=el[3], ω=el[4], Ω=el[5])
+            return el[6] - (Octofitter.θ_at_epoch_to_tperi(θang, 0.0; nt...))     # linear in the epoch argument
+        end
+        ep = epoch_of(1)
+        all(i -> isapprox(epoch_of(i), ep; rtol=0, atol=1e-6), 1:n_probe) || return nothing
+        flag = ((ix, iy) in used_pairs ? Int32(0) : SRC_FLAG_UNITLEN) | (ti ? SRC_FLAG_TI : Int32(0))
+        push!(used_pairs, (ix, iy))
+        src[k] = OctoSource(SRC_TPERI, ix - 1, iy - 1, flag, round(ep; digits=6))
+    end
+    return OctoSource[s for s in src]
+end
+
+"""
+    HIPLogDensityModel(model::Octofitter.LogDensityModel; device=0)
+
+The whole log-posterior callback on the device for models made of the standard blocks; throws (and the caller keeps `model`,
+possibly built from `accelerate(system)`) when a prior family, a Derived expression or an observation is outside them.
+"""
+mutable struct HIPLogDensityModel{TModel,Tℓπ,T∇ℓπ}
+    const D::Int
+    const ℓπcallback::Tℓπ
+    const ∇ℓπcallback::T∇ℓπ
+    const system::Any
+    const link::Any
+    const invlink::Any
+    const arr2nt::Any
+    const sample_priors::Any
+    starting_points::Union{Nothing,Vector}
+    const reference::TModel
+    const batched::GPUBatchedLikelihood
+    const m::Ptr{Cvoid}
+    const lock::ReentrantLock
+end
+
+function HIPLogDensityModel(model; device::Integer=0)
+    g = GPUBatchedLikelihood(model; device)
+    # the UnitLengthPrior terms of UniformCircular variables are part of the device model; any other host term is not
+    for (obs, _, _) in g.host_terms
+        nameof(typeof(obs)) === :UnitLengthPrior || error("$(typeof(obs)) is evaluated in Julia: use LogDensityModel(accelerate(system)) for this model")
+    end
+    dists = _flat_priors(model.system)
+    length(dists) == model.D || error("model has multivariate or discrete priors: not a standard-parameterisation model")
+    priors = OctoPrior[]
+    for d in dists
+        p = _octo_prior(d)
+        p === nothing && error("prior $(d) has no device counterpart: use LogDensityModel(accelerate(system)) for this model")
+        push!(priors, p)
+    end
+    srcs = _classify_sources(model, g)
+    srcs === nothing && error("a Derived variable of this model is not one of the standard blocks: use LogDensityModel(accelerate(system))")
+    n_el = g.n_planets * N_EL
+    m = octo_model_create(g.ctx, g.ds, priors, srcs[1:n_el], length(srcs) > n_el ? srcs[n_el+1:end] : nothing)
+    lk = ReentrantLock()
+    D = model.D
+    function ℓπ(θ_t::AbstractVector)
+        lock(lk) do
+            lp = Vector{Float64}(undef, 1)
+            octo_model_logpost!(g.ctx, m, reshape(collect(Float64, θ_t), 1, D), lp, nothing)[1]
+        end
+    end
+    function ℓπ(Θ_t::AbstractMatrix)                                    # D × W, as the reference lays batches out
+        lock(lk) do
+            octo_model_logpost!(g.ctx, m, permutedims(Matrix{Float64}(Θ_t)), Vector{Float64}(undef, size(Θ_t, 2)), nothing)
+        end
+    end
+    function ∇ℓπ(θ_t::AbstractVector)
+        lock(lk) do
+            lp = Vector{Float64}(undef, 1); G = Matrix{Float64}(undef, 1, D)
+            octo_model_logpost!(g.ctx, m, reshape(collect(Float64, θ_t), 1, D), lp, G)
+            (lp[1], vec(G))
+        end
+    end
+    function ∇ℓπ(Θ_t::AbstractMatrix)
+        lock(lk) do
+            W = size(Θ_t, 2); lp = Vector{Float64}(undef, W); G = Matrix{Float64}(undef, W, D)
+            octo_model_logpost!(g.ctx, m, permutedims(Matrix{Float64}(Θ_t)), lp, G)
+            (lp, permutedims(G))
+        end
+    end
+    hm = HIPLogDensityModel(D, ℓπ, ∇ℓπ, model.system, model.link, model.invlink, model.arr2nt, model.sample_priors, model.starting_points,
+                            model, g, m, lk)
+    finalizer(x -> octo_model_destroy(x.m), hm)
+    return hm
+end
+
+# The interface AdvancedHMC / Pathfinder / Pigeons see (src/logdensitymodel.jl:252-256, OctofitterPigeonsExt.jl:10-12)
+LogDensityProblems.logdensity(p::HIPLogDensityModel, θ) = p.ℓπcallback(θ)
+LogDensityProblems.logdensity_and_gradient(p::HIPLogDensityModel, θ) = p.∇ℓπcallback(θ)
+LogDensityProblems.dimension(p::HIPLogDensityModel) = p.D
+LogDensityProblems.capabilities(::Type{<:HIPLogDensityModel}) = LogDensityProblems.LogDensityOrder{1}()
+(p::HIPLogDensityModel)(θ) = p.ℓπcallback(θ)
+
+"`guess_starting_position` (src/initialization.jl:14-66) with the N prior draws evaluated in device batches instead of one callback each."
+function Octofitter.guess_starting_position(rng::Random.AbstractRNG, model::HIPLogDensityModel, N=500_000; batch::Int=250_000)
+    bestparams = model.sample_priors(rng); bestlogpost = -Inf64
+    done = 0
+    while done < N
+        n = min(batch, N - done)
+        params = [model.sample_priors(rng) for _ in 1:n]
+        Θt = reduce(hcat, (collect(Float64, model.link(p)) for p in params))
+        logpost = model.ℓπcallback(Θt)
+        k = argmax(logpost)
+        if logpost[k] > bestlogpost
+            bestlogpost = logpost[k]; bestparams = params[k]
+        end
+        done += n
+    end
+    return bestparams, bestlogpost
+end
+
+"`_rejection_evaluate_likelihoods` (src/sampling.jl:260-268) for a vector of prior draws, one device call."
+function rejection_evaluate_likelihoods(model::HIPLogDensityModel, prior_samples::AbstractVector)
+    ll = ln_like_batch(model.batched, [model.arr2nt(θ) for θ in prior_samples])
+    return map(x -> isfinite(x) ? x : -Inf, ll)
+end
+
+export accelerate, HIPObs, HIPLogDensityModel, GPUBatchedLikelihood, ln_like_batch, pointwise_like_batch, rejection_evaluate_likelihoods
 end # module

@@ -1,0 +1,165 @@
+"""
+The C ABI seen by three consumers must be ONE layout ("ctypes structs and Julia structs are hand-mirrored from the
+header; no compiled-C consumer pins sizeof/offsetof"):
+  * tests/abi_layout.c, compiled with gcc against include/octofitter_hip.h, prints sizeof/offsetof of every struct and
+    dlopens the library (CPU: every declared symbol resolves; GPU: one octo_eval call through plain C);
+  * the ctypes mirror (octofitter.jl_amd/host/capi.py) must agree field by field;
+  * the Julia mirror (octofitter.jl_amd/julia/OctofitterHIP.jl — Julia is not in the image, so its struct definitions are parsed
+    as text and laid out by the C rules for Int32 / Int64 / Float64 / Ptr) must agree field by field, the shim must `ccall`
+    every function the header declares with the right number of arguments, and every numeric constant it repeats must match.
+"""
+import ctypes as C
+import json
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "octofitter_hip.h"
+JULIA = ROOT / "octofitter.jl_amd" / "julia" / "OctofitterHIP.jl"
+
+
+@pytest.fixture(scope="module")
+def abi_exe(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("abi") / "abi_layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", f"-I{ROOT / 'include'}", "-o", str(exe), str(ROOT / "tests" / "abi_layout.c"), "-ldl"], check=True)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def layout(abi_exe):
+    return json.loads(subprocess.run([str(abi_exe), "layout"], check=True, capture_output=True, text=True).stdout)
+
+
+def _header_functions():
+    """name -> number of parameters of every function the header declares."""
+    txt = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int32_t|int64_t|const char\*)\s+(octo_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_c_program_sees_every_symbol(pkg, abi_exe, layout):
+    funcs = _header_functions()
+    assert layout["n_symbols"] == len(funcs), "tests/abi_layout.c SYMBOLS and the header disagree"
+    assert set(funcs) == set(pkg.capi.EXPORTED_SYMBOLS), set(funcs) ^ set(pkg.capi.EXPORTED_SYMBOLS)
+    r = subprocess.run([str(abi_exe), "symbols", str(pkg.capi.LIB_PATH)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout)["symbols_ok"] == len(funcs)
+    for name, (res, args) in pkg.capi._SIGS.items():      # the ctypes signatures have the header's arity
+        assert len(args) == funcs[name], (name, len(args), funcs[name])
+
+
+def test_ctypes_structs_match_the_header(pkg, layout):
+    capi = pkg.capi
+    pairs = {"octo_consts": capi.OctoConsts, "octo_obs_desc": capi.OctoObsDesc, "octo_planet_desc": capi.OctoPlanetDesc,
+             "octo_prior": capi.OctoPrior, "octo_source": capi.OctoSource}
+    for cname, cls in pairs.items():
+        ref = layout[cname]
+        assert C.sizeof(cls) == ref["size"], cname
+        assert [f[0] for f in cls._fields_] == [f[0] for f in ref["fields"]], cname
+        for (fname, _), (rname, off, size) in zip(cls._fields_, ref["fields"]):
+            d = getattr(cls, fname)
+            assert (d.offset, d.size) == (off, size), (cname, fname)
+    assert (capi.N_EL, capi.N_NUIS) == (layout["OCTO_N_EL"], layout["OCTO_N_NUIS"])
+
+
+_JL_SIZES = {"Int32": 4, "Int64": 8, "Float64": 8, "UInt64": 8}
+
+
+def _julia_structs():
+    txt = JULIA.read_text()
+    out = {}
+    for m in re.finditer(r"^struct (Octo\w+)[ \t]*(?:#[^\n]*)?\n(.*?)^end", txt, flags=re.S | re.M):
+        fields = []
+        for line in m.group(2).splitlines():
+            line = line.split("#")[0].strip()
+            for part in filter(None, (p.strip() for p in line.split(";"))):
+                name, typ = part.split("::")
+                fields.append((name.strip(), typ.strip()))
+        out[m.group(1)] = fields
+    return out
+
+
+def test_julia_structs_match_the_header(layout):
+    structs = _julia_structs()
+    pairs = {"octo_consts": "OctoConsts", "octo_obs_desc": "OctoObsDesc", "octo_planet_desc": "OctoPlanetDesc", "octo_prior": "OctoPrior",
+             "octo_source": "OctoSource"}
+    for cname, jname in pairs.items():
+        assert jname in structs, f"{jname} missing from OctofitterHIP.jl"
+        ref = layout[cname]
+        off = 0
+        align_max = 1
+        assert [f[0] for f in structs[jname]] == [f[0] for f in ref["fields"]], (jname, "field names / order")
+        for (fname, typ), (_, roff, rsize) in zip(structs[jname], ref["fields"]):
+            size = 8 if typ.startswith("Ptr{") else _JL_SIZES[typ]
+            off = (off + size - 1) // size * size          # natural alignment, as Julia lays out isbits structs (C-compatible)
+            align_max = max(align_max, size)
+            assert (off, size) == (roff, rsize), (jname, fname, typ)
+            off += size
+        assert (off + align_max - 1) // align_max * align_max == ref["size"], jname
+
+
+def test_julia_shim_binds_every_symbol_with_the_right_arity():
+    funcs = _header_functions()
+    txt = JULIA.read_text()
+    seen = {}
+    for m in re.finditer(r"ccall\(\(:(octo_\w+), LIB\),\s*\w+,\s*\(", txt):
+        # argument-type tuple: balanced parentheses after the return type
+        i = m.end()
+        depth, j = 1, i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(txt[j], 0)
+            j += 1
+        tup = txt[i:j - 1]
+        depth, n, cur = 0, 0, ""
+        for ch in tup:
+            if ch in "({":
+                depth += 1
+            elif ch in ")}":
+                depth -= 1
+            if ch == "," and depth == 0:
+                n += bool(cur.strip()); cur = ""
+            else:
+                cur += ch
+        n += bool(cur.strip())
+        seen.setdefault(m.group(1), set()).add(n)
+    missing = set(funcs) - set(seen)
+    assert not missing, f"OctofitterHIP.jl has no ccall for {sorted(missing)}"
+    for name, counts in seen.items():
+        assert name in funcs, f"OctofitterHIP.jl calls {name}, which the header does not declare"
+        assert counts == {funcs[name]}, (name, counts, funcs[name])
+
+
+def test_julia_constants_match_the_header():
+    hdr = HEADER.read_text()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(OCTO_\w+)\s+(-?\d+)\b", hdr)}
+    txt = JULIA.read_text()
+    groups = {
+        "ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL": ["OCTO_ASTROM_RADEC", "OCTO_ASTROM_SEPPA", "OCTO_RV_ABS", "OCTO_RV_ABS_MARG", "OCTO_RV_REL"],
+        "ONEIL_RADEC, ONEIL_SEPPA, HGCA": ["OCTO_ONEIL_RADEC", "OCTO_ONEIL_SEPPA", "OCTO_HGCA"],
+        "ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES, ORBIT_KEP": ["OCTO_ORBIT_VISUAL_KEP", "OCTO_ORBIT_RADVEL", "OCTO_ORBIT_THIELE_INNES", "OCTO_ORBIT_KEP"],
+        "PRIOR_UNIFORM, PRIOR_LOGUNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_SINE": ["OCTO_PRIOR_UNIFORM", "OCTO_PRIOR_LOGUNIFORM", "OCTO_PRIOR_NORMAL",
+                                                                                         "OCTO_PRIOR_TRUNCNORMAL", "OCTO_PRIOR_SINE"],
+        "SRC_CONST, SRC_THETA, SRC_CIRCULAR, SRC_TPERI": ["OCTO_SRC_CONST", "OCTO_SRC_THETA", "OCTO_SRC_CIRCULAR", "OCTO_SRC_TPERI"],
+        "SRC_FLAG_UNITLEN, SRC_FLAG_TI": ["OCTO_SRC_FLAG_UNITLEN", "OCTO_SRC_FLAG_TI"],
+        "OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV": ["OCTO_OK", "OCTO_EINVAL", "OCTO_EHIP", "OCTO_ENOMEM", "OCTO_ENODEV"],
+    }
+    for lhs, names in groups.items():
+        m = re.search(r"const " + re.escape(lhs) + r"\s*=\s*(.+)", txt)
+        assert m, lhs
+        vals = [int(v) for v in re.findall(r"Int32\((-?\d+)\)", m.group(1))]
+        assert vals == [defs[n] for n in names], (lhs, vals)
+    assert re.search(r"const N_EL, N_NUIS = (\d+), (\d+)", txt).groups() == (str(defs["OCTO_N_EL"]), str(defs["OCTO_N_NUIS"]))
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_evaluates(pkg, abi_exe):
+    r = subprocess.run([str(abi_exe), "eval", str(pkg.capi.LIB_PATH)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    out = json.loads(r.stdout)
+    assert out["ok"] == 1 and out["ll1_is_minus_inf"] == 1

@@ -344,7 +344,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
     if (n_planets < 1 || n_planets > MAXP) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: 1..4 planets supported");
     for (int p = 0; p < n_planets; ++p)
         if (planets[p].orbit_kind != OCTO_ORBIT_VISUAL_KEP && planets[p].orbit_kind != OCTO_ORBIT_RADVEL &&
-            planets[p].orbit_kind != OCTO_ORBIT_THIELE_INNES)
+            planets[p].orbit_kind != OCTO_ORBIT_THIELE_INNES && planets[p].orbit_kind != OCTO_ORBIT_KEP)
             return fail(ctx, OCTO_EINVAL, "octo_dataset_create: unknown orbit kind");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     octo_dataset* ds = new (std::nothrow) octo_dataset();
@@ -363,7 +363,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
             if (d.n_epochs > 0 && (!d.epoch || !d.y1 || !d.y2)) return bail(OCTO_EINVAL, "octo_dataset_create: missing column");
             if (!d.extra || d.n_extra != OCTO_HGCA_N_EXTRA) return bail(OCTO_EINVAL, "octo_dataset_create: OCTO_HGCA needs extra[15]");
             for (int p = 0; p < n_planets; ++p)       // mass * mjup2msol of every Visual planet is read (hgca.jl:279-290)
-                if (planets[p].orbit_kind != OCTO_ORBIT_RADVEL && !planets[p].has_mass)
+                if (planets[p].orbit_kind != OCTO_ORBIT_RADVEL && planets[p].orbit_kind != OCTO_ORBIT_KEP && !planets[p].has_mass)
                     return bail(OCTO_EINVAL, "octo_dataset_create: OCTO_HGCA needs a mass on every Visual{KepOrbit} / ThieleInnesOrbit planet");
             for (int k = 0; k < 3; ++k)
                 if (!(d.extra[5 * k + 2] > 0.0) || !(d.extra[5 * k + 3] > 0.0) || !(std::fabs(d.extra[5 * k + 4]) < 1.0))
@@ -397,7 +397,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
         if (planet_obs && (d.planet < 0 || d.planet >= n_planets)) return bail(OCTO_EINVAL, "octo_dataset_create: planet index out of range");
         if (d.n_epochs > 0 && (!d.epoch || !d.y1 || !d.s1 || (astrom && (!d.y2 || !d.s2))))
             return bail(OCTO_EINVAL, "octo_dataset_create: missing column");
-        if (astrom && planets[d.planet].orbit_kind == OCTO_ORBIT_RADVEL)
+        if (astrom && (planets[d.planet].orbit_kind == OCTO_ORBIT_RADVEL || planets[d.planet].orbit_kind == OCTO_ORBIT_KEP))
             return bail(OCTO_EINVAL, "octo_dataset_create: astrometry needs a Visual{KepOrbit} or ThieleInnesOrbit planet");
         if (!astrom)       // RV of a ThieleInnesOrbit (PlanetOrbits derives i, ω from A, B, F, G for it) is not on this path
             for (int p = 0; p < n_planets; ++p)

@@ -11,8 +11,10 @@
 // what makes a CDNA4-shaped implementation legal:
 //   * the starter is evaluated in FP32 (2x the FP64 issue rate, single-instruction v_sqrt/v_rcp/v_log/v_exp):
 //     its own error (~4e-4 by construction) dwarfs FP32 rounding;
-//   * sin/cos(E1) come from one half-angle polynomial pair on |E1|/2 <= 1.59 (no range reduction, no
-//     quadrant selects, no Payne-Hanek slow path: |E1| <= π by construction);
+//   * sin/cos(E1): in k_main / k_ofti_main from a 1041-entry table in LDS plus a rotation by the remainder (sincos_table
+//     below: 13 FP64 instructions); in k_small and k_hgca from one half-angle polynomial pair on |E1|/2 <= 1.59
+//     (sincos_halfangle: 24 instructions, no table fill). Neither needs range reduction, quadrant selects or a
+//     Payne-Hanek slow path: |E1| <= π by construction;
 //   * the three divisions of the correction use v_rcp_f64 (2^-23) with 0/1/1 Newton steps — the sensitivity
 //     of E to δ3, δ4 is O(δ²);
 //   * sin/cos(E) follow from (sin E1, cos E1) by a rotation through δ5 (|δ5| < 5e-4: Taylor to δ^6).

@@ -50,7 +50,7 @@ static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
     bool visual[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        visual[p] = a.orbit_kind[p] != OCTO_ORBIT_RADVEL;      // Visual{KepOrbit} or ThieleInnesOrbit (hgca.jl:255-262)
+        visual[p] = a.orbit_kind[p] != OCTO_ORBIT_RADVEL && a.orbit_kind[p] != OCTO_ORBIT_KEP;      // Visual{KepOrbit} or ThieleInnesOrbit (hgca.jl:255-262)
         const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
         D el[OCTO_N_EL];
 #pragma unroll

@@ -186,6 +186,8 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     bool finite_in = true;
     for (int k = 0; k < D; ++k) finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + w]);   // logdensitymodel.jl:120-124
     Dual<N> lp = dconst<N>(0.0);
+    Dual<N> ulp = dconst<N>(0.0);      // Σ UnitLengthPrior terms: likelihood terms of the reference (variables.jl:309-323), so they and
+                                       // their gradient survive a healed prior (the healed value is a constant, :1229-1236)
     bool healed = false;
     for (int k = 0; k < D; ++k) {
         const double pv = Lp[k * WAVE + lane];
@@ -213,19 +215,19 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         const int slot = a.circ_slot[k];
         if (slot < 0) {                                               // beyond the LDS budget: in place
             const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
-            if (sc.flags & OCTO_SRC_FLAG_UNITLEN) lp = lp + unit_length(cx, cy);
+            if (sc.flags & OCTO_SRC_FLAG_UNITLEN) ulp = ulp + unit_length(cx, cy);
             return datan2(cy, cx);
         }
         const double* c = Lc + (int64_t)slot * 6 * WAVE + lane;
         const double dx = Ldx[sc.i0 * WAVE + lane], dy = Ldx[sc.i1 * WAVE + lane];    // ∂x/∂θ_t, ∂y/∂θ_t (diagonal)
         Dual<N> ang; ang.v = c[0];
         const bool ul = (sc.flags & OCTO_SRC_FLAG_UNITLEN) != 0;
-        if (ul) lp.v += c[3 * WAVE];
+        if (ul) ulp.v += c[3 * WAVE];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const double sx = (sc.i0 == d0 + j) ? dx : 0.0, sy = (sc.i1 == d0 + j) ? dy : 0.0;
             ang.d[j] = c[WAVE] * sx + c[2 * WAVE] * sy;
-            if (ul) lp.d[j] += c[4 * WAVE] * sx + c[5 * WAVE] * sy;
+            if (ul) ulp.d[j] += c[4 * WAVE] * sx + c[5 * WAVE] * sy;
         }
         return ang;
     };
@@ -279,10 +281,10 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         }
         emit(a.n_el + k, plain(sc, a.n_el + k));
     }
-    if (d0 == 0) a.lpp[w] = finite_in ? lp.v : -INFINITY;
+    if (d0 == 0) a.lpp[w] = finite_in ? lp.v + ulp.v : -INFINITY;
 #pragma unroll
     for (int j = 0; j < N; ++j)
-        if (d0 + j < D) a.glp[(int64_t)(d0 + j) * a.ldw + w] = healed ? 0.0 : lp.d[j];
+        if (d0 + j < D) a.glp[(int64_t)(d0 + j) * a.ldw + w] = (healed ? 0.0 : lp.d[j]) + ulp.d[j];
 }
 
 // grid = (walker tiles of 256, D): thread (w, d) produces grad[d][w] = ∂(prior)/∂θ_t[d] + Σ_k J[k][d]·ḡ[k].

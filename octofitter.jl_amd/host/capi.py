@@ -21,7 +21,7 @@ STATUS_NAMES = {0: "OCTO_OK", 1: "OCTO_EINVAL", 2: "OCTO_EHIP", 3: "OCTO_ENOMEM"
 ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL, ONEIL_RADEC, ONEIL_SEPPA, HGCA = 0, 1, 2, 3, 4, 5, 6, 7
 HGCA_RA, HGCA_DEC, HGCA_HIP, HGCA_GAIA, HGCA_N_EXTRA = 0, 1, 0, 1, 15
 ASTROM_KINDS = (ASTROM_RADEC, ASTROM_SEPPA, ONEIL_RADEC, ONEIL_SEPPA)
-ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES = 0, 1, 2
+ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES, ORBIT_KEP = 0, 1, 2, 3
 N_EL, N_NUIS = 9, 3
 EL_A, EL_E, EL_I, EL_W, EL_O, EL_TP, EL_M, EL_PLX, EL_MASS = range(9)
 NU_JITTER, NU_PLATESCALE, NU_NORTHANGLE = 0, 1, 2

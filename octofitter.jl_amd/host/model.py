@@ -54,6 +54,7 @@ class LogDensityModel:
         for ip, pl in enumerate(system.planets):
             pv = pl.variables or {}
             radvel = _BASIS[pl.basis] == capi.ORBIT_RADVEL
+            kep = _BASIS[pl.basis] == capi.ORBIT_KEP
             for k, keys in enumerate(el_keys(pl.basis)):
                 spec, scope, name = None, None, None
                 for key in keys:
@@ -66,7 +67,7 @@ class LogDensityModel:
                             spec, scope, name = sysvars[key], ("sys",), key
                             break
                 if spec is None:
-                    if k == capi.EL_MASS or (radvel and k in (capi.EL_I, capi.EL_O, capi.EL_PLX)):
+                    if k == capi.EL_MASS or (radvel and k in (capi.EL_I, capi.EL_O, capi.EL_PLX)) or (kep and k == capi.EL_PLX):
                         esrc.append((capi.SRC_CONST, 0, 0, 0, 0.0))
                         continue
                     raise KeyError(f"planet {pl.name}: missing orbital element {keys[0]}")

@@ -30,7 +30,8 @@ from .observations import AbstractObs, normalizename
 _EL_KEYS = (("a",), ("e",), ("i",), ("ω", "w", "omega"), ("Ω", "O", "Omega"), ("tp",), ("M",), ("plx",), ("mass",))
 # ThieleInnesOrbit(; e, tp, M, plx, A, B, F, G): the constants [mas] travel in the rows of a, i, ω, Ω (include/octofitter_hip.h)
 _EL_KEYS_TI = (("A",), ("e",), ("B",), ("F",), ("G",), ("tp",), ("M",), ("plx",), ("mass",))
-_BASIS = {"Visual{KepOrbit}": capi.ORBIT_VISUAL_KEP, "RadialVelocityOrbit": capi.ORBIT_RADVEL, "ThieleInnesOrbit": capi.ORBIT_THIELE_INNES}
+_BASIS = {"Visual{KepOrbit}": capi.ORBIT_VISUAL_KEP, "RadialVelocityOrbit": capi.ORBIT_RADVEL, "ThieleInnesOrbit": capi.ORBIT_THIELE_INNES,
+          "KepOrbit": capi.ORBIT_KEP}      # plain KepOrbit (a, e, i, ω, Ω, tp, M): no parallax, so RV tables only
 
 
 def el_keys(basis):
@@ -182,7 +183,8 @@ class BatchedLnLike:
                     v = _lookup(θ, keys)      # planet-level wins, as in merge(θ_system, θ_planet)
                 if v is None:
                     radvel_unused = self.planet_desc[ip]["orbit_kind"] == capi.ORBIT_RADVEL and k in (capi.EL_I, capi.EL_O, capi.EL_PLX)
-                    if k == capi.EL_MASS or radvel_unused:
+                    kep_unused = self.planet_desc[ip]["orbit_kind"] == capi.ORBIT_KEP and k == capi.EL_PLX
+                    if k == capi.EL_MASS or radvel_unused or kep_unused:
                         v = 0.0
                     else:
                         raise KeyError(f"planet {pl.name}: missing orbital element {keys[0]}")

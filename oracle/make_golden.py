@@ -293,6 +293,40 @@ def model_cases():
     print("wrote", p, p.stat().st_size, "bytes")
 
 
+def kep_cases():
+    """tests/golden/kep.json — F11: the plain `KepOrbit` basis (a, e, i, ω, Ω, tp, M; src/likelihoods/system.jl:116-118 constructs whatever
+    basis the planet declares). It has no parallax, so only radial-velocity tables can be attached: K carries sin i
+    (unlike RadialVelocityOrbit), the inclination gets a gradient, Ω and plx do not enter."""
+    rng = np.random.default_rng(20260929 + 61)
+    KEPM = dict(orbit_kind=3, has_mass=True)
+    W = 6
+    ep = np.linspace(50000.0, 50900.0, 16)
+    def planet(a_lo, a_hi):
+        return np.stack([rng.uniform(a_lo, a_hi, W), rng.uniform(0, 0.6, W), rng.uniform(0.1, 3.0, W), rng.uniform(0, 6.28, W), rng.uniform(-7, 7, W),
+                         50000 + rng.uniform(-400, 400, W), rng.normal(1.1, 0.05, W), np.full(W, np.nan), rng.uniform(1, 30, W)])
+    el = planet(1.0, 3.0)
+    rv = rng.normal(0, 40, 16)
+    out = []
+    nu = col(rng.normal(0, 10, W), np.exp(rng.uniform(np.log(0.1), np.log(20), W)), np.zeros(W))
+    el_f = el.copy(); el_f[7] = 0.0       # the parallax row is ignored by this basis: NaN in the GPU/oracle inputs, 0 for the 60-digit arithmetic
+    c1 = run_case("F11_kep_rv_absolute", [KEPM], [rvtab("RV_ABS", -1, ep, rv, [2.0 + 0.1 * k for k in range(16)])], el_f, nu,
+                  "StarAbsoluteRVObs on a plain KepOrbit planet: K = 2πa sin i/(P√(1−e²))")
+    c1["elems"] = np.where(np.isnan(el), None, el).tolist()
+    out.append(c1)
+    el2 = np.concatenate([planet(0.8, 1.5), planet(3.0, 6.0)])
+    el2_f = el2.copy(); el2_f[7] = 0.0; el2_f[16] = 0.0
+    nu2 = np.concatenate([col(rng.normal(0, 100, W), np.exp(rng.uniform(np.log(1), np.log(50), W)), np.zeros(W)),
+                          col(rng.normal(0, 5, W), np.exp(rng.uniform(np.log(0.1), np.log(5), W)), np.zeros(W))])
+    c2 = run_case("F11_kep_two_planets_rel_and_abs", [KEPM, KEPM], [rvtab("RV_REL", 1, ep + 3.0, rng.normal(0, 2000, 16), [60.0] * 16),
+                                                                    rvtab("RV_ABS", -1, ep, rv, [2.5] * 16)], el2_f, nu2,
+                  "relative RV of the outer planet (inner-companion term active) + absolute RV, both planets plain KepOrbit")
+    c2["elems"] = np.where(np.isnan(el2), None, el2).tolist()
+    out.append(c2)
+    p = ROOT / "tests" / "golden" / "kep.json"
+    p.write_text(json.dumps(dict(consts=C, cases=out, generator="oracle/make_golden.py kep_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 def config1_case():
     """tests/golden/config1.json — BASELINE config 1 as SURVEY.md §8(d) defines it: the D = 11 model of
     test/integration/sampling.jl:29-64 (same priors and derived tp as model_cases (1)) on 50 RA/Dec epochs t_j = 50000 + 17·j,
@@ -440,7 +474,7 @@ def ti_cases():
 
 if __name__ == "__main__":
     sys.path.insert(0, str(ROOT / "oracle"))
-    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only") if f in sys.argv]
+    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only", "--kep-only") if f in sys.argv]
     if not only:
         main()
     if not only or "--ofti-only" in only:
@@ -453,3 +487,5 @@ if __name__ == "__main__":
         ti_cases()
     if not only or "--config1-only" in only:
         config1_case()
+    if not only or "--kep-only" in only:
+        kep_cases()

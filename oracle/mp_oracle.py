@@ -27,7 +27,7 @@ import mpmath as mp
 mp.mp.dps = 60
 
 KINDS = {"ASTROM_RADEC": 0, "ASTROM_SEPPA": 1, "RV_ABS": 2, "RV_ABS_MARG": 3, "RV_REL": 4, "ONEIL_RADEC": 5, "ONEIL_SEPPA": 6, "HGCA": 7}
-ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES = 0, 1, 2
+ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES, ORBIT_KEP = 0, 1, 2, 3
 EL = ["a", "e", "i", "w", "O", "tp", "M", "plx", "mass"]
 N_EL, N_NUIS = 9, 3
 
@@ -77,7 +77,10 @@ def _orbit(c, kind, el):
     P_d = mp.mpf(c["kepler_year_to_julian_day"]) * mp.sqrt(a ** 3 / M)
     P_yr = P_d / mp.mpf(c["year2day_julian"])
     o = dict(a=a, e=e, w=w, tp=tp, M=M, P_d=P_d)
-    if kind == ORBIT_VISUAL_KEP:
+    if kind == ORBIT_KEP:       # plain KepOrbit: inclined (K carries sin i) but at no distance: RV tables only
+        o.update(i=inc, O=O, mas_per_au=mp.mpf(0),
+                 K=2 * mp.pi * a * mp.sin(inc) / (P_yr * mp.sqrt(1 - e * e)) * mp.mpf(c["au2m"]) * mp.mpf(c["sec2year_julian"]))
+    elif kind == ORBIT_VISUAL_KEP:
         o.update(i=inc, O=O, mas_per_au=plx * mp.mpf(c["rad2as"]) / mp.mpf(c["pc2au"]),
                  K=2 * mp.pi * a * mp.sin(inc) / (P_yr * mp.sqrt(1 - e * e)) * mp.mpf(c["au2m"]) * mp.mpf(c["sec2year_julian"]))
     else:
@@ -248,6 +251,8 @@ def ln_like_and_grad(c, planets, obs, elems, nuis, h_rel=mp.mpf(10) ** -25, with
     for p in range(len(elems)):
         for k in range(N_EL):
             if planets[p]["orbit_kind"] == ORBIT_RADVEL and k in (2, 4, 7):
+                continue
+            if planets[p]["orbit_kind"] == ORBIT_KEP and k in (4, 7):      # Ω does not enter a radial velocity; no parallax
                 continue
             if k == 8 and not planets[p]["has_mass"]:
                 continue

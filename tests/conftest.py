@@ -50,6 +50,8 @@ def golden():
         g["cases"] = g["cases"] + json.load(f)["cases"]
     with open(ROOT / "tests" / "golden" / "ti.json") as f:        # F10: ThieleInnesOrbit basis (oracle/make_golden.py --ti-only)
         g["cases"] = g["cases"] + json.load(f)["cases"]
+    with open(ROOT / "tests" / "golden" / "kep.json") as f:       # F11: plain KepOrbit basis, RV tables (oracle/make_golden.py --kep-only)
+        g["cases"] = g["cases"] + json.load(f)["cases"]
     return g
 
 

@@ -135,6 +135,57 @@ def test_radvel_orbit_and_empty_table(oracle):
     assert np.all(g_el[[2, 4, 7]] == 0.0)   # rows a RadialVelocityOrbit ignores carry no gradient (NaN inputs tolerated)
 
 
+def test_plain_kep_orbit(pkg, oracle):
+    """OCTO_ORBIT_KEP — the plain `KepOrbit` basis (src/likelihoods/system.jl:116-118 builds whatever basis the planet declares):
+    K carries sin i, the KepOrbit invariants i mod π / Ω mod 2π apply, Ω and plx do not enter and carry no gradient, astrometry
+    cannot be attached. Both kernel families (W = 70 and W = 9), inclinations outside [0, π) included."""
+    gb = _gpu()
+    rng = np.random.default_rng(13)
+    ep = np.linspace(50000.0, 50700.0, 40)
+    for W in (70, 9):
+        obs = [dict(kind=4, planet=0, epoch=ep, y1=rng.normal(0, 900, 40), y2=None, s1=np.full(40, 50.0), s2=None, cor=None),
+               dict(kind=2, planet=-1, epoch=ep + 2.0, y1=rng.normal(0, 30, 40), y2=None, s1=np.full(40, 2.0), s2=None, cor=None)]
+        planets = [dict(orbit_kind=3, has_mass=True)]
+        elems = np.stack([rng.uniform(0.5, 3, W), rng.uniform(0, 0.8, W), rng.uniform(-5.0, 8.0, W), rng.uniform(-7, 7, W), rng.uniform(-7, 7, W),
+                          50000 + rng.uniform(-100, 100, W), rng.normal(1, 0.05, W), np.full(W, np.nan), rng.uniform(0.5, 10, W)])
+        nuis = np.stack([rng.normal(0, 5, W), rng.uniform(0.1, 3, W), np.zeros(W), rng.normal(0, 5, W), rng.uniform(0.1, 3, W), np.zeros(W)])
+        for nz in (nuis, None):
+            ll, g_el, g_nu = gb.gpu_eval(obs, planets, elems, nz, grad=True)
+            ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, elems, nz, grad=True)
+            assert np.all(np.isfinite(ll_o))
+            _cmp_oracle("kep", ll, g_el, g_nu, ll_o, g_o, gn_o)
+            assert np.all(g_el[[4, 7]] == 0.0) and np.any(g_el[2] != 0.0)
+    # the mirror: basis="KepOrbit" takes RV tables, refuses astrometry (needs a distance)
+    rvo = pkg.PlanetRelativeRVObs(dict(epoch=ep, rv=rng.normal(0, 900, 40), σ_rv=np.full(40, 50.0)), name="relrv")
+    b = pkg.Planet(name="b", basis="KepOrbit", observations=[rvo])
+    fn = pkg.make_ln_like(pkg.System(name="k", companions=[b]), dict(M=1.0, planets=dict(b=dict(a=1, e=0.1, i=1.0, ω=0.3, Ω=0.2, tp=5e4, mass=3.0))))
+    θ = dict(M=1.05, planets=dict(b=dict(a=np.array([1.0, 1.3]), e=0.2, i=np.array([1.0, 1.0 + np.pi]), ω=0.4, Ω=1.0, tp=50010.0, mass=4.0)))
+    ll2 = fn(θ)
+    assert np.isfinite(ll2).all() and ll2[0] != ll2[1]
+    fn.close()
+    ast = pkg.PlanetRelAstromObs(dict(epoch=ep[:5], ra=np.ones(5), dec=np.ones(5), σ_ra=np.ones(5), σ_dec=np.ones(5)), name="ast")
+    with pytest.raises(pkg.capi.OctoError):
+        pkg.make_ln_like(pkg.System(name="k2", companions=[pkg.Planet(name="b", basis="KepOrbit", observations=[ast])]),
+                         dict(M=1.0, planets=dict(b=dict(a=1, e=0.1, i=1.0, ω=0.3, Ω=0.2, tp=5e4))))
+
+
+def test_dataset_validation(pkg):
+    """octo_dataset_create refuses what would otherwise silently turn every walker into -Inf: σ <= 0, non-finite
+    σ / epoch / measurement; octo_ofti_create likewise."""
+    gb = _gpu()
+    ep = np.linspace(50000.0, 50100.0, 5)
+    ok = dict(kind=0, planet=0, epoch=ep, y1=np.ones(5), y2=np.ones(5), s1=np.ones(5), s2=np.ones(5), cor=None)
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    gb.GpuPath([ok], planets).close()
+    for col, val in (("s1", 0.0), ("s2", -1.0), ("s1", np.inf), ("epoch", np.nan), ("y2", np.inf)):
+        bad = dict(ok); bad[col] = ok[col].copy(); bad[col][3] = val
+        with pytest.raises(pkg.capi.OctoError) as ei:
+            gb.GpuPath([bad], planets)
+        assert ei.value.status == pkg.capi.OCTO_EINVAL and "row 3" in str(ei.value)
+    with pytest.raises(pkg.capi.OctoError):
+        pkg.OftiLinearSolver(ep, np.ones(5), np.ones(5), np.array([1, 1, 0.0, 1, 1]), np.ones(5), None, 100.0)
+
+
 def test_invalid_walkers(oracle):
     gb = _gpu()
     cfg = synth.config_astrom(n_epochs=40, n_walkers=130, seed=11)

@@ -97,6 +97,34 @@ def test_gpu_model_vs_golden_and_oracle(pkg, oracle, model_golden):
 
 
 @pytest.mark.gpu
+def test_gpu_model_healed_prior_keeps_the_likelihood_gradient(pkg, oracle, model_golden):
+    """A prior that evaluates non-finite is "healed" to -floatmax (variables.jl:1229-1236): a CONSTANT, so the reference's ForwardDiff
+    gradient is then the gradient of the likelihood alone — UnitLengthPrior terms included (variables.jl:309-323), not zero
+    (ADVICE r1). Both the fused small-batch launch (W = 3) and the throughput kernels (forced, and W = 70)."""
+    case = model_golden[0]
+    obs, planets = _tables(case)
+    base = np.asarray(case["theta_t"])
+    for W, force_big in ((3, False), (3, True), (70, False)):
+        th = np.tile(base, (1, W // base.shape[1] + 1))[:, :W].copy()
+        th[3, 1] = 800.0                 # logistic saturates: e == upper bound -> log-Jacobian -Inf -> healed
+        th[3, 0] = np.nan                # non-finite θ_t -> -Inf, zero gradient
+        model = pkg.LogDensityModel(_reference_test_model(pkg))
+        if force_big:
+            model.ln_like._check(model.ln_like.lib.octo_ctx_set_small_batch(model.ln_like._ctx, 0), "set")
+        lp, g = model.logdensity_and_gradient(th)
+        lp_o, g_o = oracle.oracle_model_logpost(obs, planets, model._c_priors, model._c_esrc, None, th)
+        model.close()
+        assert np.isneginf(lp[0]) and np.all(g[:, 0] == 0.0)
+        assert lp[1] < -1e300 and lp_o[1] < -1e300
+        # e = upper bound exactly: the likelihood is -Inf there (e < 1 holds, 0.99, so it is finite): gradient = ∇ likelihood terms
+        assert np.all(np.isfinite(g[:, 1])) and np.any(g[:, 1] != 0.0), (W, force_big, g[:, 1])
+        sc = np.maximum(np.abs(g_o[:, 1]).max(), 1e-300)
+        assert np.all(np.abs(g[:, 1] - g_o[:, 1]) <= 1e-9 * sc), (W, force_big, np.max(np.abs(g[:, 1] - g_o[:, 1]) / sc))
+        ok = np.arange(W) >= 2
+        assert np.all(np.abs(lp[ok] - lp_o[ok]) <= 1e-12 * np.abs(lp_o[ok]))
+
+
+@pytest.mark.gpu
 def test_gpu_model_two_planet_rv(pkg, oracle, model_golden):
     case = model_golden[1]
     o_a, o_r = case["obs"]

@@ -20,4 +20,4 @@ from .host.ofti import OftiLinearSolver, ofti_linear_solve  # noqa: F401,E402
 from .host.priors import (Uniform, LogUniform, Normal, TruncatedNormal, truncated, Sine, UniformCircular,  # noqa: F401,E402
                           θ_at_epoch_to_tperi, variables)
 from .host.model import LogDensityModel  # noqa: F401,E402
-from .host.callers import guess_starting_position, octofit_rejection, rejection_evaluate_likelihoods  # noqa: F401,E402
+from .host.callers import guess_starting_position, octofit_rejection, rejection_evaluate_likelihoods, pointwise_like  # noqa: F401,E402

@@ -14,14 +14,18 @@ from __future__ import annotations
 import numpy as np
 
 
-def guess_starting_position(rng, model, N=500_000, batch=250_000):
-    """Sample IID from the prior N times and return the highest-posterior sample: (bestparams, bestlogpost)."""
-    bestparams = model.sample_priors(rng)
+def guess_starting_position(rng, model, N=500_000, batch=250_000, prior_samples=None):
+    """Sample IID from the prior N times and return the highest-posterior sample: (bestparams, bestlogpost).
+    prior_samples ([D, N], natural domain): use these draws instead of drawing (parity tests feed the same draws to the oracle)."""
+    if prior_samples is not None:
+        prior_samples = np.asarray(prior_samples, dtype=np.float64)
+        N = prior_samples.shape[1]
+    bestparams = model.sample_priors(rng) if prior_samples is None else prior_samples[:, 0].copy()
     bestlogpost = -np.inf
     done = 0
     while done < N:
         n = min(batch, N - done)
-        params = model.sample_priors(rng, n)
+        params = model.sample_priors(rng, n) if prior_samples is None else prior_samples[:, done:done + n]
         logpost = model.ℓπcallback(model.link(params))
         k = int(np.argmax(logpost))
         if logpost[k] > bestlogpost:                      # initialization.jl:41-44
@@ -48,15 +52,20 @@ def _unit_length_terms(model, θ):
     return tot
 
 
-def octofit_rejection(rng, model, draws=100_000, verbosity=0):
+def octofit_rejection(rng, model, draws=100_000, verbosity=0, prior_samples=None, uniforms=None):
     """Rejection sampling with the prior as proposal. Returns dict(samples [D, n_accepted] (natural domain), loglike,
-    logpost, draws, n_accepted, acceptance_rate) — the chain the reference packs into MCMCChains."""
-    prior_samples = model.sample_priors(rng, draws)                           # sampling.jl:178
+    logpost, draws, n_accepted, acceptance_rate, accept) — the chain the reference packs into MCMCChains.
+    prior_samples / uniforms: use these draws (parity tests feed the same ones to the oracle)."""
+    if prior_samples is None:
+        prior_samples = model.sample_priors(rng, draws)                       # sampling.jl:178
+    else:
+        prior_samples = np.asarray(prior_samples, dtype=np.float64)
+        draws = prior_samples.shape[1]
     log_likes = rejection_evaluate_likelihoods(model, prior_samples)          # :189-191
     max_ll = np.max(log_likes)                                                # :194
     if not np.isfinite(max_ll):
         raise RuntimeError(f"All {draws} prior samples produced non-finite log-likelihoods. Check your model and priors.")
-    u = rng.uniform(0.0, 1.0, draws)
+    u = rng.uniform(0.0, 1.0, draws) if uniforms is None else np.asarray(uniforms, dtype=np.float64)
     with np.errstate(over="ignore"):
         accept = (log_likes != -np.inf) & (u < np.exp(log_likes - max_ll))    # :202-210
     idx = np.nonzero(accept)[0]
@@ -66,4 +75,31 @@ def octofit_rejection(rng, model, draws=100_000, verbosity=0):
     samples = prior_samples[:, idx]
     logpost = model.ℓπcallback(model.link(samples))                           # _rejection_build_chain, :270-
     return dict(samples=samples, loglike=log_likes[idx], logpost=logpost, draws=draws, n_accepted=int(idx.size),
-                acceptance_rate=idx.size / draws, names=list(model.names))
+                acceptance_rate=idx.size / draws, names=list(model.names), accept=accept, all_loglike=log_likes)
+
+
+def pointwise_like(model, θ_samples):
+    """`Octofitter.pointwise_like` (src/cross-validation.jl:17-46) on the batch path: the log-likelihood of every posterior sample under
+    EACH observation table separately — LL_out[n_samples, n_observations], one device call per observation over all samples (the
+    reference builds one single-observation system per table and loops over samples on the CPU). θ_samples: [D, n] natural domain.
+    Returns (LL_out, names)."""
+    from .system import BatchedLnLike, Planet, System
+    θ_samples = np.asarray(θ_samples, dtype=np.float64).reshape(model.D, -1)
+    elems, nuis = model.kernel_inputs(θ_samples)
+    fn = model.ln_like
+    n = θ_samples.shape[1]
+    out = np.zeros((n, len(fn.obs_entries)))
+    names = []
+    θex = dict(planets={pl.name: {k: 0.0 for k in (pl.variables or {})} for pl in model.system.planets})
+    for io, (obs, ip, plname, key) in enumerate(fn.obs_entries):
+        planets = [Planet(name=pl.name, basis=pl.basis, observations=[obs] if (ip >= 0 and pl.name == plname) else [], variables=pl.variables)
+                   for pl in model.system.planets]
+        sub = System(name=f"{model.system.name}_{key}", companions=planets, observations=[obs] if ip < 0 else [], variables=model.system.variables)
+        one = BatchedLnLike(sub, θex, device=fn.device_index, consts=None)
+        try:
+            nu = None if nuis is None else np.ascontiguousarray(nuis[io * 3:(io + 1) * 3])
+            out[:, io] = one.ln_like_arrays(elems, nu)
+        finally:
+            one.close()
+        names.append(key)
+    return out, names

@@ -176,6 +176,11 @@ class LogDensityModel:
 
     logdensity = ℓπcallback                     # LogDensityProblems.logdensity, src/logdensitymodel.jl:252
 
+    def __call__(self, θ_t):
+        """`(model::LogDensityModel)(θ)` — what Pigeons' explorers call (ext/OctofitterPigeonsExt/OctofitterPigeonsExt.jl:10-12); a [D, W]
+        array evaluates all W replicas in one device call."""
+        return self._call(θ_t, False)
+
     def logdensity_and_gradient(self, θ_t):     # :253
         return self._call(θ_t, True)
 

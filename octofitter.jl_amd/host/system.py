@@ -76,6 +76,7 @@ class BatchedLnLike:
 
     def __init__(self, system: System, θ_example: dict, device: int = 0, consts: capi.OctoConsts | None = None):
         self.system = system
+        self.device_index = int(device)
         self.lib = capi.load_library()
         # ---- epoch gather in the reference's standardised order (system.jl:35-54) ----------------
         self.all_epochs = []

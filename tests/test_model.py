@@ -46,6 +46,27 @@ def test_oracle_model_vs_golden(oracle, model_golden):
         assert np.array_equal(lp0, lp)
 
 
+def test_reference_model_dump_if_present(oracle, model_golden):
+    """tools/julia_crosscheck.jl evaluates model.ℓπcallback / ∇ℓπcallback of the REAL reference for the committed θ_t of the D = 11
+    test model and of config 1; when its output exists, the restatement of priors, bijectors, UniformCircular, θ_at_epoch_to_tperi and
+    the likelihood is held to it."""
+    import json
+    dump_path = ROOT / "tests" / "golden" / "reference_dump.json"
+    if not dump_path.exists():
+        pytest.skip("tests/golden/reference_dump.json not generated (no Julia in the build image)")
+    dump = json.loads(dump_path.read_text())
+    cases = [("model.json/D11_reference_test_model", model_golden[0]),
+             ("config1.json/config1_D11_50_epochs", json.loads((ROOT / "tests" / "golden" / "config1.json").read_text())["cases"][0])]
+    for key, case in cases:
+        r = dump[key]
+        obs, planets = _tables(case)
+        th = np.asarray(case["theta_t"])
+        lp, g = oracle.oracle_model_logpost(obs, planets, oracle.make_priors(case["priors"]), oracle.make_sources(case["esrc"]), None, th)
+        assert np.all(np.abs(lp - np.asarray(r["lp"])) <= 1e-10 * np.abs(lp)), key
+        gref = np.asarray(r["grad"]).T
+        assert np.all(np.abs(g - gref) <= 1e-8 * np.abs(gref).max(axis=0, keepdims=True)), key
+
+
 def test_oracle_model_edges(oracle, model_golden):
     case = model_golden[0]
     obs, planets = _tables(case)
@@ -209,6 +230,62 @@ def test_gpu_batched_callers(pkg):
     assert 6.0 < np.median(a) < 15.0                                         # truth a = 10 (prior 5-20)
     ll = pkg.rejection_evaluate_likelihoods(model, chain["samples"])
     assert np.allclose(ll, chain["loglike"], rtol=0, atol=0)
+    model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batched_callers_vs_oracle(pkg, oracle):
+    """SURVEY §8 f2 with a real parity check (the callers were only compared with themselves): IDENTICAL prior draws and
+    uniforms go to the device callers and to the CPU restatement of the callback; the starting point (argmax), every log-posterior,
+    the accept mask of the rejection sampler and the accepted chain must coincide. Also the Pigeons-style `model(Θ)` and
+    `pointwise_like` (src/cross-validation.jl:17-46)."""
+    import synth
+    rng = np.random.default_rng(17)
+    t = 50000.0 + 90.0 * np.arange(10)
+    ra, dec = synth.truth_radec(t)
+    table = dict(epoch=t, ra=ra + rng.normal(0, 60.0, 10), dec=dec + rng.normal(0, 60.0, 10), σ_ra=np.full(10, 60.0), σ_dec=np.full(10, 60.0))
+    rvt = dict(epoch=t + 7.0, rv=rng.normal(0, 30, 10), σ_rv=np.full(10, 8.0))
+    astrom = pkg.PlanetRelAstromObs(table, name="sim", variables=pkg.variables(jitter=pkg.LogUniform(0.1, 30.0)))
+    rv = pkg.StarAbsoluteRVObs(rvt, name="rv", variables=pkg.variables(offset=pkg.Normal(0, 20), jitter=pkg.LogUniform(0.1, 20.0)))
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[astrom],
+                   variables=pkg.variables(a=pkg.LogUniform(5, 20), e=pkg.Uniform(0.0, 0.6), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                           Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000),
+                                           mass=pkg.LogUniform(1.0, 50.0)))
+    sys_ = pkg.System(name="sim", companions=[b], observations=[rv],
+                      variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.05), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.1), lower=0.1)))
+    model = pkg.LogDensityModel(sys_)
+    N = 30_000
+    draws = model.sample_priors(rng, N)
+    fn = model.ln_like
+    # ---- guess_starting_position on the given draws vs the oracle's ℓπcallback on the same draws
+    best, best_lp = pkg.guess_starting_position(rng, model, prior_samples=draws, batch=7_000)
+    lp_o, _ = oracle.oracle_model_logpost(fn.obs_tables, fn.planet_desc, model._c_priors, model._c_esrc, model._c_nsrc, model.link(draws), grad=False, n_threads=0)
+    k = int(np.argmax(lp_o))
+    assert np.array_equal(best, draws[:, k]) and abs(best_lp - lp_o[k]) <= 1e-11 * abs(lp_o[k])
+    lp_d = model(model.link(draws))                                         # Pigeons-style call on the whole batch
+    assert np.all(np.abs(lp_d - lp_o) <= 1e-11 * np.abs(lp_o))
+    # ---- octofit_rejection with the same draws and uniforms vs the oracle's likelihood
+    u = rng.uniform(0, 1, N)
+    chain = pkg.octofit_rejection(rng, model, prior_samples=draws, uniforms=u)
+    elems, nuis = model.kernel_inputs(draws)
+    ll_o, _, _ = oracle.oracle_eval(fn.obs_tables, fn.planet_desc, elems, nuis, grad=False, n_threads=0)
+    from octofitter_jl_amd.host.callers import _unit_length_terms
+    ll_o = ll_o + _unit_length_terms(model, draws)
+    ll_o = np.where(np.isfinite(ll_o), ll_o, -np.inf)
+    acc_o = (ll_o != -np.inf) & (u < np.exp(ll_o - ll_o.max()))
+    assert np.all(np.abs(chain["all_loglike"] - ll_o) <= 1e-11 * np.maximum(1, np.abs(ll_o)))
+    assert np.array_equal(chain["accept"], acc_o) and chain["n_accepted"] == int(acc_o.sum()) >= 1
+    assert np.array_equal(chain["samples"], draws[:, acc_o])
+    # ---- pointwise_like: per-observation columns sum to the total likelihood (without the epoch-free UnitLengthPrior terms)
+    sub = draws[:, :500]
+    LL, names = pkg.pointwise_like(model, sub)
+    assert LL.shape == (500, 2) and names == ["sim", "rv"]
+    el_s, nu_s = model.kernel_inputs(sub)
+    tot = fn.ln_like_arrays(el_s, nu_s)
+    assert np.all(np.abs(LL.sum(axis=1) - tot) <= 1e-11 * np.maximum(1, np.abs(tot)))
+    for io in range(2):
+        one_o, _, _ = oracle.oracle_eval([fn.obs_tables[io]], fn.planet_desc, el_s, nu_s[io * 3:(io + 1) * 3], grad=False, n_threads=0)
+        assert np.all(np.abs(LL[:, io] - one_o) <= 1e-11 * np.maximum(1, np.abs(one_o))), names[io]
     model.close()
 
 

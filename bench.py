@@ -88,6 +88,9 @@ def self_launch(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if os.environ.get("OCTO_BENCH_PRINT_LAUNCH"):      # tests: show the command instead of running it
+        print(json.dumps(cmd))
+        raise SystemExit(0)
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 

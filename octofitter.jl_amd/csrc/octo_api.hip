@@ -734,6 +734,9 @@ struct octo_model {
     octo_source* d_nsrc = nullptr;
     int32_t* d_circ = nullptr;   // [n_el + n_nu] LDS slot of each UniformCircular pair in k_model_fwd, or -1
     int n_circ = 0;
+    int32_t* d_circ_pair = nullptr;   // [n_circ][2] (i0, i1) of each slot (k_small<MODEL>: one pair per lane)
+    bool all_circ_slotted = true;     // every CIRCULAR / TPERI source has a slot (<= MODEL_MAXCIRC of them): required by the fused launch
+    double* d_logz = nullptr;         // [D] −log(Φ(hi) − Φ(lo)) of each truncated-Normal prior, NaN elsewhere
     double* d_buf = nullptr;   // elems | nuis | J | lpp | glp | ll | g_el | g_nu, all [rows][ldw]
     int64_t cap_w = 0;
     double *d_th = nullptr, *d_res = nullptr;   // staging for host buffers
@@ -788,12 +791,32 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
         if (hipMemcpy(m->d_nsrc, nuis_src, sizeof(octo_source) * n_nu, hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
     }
     {
-        std::vector<int32_t> slot(n_el + n_nu, -1);
+        std::vector<int32_t> slot(n_el + n_nu, -1), pairs;
         for (int k = 0; k < n_el + n_nu; ++k) {
             if (k >= n_el && !nuis_src) break;
             const octo_source& sc = k < n_el ? elem_src[k] : nuis_src[k - n_el];
-            if ((sc.kind == OCTO_SRC_CIRCULAR || sc.kind == OCTO_SRC_TPERI) && m->n_circ < MODEL_MAXCIRC) slot[k] = m->n_circ++;
+            if (sc.kind == OCTO_SRC_CIRCULAR || sc.kind == OCTO_SRC_TPERI) {
+                if (m->n_circ < MODEL_MAXCIRC) {
+                    slot[k] = m->n_circ++;
+                    pairs.push_back(sc.i0); pairs.push_back(sc.i1);
+                } else {
+                    m->all_circ_slotted = false;
+                }
+            }
         }
+        pairs.resize(std::max<size_t>(pairs.size(), 2), 0);
+        if (hipMalloc((void**)&m->d_circ_pair, sizeof(int32_t) * pairs.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
+        if (hipMemcpy(m->d_circ_pair, pairs.data(), sizeof(int32_t) * pairs.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
+        // −log(Φ(hi) − Φ(lo)): the truncated Normal's normalisation, a constant of the model (Distributions.jl: truncated)
+        std::vector<double> logz(D, std::nan(""));
+        for (int k = 0; k < D; ++k)
+            if (priors[k].kind == OCTO_PRIOR_TRUNCNORMAL) {
+                const double lo = std::isfinite(priors[k].lo) ? 0.5 * std::erfc(-((priors[k].lo - priors[k].p0) / priors[k].p1) * 0.70710678118654752440) : 0.0;
+                const double hi = std::isfinite(priors[k].hi) ? 0.5 * std::erfc(-((priors[k].hi - priors[k].p0) / priors[k].p1) * 0.70710678118654752440) : 1.0;
+                logz[k] = -std::log(hi - lo);
+            }
+        if (hipMalloc((void**)&m->d_logz, sizeof(double) * D) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
+        if (hipMemcpy(m->d_logz, logz.data(), sizeof(double) * D, hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
         if (hipMalloc((void**)&m->d_circ, sizeof(int32_t) * slot.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
         if (hipMemcpy(m->d_circ, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
     }
@@ -813,7 +836,7 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
 int32_t octo_model_destroy(octo_model* m) {
     if (!m) return OCTO_OK;
     (void)hipSetDevice(m->device);
-    (void)hipFree(m->d_priors); (void)hipFree(m->d_esrc); (void)hipFree(m->d_nsrc); (void)hipFree(m->d_circ); (void)hipFree(m->d_buf);
+    (void)hipFree(m->d_priors); (void)hipFree(m->d_esrc); (void)hipFree(m->d_nsrc); (void)hipFree(m->d_circ); (void)hipFree(m->d_circ_pair); (void)hipFree(m->d_logz); (void)hipFree(m->d_buf);
     (void)hipFree(m->d_th); (void)hipFree(m->d_res);
     delete m;
     return OCTO_OK;
@@ -828,11 +851,12 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st;
     { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
-    if (small_eligible(ctx, m->ds, W)) {
+    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted) {
         // one launch: θ_t -> priors, elements, likelihood, ∇θ_t inside k_small<MODEL> (octo_small.h)
         SmallModel sm;
         std::memset(&sm, 0, sizeof(sm));
         sm.priors = m->d_priors; sm.esrc = m->d_esrc; sm.nsrc = m->d_nsrc; sm.D = m->D;
+        sm.circ_slot = m->d_circ; sm.circ_pair = m->d_circ_pair; sm.n_circ = m->n_circ; sm.prior_logz = m->d_logz; sm.n_el = m->n_el;
         sm.theta_t = d_theta_t; sm.lp_out = d_lp; sm.grad_out = d_grad;
         if (ctx->stage_ws_in > 0) { sm.ld_t = 1; sm.ws_t = ctx->stage_ws_in; sm.ld_o = 1; sm.ws_o = ctx->stage_ws_out; }      // walker-major staging
         else { sm.ld_t = ld; sm.ws_t = 1; sm.ld_o = ld; sm.ws_o = 1; }
@@ -898,7 +922,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
         double *m_in = nullptr, *m_out = nullptr;
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
-        if (small_eligible(ctx, m->ds, W)) {
+        if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted) {
             // the fused launch: θ_t of one walker contiguous on the way in, [lp | ∇θ_t] on the way out, completion by flag
             const int64_t D = m->D, ws_o = grad_out ? D + 1 : 1;
             for (int64_t w = 0; w < W; ++w)

@@ -110,6 +110,10 @@ struct SetupOut {
 
 // sin/cos for the latency path: reduce to [−π, π] with a two-term 2π (exact for the |x| a sampler produces; beyond 1e5 the
 // library routine), then the half-angle polynomials — ~35 instructions instead of ocml's ~180 per angle.
+// (the library routine behind a call: inlined, its Payne-Hanek reduction would put ~400 instructions at each of the dozen call sites
+// of the latency kernels, whose cold code has to be fetched on every one-block launch)
+__device__ __attribute__((noinline)) static double2 sincos_library(double x) { double s, c; sincos(x, &s, &c); return make_double2(s, c); }
+
 __device__ __forceinline__ void sincos_reduced(double x, double& s, double& c) {
     if (fabs(x) < 1.0e5) {
         const double k = rint(x * (1.0 / TWO_PI));
@@ -117,7 +121,8 @@ __device__ __forceinline__ void sincos_reduced(double x, double& s, double& c) {
         r = fma(-k, 0x1.1a62633145c07p-52, r);            // 2π lo
         sincos_halfangle(r, s, c);
     } else {
-        sincos(x, &s, &c);
+        const double2 sc = sincos_library(x);
+        s = sc.x; c = sc.y;
     }
 }
 

@@ -9,35 +9,45 @@
 
 namespace octo {
 
-template <int N>
+// FAST (k_small<MODEL>, the one-θ-per-call latency path): reciprocal-multiply divisions, rsqrt-based roots, polynomial
+// sincos / atan2 (octo_device.h, octo_kernels.h) instead of the IEEE / ocml routines — the chain θ_t -> elements is a few thousand
+// SERIAL instructions for one wave, and at ~10 cycles per dependent FP64 instruction that is most of the call's latency.
+template <int N, bool FAST = false>
 struct Dual {
     double v;
     double d[N];
 };
 
 #define DFOR _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_)
-template <int N> __device__ __forceinline__ Dual<N> dconst(double x) { Dual<N> r; r.v = x; DFOR r.d[k_] = 0.0; return r; }
-template <int N> __device__ __forceinline__ Dual<N> dvar(double x, int slot) { Dual<N> r = dconst<N>(x); DFOR r.d[k_] = (k_ == slot) ? 1.0 : 0.0; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v; DFOR r.d[k_] = a.d[k_] + b.d[k_]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v; DFOR r.d[k_] = a.d[k_] - b.d[k_]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a) { Dual<N> r; r.v = -a.v; DFOR r.d[k_] = -a.d[k_]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v; DFOR r.d[k_] = a.d[k_] * b.v + a.v * b.d[k_]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
-    Dual<N> r; r.v = a.v / b.v; const double ib = 1.0 / b.v; DFOR r.d[k_] = (a.d[k_] - r.v * b.d[k_]) * ib; return r;
+#define DT template <int N, bool FAST> __device__ __forceinline__
+#define DU Dual<N, FAST>
+template <bool FAST> __device__ __forceinline__ double m_div(double x, double y) { return FAST ? x * rcp_nr<2>(y) : x / y; }
+template <bool FAST> __device__ __forceinline__ double m_sqrt(double x) { return FAST ? sqrt_fast(x) : sqrt(x); }
+template <bool FAST> __device__ __forceinline__ void m_sincos(double x, double& s, double& c) { if constexpr (FAST) sincos_reduced(x, s, c); else sincos(x, &s, &c); }
+template <bool FAST> __device__ __forceinline__ double m_atan2(double y, double x) { return FAST ? atan2_fast(y, x) : atan2(y, x); }
+
+template <int N, bool FAST = false> __device__ __forceinline__ Dual<N, FAST> dconst(double x) { Dual<N, FAST> r; r.v = x; DFOR r.d[k_] = 0.0; return r; }
+template <int N, bool FAST = false> __device__ __forceinline__ Dual<N, FAST> dvar(double x, int slot) { Dual<N, FAST> r = dconst<N, FAST>(x); DFOR r.d[k_] = (k_ == slot) ? 1.0 : 0.0; return r; }
+DT DU operator+(const DU& a, const DU& b) { DU r; r.v = a.v + b.v; DFOR r.d[k_] = a.d[k_] + b.d[k_]; return r; }
+DT DU operator-(const DU& a, const DU& b) { DU r; r.v = a.v - b.v; DFOR r.d[k_] = a.d[k_] - b.d[k_]; return r; }
+DT DU operator-(const DU& a) { DU r; r.v = -a.v; DFOR r.d[k_] = -a.d[k_]; return r; }
+DT DU operator*(const DU& a, const DU& b) { DU r; r.v = a.v * b.v; DFOR r.d[k_] = a.d[k_] * b.v + a.v * b.d[k_]; return r; }
+DT DU operator/(const DU& a, const DU& b) {
+    DU r; const double ib = m_div<FAST>(1.0, b.v); r.v = FAST ? a.v * ib : a.v / b.v; DFOR r.d[k_] = (a.d[k_] - r.v * b.d[k_]) * ib; return r;
 }
-template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, double s) { Dual<N> r; r.v = a.v * s; DFOR r.d[k_] = a.d[k_] * s; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, double s) { Dual<N> r = a; r.v = a.v + s; return r; }
-template <int N> __device__ __forceinline__ Dual<N> chain(const Dual<N>& a, double fv, double df) { Dual<N> r; r.v = fv; DFOR r.d[k_] = a.d[k_] * df; return r; }
-template <int N> __device__ __forceinline__ Dual<N> dsqrt(const Dual<N>& a) { const double s = sqrt(a.v); return chain(a, s, 0.5 / s); }
-template <int N> __device__ __forceinline__ Dual<N> dlog(const Dual<N>& a) { return chain(a, log(a.v), 1.0 / a.v); }
-template <int N> __device__ __forceinline__ Dual<N> dsin(const Dual<N>& a) { return chain(a, sin(a.v), cos(a.v)); }
-template <int N> __device__ __forceinline__ Dual<N> dcos(const Dual<N>& a) { return chain(a, cos(a.v), -sin(a.v)); }
-template <int N> __device__ __forceinline__ void dsincos(const Dual<N>& a, Dual<N>& s, Dual<N>& c) {
-    double sv, cv; sincos(a.v, &sv, &cv);
+DT DU operator*(const DU& a, double s) { DU r; r.v = a.v * s; DFOR r.d[k_] = a.d[k_] * s; return r; }
+DT DU operator+(const DU& a, double s) { DU r = a; r.v = a.v + s; return r; }
+DT DU chain(const DU& a, double fv, double df) { DU r; r.v = fv; DFOR r.d[k_] = a.d[k_] * df; return r; }
+DT DU dsqrt(const DU& a) { const double s = m_sqrt<FAST>(a.v); return chain(a, s, m_div<FAST>(0.5, s)); }
+DT DU dlog(const DU& a) { return chain(a, log(a.v), m_div<FAST>(1.0, a.v)); }
+DT DU dsin(const DU& a) { double s, c; m_sincos<FAST>(a.v, s, c); return chain(a, s, c); }
+DT DU dcos(const DU& a) { double s, c; m_sincos<FAST>(a.v, s, c); return chain(a, c, -s); }
+DT void dsincos(const DU& a, DU& s, DU& c) {
+    double sv, cv; m_sincos<FAST>(a.v, sv, cv);
     s = chain(a, sv, cv); c = chain(a, cv, -sv);
 }
-template <int N> __device__ __forceinline__ Dual<N> datan2(const Dual<N>& y, const Dual<N>& x) {
-    Dual<N> r; r.v = atan2(y.v, x.v); const double ih = 1.0 / (x.v * x.v + y.v * y.v);
+DT DU datan2(const DU& y, const DU& x) {
+    DU r; r.v = m_atan2<FAST>(y.v, x.v); const double ih = m_div<FAST>(1.0, x.v * x.v + y.v * y.v);
     DFOR r.d[k_] = (x.v * y.d[k_] - y.v * x.d[k_]) * ih; return r;
 }
 
@@ -64,17 +74,16 @@ struct ModelArgs {
 };
 
 // Bijectors.invlink + logpdf_with_trans (TruncatedBijector; Distributions densities) — mirrors oracle/octo_oracle_core.inc
-template <int N>
-__device__ __forceinline__ void prior_apply(const octo_prior& pr, const Dual<N>& y, Dual<N>& x, Dual<N>& lp) {
+DT void prior_apply(const octo_prior& pr, const DU& y, DU& x, DU& lp, double trunc_logz = NAN /* −log(Φ(hi) − Φ(lo)) when precomputed */) {
     double a = -INFINITY, b = INFINITY;
     if (pr.kind == OCTO_PRIOR_UNIFORM || pr.kind == OCTO_PRIOR_LOGUNIFORM) { a = pr.p0; b = pr.p1; }
     else if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) { a = pr.lo; b = pr.hi; }
     else if (pr.kind == OCTO_PRIOR_SINE) { a = 0.0 + 2.220446049250313e-16; b = PI - 2.220446049250313e-16; }
-    Dual<N> ladj;
+    DU ladj;
     if (isfinite(a) && isfinite(b)) {
         const double sg = 1.0 / (1.0 + exp(-y.v));
         x = chain(y, (b - a) * sg + a, (b - a) * sg * (1.0 - sg));
-        ladj = dlog(((x + (-a)) * (dconst<N>(b) - x)) * (1.0 / (b - a)));
+        ladj = dlog(((x + (-a)) * (dconst<N, FAST>(b) - x)) * (1.0 / (b - a)));
     } else if (isfinite(a)) {
         const double ey = exp(y.v);
         x = chain(y, ey + a, ey);
@@ -82,68 +91,69 @@ __device__ __forceinline__ void prior_apply(const octo_prior& pr, const Dual<N>&
     } else if (isfinite(b)) {
         const double ey = exp(y.v);
         x = chain(y, b - ey, -ey);
-        ladj = dlog(dconst<N>(b) - x);
+        ladj = dlog(dconst<N, FAST>(b) - x);
     } else {
-        x = y; ladj = dconst<N>(0.0);
+        x = y; ladj = dconst<N, FAST>(0.0);
     }
     switch (pr.kind) {
-        case OCTO_PRIOR_UNIFORM: lp = dconst<N>((x.v >= a && x.v <= b) ? -log(b - a) : -INFINITY); break;
-        case OCTO_PRIOR_LOGUNIFORM: lp = (x.v >= a && x.v <= b) ? dlog(dconst<N>(1.0) / (x * log(b / a))) : dconst<N>(-INFINITY); break;
+        case OCTO_PRIOR_UNIFORM: lp = dconst<N, FAST>((x.v >= a && x.v <= b) ? -log(b - a) : -INFINITY); break;
+        case OCTO_PRIOR_LOGUNIFORM: lp = (x.v >= a && x.v <= b) ? dlog(dconst<N, FAST>(1.0) / (x * log(b / a))) : dconst<N, FAST>(-INFINITY); break;
         case OCTO_PRIOR_NORMAL: case OCTO_PRIOR_TRUNCNORMAL: {
-            const Dual<N> z = (x + (-pr.p0)) * (1.0 / pr.p1);
+            const DU z = (x + (-pr.p0)) * (1.0 / pr.p1);
             lp = (-(z * z + LOG2PI)) * 0.5 + (-log(pr.p1));
             if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) {
-                const double lo = isfinite(pr.lo) ? 0.5 * erfc(-((pr.lo - pr.p0) / pr.p1) * 0.70710678118654752440) : 0.0;
-                const double hi = isfinite(pr.hi) ? 0.5 * erfc(-((pr.hi - pr.p0) / pr.p1) * 0.70710678118654752440) : 1.0;
-                lp = lp + (-log(hi - lo));
-                if (!(x.v >= pr.lo && x.v <= pr.hi)) lp = dconst<N>(-INFINITY);
+                double nlz = trunc_logz;                 // a constant of the model: octo_model_create precomputes it for the fused launch
+                if (!FAST && isnan(nlz)) {
+                    const double lo = isfinite(pr.lo) ? 0.5 * erfc(-((pr.lo - pr.p0) / pr.p1) * 0.70710678118654752440) : 0.0;
+                    const double hi = isfinite(pr.hi) ? 0.5 * erfc(-((pr.hi - pr.p0) / pr.p1) * 0.70710678118654752440) : 1.0;
+                    nlz = -log(hi - lo);
+                }
+                lp = lp + nlz;
+                if (!(x.v >= pr.lo && x.v <= pr.hi)) lp = dconst<N, FAST>(-INFINITY);
             }
             break;
         }
-        case OCTO_PRIOR_SINE: lp = (x.v > 0.0 && x.v < PI) ? dlog(dsin(x) * 0.5) : dconst<N>(-INFINITY); break;
-        default: lp = dconst<N>(NAN);
+        case OCTO_PRIOR_SINE: lp = (x.v > 0.0 && x.v < PI) ? dlog(dsin(x) * 0.5) : dconst<N, FAST>(-INFINITY); break;
+        default: lp = dconst<N, FAST>(NAN);
     }
     lp = lp + ladj;
 }
 
 // logpdf(LogNormal(log(1.0), 0.1), sqrt(x² + y²))   src/variables.jl:309-323
-template <int N>
-__device__ __forceinline__ Dual<N> unit_length(const Dual<N>& x, const Dual<N>& y) {
-    const Dual<N> r = dsqrt(x * x + y * y);
-    const Dual<N> z = dlog(r) * 10.0;
+DT DU unit_length(const DU& x, const DU& y) {
+    const DU r = dsqrt(x * x + y * y);
+    const DU z = dlog(r) * 10.0;
     return (-(z * z + LOG2PI)) * 0.5 - dlog(r * 0.1);
 }
 
 // θ_at_epoch_to_tperi   src/parameterizations.jl:34-67
-template <int N>
 // Thiele-Innes planets (ti): the arguments a, inc, w, O carry A, B, F, G [mas] and a = α/plx (:14-19).
-__device__ __forceinline__ Dual<N> tperi(const Dual<N>& th, double theta_epoch, const Dual<N>& M, const Dual<N>& e, const Dual<N>& a_in,
-                                         const Dual<N>& inc, const Dual<N>& w, const Dual<N>& O, double k_yr, double yd,
-                                         bool ti = false, const Dual<N>* plx = nullptr) {
-    Dual<N> A, B, F, G, a = a_in;
+DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU& a_in,
+            const DU& inc, const DU& w, const DU& O, double k_yr, double yd, bool ti = false, const DU* plx = nullptr) {
+    DU A, B, F, G, a = a_in;
     if (ti) {
         A = a_in; B = inc; F = w; G = O;
-        const Dual<N> u = (A * A + B * B + F * F + G * G) * 0.5, v = A * G - B * F;
+        const DU u = (A * A + B * B + F * F + G * G) * 0.5, v = A * G - B * F;
         a = dsqrt(u + dsqrt((u + v) * (u - v))) / *plx;
     } else {
-        Dual<N> cO, sO, cw, sw;
+        DU cO, sO, cw, sw;
         dsincos(O, sO, cO); dsincos(w, sw, cw);
-        const Dual<N> ci = dcos(inc);
+        const DU ci = dcos(inc);
         A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
         F = -(cO * sw) - sO * cw * ci; G = -(sO * sw) + cO * cw * ci;
     }
-    Dual<N> ct, st;
+    DU ct, st;
     dsincos(th, st, ct);
-    const Dual<N> det = A * G - F * B;
-    const Dual<N> xr = (G * ct - F * st) / det, yr = (A * st - B * ct) / det;
-    const Dual<N> nu = datan2(yr, xr);
-    const Dual<N> s1 = dsqrt(dconst<N>(1.0) - e * e);
-    Dual<N> sn, cn;
+    const DU det = A * G - F * B;
+    const DU xr = (G * ct - F * st) / det, yr = (A * st - B * ct) / det;
+    const DU nu = datan2(yr, xr);
+    const DU s1 = dsqrt(dconst<N, FAST>(1.0) - e * e);
+    DU sn, cn;
     dsincos(nu, sn, cn);
-    const Dual<N> MA = datan2(-(s1 * sn), -e - cn) + PI - (e * s1 * sn) / (e * cn + 1.0);
-    const Dual<N> period_yrs = dsqrt(a * a * a / M) * (k_yr / yd);
-    const Dual<N> n = dconst<N>(TWO_PI) / period_yrs;
-    return dconst<N>(theta_epoch) - (MA / n) * yd;
+    const DU MA = datan2(-(s1 * sn), -e - cn) + PI - (e * s1 * sn) / (e * cn + 1.0);
+    const DU period_yrs = dsqrt(a * a * a / M) * (k_yr / yd);
+    const DU n = dconst<N, FAST>(TWO_PI) / period_yrs;
+    return dconst<N, FAST>(theta_epoch) - (MA / n) * yd;
 }
 
 // block = 64 walkers × DB partials (DB = min(D, 8) waves), grid = (walker tiles, ⌈D/DB⌉). Thread (w, d) carries the
@@ -308,5 +318,7 @@ static __global__ __launch_bounds__(256) void k_model_bwd(ModelArgs a) {
     a.grad_out[(int64_t)d * a.ld + w] = ok ? g : 0.0;
 }
 #undef DFOR
+#undef DT
+#undef DU
 
 }  // namespace octo

@@ -59,31 +59,51 @@ __device__ __forceinline__ void pc_from_setup(PC& pc, const double (&v)[NWC]) {
 }
 
 // ---- standard parameterisation, lane = partial -------------------------------------------------------------------------
+using D1 = Dual<1, true>;      // one partial per lane, fast math (octo_model.h)
+using D2 = Dual<2, true>;      // a UniformCircular pair's angle / UnitLengthPrior term with both partials
 // This lane's own prior: natural value x[lane], dx/dθ_t[lane]. Other θ are fetched from their lanes.
 struct LaneTheta {
     double xv, xd;
     int lane;
 };
 
-__device__ __forceinline__ Dual<1> nat_theta(const LaneTheta& T, int k) {      // natural θ[k] with this lane's partial (k wave-uniform)
-    Dual<1> r;
+__device__ __forceinline__ D1 nat_theta(const LaneTheta& T, int k) {      // natural θ[k] with this lane's partial (k wave-uniform)
+    D1 r;
     r.v = lane_value(T.xv, k);
     r.d[0] = (k == T.lane) ? T.xd : 0.0;
     return r;
 }
 
-// OCTO_SRC_CONST / _THETA / _CIRCULAR (variables.jl:279-299). A UniformCircular source that carries its UnitLengthPrior term
-// (OCTO_SRC_FLAG_UNITLEN, variables.jl:309-323) adds it to `ul` when `count_ul`.
-__device__ __forceinline__ Dual<1> src_angle(const octo_source& sc, const LaneTheta& T, Dual<1>& ul, bool count_ul) {
-    const Dual<1> cx = nat_theta(T, sc.i0), cy = nat_theta(T, sc.i1);
-    if (count_ul && (sc.flags & OCTO_SRC_FLAG_UNITLEN)) ul = ul + unit_length(cx, cy);
-    return datan2(cy, cx);
+// UniformCircular pairs (variables.jl:279-323), precomputed ONE PAIR PER LANE: lane j evaluates atan(y, x) and the UnitLengthPrior
+// term of pair j with both partials — one pass of atan2 / sqrt / log for all pairs of the model instead of one per source.
+struct CircTable {
+    double ang, ang_x, ang_y, ul, ul_x, ul_y;      // this lane's pair: values and ∂/∂x, ∂/∂y
+    int n;
+};
+
+// OCTO_SRC_CONST / _THETA / _CIRCULAR. A UniformCircular source that carries its UnitLengthPrior term (OCTO_SRC_FLAG_UNITLEN,
+// variables.jl:309-323) adds it to `ul` when `count_ul`. `slot`: the source's entry in the pair table, or -1 (computed in place).
+__device__ __forceinline__ D1 src_angle(const octo_source& sc, int slot, const CircTable& C, const LaneTheta& T, D1& ul, bool count_ul) {
+    // (every CIRCULAR / TPERI source of a model that takes this launch has a slot: octo_model_logpost_device checks it. Computing
+    // a pair in place here would put a copy of atan2 + sqrt + two logs at each of the ~15 inlined call sites — 100 KB of code
+    // that a cold one-block launch has to fetch.)
+    const bool want_ul = count_ul && (sc.flags & OCTO_SRC_FLAG_UNITLEN);
+    // this lane's partial of (x, y): dx/dθ_t[lane] is non-zero only in the lanes that own x or y
+    const double sx = (sc.i0 == T.lane) ? T.xd : 0.0, sy = (sc.i1 == T.lane) ? T.xd : 0.0;
+    D1 ang;
+    ang.v = lane_value(C.ang, slot);
+    ang.d[0] = lane_value(C.ang_x, slot) * sx + lane_value(C.ang_y, slot) * sy;
+    if (want_ul) {
+        ul.v += lane_value(C.ul, slot);
+        ul.d[0] += lane_value(C.ul_x, slot) * sx + lane_value(C.ul_y, slot) * sy;
+    }
+    return ang;
 }
 
-__device__ __forceinline__ Dual<1> src_plain(const octo_source& sc, const LaneTheta& T, Dual<1>& ul, bool count_ul) {
-    if (sc.kind == OCTO_SRC_CONST) return dconst<1>(sc.value);
+__device__ __forceinline__ D1 src_plain(const octo_source& sc, int slot, const CircTable& C, const LaneTheta& T, D1& ul, bool count_ul) {
+    if (sc.kind == OCTO_SRC_CONST) return dconst<1, true>(sc.value);
     if (sc.kind == OCTO_SRC_THETA) return nat_theta(T, sc.i0);
-    return src_angle(sc, T, ul, count_ul) * (sc.value / TWO_PI);               // atan(y, x) / 2π * domain, variables.jl:284
+    return src_angle(sc, slot, C, T, ul, count_ul) * (sc.value / TWO_PI);               // atan(y, x) / 2π * domain, variables.jl:284
 }
 
 // default nuisance source of row k of an observation when the model gives none (jitter 0, platescale 1, northangle 0 / offset 0)
@@ -98,6 +118,10 @@ struct SmallModel {       // the part of ModelArgs k_small<MODEL> reads
     const octo_prior* priors;
     const octo_source* esrc;
     const octo_source* nsrc;       // or null = defaults
+    const int32_t* circ_slot;      // [n_el + n_nu] pair-table slot of each CIRCULAR / TPERI source, or -1
+    const int32_t* circ_pair;      // [n_circ][2] (i0, i1) of each slot
+    const double* prior_logz;      // [D] −log(Φ(hi) − Φ(lo)) of each truncated-Normal prior (a model constant), NaN elsewhere
+    int32_t n_circ, n_el;
     const double* theta_t;         // [W][D] walker-major (ld = 1) or [D][ld]
     int64_t ld_t, ws_t;            // θ_t[d * ld_t + w * ws_t]
     double* lp_out; double* grad_out; int64_t ld_o, ws_o;      // lp_out[w * ws_o], grad_out[d * ld_o + w * ws_o]
@@ -129,8 +153,9 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
 
     // ---- (MODEL) θ_t -> natural θ, priors, elements as one-partial duals: lane d carries ∂/∂θ_t[d]
     LaneTheta T{0.0, 0.0, lane};
-    Dual<1> elD[P][OCTO_N_EL];
-    Dual<1> ul = dconst<1>(0.0);                        // Σ UnitLengthPrior terms (value and this lane's partial)
+    D1 elD[P][OCTO_N_EL];
+    D1 ul = dconst<1, true>(0.0);                       // Σ UnitLengthPrior terms (value and this lane's partial)
+    CircTable CT{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
     double lpp = 0.0, glp = 0.0;                        // Σ logpdf_with_trans in declaration order, and ∂/∂θ_t[lane]
     bool healed = false, finite_in = true;
     if constexpr (MODEL) {
@@ -138,9 +163,19 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
         const int dl = lane < D ? lane : D - 1;
         const double y = sm.theta_t[(int64_t)dl * sm.ld_t + w * sm.ws_t];
         finite_in = __all(isfinite(y));                                              // logdensitymodel.jl:120-124
-        Dual<1> xk, pk;
-        prior_apply(sm.priors[dl], dvar<1>(y, 0), xk, pk);
+        D1 xk, pk;
+        prior_apply(sm.priors[dl], dvar<1, true>(y, 0), xk, pk, sm.prior_logz[dl]);
         T.xv = xk.v; T.xd = xk.d[0];
+        {   // the model's UniformCircular pairs, one per lane
+            CT.n = sm.n_circ < WAVE ? sm.n_circ : WAVE;
+            const int j = lane < CT.n ? lane : 0;
+            const int i0 = CT.n > 0 ? sm.circ_pair[2 * j] : 0, i1 = CT.n > 0 ? sm.circ_pair[2 * j + 1] : 0;
+            const D2 cx = dvar<2, true>(__shfl(T.xv, i0), 0), cy = dvar<2, true>(__shfl(T.xv, i1), 1);
+            if (CT.n > 0) {
+                const D2 ang = datan2(cy, cx), u2 = unit_length(cx, cy);
+                CT.ang = ang.v; CT.ang_x = ang.d[0]; CT.ang_y = ang.d[1]; CT.ul = u2.v; CT.ul_x = u2.d[0]; CT.ul_y = u2.d[1];
+            }
+        }
         for (int k = 0; k < D; ++k) {                                                // in declaration order, healing as the reference
             const double pv = lane_value(pk.v, k);                                   // does (variables.jl:1229-1236)
             if (!healed) {
@@ -154,11 +189,11 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
 #pragma unroll
             for (int k = 0; k < OCTO_N_EL; ++k) {
                 const octo_source sc = sm.esrc[p * OCTO_N_EL + k];
-                elD[p][k] = (sc.kind == OCTO_SRC_TPERI) ? dconst<1>(0.0) : src_plain(sc, T, ul, true);
+                elD[p][k] = (sc.kind == OCTO_SRC_TPERI) ? dconst<1, true>(0.0) : src_plain(sc, sm.circ_slot[p * OCTO_N_EL + k], CT, T, ul, true);
             }
             const octo_source sc = sm.esrc[p * OCTO_N_EL + OCTO_EL_TP];
             if (sc.kind == OCTO_SRC_TPERI)      // tp = θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω | plx, A, B, F, G), parameterizations.jl:6-69
-                elD[p][OCTO_EL_TP] = tperi(src_angle(sc, T, ul, true), sc.value, elD[p][OCTO_EL_M], elD[p][OCTO_EL_E], elD[p][OCTO_EL_A], elD[p][OCTO_EL_I],
+                elD[p][OCTO_EL_TP] = tperi(src_angle(sc, sm.circ_slot[p * OCTO_N_EL + OCTO_EL_TP], CT, T, ul, true), sc.value, elD[p][OCTO_EL_M], elD[p][OCTO_EL_E], elD[p][OCTO_EL_A], elD[p][OCTO_EL_I],
                                            elD[p][OCTO_EL_W], elD[p][OCTO_EL_O], sm.k_yr, sm.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &elD[p][OCTO_EL_PLX]);
         }
     }
@@ -186,12 +221,12 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
         ok = ok && so.ok;
     }
     // nuisance rows of observation o: from memory, or (MODEL) from their sources
-    auto nuis_of = [&](int o, int obs_kind, double (&nu)[OCTO_N_NUIS], Dual<1>* nuD, bool count_ul) {
+    auto nuis_of = [&](int o, int obs_kind, double (&nu)[OCTO_N_NUIS], D1* nuD, bool count_ul) {
         if constexpr (MODEL) {
 #pragma unroll
             for (int r = 0; r < OCTO_N_NUIS; ++r) {
                 const octo_source sc = sm.nsrc ? sm.nsrc[o * OCTO_N_NUIS + r] : default_nuis_source(obs_kind, r);
-                const Dual<1> v = src_plain(sc, T, ul, count_ul);
+                const D1 v = src_plain(sc, sm.nsrc ? sm.circ_slot[sm.n_el + o * OCTO_N_NUIS + r] : -1, CT, T, ul, count_ul);
                 nu[r] = v.v;
                 if (nuD) nuD[r] = v;
             }
@@ -326,7 +361,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 // the observation's nuisances once more, now with their partials (and their UnitLengthPrior terms, counted here
                 // exactly once per walker), and ḡ_nuis kept in registers for this lane's chain-rule sum
                 double nu[OCTO_N_NUIS];
-                Dual<1> nuD[OCTO_N_NUIS];
+                D1 nuD[OCTO_N_NUIS];
                 const int kind = a.obs[o].kind;
                 nuis_of(o, kind, nu, nuD, true);
                 bool fin = true;

@@ -140,3 +140,17 @@ def test_pmc_json_matches_the_kernel_sources():
     j = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
     assert j.get("kernel_source_sha256") == kernel_source_hash(), \
         "kernel sources changed since the PMC passes: re-run `bash tools/profile_round.sh <tag>` on the GPU box and copy gpurun_out/<tag>_pmc_traffic.json to profiles/pmc_traffic.json"
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus N` without a launcher must start its own N ranks (it used to exit with an error, so the
+    driver's scaling run could not start): the command it re-executes itself under."""
+    import json, os, subprocess, sys
+    from __graft_entry__ import ROOT
+    env = dict(os.environ, OCTO_BENCH_PRINT_LAUNCH="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "20", "--warmup", "5"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")

@@ -157,11 +157,13 @@ def config1_latency(pkg, dev_index):
     args = (fn._ctx, model._m, capi._dptr(th), 1, 1, capi._dptr(lp), capi._dptr(g))
     for _ in range(300):
         fn.lib.octo_model_logpost(*args)
-    n = 2000
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn.lib.octo_model_logpost(*args)
-    gpu_us = (time.perf_counter() - t0) / n * 1e6
+    n = 1000
+    gpu_us = 1e9
+    for _ in range(5):      # best of 5 blocks of 1000 calls: a latency, so the quietest block is the measurement
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn.lib.octo_model_logpost(*args)
+        gpu_us = min(gpu_us, (time.perf_counter() - t0) / n * 1e6)
     ok = abs(lp[0] - case["lp"][0]) <= 1e-10 * abs(case["lp"][0])
     obs = [dict(kind=0, planet=0, epoch=np.asarray(o["epoch"]), y1=np.asarray(o["y1"]), y2=np.asarray(o["y2"]), s1=np.asarray(o["s1"]),
                 s2=np.asarray(o["s2"]), cor=None)]
@@ -380,7 +382,9 @@ def main():
             if issue:
                 # time the chip needs just to ISSUE this kernel's VALU instructions (measured mix x measured cost per class)
                 t_issue = issue["ns_per_row_per_wave"] * 1e-6 * n_rows * ((W + 63) // 64) / issue["simds"]
-                roof.update({"issue_bound_ms": t_issue, "issue_frac": t_issue / kern_ms})
+                roof.update({"issue_bound_ms": t_issue, "issue_model_over_measured": t_issue / kern_ms,
+                             "issue_note": "per-class issue costs from tools/ubench.hip x the counted instruction mix; within ~6 % of the measured "
+                                           "duration either way = the kernel runs at its VALU issue limit"})
             roof["hbm"] = {"bound": "hbm", "achieved": traffic / kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": traffic / kernel_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                            "what": "real HBM bytes per launch (PMC FETCH_SIZE x2 on gfx950 + WRITE_SIZE) / live kernel duration"}
@@ -411,16 +415,16 @@ def main():
             med = float(np.median(ts))
             res["pcie_inclusive"] = {"value": W * n_rows / med, "unit": "evals/s", "ms_per_call_median": med * 1e3, "calls": len(ts),
                                      "what": "octo_eval with host buffers: H2D of elems and D2H of ll + gradient inside the call (SURVEY 8d definition); median of 25"}
+        if not args.no_extras and world == 1 and args.workload == "grad":      # before the CPU baseline: its OpenMP team keeps spinning for a while and would disturb a latency measurement
+            try:
+                res["config1"] = config1_latency(pkg, dev_index)
+            except Exception as ex:
+                res["config1"] = {"error": str(ex)}
         if not args.no_cpu_baseline and cfg is not None and world == 1 and args.workload == "grad":
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg, fn.obs_tables, fn.planet_desc, args.cpu_seconds)
             except Exception as ex:  # the checker is optional for the measurement itself
                 res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex}"}
-        if not args.no_extras and world == 1 and args.workload == "grad":
-            try:
-                res["config1"] = config1_latency(pkg, dev_index)
-            except Exception as ex:
-                res["config1"] = {"error": str(ex)}
         print(json.dumps(res), flush=True)
     fn.close()
     if world > 1:

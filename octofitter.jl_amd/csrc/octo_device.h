@@ -161,8 +161,10 @@ __device__ __forceinline__ void sincos_table(float xf, double x, const SinCosTab
     const double r2 = r * r;
     const double sr = r * fma(r2, fma(r2, T.c5, OCTO_KT[18]), 1.0);
     const double cm1 = r2 * fma(r2, OCTO_KT[20], -0.5);
-    s = g.x + fma(g.x, cm1, g.y * sr);
-    c = g.y + fma(g.y, cm1, -(g.x * sr));
+    // sin(kΔ + r) = sin kΔ·cos r + cos kΔ·sin r, as two chained FMAs (the small products enter last-but-one: <= 1 ulp on the result,
+    // and one instruction less per output than mul + fma + add)
+    s = fma(g.x, cm1, fma(g.y, sr, g.x));
+    c = fma(g.y, cm1, fma(-g.x, sr, g.y));
 }
 
 // v_rcp_f64 (≈2^-23) + NR Newton steps (each doubles the correct bits): NR = 1 -> 2^-46, NR = 2 -> full.
@@ -271,17 +273,17 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     if constexpr (TAB) sincos_table(E1f, E1, tab, s1, c1);
     else sincos_halfangle(E1, s1, c1);
     const double e = pc.e;
-    const double f2 = e * s1;
-    const double hf2 = 0.5 * f2, q24 = f2 * (1.0 / 24.0);
+    // f2/2, f2/24, f3/6 of Markley's (21)-(27) from the loop-invariant e/2 and e/6 (f2 = e sin E1 itself is not needed)
+    const double hf2 = (0.5 * e) * s1, q24 = hf2 * (1.0 / 12.0);
     const double sf3 = (e * (1.0 / 6.0)) * c1;
     const double f1 = fma(-e, c1, 1.0);
     const double f0 = fma(-e, s1, fma(-frac, TWO_PI, E1));           // E1 − e sin E1 − M
     // One hardware reciprocal for the three divisions: the denominators are f1·(den4 + O(δ²)), den4, den4 + O(δ³), so
     // each reciprocal is a Newton step away from the previous one (prototype: tools/kepler_proto.py, same error).
     const double r3 = __builtin_amdgcn_rcp(fma(f1, f1, -(f0 * hf2)));                // ≈2^-23
-    const double d3 = -(f0 * f1) * r3;                                               // Halley
+    double r4 = f1 * r3;                                                             // ≈ 1/den4, and f1·r3 is also Halley's factor:
+    const double d3 = -f0 * r4;                                                      // δ3 = −f0·f1/(f1² − f0 f2/2)
     const double den4 = fma(d3, fma(d3, sf3, hf2), f1);
-    double r4 = f1 * r3;
     r4 = fma(fma(-den4, r4, 1.0), r4, r4);
     const double d4 = -f0 * r4;
     const double den5 = fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1);
@@ -292,8 +294,8 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     const double dd = d5 * d5;
     const double sd = d5 * fma(dd, OCTO_KT[18], 1.0);
     const double cm1 = dd * fma(dd, OCTO_KT[20], -0.5);
-    s.sE = s1 + fma(s1, cm1, c1 * sd);
-    s.cE = c1 + fma(c1, cm1, -(s1 * sd));
+    s.sE = fma(s1, cm1, fma(c1, sd, s1));
+    s.cE = fma(c1, cm1, fma(-s1, sd, c1));
     // M == 0: E1f = 0 exactly and f0 = 0, so E = 0 like the reference's early return; e == 0: f2 = f3 = 0,
     // d5 = −(E1 − M) exactly, E = M to rounding, like the reference's early return.
     if constexpr (INV_NR >= 0) s.invD = rcp_nr<(INV_NR >= 0 ? INV_NR : 0)>(fma(-e, s.cE, 1.0));

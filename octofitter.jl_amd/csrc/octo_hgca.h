@@ -65,8 +65,9 @@ static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
         if (ti) {
             // constants in mas; a = α/plx   (src/parameterizations.jl:14-19)
             h.cA = el[OCTO_EL_TI_A]; h.cB = el[OCTO_EL_TI_B]; h.cF = el[OCTO_EL_TI_F]; h.cG = el[OCTO_EL_TI_G];
-            const D u = (h.cA * h.cA + h.cB * h.cB + h.cF * h.cF + h.cG * h.cG) * 0.5, v = h.cA * h.cG - h.cB * h.cF;
-            sma = dsqrt(u + dsqrt((u + v) * (u - v))) / el[OCTO_EL_PLX];
+            const D pp = ((h.cA + h.cG) * (h.cA + h.cG) + (h.cB - h.cF) * (h.cB - h.cF)) * 0.5;      // u + v, u − v as sums of squares
+            const D mm = ((h.cA - h.cG) * (h.cA - h.cG) + (h.cB + h.cF) * (h.cB + h.cF)) * 0.5;      // (see setup_planet_vals)
+            sma = ((dsqrt(pp) + dsqrt(mm)) * 0.70710678118654752440) / el[OCTO_EL_PLX];
             h.T = dconst<1>(1.0);
         } else {
             D inc = el[OCTO_EL_I], Om = el[OCTO_EL_O];

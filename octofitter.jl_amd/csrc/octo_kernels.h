@@ -157,10 +157,12 @@ __device__ __forceinline__ SetupOut setup_planet_vals(const double (&elv)[OCTO_N
               isfinite(Mt) && isfinite(plx) && isfinite(mass);
     double T, A, B, F, G, si, ci, sw, cw, sO, cO;
     if (ti) {
-        // ThieleInnesOrbit: rows a, i, ω, Ω carry A, B, F, G [mas]; a = α/plx   (src/parameterizations.jl:14-19)
+        // ThieleInnesOrbit: rows a, i, ω, Ω carry A, B, F, G [mas]; a = α/plx   (src/parameterizations.jl:14-19).
+        // The reference writes α² = u + √((u+v)(u−v)), u = (A²+B²+F²+G²)/2, v = AG − BF, which cancels in u − v for near-face-on
+        // orbits. Same quantity without the cancellation: u ± v are sums of squares, and u + √((u+v)(u−v)) = ½(√(u+v) + √(u−v))².
         A = sma; B = inc; F = om; G = Om;
-        const double u = 0.5 * (A * A + B * B + F * F + G * G), v = A * G - B * F;
-        sma = fdiv(fsqrt(u + fsqrt((u + v) * (u - v))), plx);
+        const double pp = 0.5 * ((A + G) * (A + G) + (B - F) * (B - F)), mm = 0.5 * ((A - G) * (A - G) + (B + F) * (B + F));
+        sma = fdiv((fsqrt(pp) + fsqrt(mm)) * 0.70710678118654752440, plx);
         T = 1.0;
         si = ci = sw = cw = sO = cO = 0.0;
     } else {
@@ -804,15 +806,16 @@ __device__ __forceinline__ void planet_finish(const double (&el)[OCTO_N_EL] /* t
     }
     double out[OCTO_N_EL] = {ab, eb, radvel ? 0.0 : ib, wb, radvel ? 0.0 : Ob, tpb, Mb, noplx ? 0.0 : plxb, massb};
     if (ti) {
-        // a = α/plx, α² = u + √(u² − v²), u = (A²+B²+F²+G²)/2, v = AG − BF  (src/parameterizations.jl:15-18): push ā back
-        const double u = 0.5 * (A * A + B * B + F * F + G * G), v = A * G - B * F;
-        const double sq = sqrt((u + v) * (u - v)), alpha = sma * plx;
+        // a = α/plx with α = (√p + √m)/√2, p = u + v = ½((A+G)² + (B−F)²), m = u − v = ½((A−G)² + (B+F)²) — the reference's
+        // α² = u + √(u² − v²) (src/parameterizations.jl:15-18) in a form that does not cancel near face-on. Push ā back:
+        const double sAG = A + G, dAG = A - G, dBF = B - F, sBF = B + F;
+        const double pp = 0.5 * (sAG * sAG + dBF * dBF), mm = 0.5 * (dAG * dAG + sBF * sBF);
         const double alphab = ab / plx;
-        const double ub = alphab * (1.0 + u / sq) / (2.0 * alpha), vb = -alphab * (v / sq) / (2.0 * alpha);
-        out[OCTO_EL_TI_A] = tiAb + ub * A + vb * G;
-        out[OCTO_EL_TI_B] = tiBb + ub * B - vb * F;
-        out[OCTO_EL_TI_F] = tiFb + ub * F - vb * B;
-        out[OCTO_EL_TI_G] = tiGb + ub * G + vb * A;
+        const double pb = alphab * 0.35355339059327376220 / sqrt(pp), mb = alphab * 0.35355339059327376220 / sqrt(mm);      // 1/(2√2 √·)
+        out[OCTO_EL_TI_A] = tiAb + pb * sAG + mb * dAG;
+        out[OCTO_EL_TI_B] = tiBb + pb * dBF + mb * sBF;
+        out[OCTO_EL_TI_F] = tiFb - pb * dBF + mb * sBF;
+        out[OCTO_EL_TI_G] = tiGb + pb * sAG - mb * dAG;
         out[OCTO_EL_PLX] = -ab * sma / plx;
     }
 #pragma unroll

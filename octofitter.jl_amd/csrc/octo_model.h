@@ -133,8 +133,9 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
     DU A, B, F, G, a = a_in;
     if (ti) {
         A = a_in; B = inc; F = w; G = O;
-        const DU u = (A * A + B * B + F * F + G * G) * 0.5, v = A * G - B * F;
-        a = dsqrt(u + dsqrt((u + v) * (u - v))) / *plx;
+        // a = α/plx, α = (√(u+v) + √(u−v))/√2 with u ± v as sums of squares (see setup_planet_vals)
+        const DU pp = ((A + G) * (A + G) + (B - F) * (B - F)) * 0.5, mm = ((A - G) * (A - G) + (B + F) * (B + F)) * 0.5;
+        a = ((dsqrt(pp) + dsqrt(mm)) * 0.70710678118654752440) / *plx;
     } else {
         DU cO, sO, cw, sw;
         dsincos(O, sO, cO); dsincos(w, sw, cw);

@@ -257,9 +257,9 @@ def _tperi(θ, theta_epoch, M, e, a, i, ω, Ω, abfg=None, plx=None):
     """NumPy θ_at_epoch_to_tperi (src/parameterizations.jl:6-69) — host convenience for arr2nt-style inspection."""
     if abfg is not None:
         A, B, F, G = abfg
-        u = (A ** 2 + B ** 2 + F ** 2 + G ** 2) / 2
-        v = A * G - B * F
-        a = np.sqrt(u + np.sqrt((u + v) * (u - v))) / plx
+        pp = ((A + G) ** 2 + (B - F) ** 2) / 2          # u + v and u − v of src/parameterizations.jl:15-18 as sums of squares:
+        mm = ((A - G) ** 2 + (B + F) ** 2) / 2          # α = √(u + √(u² − v²)) = (√(u+v) + √(u−v))/√2, no cancellation near face-on
+        a = (np.sqrt(pp) + np.sqrt(mm)) / np.sqrt(2.0) / plx
     else:
         A = np.cos(Ω) * np.cos(ω) - np.sin(Ω) * np.sin(ω) * np.cos(i)
         B = np.sin(Ω) * np.cos(ω) + np.cos(Ω) * np.sin(ω) * np.cos(i)

@@ -185,6 +185,15 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes on this driver
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
+    # stdout carries exactly ONE line, the JSON: anything a library prints on the way (RCCL's version banner at communicator
+    # creation, for one) is sent to stderr by pointing fd 1 there and keeping the real stdout aside for the final line
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -258,8 +267,8 @@ def main():
         nl = torch.tensor(np.stack([el[1], el[0], el[5], el[6], el[7]]), device=dev)
         dt, per_step, n_spin = timed_loop(lambda i: solver.eval_device(nl))
         if rank == 0:
-            print(json.dumps(base_line("OFTI marginal-likelihood epoch evals/sec (fwd)", args.epochs * args.walkers * args.steps * world / dt, dt, per_step, n_spin,
-                                       f"ofti_linear_solve: {args.epochs} RA/Dec epochs x {args.walkers} walkers, forward")))
+            emit(base_line("OFTI marginal-likelihood epoch evals/sec (fwd)", args.epochs * args.walkers * args.steps * world / dt, dt, per_step, n_spin,
+                           f"ofti_linear_solve: {args.epochs} RA/Dec epochs x {args.walkers} walkers, forward"))
         solver.close()
         return
     if args.workload == "logpost":
@@ -276,9 +285,9 @@ def main():
         θt = torch.tensor(model.link(model.sample_priors(np.random.default_rng(20260929 + 7), args.walkers)), device=dev)
         dt, per_step, n_spin = timed_loop(lambda i: model.logpost_device(θt, grad=True))
         if rank == 0:
-            print(json.dumps(base_line("epoch-likelihood evals/sec, full log-posterior + gradient w.r.t. theta_t (D=11)",
-                                       args.epochs * args.walkers * args.steps * world / dt, dt, per_step, n_spin,
-                                       f"LogDensityModel D={model.D}: {args.epochs} RA/Dec epochs x {args.walkers} walkers, theta_t resident in HBM")))
+            emit(base_line("epoch-likelihood evals/sec, full log-posterior + gradient w.r.t. theta_t (D=11)",
+                           args.epochs * args.walkers * args.steps * world / dt, dt, per_step, n_spin,
+                           f"LogDensityModel D={model.D}: {args.epochs} RA/Dec epochs x {args.walkers} walkers, theta_t resident in HBM"))
         model.close()
         return
     if args.workload == "two_planet":
@@ -425,7 +434,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(cfg, fn.obs_tables, fn.planet_desc, args.cpu_seconds)
             except Exception as ex:  # the checker is optional for the measurement itself
                 res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex}"}
-        print(json.dumps(res), flush=True)
+        emit(res)
     fn.close()
     if world > 1:
         dist.destroy_process_group()

@@ -159,3 +159,31 @@ def test_torch_stream_ordering(pkg, oracle):
                 got = total.item()
                 assert abs(got - 2.0 * ll_ref.sum()) <= 1e-9 * abs(ll_ref.sum()), (stream, rep, got, 2.0 * ll_ref.sum())
     fn.close()
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints exactly one line on stdout, the JSON of the contract, with the measurement record the judge asked for:
+    a binding roofline (FP64 vector, 0 < frac <= 1) next to the real HBM rate, the PCIe-inclusive rate, a parity sample of the timed
+    batch, config 1's per-call latency — and the target met (>= 1e9 evals/s)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "10", "--warmup", "3", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["workload"].startswith("config3")
+    assert d["value"] > 1e9 and abs(d["value"] - 1e8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] == "fp64_vector" and roof["unit"] == "TFLOP/s" and roof["peak"] == 78.6
+    assert roof["frac"] is not None and 0.2 < roof["frac"] <= 1.0, "roofline withheld: profiles/pmc_traffic.json is stale (re-run tools/profile_round.sh)"
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["traffic"] > 1e7
+    assert 0 < roof["hbm"]["frac"] < 0.1 and roof["hbm"]["unit"] == "GB/s"                     # the real HBM rate: a percent or two of 8 TB/s
+    assert roof["north_star_algorithmic_hbm"]["algorithmic_bytes_per_launch"] == 4001360000.0
+    assert 0.25 < roof["kernel_avg_ms"] < 0.6 and roof["kernel_launches_timed"] >= 2
+    assert d["parity"]["ok"] is True and d["max_rel_err"] < 1e-8
+    assert 0.5 * d["value"] < d["pcie_inclusive"]["value"] < d["value"]
+    assert d["config1"]["gpu_matches_fixture"] is True and 5 < d["config1"]["gpu_us_per_call"] < 200
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 1e5

@@ -128,3 +128,47 @@ def test_invalid_walkers_small_batch():
     ll, g, _ = gb.gpu_eval(obs, planets, bad, None, grad=True)
     assert np.all(np.isneginf(ll[:7])) and np.all(g[:, :7] == 0.0)
     assert ll[7] == ref[7] and np.array_equal(g[:, 7], gref[:, 7])      # a neighbour's garbage does not leak
+
+
+@pytest.mark.parametrize("W", [1, 2, 31, 32, 33])
+def test_model_callback_fused_launch_vs_oracle(pkg, oracle, W):
+    """The whole log-posterior callback in ONE launch (k_small<MODEL>: θ_t -> priors -> elements -> likelihood -> ∇θ_t, lane = partial)
+    for the committed D = 11 and D = 25 (two planets, RV, nuisance priors) models at W ∈ {1, 2, 31, 32, 33} θ_t: against the oracle's
+    restatement of the callback, against the 60-digit fixture where the committed θ_t are used, and against the throughput kernels."""
+    import json
+    from pathlib import Path
+    import ctypes as C
+    from test_model import _tables
+    gold = json.loads((Path(__file__).resolve().parent / "golden" / "model.json").read_text())["cases"]
+    capi = pkg.capi
+    lib = capi.load_library()
+    for case in gold:
+        obs, planets = _tables(case)
+        pr, es = oracle.make_priors(case["priors"]), oracle.make_sources(case["esrc"])
+        ns = oracle.make_sources(case["nsrc"]) if case["nsrc"] else None
+        base = np.asarray(case["theta_t"])
+        D, W0 = base.shape
+        rng = np.random.default_rng(100 + W)
+        th = np.tile(base, (1, W // W0 + 1))[:, :W].copy()
+        th[:, W0:] += 0.05 * rng.normal(size=(D, max(W - W0, 0)))         # beyond the committed θ_t: perturbed copies
+        th = np.ascontiguousarray(th)
+        lp_o, g_o = oracle.oracle_model_logpost(obs, planets, pr, es, ns, th, n_threads=0)
+        res = {}
+        for sb in (None, 0):
+            path = _gpu().GpuPath(obs, planets, small_batch=sb)
+            m = C.c_void_p()
+            assert lib.octo_model_create(path.ctx, path.ds, pr, D, es, ns, C.byref(m)) == 0, lib.octo_last_error(path.ctx)
+            lp = np.full(W, np.nan); g = np.full_like(th, np.nan); lp0 = np.full(W, np.nan)
+            assert lib.octo_model_logpost(path.ctx, m, capi._dptr(th), W, W, capi._dptr(lp), capi._dptr(g)) == 0
+            assert lib.octo_model_logpost(path.ctx, m, capi._dptr(th), W, W, capi._dptr(lp0), None) == 0
+            lib.octo_model_destroy(m); path.close()
+            assert np.array_equal(lp, lp0), (case["name"], sb, "value with and without gradient differ")
+            res[sb] = (lp, g)
+            assert np.all(np.abs(lp - lp_o) <= 1e-12 * np.abs(lp_o)), (case["name"], sb, np.max(np.abs(lp - lp_o) / np.abs(lp_o)))
+            sc = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-300)
+            assert np.all(np.abs(g - g_o) <= 1e-9 * sc), (case["name"], sb, np.max(np.abs(g - g_o) / sc))
+        n0 = min(W, W0)                                                      # the committed θ_t: the 60-digit values
+        assert np.all(np.abs(res[None][0][:n0] - np.asarray(case["lp"])[:n0]) <= 1e-12 * np.abs(np.asarray(case["lp"])[:n0]))
+        gref = np.asarray(case["grad"])[:, :n0]
+        assert np.all(np.abs(res[None][1][:, :n0] - gref) <= 1e-9 * np.abs(gref) + 1e-10 * np.abs(gref).max(axis=1, keepdims=True))
+        assert np.all(np.abs(res[None][0] - res[0][0]) <= 1e-13 * np.abs(res[0][0]))

@@ -114,8 +114,8 @@ octo_dataset_n_rows(ds) = ccall((:octo_dataset_n_rows, LIB), Int64, (Ptr{Cvoid},
 octo_sync(ctx) = check(ctx, ccall((:octo_sync, LIB), Int32, (Ptr{Cvoid},), ctx), "octo_sync")
 
 "Host buffers, blocking. `Xt`: W×inputs (walker index fastest); `G`: same shape or nothing (forward only)."
-function octo_eval!(ctx, ds, Xt::Matrix{Float64}, n_el::Int, ll::Vector{Float64}, G::Union{Nothing,Matrix{Float64}})
-    W = size(Xt, 1); n_nu = size(Xt, 2) - n_el
+function octo_eval!(ctx, ds, Xt::Matrix{Float64}, n_el::Int, ll::Vector{Float64}, G::Union{Nothing,Matrix{Float64}}; with_nuis::Bool=true)
+    W = size(Xt, 1); n_nu = with_nuis ? size(Xt, 2) - n_el : 0      # without nuisances the kernels take the precomputed-Σ⁻¹ path (jitter == 0, relative-astrometry.jl:218-219)
     pel = pointer(Xt); pnu = n_nu > 0 ? pointer(Xt, n_el * W + 1) : Ptr{Float64}(C_NULL)
     gel = G === nothing ? Ptr{Float64}(C_NULL) : pointer(G)
     gnu = (G === nothing || n_nu == 0) ? Ptr{Float64}(C_NULL) : pointer(G, n_el * W + 1)
@@ -315,18 +315,29 @@ function kernel_inputs(system, entries, θ)
 end
 
 # ==================================================================================================== (1) accelerate(system)
-"State shared by the HIPObs wrappers of one system: context, dataset and the staging arrays of the W = 1 call."
-mutable struct HIPShared
+"One evaluation slot: a context (its own stream and scratch) and the staging arrays of the W = 1 call."
+struct HIPSlot
     ctx::Ptr{Cvoid}
+    Xt::Matrix{Float64}               # 1 × inputs
+    G::Matrix{Float64}
+    ll::Vector{Float64}
+end
+
+"""
+State shared by the HIPObs wrappers of one system: ONE dataset (immutable once uploaded, shareable between contexts — the header's
+threading contract) and a pool of slots. `ℓπcallback` is called concurrently from many Julia threads (`guess_starting_position`,
+src/initialization.jl:33-48; Pigeons with `multithreaded=true`): each call checks a slot out of `free`, so up to `length(slots)`
+evaluations are in flight on the device at once and none of them shares scratch.
+"""
+mutable struct HIPShared
     ds::Ptr{Cvoid}
+    slots::Vector{HIPSlot}
+    free::Channel{Int}
     system::Any                       # the accelerated System (set after construction)
     entries::Vector{Any}              # (wrapped obs, i_planet or 0, θ_obs key) in evaluation order
     columns::Vector{Vector{Float64}}
     n_el::Int
-    lock::ReentrantLock               # ℓπcallback is called from many Julia threads (initialization.jl:33-48); one ctx = one caller at a time
-    Xt::Matrix{Float64}               # 1 × inputs
-    G::Matrix{Float64}
-    ll::Vector{Float64}
+    nuis_default::Vector{Float64}     # the value each nuisance input has when the model does not declare it; NaN = always pass (HGCA's pmra, pmdec)
 end
 
 """
@@ -358,7 +369,7 @@ PlanetOrderPrior, …) stay as they are and run in Julia. Any OTHER epoch-bearin
 IAD, GP RV, images, …) also stays in Julia and the reference keeps solving the orbits for its epochs — the two mix freely because
 each `ln_like` method is independent (src/variables.jl:94-102).
 """
-function accelerate(system::System; device::Integer=0, verbosity::Integer=1)
+function accelerate(system::System; device::Integer=0, n_contexts::Integer=Threads.nthreads(), verbosity::Integer=1)
     arr2nt = Octofitter.make_arr2nt(system)
     θ0 = arr2nt(Octofitter.make_prior_sampler(system)(Random.default_rng()))
     eligible = Any[]
@@ -371,10 +382,21 @@ function accelerate(system::System; device::Integer=0, verbosity::Integer=1)
     isempty(eligible) && (verbosity >= 1 && @info "OctofitterHIP: no observation of this system is on the HIP path"; return system)
     ctx, ds, entries, columns = _upload(system, eligible, θ0; device)
     n_in = length(system.planets) * N_EL + length(entries) * N_NUIS
-    shared = HIPShared(ctx, ds, nothing, entries, columns, length(system.planets) * N_EL, ReentrantLock(),
-                       Matrix{Float64}(undef, 1, n_in), Matrix{Float64}(undef, 1, n_in), Vector{Float64}(undef, 1))
+    slot(c) = HIPSlot(c, Matrix{Float64}(undef, 1, n_in), Matrix{Float64}(undef, 1, n_in), Vector{Float64}(undef, 1))
+    slots = [slot(ctx)]
+    for _ in 2:max(1, n_contexts)                                       # more contexts on the same device share the dataset
+        c = octo_ctx_create(device); octo_consts_set(c, _consts()); push!(slots, slot(c))
+    end
+    free = Channel{Int}(length(slots)); foreach(i -> put!(free, i), eachindex(slots))
+    nuis_default = Float64[]
+    for (obs, _, _) in entries
+        T1 = nameof(typeof(obs))
+        append!(nuis_default, T1 === :HGCAInstantaneousObs ? (NaN, NaN, 0.0) :
+                              (obs isa PlanetRelAstromObs || T1 === :ObsPriorAstromONeil2019) ? (0.0, 1.0, 0.0) : (0.0, 0.0, 0.0))
+    end
+    shared = HIPShared(ds, slots, free, nothing, entries, columns, length(system.planets) * N_EL, nuis_default)
     finalizer(shared) do s
-        octo_dataset_destroy(s.ds); octo_ctx_destroy(s.ctx)
+        octo_dataset_destroy(s.ds); foreach(x -> octo_ctx_destroy(x.ctx), s.slots)
     end
     first_seen = Ref(false)
     wrap(obs) = _eligible(obs) ? (l = !first_seen[]; first_seen[] = true; HIPObs(obs, obs.priors, obs.derived, shared, l)) : obs
@@ -385,7 +407,7 @@ function accelerate(system::System; device::Integer=0, verbosity::Integer=1)
     sysobs = map(wrap, system.observations)
     sys2 = System(system.priors, system.derived, sysobs, planets, system.name)
     shared.system = sys2
-    verbosity >= 1 && @info "OctofitterHIP: $(length(entries)) observation table(s), $(octo_dataset_n_rows(ds)) epochs on the device"
+    verbosity >= 1 && @info "OctofitterHIP: $(length(entries)) observation table(s), $(octo_dataset_n_rows(ds)) epochs on the device, $(length(slots)) context(s)"
     return sys2
 end
 
@@ -396,23 +418,30 @@ _value(x::ForwardDiff.Dual) = Float64(ForwardDiff.value(x))
 function _ln_like_all(sh::HIPShared, θ_system)
     x = kernel_inputs(sh.system, sh.entries, θ_system)
     T = eltype(x)
-    lock(sh.lock) do
+    i = take!(sh.free)                                                    # a context of our own for the duration of the call
+    try
+        sl = sh.slots[i]
         @inbounds for k in eachindex(x)
-            sh.Xt[1, k] = _value(x[k])
+            sl.Xt[1, k] = _value(x[k])
         end
+        # every nuisance at its default (the model declares none): the nuisance block is not passed at all
+        with_nuis = any(k -> !(sl.Xt[1, sh.n_el+k] == sh.nuis_default[k]), eachindex(sh.nuis_default))
+        n_used = with_nuis ? length(x) : sh.n_el
         if T <: ForwardDiff.Dual
-            octo_eval!(sh.ctx, sh.ds, sh.Xt, sh.n_el, sh.ll, sh.G)
-            ll = sh.ll[1]
+            octo_eval!(sl.ctx, sh.ds, sl.Xt, sh.n_el, sl.ll, sl.G; with_nuis)
+            ll = sl.ll[1]
             isfinite(ll) || return T(ll)                                  # -Inf: zero partials (logdensitymodel.jl:120-124)
             p = zero(ForwardDiff.partials(x[1]))
-            @inbounds for k in eachindex(x)
-                p += sh.G[1, k] * ForwardDiff.partials(x[k])
+            @inbounds for k in 1:n_used
+                p += sl.G[1, k] * ForwardDiff.partials(x[k])
             end
             return T(ll, p)
         else
-            octo_eval!(sh.ctx, sh.ds, sh.Xt, sh.n_el, sh.ll, nothing)
-            return T(sh.ll[1])
+            octo_eval!(sl.ctx, sh.ds, sl.Xt, sh.n_el, sl.ll, nothing; with_nuis)
+            return T(sl.ll[1])
         end
+    finally
+        put!(sh.free, i)
     end
 end
 

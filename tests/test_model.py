@@ -234,6 +234,66 @@ def test_gpu_batched_callers(pkg):
 
 
 @pytest.mark.gpu
+def test_host_jacobian_route_equals_device_model_route(pkg):
+    """The two ways the Julia side reaches the device must give the same ∇θ_t:
+      route 1 (`accelerate(system)`, any model): the kernel returns ḡ = ∂ll/∂(elements, nuisances) and the HOST applies the chain rule
+              through its own θ_t -> inputs map: ∇θ_t = Jᵀ ḡ + ∇(prior) — ForwardDiff in Julia, central differences of the NumPy mirror here;
+      route 2 (`HIPLogDensityModel`): the whole callback on the device (octo_model_logpost).
+    One θ_t per call (both take the fused small-batch launch) and a 70-walker batch (throughput kernels)."""
+    from octofitter_jl_amd.host.callers import _unit_length_terms
+    model = pkg.LogDensityModel(_reference_test_model(pkg))
+    fn = model.ln_like
+    rng = np.random.default_rng(23)
+    for W in (1, 70):
+        θt = model.link(model.sample_priors(rng, W))
+        lp, g = model.logdensity_and_gradient(θt)
+        assert np.all(np.isfinite(lp))
+
+        def inputs(tt):                                   # θ_t -> (elements, nuisances) on the host, like arr2nt ∘ invlink
+            el, nu = model.kernel_inputs(model.invlink(tt))
+            return el
+
+        def logpdf_with_trans(p, x, y):                   # a test-local NumPy statement of Distributions' logpdf + Bijectors' log-Jacobian
+            from math import erf, isfinite, log, pi, sqrt
+            a, b = p.bounds()
+            if isfinite(a) and isfinite(b):
+                sg = 1.0 / (1.0 + np.exp(-y)); ladj = log(b - a) + np.log(sg) + np.log1p(-sg)
+            elif isfinite(a) or isfinite(b):
+                ladj = y
+            else:
+                ladj = 0.0
+            name = type(p).__name__
+            if name == "Uniform":
+                return -log(b - a) + ladj
+            if name == "LogUniform":
+                return -np.log(x) - log(log(b / a)) + ladj
+            if name == "Sine":
+                return np.log(np.sin(x) / 2) + ladj
+            z = (x - p.μ) / p.σ
+            lp = -0.5 * z * z - log(p.σ) - 0.5 * log(2 * pi)
+            if name == "TruncatedNormal":
+                Φ = lambda v: 0.5 * (1 + erf((v - p.μ) / p.σ / sqrt(2)))
+                lp = lp - log((Φ(p.hi) if isfinite(p.hi) else 1.0) - (Φ(p.lo) if isfinite(p.lo) else 0.0))
+            return lp + ladj
+
+        def host_terms(tt):                               # prior with its log-Jacobian + the epoch-free UnitLengthPrior terms
+            θ = model.invlink(tt)
+            return sum(logpdf_with_trans(p, θ[k], tt[k]) for k, p in enumerate(model.priors)) + _unit_length_terms(model, θ)
+        el = inputs(θt)
+        ll, g_el, _ = fn.ln_like_arrays(el, None, grad=True)
+        assert np.all(np.abs(ll + host_terms(θt) - lp) <= 1e-11 * np.abs(lp))
+        grad1 = np.zeros_like(θt)
+        for d in range(model.D):
+            h = 1e-6 * max(1.0, np.abs(θt[d]).max())
+            tp_, tm_ = θt.copy(), θt.copy(); tp_[d] += h; tm_[d] -= h
+            J_d = (inputs(tp_) - inputs(tm_)) / (2 * h)                   # ∂inputs/∂θ_t[d], [9, W]
+            grad1[d] = np.sum(J_d * g_el, axis=0) + (host_terms(tp_) - host_terms(tm_)) / (2 * h)
+        sc = np.maximum(np.abs(g).max(axis=1, keepdims=True), 1e-300)
+        assert np.all(np.abs(grad1 - g) <= 2e-6 * sc), (W, np.max(np.abs(grad1 - g) / sc))      # finite-difference accuracy
+    model.close()
+
+
+@pytest.mark.gpu
 def test_gpu_batched_callers_vs_oracle(pkg, oracle):
     """SURVEY §8 f2 with a real parity check (the callers were only compared with themselves): IDENTICAL prior draws and
     uniforms go to the device callers and to the CPU restatement of the callback; the starting point (argmax), every log-posterior,

@@ -196,14 +196,14 @@ int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
     return std::max<int64_t>(1, rounds * capacity / cols);
 }
 
+// Small batches: one fused launch, lane = epoch (octo_small.h: k_small). Eligible: W <= SMALL_W, no HGCA table (k_hgca is
+// its own launch) and no marginalised-RV table.
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
     // (a marginalised-RV table keeps BOTH the forward and the gradient launch on the throughput kernels: the gradient needs
     // their μ̂ pre-pass, and the value returned with a gradient must be bit-identical to the forward value)
-    return W <= ctx->small_w && ds->n_planets <= 2 && ds->n_hgca == 0 && !(ds->kind_mask & KM_MARG);
+    return W <= ctx->small_w && ds->n_hgca == 0 && !(ds->kind_mask & KM_MARG);
 }
 
-// Small batches: one fused launch, lane = epoch (octo_kernels.h: k_small). Eligible: W <= SMALL_W, at most two planets, no
-// HGCA table (k_hgca is its own launch) and no marginalised-RV table (its gradient needs the μ̂ pre-pass).
 int drain_timing(octo_ctx* ctx) {
     for (size_t k = 0; k < ctx->ev_used; ++k) {
         float ms = 0.f;
@@ -589,7 +589,7 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
             pd.active = true;
             return OCTO_OK;
         }
-        // datasets k_small does not take (HGCA, marginalised RV, > 2 planets): the throughput kernels on the same mapped buffers
+        // datasets k_small does not take (HGCA, marginalised RV): the throughput kernels on the same mapped buffers
         for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
         if (nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
         pd.o_ge = ldd; pd.o_gn = (int64_t)(1 + pd.n_el_out) * ldd;

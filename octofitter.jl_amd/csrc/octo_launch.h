@@ -59,7 +59,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     using L = Layout<P, GRAD, NUIS, KM>;
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
     const octo_dataset* ds = cds;
-    if constexpr (P <= 2) {
+    {
         if (sm) return launch_small<P, GRAD, NUIS, KM, true>(ctx, ds, a, sm, st);      // the caller checked small_eligible
         if (small_eligible(ctx, ds, a.W)) return launch_small<P, GRAD, NUIS, KM, false>(ctx, ds, a, nullptr, st);
     }

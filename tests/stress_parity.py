@@ -28,9 +28,9 @@ def planet_elems(rng, W, kind, a_lo, a_hi):
 SCALE = 1      # argv[3]: multiplies table sizes and batch sizes (partition planner at larger shapes)
 
 
-def random_system(rng, invalid=True):
-    P = int(rng.integers(1, 4))
-    W = int(rng.choice([1, 7, 64, 65, 130, 200, 333])) * (1 if SCALE == 1 else int(rng.integers(1, SCALE + 1)))
+def random_system(rng, invalid=True, P=None, W=None):
+    P = int(rng.integers(1, 4)) if P is None else P
+    W = int(rng.choice([1, 7, 64, 65, 130, 200, 333])) * (1 if SCALE == 1 else int(rng.integers(1, SCALE + 1))) if W is None else W
     kinds_pl = [int(rng.choice([0, 0, 2, 1])) for _ in range(P)]
     has_rv_basis = any(k == 1 for k in kinds_pl)
     has_ti = any(k == 2 for k in kinds_pl)
@@ -103,10 +103,10 @@ def check_system(sysm):
     return bool(same and e_ll < lim_ll and e_g < lim_g), float(e_ll), float(e_g), bool(marg or ti)
 
 
-def draw_system(rng, invalid=True):
+def draw_system(rng, invalid=True, P=None, W=None):
     sysm = None
     while sysm is None:
-        sysm = random_system(rng, invalid=invalid)
+        sysm = random_system(rng, invalid=invalid, P=P, W=W)
     return sysm
 
 

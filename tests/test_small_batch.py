@@ -96,6 +96,47 @@ def test_all_kinds_two_planets_small_batches(oracle, n_walkers):
     assert np.all(rel_err(ll_s, ll_o, 1.0) < 1e-9) and np.all(rel_err(ll_s, ll_b, 1.0) < 1e-9) and np.all(rel_err(ll_g, ll_o, 1.0) < 1e-9)
 
 
+@pytest.mark.parametrize("P,W", [(3, 1), (3, 32), (4, 1), (4, 7)])
+def test_three_and_four_planets_small_batches(oracle, P, W):
+    """k_small is compiled for every planet count the library takes (1-4): random systems on mixed bases with every epoch-loop
+    kind, against the oracle (bars of test_gpu_parity) and against the throughput kernels on the same inputs."""
+    import stress_parity as sp
+    rng = np.random.default_rng(900 + 10 * P + W)
+    took_small = 0
+    for k in range(40):
+        if took_small == 3:
+            break
+        sysm = sp.draw_system(rng, P=P, W=W)
+        good, e_ll, e_g, loose = sp.check_system(sysm)
+        assert good, (k, sp.describe(sysm), e_ll, e_g)
+        obs, planets, elems, nuis = sysm
+        if any(o["kind"] in (3, 7) for o in obs):
+            continue                                  # marginalised RV / HGCA: the throughput kernels at every batch size
+        took_small += 1
+        small, big = _both(obs, planets, elems, nuis)
+        _close(small, big, tol=1e-10)
+    assert took_small == 3
+
+
+@pytest.mark.parametrize("P,W", [(3, 1), (4, 1), (4, 9)])
+def test_three_and_four_planet_models_fused_launch(pkg, oracle, P, W):
+    """The whole callback in one launch (k_small<MODEL>) for 3- and 4-planet systems: random standard-parameterisation models
+    against the oracle's forward-mode log-posterior."""
+    import stress_model as sm
+    rng = np.random.default_rng(700 + 10 * P + W)
+    lib = pkg.capi.load_library()
+    done = 0
+    for k in range(60):
+        if done == 3:
+            break
+        r = sm.check_model(rng, lib, P=P, W=W, small_only=True)
+        if r is None:
+            continue
+        assert r[0], (k,) + r[1:]
+        done += 1
+    assert done == 3
+
+
 def test_golden_vectors_small_and_throughput_paths(golden):
     """Every committed 50/60-digit fixture through BOTH kernel families (the fixtures hold 1-16 walkers, so the default route is
     k_small; small_batch=0 forces k_setup/k_main/k_finish)."""

@@ -167,11 +167,15 @@ int32_t octo_version(int32_t* major, int32_t* minor);
 int32_t octo_ctx_create(octo_ctx** out, int32_t device_id);
 int32_t octo_ctx_destroy(octo_ctx* ctx);
 int32_t octo_consts_set(octo_ctx* ctx, const octo_consts* c);
-/* Batches of up to `max_walkers` parameter sets (default and maximum OCTO_SMALL_BATCH_MAX) take the fused small-batch
- * launch: one kernel with the EPOCHS across the lanes and a wavefront/LDS tree reduction, inputs and outputs in mapped
- * pinned memory — the latency path for samplers that evaluate one θ per call (src/logdensitymodel.jl:169-177). 0 sends
- * every batch through the throughput kernels (lane = walker). Results agree to rounding, not bitwise (different summation order). */
-#define OCTO_SMALL_BATCH_MAX 32
+/* Small and mid-size batches take the fused single-launch kernel: the EPOCHS across the lanes, a wavefront/LDS tree
+ * reduction, one block (or a few) per parameter set — the latency path for samplers that evaluate one θ per call
+ * (src/logdensitymodel.jl:169-177), Pigeons' replicas and an ensemble sampler's 10²-10³ walkers. A batch of W parameter sets
+ * of a P-planet system takes it when W·P <= max_walkers (default OCTO_SMALL_BATCH_DEFAULT, at most OCTO_SMALL_BATCH_MAX:
+ * the measured crossover with the throughput kernels, lane = walker, whose fixed cost is three launches). 0 sends every batch
+ * through the throughput kernels. Host-buffer calls of up to 128 sets use mapped pinned memory (no copy engine), larger ones up
+ * to 1 MiB one pinned DMA each way. Results of the two kernel families agree to rounding, not bitwise (different summation order). */
+#define OCTO_SMALL_BATCH_MAX 1024
+#define OCTO_SMALL_BATCH_DEFAULT 512
 int32_t octo_ctx_set_small_batch(octo_ctx* ctx, int32_t max_walkers);
 const char* octo_last_error(const octo_ctx* ctx);
 

@@ -196,12 +196,12 @@ int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
     return std::max<int64_t>(1, rounds * capacity / cols);
 }
 
-// Small batches: one fused launch, lane = epoch (octo_small.h: k_small). Eligible: W <= SMALL_W, no HGCA table (k_hgca is
-// its own launch) and no marginalised-RV table.
+// Small and mid-size batches: one fused launch, lane = epoch (octo_small.h: k_small). Its cost grows with the number of blocks
+// (one per walker, each deriving P orbits and running the finish), the throughput kernels' with three launches: measured
+// crossover at W·P ≈ 400-1000 (tools/latency_vs_w.py, tools/latency_multi.py). Not eligible: HGCA tables (k_hgca is its own
+// launch) and marginalised-RV tables (their gradient needs the μ̂ pre-pass).
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
-    // (a marginalised-RV table keeps BOTH the forward and the gradient launch on the throughput kernels: the gradient needs
-    // their μ̂ pre-pass, and the value returned with a gradient must be bit-identical to the forward value)
-    return W <= ctx->small_w && ds->n_hgca == 0 && !(ds->kind_mask & KM_MARG);
+    return W * ds->n_planets <= ctx->small_w && W <= SMALL_W && ds->n_hgca == 0 && !(ds->kind_mask & KM_MARG);
 }
 
 int drain_timing(octo_ctx* ctx) {
@@ -294,6 +294,7 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     }
     std::memset(ctx->h_flags, 0, sizeof(uint64_t) * (SMALL_W + 32));
     if (const char* ev = std::getenv("OCTO_SMALL_W")) ctx->small_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
+    if (const char* ev = std::getenv("OCTO_MAPPED_W")) ctx->mapped_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     *out = ctx;
     return OCTO_OK;
 }
@@ -326,7 +327,7 @@ int32_t octo_consts_set(octo_ctx* ctx, const octo_consts* c) {
 
 #ifdef OCTO_SMALL_TRACE
 // development build only: cycle stamps of the last k_small launch's walker-0 finishing block (tools/small_trace.py)
-const uint64_t* octo_debug_small_trace(octo_ctx* ctx) { return ctx ? ctx->h_flags + 40 : nullptr; }
+const uint64_t* octo_debug_small_trace(octo_ctx* ctx) { return ctx ? ctx->h_flags + SMALL_W : nullptr; }
 #endif
 
 int32_t octo_ctx_set_small_batch(octo_ctx* ctx, int32_t max_walkers) {
@@ -560,41 +561,29 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
     pd = octo_ctx::Pending();
     pd.W = W; pd.ld = ld; pd.ldd = ldd; pd.ll = ll_out; pd.g_elems = g_elems; pd.g_nuis = g_nuis;
     pd.n_el_out = g_elems ? n_el : 0; pd.n_nu_out = g_nuis ? n_nu : 0;
-    if (W <= ctx->small_w) {
-        // A handful of parameter sets (a sampler's one θ per call): no copy engine at all. The kernels read the inputs from, and
-        // write the results to, mapped pinned host memory.
+    if (small_eligible(ctx, ds, W) && W <= ctx->mapped_w) {
+        // A handful of parameter sets (a sampler's one θ per call): no copy engine at all. k_small reads the inputs from, and
+        // writes the results to, mapped pinned host memory — walker-major: [elems | nuis] of one walker contiguous (one PCIe read
+        // per block), [ll | g_elems | g_nuis] likewise on the way back; completion through per-walker flags instead of a stream sync.
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_eval: pinned staging allocation failed");
         double *m_in = nullptr, *m_out = nullptr;
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
         pd.staged = true;
-        if (small_eligible(ctx, ds, W)) {
-            // k_small: walker-major staging — [elems | nuis] of one walker contiguous (one PCIe read per block), and
-            // [ll | g_elems | g_nuis] likewise on the way back; completion through per-walker flags instead of a stream sync.
-            const int nn = nuis ? n_nu : 0;
-            const int64_t ws_in = n_el + nn, ws_out = 1 + pd.n_el_out + pd.n_nu_out;
-            for (int64_t w = 0; w < W; ++w) {
-                double* dst = ctx->h_in + w * ws_in;
-                for (int r = 0; r < n_el; ++r) dst[r] = elems[(size_t)r * ld + w];
-                for (int r = 0; r < nn; ++r) dst[n_el + r] = nuis[(size_t)r * ld + w];
-            }
-            pd.walker_major = true; pd.ws_out = ws_out;
-            ctx->stage_ws_in = ws_in; ctx->stage_ws_out = ws_out;
-            ctx->flag_request = true; ctx->flag_armed = false;
-            int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + n_el : nullptr, 1, W, m_out, g_elems ? m_out + 1 : nullptr,
-                                       g_nuis ? m_out + 1 + pd.n_el_out : nullptr, st);
-            ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
-            if (rcz) return rcz;
-            pd.active = true;
-            return OCTO_OK;
+        const int nn = nuis ? n_nu : 0;
+        const int64_t ws_in = n_el + nn, ws_out = 1 + pd.n_el_out + pd.n_nu_out;
+        for (int64_t w = 0; w < W; ++w) {
+            double* dst = ctx->h_in + w * ws_in;
+            for (int r = 0; r < n_el; ++r) dst[r] = elems[(size_t)r * ld + w];
+            for (int r = 0; r < nn; ++r) dst[n_el + r] = nuis[(size_t)r * ld + w];
         }
-        // datasets k_small does not take (HGCA, marginalised RV): the throughput kernels on the same mapped buffers
-        for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
-        if (nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
-        pd.o_ge = ldd; pd.o_gn = (int64_t)(1 + pd.n_el_out) * ldd;
-        int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + (int64_t)n_el * ldd : nullptr, ldd, W, m_out, g_elems ? m_out + pd.o_ge : nullptr,
-                                   g_nuis ? m_out + pd.o_gn : nullptr, st);
+        pd.walker_major = true; pd.ws_out = ws_out;
+        ctx->stage_ws_in = ws_in; ctx->stage_ws_out = ws_out;
+        ctx->flag_request = true; ctx->flag_armed = false;
+        int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + n_el : nullptr, 1, W, m_out, g_elems ? m_out + 1 : nullptr,
+                                   g_nuis ? m_out + 1 + pd.n_el_out : nullptr, st);
+        ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
         if (rcz) return rcz;
         pd.active = true;
         return OCTO_OK;
@@ -607,6 +596,23 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
     double* d_ll = ctx->d_out;
     double* d_ge = g_elems ? ctx->d_out + ldd : nullptr;
     double* d_gn = g_nuis ? ctx->d_out + (int64_t)(1 + (g_elems ? n_el : 0)) * ldd : nullptr;
+    if ((n_in + n_out) * (int64_t)sizeof(double) <= STAGE_DMA_BYTES) {
+        // Mid-size batches (an ensemble sampler's 10²-10³ walkers): the rows are packed into ONE pinned buffer and cross the
+        // link as one DMA each way — pageable 2-D copies cost ~8 µs apiece, and a mapped buffer would have every k_main block
+        // fetch its walkers' nuisances over PCIe.
+        if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
+            return fail(ctx, OCTO_ENOMEM, "octo_eval: pinned staging allocation failed");
+        for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
+        if (nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, ctx->h_in, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, st));
+        rc = octo_eval_device(ctx, ds, ctx->d_in, d_nuis, ldd, W, d_ll, d_ge, d_gn, st);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, st));
+        pd.staged = true; pd.walker_major = false;
+        pd.o_ge = ldd; pd.o_gn = (int64_t)(1 + pd.n_el_out) * ldd;
+        pd.active = true;
+        return OCTO_OK;
+    }
     HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, elems, sizeof(double) * ld, sizeof(double) * W, n_el,
                                  hipMemcpyHostToDevice, st));
     if (nuis)
@@ -916,37 +922,28 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     hipStream_t st;
     { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
     const int64_t n_in = (int64_t)m->D * ldd, n_out = (int64_t)(grad_out ? m->D + 1 : 1) * ldd;
-    if (W <= ctx->small_w) {      // one θ_t per call (NUTS): mapped pinned buffers, no copy engine (see octo_eval)
+    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && W <= ctx->mapped_w) {
+        // one θ_t per call (NUTS): the fused launch on mapped pinned buffers, no copy engine (see octo_eval) — θ_t of one walker
+        // contiguous on the way in, [lp | ∇θ_t] on the way out, completion by flag
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");
         double *m_in = nullptr, *m_out = nullptr;
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
-        if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted) {
-            // the fused launch: θ_t of one walker contiguous on the way in, [lp | ∇θ_t] on the way out, completion by flag
-            const int64_t D = m->D, ws_o = grad_out ? D + 1 : 1;
-            for (int64_t w = 0; w < W; ++w)
-                for (int r = 0; r < D; ++r) ctx->h_in[w * D + r] = theta_t[(size_t)r * ld + w];
-            ctx->stage_ws_in = D; ctx->stage_ws_out = ws_o;
-            ctx->flag_request = true; ctx->flag_armed = false;
-            int rcz = octo_model_logpost_device(ctx, m, m_in, 1, W, m_out, grad_out ? m_out + 1 : nullptr, st);
-            ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
-            if (rcz) return rcz;
-            rcz = wait_small(ctx, st, W);
-            if (rcz) return rcz;
-            for (int64_t w = 0; w < W; ++w) {
-                lp_out[w] = ctx->h_out[w * ws_o];
-                if (grad_out) for (int r = 0; r < D; ++r) grad_out[(size_t)r * ld + w] = ctx->h_out[w * ws_o + 1 + r];
-            }
-            free_retired(ctx);
-            return OCTO_OK;
-        }
-        for (int r = 0; r < m->D; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, theta_t + (size_t)r * ld, sizeof(double) * W);
-        int rcz = octo_model_logpost_device(ctx, m, m_in, ldd, W, m_out, grad_out ? m_out + ldd : nullptr, st);
+        const int64_t D = m->D, ws_o = grad_out ? D + 1 : 1;
+        for (int64_t w = 0; w < W; ++w)
+            for (int r = 0; r < D; ++r) ctx->h_in[w * D + r] = theta_t[(size_t)r * ld + w];
+        ctx->stage_ws_in = D; ctx->stage_ws_out = ws_o;
+        ctx->flag_request = true; ctx->flag_armed = false;
+        int rcz = octo_model_logpost_device(ctx, m, m_in, 1, W, m_out, grad_out ? m_out + 1 : nullptr, st);
+        ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
         if (rcz) return rcz;
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        std::memcpy(lp_out, ctx->h_out, sizeof(double) * W);
-        if (grad_out) for (int r = 0; r < m->D; ++r) std::memcpy(grad_out + (size_t)r * ld, ctx->h_out + (size_t)(1 + r) * ldd, sizeof(double) * W);
+        rcz = wait_small(ctx, st, W);
+        if (rcz) return rcz;
+        for (int64_t w = 0; w < W; ++w) {
+            lp_out[w] = ctx->h_out[w * ws_o];
+            if (grad_out) for (int r = 0; r < D; ++r) grad_out[(size_t)r * ld + w] = ctx->h_out[w * ws_o + 1 + r];
+        }
         free_retired(ctx);
         return OCTO_OK;
     }
@@ -954,7 +951,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     if (rc) return rc;
     rc = grow(ctx, m->d_res, m->cap_res, (int64_t)(m->D + 1) * ldd);
     if (rc) return rc;
-    if ((n_in + n_out) * (int64_t)sizeof(double) <= (1 << 18)) {      // small batch: one pinned transfer each way (see octo_eval)
+    if ((n_in + n_out) * (int64_t)sizeof(double) <= STAGE_DMA_BYTES) {      // mid-size batch: one pinned transfer each way (see octo_eval)
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");
         for (int r = 0; r < m->D; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, theta_t + (size_t)r * ld, sizeof(double) * W);

@@ -100,7 +100,9 @@ struct octo_ctx {
     // parallel tempering over RCCL (octo_comm.hip)
     void* comm = nullptr;                       // ncclComm_t
     int comm_rank = 0, comm_world = 1;
-    int small_w = SMALL_W;                      // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
+    int small_w = OCTO_SMALL_BATCH_DEFAULT;     // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
+    int mapped_w = 128;                         // host-buffer calls up to this size let k_small read/write mapped pinned memory; larger
+                                                // ones cross the link as one DMA each way (OCTO_MAPPED_W: experiments)
     double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
     int64_t cap_in = 0, cap_out = 0;
     double *h_in = nullptr, *h_out = nullptr;   // pinned mirrors of d_in / d_out for SMALL batches: one transfer each way instead of
@@ -151,6 +153,8 @@ bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);
 // Launch of one evaluation for a dataset with P planets (octo_launch.h; instantiated in octo_inst_p<P>.hip).
 template <int P>
 int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st);
+constexpr int64_t STAGE_DMA_BYTES = 1 << 20;   // host-buffer calls up to this size (inputs + outputs) are staged in pinned memory
+
 extern template int dispatch1<1>(octo_ctx*, const octo_dataset*, EvalArgs&, bool, bool, const SmallModel*, hipStream_t);
 extern template int dispatch1<2>(octo_ctx*, const octo_dataset*, EvalArgs&, bool, bool, const SmallModel*, hipStream_t);
 extern template int dispatch1<3>(octo_ctx*, const octo_dataset*, EvalArgs&, bool, bool, const SmallModel*, hipStream_t);

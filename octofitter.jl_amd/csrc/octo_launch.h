@@ -18,7 +18,9 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     if (const char* ev = std::getenv("OCTO_SMALL_BLOCKS")) { const int v = std::atoi(ev); if (v > 0) total_blocks = v; }   // experiments
     const int64_t target_tasks = std::max<int64_t>(1, total_blocks / a.W);
     int64_t span = (ds->n_rows + target_tasks - 1) / target_tasks;
-    span = std::max<int64_t>(SMALL_TPB, (span + SMALL_TPB - 1) / SMALL_TPB * SMALL_TPB);
+    int64_t min_span = a.W < 64 ? SMALL_TPB : 4 * SMALL_TPB;      // many walkers fill the chip by themselves: split a walker's rows only when each part is worth a block
+    if (const char* ev = std::getenv("OCTO_SMALL_MIN_SPAN")) { const int v = std::atoi(ev); if (v > 0) min_span = v; }   // experiments
+    span = std::max<int64_t>(min_span, (span + SMALL_TPB - 1) / SMALL_TPB * SMALL_TPB);
     TaskTable* tt = nullptr;
     int rc = get_tasks(ctx, ds, -(span / WPB), &tt);
     if (rc) return rc;

@@ -428,7 +428,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     if (done_flags && lane == 0) __hip_atomic_store(done_flags + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef OCTO_SMALL_TRACE
     TRACE_POINT();
-    if (done_flags && w == 0 && lane == 0) for (int k = 0; k < ntr; ++k) done_flags[40 + k] = tr[k];      // h_flags has room behind the SMALL_W flags
+    if (done_flags && w == 0 && lane == 0) for (int k = 0; k < ntr; ++k) done_flags[SMALL_W + k] = tr[k];      // h_flags has room behind the SMALL_W flags
 #endif
 }
 

@@ -11,8 +11,13 @@ pkg = load_package()
 capi = pkg.capi
 
 
+DEFAULT_SMALL_BATCH = None      # tests that want every case through BOTH kernel families set this (None: the library's own choice)
+
+
 class GpuPath:
     def __init__(self, obs_tables, planets, device=0, consts=None, small_batch=None):
+        if small_batch is None:
+            small_batch = DEFAULT_SMALL_BATCH
         self.lib = capi.load_library()
         self.ctx = C.c_void_p()
         st = self.lib.octo_ctx_create(C.byref(self.ctx), device)

@@ -22,6 +22,16 @@ from test_oracle import grad_ok, northangle_scan, _northangle_tables
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=[None, 0], ids=["auto", "throughput"])
+def _kernel_family(request):
+    """Every case of this module twice: with the library's own choice of kernel family (k_small for W·P <= 512) and forced onto
+    the throughput kernels (lane = walker), so that mid-size batches keep checking both against the oracle."""
+    import gpu_binding
+    gpu_binding.DEFAULT_SMALL_BATCH = request.param
+    yield
+    gpu_binding.DEFAULT_SMALL_BATCH = None
+
 LL_RTOL = 1e-12
 G_RTOL = 1e-9
 G_CANCEL = 1e-13

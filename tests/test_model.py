@@ -229,7 +229,7 @@ def test_gpu_batched_callers(pkg):
     a = chain["samples"][model.names.index("b_a")]
     assert 6.0 < np.median(a) < 15.0                                         # truth a = 10 (prior 5-20)
     ll = pkg.rejection_evaluate_likelihoods(model, chain["samples"])
-    assert np.allclose(ll, chain["loglike"], rtol=0, atol=0)
+    assert np.allclose(ll, chain["loglike"], rtol=1e-13, atol=0)      # another batch size may take the other kernel family: equal to rounding
     model.close()
 
 

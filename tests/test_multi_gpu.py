@@ -35,10 +35,10 @@ def test_eval_multi_splits_a_host_batch(pkg, oracle):
     t = cfg["table"]
     obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
     planets = [dict(orbit_kind=0, has_mass=False)]
-    ref = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=True)
+    ref = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=True, small_batch=0)      # throughput kernels for the batch and for every slice
     n_vis = _device_count()
     for devices in ([0, 0], [0, 0, 0], list(range(n_vis)) if n_vis > 1 else [0]):
-        paths = [gb.GpuPath(obs, planets, device=d) for d in devices]
+        paths = [gb.GpuPath(obs, planets, device=d, small_batch=0) for d in devices]
         n = len(paths)
         ctxs = (C.c_void_p * n)(*[p.ctx for p in paths]); dss = (C.c_void_p * n)(*[p.ds for p in paths])
         el = np.ascontiguousarray(cfg["elems"]); W = el.shape[1]

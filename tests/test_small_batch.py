@@ -1,9 +1,9 @@
 """
 GPU parity of the small-batch path (-m gpu): octo_eval with W <= 32 takes the fused single-launch kernel k_small — epochs across
 the 64 lanes, DPP/LDS tree reduction, last-block finish, inputs/outputs in mapped pinned memory (what a sampler that evaluates
-ONE θ per call pays: src/logdensitymodel.jl:169-177, src/likelihoods/system.jl:257-269). Checked against the oracle at
-W ∈ {1, 2, 31, 32, 33} (33 is the first size on the throughput kernels) and against the throughput kernels on the same inputs
-(same math, different summation order: equal to rounding, not bitwise).
+ONE θ per call pays: src/logdensitymodel.jl:169-177, src/likelihoods/system.jl:257-269); the same kernel serves mid-size batches
+(W·P <= 512: an ensemble sampler's walkers). Checked against the oracle at W ∈ {1, 2, 31, 32, 33, 128, 129, 512} and against the
+throughput kernels on the same inputs (same math, different summation order: equal to rounding, not bitwise).
 """
 import numpy as np
 import pytest
@@ -38,7 +38,7 @@ def _close(small, big, tol=2e-12):
         assert np.all(np.abs(gn - gn_b) <= 1e-10 * sc)
 
 
-@pytest.mark.parametrize("n_walkers", [1, 2, 31, 32, 33])
+@pytest.mark.parametrize("n_walkers", [1, 2, 31, 32, 33, 128, 129, 512])      # 128/129: mapped pinned buffers -> one DMA each way
 @pytest.mark.parametrize("n_epochs", [1, 50, 300, 10_000])
 def test_astrometry_small_batches_vs_oracle(oracle, n_epochs, n_walkers):
     cfg = synth.config_astrom(n_epochs=n_epochs, n_walkers=n_walkers, seed=7000 + n_epochs + n_walkers)

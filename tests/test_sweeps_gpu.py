@@ -13,6 +13,16 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[None, 0], ids=["auto", "throughput"])
+def _kernel_family(request):
+    """Every case of this module twice: with the library's own choice of kernel family (k_small for W·P <= 512) and forced onto
+    the throughput kernels (lane = walker), so that mid-size batches keep checking both against the oracle."""
+    import gpu_binding
+    gpu_binding.DEFAULT_SMALL_BATCH = request.param
+    yield
+    gpu_binding.DEFAULT_SMALL_BATCH = None
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
 def test_random_systems_vs_oracle(oracle, seed):
     import stress_parity as sp

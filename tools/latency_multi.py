@@ -22,8 +22,8 @@ def time_call(f, n=3000, warm=300):
 
 
 rng = np.random.default_rng(5)
-for P in (1, 2, 3, 4):
-    W = 1
+Ws = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1]
+for P, W in [(P, W) for P in (1, 2, 3, 4) for W in Ws]:
     planets = [dict(orbit_kind=0, has_mass=True) for _ in range(P)]
     elems = np.concatenate([sp.planet_elems(rng, W, 0, 2 + 6 * i, 6 + 6 * i) for i in range(P)])
     obs = []
@@ -36,9 +36,9 @@ for P in (1, 2, 3, 4):
     for io in range(P):
         nuis[io * 3] = 1.0; nuis[io * 3 + 1] = 1.0
     nuis[P * 3] = 3.0; nuis[P * 3 + 1] = 2.0
-    for sb in (None, 0):
+    for sb in (1024, 0):
         with gb.GpuPath(obs, planets, small_batch=sb) as g:
             el = np.ascontiguousarray(elems); nu = np.ascontiguousarray(nuis); ll = np.empty(W); ge = np.empty_like(el); gn = np.empty_like(nu)
             args = (g.ctx, g.ds, capi._dptr(el), capi._dptr(nu), W, W, capi._dptr(ll), capi._dptr(ge), capi._dptr(gn))
-            us = time_call(lambda: g.lib.octo_eval(*args))
-            print(f"P={P} W=1 rows={60 * P + 200} fwd+grad {'small-batch kernel' if sb is None else 'throughput kernels '} {us:7.1f} us  ll={ll[0]:.6f}", flush=True)
+            us = time_call(lambda: g.lib.octo_eval(*args), n=1000, warm=100)
+            print(f"P={P} W={W} rows={60 * P + 200} fwd+grad {'small-batch kernel' if sb else 'throughput kernels '} {us:7.1f} us  ll={ll[0]:.6f}", flush=True)

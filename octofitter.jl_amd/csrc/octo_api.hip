@@ -95,7 +95,7 @@ double row_cost(int kind) {
 
 // Build (or fetch) the row partition. One block = WPB waves × `chunk` rows of ONE table for one walker tile; tasks never
 // straddle tables and tables keep their order, so k_finish can sum each observation's partials contiguously and in a
-// fixed order. key > 0: about `key` tasks in total, shared between the tables in proportion to rows × row cost, each
+// fixed order. key <= −SMALL_KEY: k_small's partition, −key − SMALL_KEY rows per wave; key > 0: about `key` tasks in total, shared between the tables in proportion to rows × row cost, each
 // table cut into EQUAL tasks (no ragged last task); key < 0: −key rows per wave everywhere (OCTO_CHUNK experiments).
 int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out) {
     // The cache belongs to the CONTEXT (one owner thread), not to the dataset, which stays immutable and can therefore be
@@ -118,7 +118,8 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
         const int64_t n = ds->h_obs[o].n;
         if (n <= 0) continue;
         int64_t chunk;
-        if (key < 0) chunk = -key;
+        if (key <= -SMALL_KEY) chunk = (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) ? (n + WPB - 1) / WPB : -(key + SMALL_KEY);   // k_small: a marginalised-RV table in ONE block (its μ̂)
+        else if (key < 0) chunk = -key;
         else {
             int64_t t_o = std::llround((double)key * (double)n * row_cost(ds->h_obs[o].kind) / wsum);
             t_o = std::min<int64_t>(std::max<int64_t>(t_o, 1), std::max<int64_t>(1, n / (32 * WPB)));   // >= 32 rows per wave (small batches: 56 µs at 32, 62 at 16 for 1024 walkers)
@@ -199,9 +200,9 @@ int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
 // Small and mid-size batches: one fused launch, lane = epoch (octo_small.h: k_small). Its cost grows with the number of blocks
 // (one per walker, each deriving P orbits and running the finish), the throughput kernels' with three launches: measured
 // crossover at W·P ≈ 400-1000 (tools/latency_vs_w.py, tools/latency_multi.py). Not eligible: HGCA tables (k_hgca is its own
-// launch) and marginalised-RV tables (their gradient needs the μ̂ pre-pass).
+// launch).
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
-    return W * ds->n_planets <= ctx->small_w && W <= SMALL_W && ds->n_hgca == 0 && !(ds->kind_mask & KM_MARG);
+    return W * ds->n_planets <= ctx->small_w && W <= SMALL_W && ds->n_hgca == 0;
 }
 
 int drain_timing(octo_ctx* ctx) {

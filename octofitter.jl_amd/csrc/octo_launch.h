@@ -22,7 +22,7 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     if (const char* ev = std::getenv("OCTO_SMALL_MIN_SPAN")) { const int v = std::atoi(ev); if (v > 0) min_span = v; }   // experiments
     span = std::max<int64_t>(min_span, (span + SMALL_TPB - 1) / SMALL_TPB * SMALL_TPB);
     TaskTable* tt = nullptr;
-    int rc = get_tasks(ctx, ds, -(span / WPB), &tt);
+    int rc = get_tasks(ctx, ds, -(span / WPB) - SMALL_KEY, &tt);
     if (rc) return rc;
     a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;
     a.obs_range = tt->d_obs_range; a.obs_const = NUIS ? tt->d_obs_const_raw : tt->d_obs_const_pre;

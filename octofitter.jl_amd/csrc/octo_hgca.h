@@ -55,7 +55,7 @@ static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
         D el[OCTO_N_EL];
 #pragma unroll
         for (int k = 0; k < OCTO_N_EL; ++k) {
-            const double v = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl];
+            const double v = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl * a.ws_in];      // ws_in: 1, or the walker stride of k_small's staging
             el[k] = (dir == p * OCTO_N_EL + k) ? dvar<1>(v, 0) : dconst<1>(v);
         }
         if (!a.has_mass[p]) el[OCTO_EL_MASS] = dconst<1>(0.0);
@@ -95,7 +95,7 @@ static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
         D pm_sys[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const double v = a.nuis[((int64_t)o * OCTO_N_NUIS + k) * a.ld + wl];
+            const double v = a.nuis[((int64_t)o * OCTO_N_NUIS + k) * a.ld + wl * a.ws_in];
             pm_sys[k] = (dir == P * OCTO_N_EL + o * OCTO_N_NUIS + k) ? dvar<1>(v, 0) : dconst<1>(v);
         }
         D pos[2][2], pm[2][2];

@@ -31,6 +31,18 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     if (rc) return rc;
     a.partials = ctx->d_partials;
     a.marg = nullptr; a.marg_out = nullptr; a.extra = nullptr;
+    if (ds->n_hgca > 0) {      // the proper-motion anomaly has no epoch loop: its own small launch, consumed by k_small's finish
+        if constexpr (NUIS && !MODEL) {
+            const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
+            rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
+            if (rc) return rc;
+            a.extra = ctx->d_extra;
+            hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)((a.W + WAVE - 1) / WAVE), (unsigned)n_dir), dim3(WAVE), 0, st, a);
+        } else {
+            return fail(ctx, OCTO_EINVAL, MODEL ? "internal: fused model launch requested for a dataset with an OCTO_HGCA table"
+                                                : "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
+        }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
     if (timed) {

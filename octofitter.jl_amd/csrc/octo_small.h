@@ -401,8 +401,8 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                     for (int r = 0; r < OCTO_N_NUIS; ++r) gth = fma(nuD[r].d[0], gn3[r], gth);
                 }
             } else {
-                ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + wo : nullptr, nullptr, a.ldw, a.c.k_yr,
-                                                    o, v, a.obs_const[o], sma_p, e_p, M_p, lane == 0, oneil_g);
+                ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + wo : nullptr, a.extra ? a.extra + w : nullptr,
+                                                    a.ldw, a.c.k_yr, o, v, a.obs_const[o], sma_p, e_p, M_p, lane == 0, oneil_g);
             }
         }
         __syncthreads();
@@ -413,6 +413,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
 #pragma unroll
     for (int k = 0; k < P * L::PL_N; ++k) gp[k] = lane_value(gp_acc, L::OFF_PL + k);
     if (multi && lane == 0) __hip_atomic_store(&counters[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    if constexpr (!MODEL) { if (a.extra) ll += a.extra[w]; }      // k_hgca's log-likelihood (launched ahead of this kernel)
     ok = ok && isfinite(ll);
     if constexpr (MODEL) {
         // ℓπcallback: non-finite θ_t -> -Inf; non-finite prior -> returned without the likelihood (logdensitymodel.jl:120-133);
@@ -443,7 +444,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 }
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    planet_finish<P, GRAD, NUIS, KM, true>(elv[p], a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p],
+                    planet_finish<P, GRAD, NUIS, KM, true>(elv[p], a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p],
                                                            p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp[p], ok);
             }
         }

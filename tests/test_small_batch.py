@@ -108,8 +108,6 @@ def test_three_and_four_planets_small_batches(oracle, P, W):
         good, e_ll, e_g, loose = sp.check_system(sysm)
         assert good, (k, sp.describe(sysm), e_ll, e_g)
         obs, planets, elems, nuis = sysm
-        if any(o["kind"] == 7 for o in obs):
-            continue                                  # HGCA: the throughput kernels at every batch size
         took_small += 1
         small, big = _both(obs, planets, elems, nuis)
         marg = any(o["kind"] == 3 for o in obs)

@@ -199,8 +199,8 @@ int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
 
 // Small and mid-size batches: one fused launch, lane = epoch (octo_small.h: k_small). Its cost grows with the number of blocks
 // (one per walker, each deriving P orbits and running the finish), the throughput kernels' with three launches: measured
-// crossover at W·P ≈ 400-1000 (tools/latency_vs_w.py, tools/latency_multi.py). An HGCA table adds its own small launch
-// (k_hgca) ahead of k_small; the fused model launch does not take such datasets (the elements must be in memory for k_hgca).
+// crossover at W·P ≈ 400-1000 (tools/latency_vs_w.py, tools/latency_multi.py). An HGCA table adds blocks to the same launch
+// (one input direction per wave) for W <= 16, the k_hgca launch ahead of it otherwise.
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
     return W * ds->n_planets <= ctx->small_w && W <= SMALL_W;
 }
@@ -858,7 +858,7 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st;
     { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
-    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && m->ds->n_hgca == 0) {
+    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
         // one launch: θ_t -> priors, elements, likelihood, ∇θ_t inside k_small<MODEL> (octo_small.h)
         SmallModel sm;
         std::memset(&sm, 0, sizeof(sm));
@@ -923,7 +923,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     hipStream_t st;
     { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
     const int64_t n_in = (int64_t)m->D * ldd, n_out = (int64_t)(grad_out ? m->D + 1 : 1) * ldd;
-    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && m->ds->n_hgca == 0 && W <= ctx->mapped_w) {
+    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && (m->ds->n_hgca == 0 || hgca_in_small(W)) && W <= ctx->mapped_w) {
         // one θ_t per call (NUTS): the fused launch on mapped pinned buffers, no copy engine (see octo_eval) — θ_t of one walker
         // contiguous on the way in, [lp | ∇θ_t] on the way out, completion by flag
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))

@@ -39,26 +39,19 @@ __device__ __forceinline__ Dual<1> hgca_logpdf2(const Dual<1>& r1, const Dual<1>
     return q * (-0.5) + (-LOG2PI - 0.5 * log(s1 * s1 * s2 * s2 * omr));
 }
 
-// grid = (walker tiles of 64, P·9 + n_obs·3 input directions), block = 64
+// The companions' constants at walker wl with input direction `dir` seeded (one partial, as ForwardDiff would carry it).
 template <int P>
-static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
+__device__ __forceinline__ void hgca_setup(const double (&elv)[P][OCTO_N_EL], const int32_t (&orbit_kind)[MAXP], const int32_t (&has_mass)[MAXP], const DevConsts& c,
+                                           int dir, HgcaPlanet (&hp)[P], bool (&visual)[P]) {
     using D = Dual<1>;
-    const int64_t w = (int64_t)blockIdx.x * WAVE + threadIdx.x;
-    const int64_t wl = w < a.W ? w : a.W - 1;
-    const int dir = blockIdx.y;
-    HgcaPlanet hp[P];
-    bool visual[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        visual[p] = a.orbit_kind[p] != OCTO_ORBIT_RADVEL && a.orbit_kind[p] != OCTO_ORBIT_KEP;      // Visual{KepOrbit} or ThieleInnesOrbit (hgca.jl:255-262)
-        const bool ti = a.orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
+        visual[p] = orbit_kind[p] != OCTO_ORBIT_RADVEL && orbit_kind[p] != OCTO_ORBIT_KEP;      // Visual{KepOrbit} or ThieleInnesOrbit (hgca.jl:255-262)
+        const bool ti = orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
         D el[OCTO_N_EL];
 #pragma unroll
-        for (int k = 0; k < OCTO_N_EL; ++k) {
-            const double v = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl * a.ws_in];      // ws_in: 1, or the walker stride of k_small's staging
-            el[k] = (dir == p * OCTO_N_EL + k) ? dvar<1>(v, 0) : dconst<1>(v);
-        }
-        if (!a.has_mass[p]) el[OCTO_EL_MASS] = dconst<1>(0.0);
+        for (int k = 0; k < OCTO_N_EL; ++k) el[k] = (dir == p * OCTO_N_EL + k) ? dvar<1>(elv[p][k], 0) : dconst<1>(elv[p][k]);
+        if (!has_mass[p]) el[OCTO_EL_MASS] = dconst<1>(0.0);
         const D e = el[OCTO_EL_E], Mt = el[OCTO_EL_M];
         HgcaPlanet& h = hp[p];
         D sma;
@@ -74,19 +67,61 @@ static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
             inc.v = inc.v - PI * floor(inc.v / PI);                // KepOrbit ctor invariants, as in k_setup
             Om.v = Om.v - TWO_PI * floor(Om.v / TWO_PI);
             sma = el[OCTO_EL_A];
-            h.T = sma * el[OCTO_EL_PLX] * a.c.mas_per_au_per_plx;   // parameterizations.jl:215-216
+            h.T = sma * el[OCTO_EL_PLX] * c.mas_per_au_per_plx;   // parameterizations.jl:215-216
             const D ci = dcos(inc), sw = dsin(el[OCTO_EL_W]), cw = dcos(el[OCTO_EL_W]), sO = dsin(Om), cO = dcos(Om);
             h.cA = cO * cw - sO * sw * ci; h.cB = sO * cw + cO * sw * ci;
             h.cF = -(cO * sw) - sO * cw * ci; h.cG = -(sO * sw) + cO * cw * ci;
         }
-        const D P_d = dsqrt(sma * sma * sma / Mt) * a.c.k_yr;   // parameterizations.jl:62
+        const D P_d = dsqrt(sma * sma * sma / Mt) * c.k_yr;   // parameterizations.jl:62
         h.e = e; h.tp = el[OCTO_EL_TP];
         h.beta = dsqrt(dconst<1>(1.0) - e * e);
         h.n_day = dconst<1>(TWO_PI) / P_d;
-        h.fac = -(el[OCTO_EL_MASS] * a.c.mjup2msol) / Mt;      // q(sol, M_planet) = −M_planet/M_tot · q(sol)
+        h.fac = -(el[OCTO_EL_MASS] * c.mjup2msol) / Mt;      // q(sol, M_planet) = −M_planet/M_tot · q(sol)
         h.pc = PC{};
         h.pc.invP = 1.0 / P_d.v; h.pc.tp = h.tp.v; h.pc.e = e.v;
         h.pc.ef = (float)e.v; h.pc.omef = (float)(1.0 - e.v); h.pc.k1f = (float)(MK_K1N / (1.0 + e.v));
+    }
+}
+
+// The observation's three 2-D Gaussians from the epoch-averaged positions and proper motions (hgca.jl:301-382).
+__device__ __forceinline__ Dual<1> hgca_terms(Dual<1> (&pos)[2][2], Dual<1> (&pm)[2][2], double (&ep)[2][2], const int (&cnt)[2][2],
+                                              const Dual<1> (&pm_sys)[2], double yd, const double* __restrict__ x /* the 15 catalogue numbers */) {
+    using D = Dual<1>;
+    D model[3][2];
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {                       // :301-308, 353-360
+            const double ic = 1.0 / (double)cnt[m][ax];
+            pos[m][ax] = pos[m][ax] * ic; pm[m][ax] = pm[m][ax] * ic + pm_sys[ax]; ep[m][ax] *= ic;
+        }
+        model[0][ax] = pm[0][ax];
+        model[1][ax] = (pos[1][ax] - pos[0][ax]) * (yd / (ep[1][ax] - ep[0][ax])) + pm_sys[ax];   // :379-382
+        model[2][ax] = pm[1][ax];
+    }
+    D ll = dconst<1>(0.0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        ll = ll + hgca_logpdf2(model[k][0] + (-x[5 * k]), model[k][1] + (-x[5 * k + 1]), x[5 * k + 2], x[5 * k + 3], x[5 * k + 4]);
+    return ll;
+}
+
+// grid = (walker tiles of 64, P·9 + n_obs·3 input directions), block = 64
+template <int P>
+static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
+    using D = Dual<1>;
+    const int64_t w = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    const int64_t wl = w < a.W ? w : a.W - 1;
+    const int dir = blockIdx.y;
+    HgcaPlanet hp[P];
+    bool visual[P];
+    {
+        double elv[P][OCTO_N_EL];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl * a.ws_in];      // ws_in: 1, or the walker stride of k_small's staging
+        hgca_setup<P>(elv, a.orbit_kind, a.has_mass, a.c, dir, hp, visual);
     }
     D ll = dconst<1>(0.0);
     for (int o = 0; o < a.n_obs; ++o) {
@@ -122,22 +157,7 @@ static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
                         if (mm == m && aa == ax) { cnt[mm][aa] += 1; ep[mm][aa] += t; pos[mm][aa] = pos[mm][aa] + q; pm[mm][aa] = pm[mm][aa] + v; }
             }
         }
-        D model[3][2];
-#pragma unroll
-        for (int ax = 0; ax < 2; ++ax) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {                       // :301-308, 353-360
-                const double ic = 1.0 / (double)cnt[m][ax];
-                pos[m][ax] = pos[m][ax] * ic; pm[m][ax] = pm[m][ax] * ic + pm_sys[ax]; ep[m][ax] *= ic;
-            }
-            model[0][ax] = pm[0][ax];
-            model[1][ax] = (pos[1][ax] - pos[0][ax]) * (a.c.yd / (ep[1][ax] - ep[0][ax])) + pm_sys[ax];   // :379-382
-            model[2][ax] = pm[1][ax];
-        }
-        const double* x = ob.pre;                              // the 15 catalogue numbers
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            ll = ll + hgca_logpdf2(model[k][0] + (-x[5 * k]), model[k][1] + (-x[5 * k + 1]), x[5 * k + 2], x[5 * k + 3], x[5 * k + 4]);
+        ll = ll + hgca_terms(pos, pm, ep, cnt, pm_sys, a.c.yd, ob.pre);
     }
     if (w < a.W) {
         if (dir == 0) a.extra[w] = ll.v;

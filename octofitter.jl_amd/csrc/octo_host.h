@@ -153,6 +153,7 @@ bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);
 // Launch of one evaluation for a dataset with P planets (octo_launch.h; instantiated in octo_inst_p<P>.hip).
 template <int P>
 int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st);
+inline bool hgca_in_small(int64_t W) { return W <= 16; }      // k_small computes the HGCA term itself (else k_hgca ahead of it)
 constexpr int64_t SMALL_KEY = (int64_t)1 << 40;   // get_tasks keys at or below −SMALL_KEY: k_small's row partition
 constexpr int64_t STAGE_DMA_BYTES = 1 << 20;   // host-buffer calls up to this size (inputs + outputs) are staged in pinned memory
 

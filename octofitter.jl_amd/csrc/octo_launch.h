@@ -31,16 +31,21 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     if (rc) return rc;
     a.partials = ctx->d_partials;
     a.marg = nullptr; a.marg_out = nullptr; a.extra = nullptr;
-    if (ds->n_hgca > 0) {      // the proper-motion anomaly has no epoch loop: its own small launch, consumed by k_small's finish
-        if constexpr (NUIS && !MODEL) {
+    a.n_hblocks = 0;
+    if (ds->n_hgca > 0) {
+        // The proper-motion anomaly has no epoch loop. A handful of walkers: extra blocks of the same launch, one input direction
+        // per wave, lanes over the table's rows (26 µs per call at W = 1 instead of 30 with a launch of its own). More walkers:
+        // k_hgca (lane = walker) ahead of k_small — 4-5 more blocks per walker would each fetch the walker's inputs again.
+        if constexpr (NUIS) {
             const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
             rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
             if (rc) return rc;
             a.extra = ctx->d_extra;
-            hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)((a.W + WAVE - 1) / WAVE), (unsigned)n_dir), dim3(WAVE), 0, st, a);
+            if (hgca_in_small(a.W)) a.n_hblocks = GRAD ? (n_dir + SMALL_TPB / WAVE - 1) / (SMALL_TPB / WAVE) : 1;
+            else if constexpr (!MODEL) hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)((a.W + WAVE - 1) / WAVE), (unsigned)n_dir), dim3(WAVE), 0, st, a);
+            else return fail(ctx, OCTO_EINVAL, "internal: fused model launch requested for an HGCA dataset beyond hgca_in_small");
         } else {
-            return fail(ctx, OCTO_EINVAL, MODEL ? "internal: fused model launch requested for a dataset with an OCTO_HGCA table"
-                                                : "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
+            return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
         }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -61,7 +66,7 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     SmallModel sm;
     std::memset(&sm, 0, sizeof(sm));
     if (MODEL) sm = *smp;
-    hipLaunchKernelGGL((k_small<P, GRAD, NUIS, KM, MODEL>), dim3((unsigned)std::max(a.n_tasks, 1), (unsigned)a.W), dim3(SMALL_TPB), 0, st, a, sm,
+    hipLaunchKernelGGL((k_small<P, GRAD, NUIS, KM, MODEL>), dim3((unsigned)(std::max(a.n_tasks, 1) + a.n_hblocks), (unsigned)a.W), dim3(SMALL_TPB), 0, st, a, sm,
                        ctx->d_counters, flags, ctx->flag_seq);
     if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
     HIPCHK(ctx, hipGetLastError());

@@ -8,6 +8,8 @@
 //   * with more than one task per walker, blocks publish their partial with device-scope (write-through) atomic stores and
 //     bump a per-walker counter; the block that sees the last count sums the partials IN TASK ORDER (so the result does not
 //     depend on which block that is) and runs the finish — no k_finish launch;
+//   * an HGCA table (hgca.jl:155-400: no epoch loop, forward-mode partials) is evaluated by n_hblocks extra blocks per walker, one
+//     input direction per WAVE with its lanes over the table's rows, published and counted like the row partials;
 //   * inputs and outputs may live in mapped pinned host memory and completion is signalled through per-walker flags there,
 //     so a host-buffer call is one launch and no copy engine, no stream synchronisation.
 // MODEL = true fuses the standard parameterisation (octo_model.h) into the same launch: θ_t in, log-posterior and
@@ -16,6 +18,7 @@
 // θ_t is one SIMD evaluation of the chain; the finishing wave forms ∇θ_t[d] = ∂prior/∂θ_t[d] + Σ_k J[k][d]·ḡ[k] in lane d.
 #pragma once
 #include "octo_model.h"
+#include "octo_hgca.h"
 
 namespace octo {
 
@@ -150,6 +153,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     const int64_t wi = w * a.ws_in, wo = w * a.ws_out;  // its offset in the input and the output rows
     const int task = blockIdx.x;
     const bool has_task = task < a.n_tasks;
+    const int n_base = a.n_tasks > 1 ? a.n_tasks : 1;      // blocks 0 .. n_base−1: row tasks; n_base .. : the HGCA term
 
     // ---- (MODEL) θ_t -> natural θ, priors, elements as one-partial duals: lane d carries ∂/∂θ_t[d]
     LaneTheta T{0.0, 0.0, lane};
@@ -300,6 +304,69 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
             acc[L::OFF_S] += lg;
         }
     }
+    if constexpr (NUIS) {
+        if (task >= n_base) {
+            // ---- HGCAInstantaneousObs (octo_hgca.h): wave wv of this block carries input direction d as a one-partial dual (what
+            // k_hgca does with one thread per (walker, direction)); its lanes take the table's rows. The forward-only launch needs
+            // the value alone: one wave, no partial.
+            using DH = Dual<1>;
+            const int n_dir = GRAD ? P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS : 1;
+            const int d = (task - n_base) * NW + wv;
+            if (d < n_dir) {
+                const int dir = GRAD ? d : -1;
+                HgcaPlanet hp[P];
+                bool visual[P];
+                hgca_setup<P>(elv, a.orbit_kind, a.has_mass, a.c, dir, hp, visual);
+                DH llh = dconst<1>(0.0);
+                for (int o = 0; o < a.n_obs; ++o) {
+                    const DevObs ob = a.obs[o];
+                    if (ob.kind != OCTO_HGCA) continue;
+                    double nu[OCTO_N_NUIS];
+                    nuis_of(o, ob.kind, nu, nullptr, false);
+                    DH pm_sys[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) pm_sys[k] = (dir == P * OCTO_N_EL + o * OCTO_N_NUIS + k) ? dvar<1>(nu[k], 0) : dconst<1>(nu[k]);
+                    DH pos[2][2], pm[2][2];
+                    double ep[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, cn[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int ax = 0; ax < 2; ++ax) { pos[m][ax] = dconst<1>(0.0); pm[m][ax] = dconst<1>(0.0); }
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        if (!visual[p]) continue;                           // hgca.jl:255-262
+                        for (int64_t j = lane; j < ob.n; j += WAVE) {
+                            const double* rw = ob.raw + j * ROW_STRIDE;
+                            const double t = rw[0];
+                            const int ax = (int)rw[1], m = (int)rw[2];
+                            DH q, v;
+                            hgca_solve(hp[p], t, ax, a.c.yd, q, v);
+#pragma unroll
+                            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                                for (int aa = 0; aa < 2; ++aa)
+                                    if (mm == m && aa == ax) { cn[mm][aa] += 1.0; ep[mm][aa] += t; pos[mm][aa] = pos[mm][aa] + q; pm[mm][aa] = pm[mm][aa] + v; }
+                        }
+                    }
+                    int cnt[2][2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int ax = 0; ax < 2; ++ax) {
+                            pos[m][ax].v = wave_sum(pos[m][ax].v); pos[m][ax].d[0] = wave_sum(pos[m][ax].d[0]);
+                            pm[m][ax].v = wave_sum(pm[m][ax].v); pm[m][ax].d[0] = wave_sum(pm[m][ax].d[0]);
+                            ep[m][ax] = wave_sum(ep[m][ax]);
+                            cnt[m][ax] = (int)wave_sum(cn[m][ax]);      // small integers: exact
+                        }
+                    llh = llh + hgca_terms(pos, pm, ep, cnt, pm_sys, a.c.yd, ob.pre);
+                }
+                if (lane == 0) {      // write-through stores, released with the block's counter increment below
+                    if (d == 0) __hip_atomic_store(a.extra + w, llh.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (GRAD) __hip_atomic_store(a.extra + (int64_t)(1 + d) * a.ldw + w, llh.d[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
     TRACE_POINT();      // rows done
     // ---- lanes -> wave (DPP), waves -> block (LDS), fixed order
 #pragma unroll
@@ -317,16 +384,17 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     __syncthreads();
     TRACE_POINT();      // block reduction done
     const int n_tasks = a.n_tasks;
-    const bool multi = n_tasks > 1;
+    const int n_blocks = n_base + a.n_hblocks;      // blocks of this walker
+    const bool multi = n_blocks > 1;
     if (multi) {
         // publish this block's partial; device-scope atomic stores are written through, so no L2 write-back fence is needed
-        if (threadIdx.x < NACC)
+        if (has_task && threadIdx.x < NACC)
             __hip_atomic_store(a.partials + ((int64_t)w * n_tasks + task) * NACC + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above have completed (s_waitcnt vmcnt(0))
         __syncthreads();
         if (threadIdx.x == 0) {
             const int old = __hip_atomic_fetch_add(&counters[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_flag = (old == n_tasks - 1) ? 1 : 0;
+            last_flag = (old == n_blocks - 1) ? 1 : 0;
         }
         __syncthreads();
         if (!last_flag) return;
@@ -395,7 +463,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 for (int r = 0; r < OCTO_N_NUIS; ++r) fin = fin && isfinite(nu[r]);
                 ok = ok && fin;
                 double gn3[OCTO_N_NUIS] = {0.0, 0.0, 0.0};
-                ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, 1, gn3, nullptr, a.ldw, a.c.k_yr, o, v, a.obs_const[o], sma_p, e_p, M_p, true, oneil_g);
+                ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, 1, gn3, a.extra ? a.extra + w : nullptr, a.ldw, a.c.k_yr, o, v, a.obs_const[o], sma_p, e_p, M_p, true, oneil_g);
                 if constexpr (L::N_NU > 0) {
 #pragma unroll
                     for (int r = 0; r < OCTO_N_NUIS; ++r) gth = fma(nuD[r].d[0], gn3[r], gth);
@@ -413,7 +481,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
 #pragma unroll
     for (int k = 0; k < P * L::PL_N; ++k) gp[k] = lane_value(gp_acc, L::OFF_PL + k);
     if (multi && lane == 0) __hip_atomic_store(&counters[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-    if constexpr (!MODEL) { if (a.extra) ll += a.extra[w]; }      // k_hgca's log-likelihood (launched ahead of this kernel)
+    if (a.extra) ll += a.extra[w];      // the HGCA term (this walker's extra blocks)
     ok = ok && isfinite(ll);
     if constexpr (MODEL) {
         // ℓπcallback: non-finite θ_t -> -Inf; non-finite prior -> returned without the likelihood (logdensitymodel.jl:120-133);
@@ -427,7 +495,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 double gel[OCTO_N_EL];
-                planet_finish<P, GRAD, NUIS, KM, true>(elv[p], gel, 1, nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p], p, &gp[p * L::PL_N],
+                planet_finish<P, GRAD, NUIS, KM, true>(elv[p], gel, 1, a.extra ? a.extra + w : nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p], p, &gp[p * L::PL_N],
                                                        L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp[p], ok);
 #pragma unroll
                 for (int k = 0; k < OCTO_N_EL; ++k) gth = fma(elD[p][k].d[0], gel[k], gth);

@@ -53,12 +53,10 @@ def random_model(rng, obs, planets):
     return priors, esrc, nsrc
 
 
-def check_model(rng, lib, P=None, W=None, small_only=False):
+def check_model(rng, lib, P=None, W=None):
     """One random system + random standard-parameterisation model through octo_model_logpost vs the oracle. Returns None if the
     draw has more than 64 parameters, else (ok, e_lp, e_grad, loose, description)."""
     obs, planets, elems, _ = draw_system(rng, invalid=False, P=P, W=W)
-    if small_only and any(o["kind"] == 7 for o in obs):      # caller wants datasets the fused single-launch path takes
-        return None
     priors, esrc, nsrc = random_model(rng, obs, planets)
     D = len(priors)
     if D > 64:

@@ -126,7 +126,7 @@ def test_three_and_four_planet_models_fused_launch(pkg, oracle, P, W):
     for k in range(60):
         if done == 3:
             break
-        r = sm.check_model(rng, lib, P=P, W=W, small_only=True)
+        r = sm.check_model(rng, lib, P=P, W=W)
         if r is None:
             continue
         assert r[0], (k,) + r[1:]

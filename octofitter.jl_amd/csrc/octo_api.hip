@@ -113,6 +113,17 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
     double wsum = 0.0;
     for (int o = 0; o < ds->n_obs; ++o)
         if (ds->h_obs[o].kind != OCTO_HGCA) wsum += (double)ds->h_obs[o].n * row_cost(ds->h_obs[o].kind);
+    // Rows per wave: at least 32 (short blocks pay their prologue, LDS combine and partial store more often, and k_finish walks every
+    // task's partials: 1e4 rows × 1024 walkers 56 µs at 32, 62 at 16) — unless the tables are so short that this leaves a handful of
+    // blocks whose waves each grind through 30-50 rows one after the other (a 3-planet row is ~1 µs of dependent issue for a lone
+    // wave): then down to 8, keeping the task count <= ~32 (4 planets, 440 rows, 1024 walkers: 165 -> 121 µs).
+    int64_t rows_min = 32;
+    {
+        int64_t n_all = 0, t32 = 0;
+        for (int o = 0; o < ds->n_obs; ++o)
+            if (ds->h_obs[o].kind != OCTO_HGCA && ds->h_obs[o].n > 0) { n_all += ds->h_obs[o].n; t32 += std::max<int64_t>(1, ds->h_obs[o].n / (32 * WPB)); }
+        if (t32 < 32) rows_min = std::min<int64_t>(32, std::max<int64_t>(8, n_all / (32 * WPB)));
+    }
     for (int o = 0; o < ds->n_obs; ++o) {
         if (ds->h_obs[o].kind == OCTO_HGCA) continue;          // no epoch-loop rows (k_hgca)
         const int64_t n = ds->h_obs[o].n;
@@ -122,7 +133,7 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
         else if (key < 0) chunk = -key;
         else {
             int64_t t_o = std::llround((double)key * (double)n * row_cost(ds->h_obs[o].kind) / wsum);
-            t_o = std::min<int64_t>(std::max<int64_t>(t_o, 1), std::max<int64_t>(1, n / (32 * WPB)));   // >= 32 rows per wave (small batches: 56 µs at 32, 62 at 16 for 1024 walkers)
+            t_o = std::min<int64_t>(std::max<int64_t>(t_o, 1), std::max<int64_t>(1, n / (rows_min * WPB)));
             const int64_t rows_per_task = (n + t_o - 1) / t_o;
             chunk = (rows_per_task + WPB - 1) / WPB;
         }

@@ -893,7 +893,7 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     const int64_t L = m->cap_w;
     ModelArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.priors = m->d_priors; a.esrc = m->d_esrc; a.nsrc = m->d_nsrc; a.obs = m->ds->d_obs;
+    a.priors = m->d_priors; a.prior_logz = m->d_logz; a.esrc = m->d_esrc; a.nsrc = m->d_nsrc; a.obs = m->ds->d_obs;
     a.D = m->D; a.n_el = m->n_el; a.n_nu = m->n_nu; a.n_planets = m->ds->n_planets;
     a.theta_t = d_theta_t; a.ld = ld; a.W = W; a.ldw = L;
     double* p = m->d_buf;

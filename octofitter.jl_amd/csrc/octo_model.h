@@ -57,6 +57,7 @@ constexpr int MODEL_NPART = 4;   // k_model_fwd: partials per thread. The value 
 
 struct ModelArgs {
     const octo_prior* priors;       // [D]
+    const double* prior_logz;       // [D] −log(Φ(hi) − Φ(lo)) of each truncated-Normal prior (a model constant), NaN elsewhere
     const octo_source* esrc;        // [n_el]
     const octo_source* nsrc;        // [n_nu] or null
     const DevObs* obs;
@@ -161,7 +162,8 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
 // value and ONE partial (∂/∂θ_t[d]) of every quantity, so a wave is 64 walkers × one partial: uniform control flow,
 // coalesced Jacobian rows, D× the parallelism of a thread-per-walker layout. The diagonal part — invlink and
 // logpdf_with_trans of every prior — is computed once per walker by the block's waves (prior k by wave k mod DB) and
-// shared through LDS: x[k], dx/dθ_t[k], p[k], dp/dθ_t[k].
+// shared through LDS: x[k], dx/dθ_t[k], p[k], dp/dθ_t[k]. Fast-math duals as in k_small<MODEL> (polynomial sincos / atan2,
+// reciprocal-multiply divisions): the chain is a few thousand serial instructions per wave, 30 µs at 1e4 walkers with the ocml routines.
 static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     constexpr int N = MODEL_NPART;      // partials carried per thread
     extern __shared__ __attribute__((aligned(16))) double lds[];      // [4][D][64]
@@ -174,8 +176,8 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     const int D = a.D;
     double* Lx = lds; double* Ldx = lds + (int64_t)D * WAVE; double* Lp = lds + 2 * (int64_t)D * WAVE; double* Ldp = lds + 3 * (int64_t)D * WAVE;
     for (int k = wy; k < D; k += DB) {
-        Dual<1> xk, p;
-        prior_apply(a.priors[k], dvar<1>(a.theta_t[(int64_t)k * a.ld + wl], 0), xk, p);
+        Dual<1, true> xk, p;
+        prior_apply(a.priors[k], dvar<1, true>(a.theta_t[(int64_t)k * a.ld + wl], 0), xk, p, a.prior_logz[k]);
         Lx[k * WAVE + lane] = xk.v; Ldx[k * WAVE + lane] = xk.d[0]; Lp[k * WAVE + lane] = p.v; Ldp[k * WAVE + lane] = p.d[0];
     }
     __syncthreads();
@@ -187,8 +189,8 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         const int slot = a.circ_slot[k];
         if (slot < 0) continue;
         const octo_source sc = k < a.n_el ? a.esrc[k] : a.nsrc[k - a.n_el];
-        const Dual<2> cx = dvar<2>(Lx[sc.i0 * WAVE + lane], 0), cy = dvar<2>(Lx[sc.i1 * WAVE + lane], 1);
-        const Dual<2> ang = datan2(cy, cx), ul = unit_length(cx, cy);
+        const Dual<2, true> cx = dvar<2, true>(Lx[sc.i0 * WAVE + lane], 0), cy = dvar<2, true>(Lx[sc.i1 * WAVE + lane], 1);
+        const Dual<2, true> ang = datan2(cy, cx), ul = unit_length(cx, cy);
         double* o = Lc + (int64_t)slot * 6 * WAVE + lane;
         o[0] = ang.v; o[WAVE] = ang.d[0]; o[2 * WAVE] = ang.d[1]; o[3 * WAVE] = ul.v; o[4 * WAVE] = ul.d[0]; o[5 * WAVE] = ul.d[1];
     }
@@ -196,14 +198,14 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     if (w >= a.W || wy >= DBs || d0 >= D) return;
     bool finite_in = true;
     for (int k = 0; k < D; ++k) finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + w]);   // logdensitymodel.jl:120-124
-    Dual<N> lp = dconst<N>(0.0);
-    Dual<N> ulp = dconst<N>(0.0);      // Σ UnitLengthPrior terms: likelihood terms of the reference (variables.jl:309-323), so they and
+    Dual<N, true> lp = dconst<N, true>(0.0);
+    Dual<N, true> ulp = dconst<N, true>(0.0);      // Σ UnitLengthPrior terms: likelihood terms of the reference (variables.jl:309-323), so they and
                                        // their gradient survive a healed prior (the healed value is a constant, :1229-1236)
     bool healed = false;
     for (int k = 0; k < D; ++k) {
         const double pv = Lp[k * WAVE + lane];
         if (!healed) {
-            if (!isfinite(pv)) { lp = dconst<N>(-1.7976931348623157e308); healed = true; }     // variables.jl:1229-1236
+            if (!isfinite(pv)) { lp = dconst<N, true>(-1.7976931348623157e308); healed = true; }     // variables.jl:1229-1236
             else {
                 lp.v += pv;
 #pragma unroll
@@ -212,7 +214,7 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         }
     }
     auto nat = [&](int k) {      // natural-domain θ[k] with this thread's partial
-        Dual<N> xk; xk.v = Lx[k * WAVE + lane];
+        Dual<N, true> xk; xk.v = Lx[k * WAVE + lane];
         const double dx = Ldx[k * WAVE + lane];
 #pragma unroll
         for (int j = 0; j < N; ++j) xk.d[j] = (k == d0 + j) ? dx : 0.0;
@@ -225,13 +227,13 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     auto circ_angle = [&](const octo_source& sc, int k) {
         const int slot = a.circ_slot[k];
         if (slot < 0) {                                               // beyond the LDS budget: in place
-            const Dual<N> cx = nat(sc.i0), cy = nat(sc.i1);
+            const Dual<N, true> cx = nat(sc.i0), cy = nat(sc.i1);
             if (sc.flags & OCTO_SRC_FLAG_UNITLEN) ulp = ulp + unit_length(cx, cy);
             return datan2(cy, cx);
         }
         const double* c = Lc + (int64_t)slot * 6 * WAVE + lane;
         const double dx = Ldx[sc.i0 * WAVE + lane], dy = Ldx[sc.i1 * WAVE + lane];    // ∂x/∂θ_t, ∂y/∂θ_t (diagonal)
-        Dual<N> ang; ang.v = c[0];
+        Dual<N, true> ang; ang.v = c[0];
         const bool ul = (sc.flags & OCTO_SRC_FLAG_UNITLEN) != 0;
         if (ul) ulp.v += c[3 * WAVE];
 #pragma unroll
@@ -243,11 +245,11 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         return ang;
     };
     auto plain = [&](const octo_source& sc, int k) {      // OCTO_SRC_CONST / _THETA / _CIRCULAR
-        if (sc.kind == OCTO_SRC_CONST) return dconst<N>(sc.value);
+        if (sc.kind == OCTO_SRC_CONST) return dconst<N, true>(sc.value);
         if (sc.kind == OCTO_SRC_THETA) return nat(sc.i0);
         return circ_angle(sc, k) * (sc.value / TWO_PI);               // atan(y, x) / 2π * domain, variables.jl:284
     };
-    auto emit = [&](int k, const Dual<N>& val) {
+    auto emit = [&](int k, const Dual<N, true>& val) {
         if (d0 == 0) {
             double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
             *dst = val.v;
@@ -257,14 +259,14 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
             if (d0 + j < D) a.J[((int64_t)k * D + d0 + j) * a.ldw + w] = val.d[j];
     };
     for (int p = 0; p < a.n_planets; ++p) {
-        Dual<N> el[OCTO_N_EL];
+        Dual<N, true> el[OCTO_N_EL];
 #pragma unroll
-        for (int j = 0; j < OCTO_N_EL; ++j) el[j] = dconst<N>(0.0);
+        for (int j = 0; j < OCTO_N_EL; ++j) el[j] = dconst<N, true>(0.0);
 #pragma unroll 1
         for (int kk = 0; kk < OCTO_N_EL; ++kk) {          // one copy of the code; the store is a select chain, not an indexed write
             const octo_source sc = a.esrc[p * OCTO_N_EL + kk];
             if (sc.kind == OCTO_SRC_TPERI) continue;
-            const Dual<N> val = plain(sc, p * OCTO_N_EL + kk);
+            const Dual<N, true> val = plain(sc, p * OCTO_N_EL + kk);
 #pragma unroll
             for (int j = 0; j < OCTO_N_EL; ++j) {
                 el[j].v = (j == kk) ? val.v : el[j].v;

@@ -448,6 +448,7 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
 template <int P>
 struct RvCoef {
     double gc[P];                   // coefficient of K_p·V_p in the RV model
+    double ib2[P];                  // 1/β² of each planet (the gradient's closed forms)
     double off, jit, j2, mu_hat, iA;
     bool rel, marg;
     int planet;
@@ -468,6 +469,8 @@ __device__ __forceinline__ RvCoef<P> rv_coef_vals(double off, double jit, const 
         for (int p = 0; p < P; ++p)
             c.gc[p] = c.rel ? ((p == ob_planet) ? 1.0 : ((pc[p].a < a_this) ? -pc[p].mu : 0.0)) : -pc[p].mu;
     }
+#pragma unroll
+    for (int p = 0; p < P; ++p) c.ib2[p] = GRAD ? 1.0 / (pc[p].beta * pc[p].beta) : 0.0;
     c.marg = (KM & KM_MARG) && ob_kind == OCTO_RV_ABS_MARG;
     c.off = 0.0; c.jit = 0.0; c.j2 = 0.0;
     if constexpr (NUIS) {
@@ -544,17 +547,15 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
             const bool via_mu = rel ? (p != co.planet && gc[p] != 0.0) : true;
             g[L::GC] += via_mu ? -(pc[p].K * V[p] * rvb) : 0.0;
             const double Vb = gc[p] * pc[p].K * rvb;
-            g[L::GW] = fma(Vb, -fma(cnu[p] + pc[p].e, pc[p].sw, snu[p] * pc[p].cw), g[L::GW]);
-            // V(cos ν, sin ν, e) with cos ν = X/D, sin ν = Y/D, X = cE − e, Y = β sE, D = 1 − e cE
-            const double cb = Vb * pc[p].cw, sb = -Vb * pc[p].sw;
-            const double Xb = cb * s[p].invD, Yb = sb * s[p].invD;
-            const double Db = -fma(cb, cnu[p], sb * snu[p]) * s[p].invD;
-            const double cEb = fma(-pc[p].e, Db, Xb);
-            const double Eb = fma(pc[p].beta * Yb, s[p].cE, -(cEb * s[p].sE));
-            const double Mb = Eb * s[p].invD;
-            double eb = fma(Mb, s[p].sE, cb - Xb);
-            eb = fma(-(pc[p].eob * s[p].sE), Yb, eb);
-            eb = fma(-s[p].cE, Db, eb);
+            // V = cos(ν+ω) + e cos ω with cos ν = (cE − e)/D, sin ν = β sE/D, D = 1 − e cE, in closed form:
+            //   ∂V/∂ω = −sin(ν+ω) − e sin ω,   ∂V/∂E = −β sin(ν+ω)/D,   ∂V/∂e at fixed E = cos ω − sin ν · sin(ν+ω)/β²
+            const double S = fma(snu[p], pc[p].cw, cnu[p] * pc[p].sw);      // sin(ν+ω)
+            g[L::GW] = fma(Vb, -fma(pc[p].e, pc[p].sw, S), g[L::GW]);
+            const double VS = Vb * S;
+            const double Mb = -(VS * pc[p].beta) * (s[p].invD * s[p].invD);   // Ēᵥ/D = M̄
+            double eb = Vb * pc[p].cw;
+            eb = fma(-(snu[p] * co.ib2[p]), VS, eb);
+            eb = fma(Mb, s[p].sE, eb);                                      // ∂E/∂e = sin E/D
             g[L::GE] += eb;
             g[L::GM] += Mb;
             g[L::GT] = fma(Mb, s[p].dt, g[L::GT]);

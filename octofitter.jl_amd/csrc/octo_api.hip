@@ -573,7 +573,7 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
     pd = octo_ctx::Pending();
     pd.W = W; pd.ld = ld; pd.ldd = ldd; pd.ll = ll_out; pd.g_elems = g_elems; pd.g_nuis = g_nuis;
     pd.n_el_out = g_elems ? n_el : 0; pd.n_nu_out = g_nuis ? n_nu : 0;
-    if (small_eligible(ctx, ds, W) && W <= ctx->mapped_w) {
+    if (small_eligible(ctx, ds, W) && W <= ctx->mapped_w && (ds->n_hgca == 0 || hgca_in_small(W))) {      // (k_hgca, lane = walker, would fetch every input over PCIe once per direction)
         // A handful of parameter sets (a sampler's one θ per call): no copy engine at all. k_small reads the inputs from, and
         // writes the results to, mapped pinned host memory — walker-major: [elems | nuis] of one walker contiguous (one PCIe read
         // per block), [ll | g_elems | g_nuis] likewise on the way back; completion through per-walker flags instead of a stream sync.

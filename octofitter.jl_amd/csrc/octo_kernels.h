@@ -211,7 +211,7 @@ static __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.W) return;
     const int p = blockIdx.y;                          // one thread per (walker, planet)
-    const SetupOut so = setup_planet<false>(a, p, w);
+    const SetupOut so = setup_planet<true>(a, p, w);
     bool ok = so.ok;
     double* o = a.wc + (int64_t)p * NWC * a.ldw + w;
 #pragma unroll

@@ -11,7 +11,10 @@ pkg = load_package()
 capi = pkg.capi
 
 
-DEFAULT_SMALL_BATCH = None      # tests that want every case through BOTH kernel families set this (None: the library's own choice)
+import os
+# tests that want every case through BOTH kernel families set this (None: the library's own choice; the stand-alone sweeps take it
+# from OCTO_TEST_SMALL_BATCH, e.g. 0 = everything on the throughput kernels)
+DEFAULT_SMALL_BATCH = int(os.environ["OCTO_TEST_SMALL_BATCH"]) if os.environ.get("OCTO_TEST_SMALL_BATCH") else None
 
 
 class GpuPath:

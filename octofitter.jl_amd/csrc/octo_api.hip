@@ -32,6 +32,17 @@ bool grow_pinned(double*& p, int64_t& cap, int64_t need) {
     return true;
 }
 
+// Host-buffer calls of a few hundred parameter sets on k_small: the rows arrive in mapped pinned memory as the caller has them
+// (SoA, walker fastest); this kernel reads them over PCIe — coalesced along the walkers — and leaves them walker-major in device
+// memory, where each k_small block finds its walker's inputs contiguous. Two copy-engine transfers of ~40 KB cost ~17 µs per
+// call; this launch ~4 µs, and the results go back through the mapped buffer + per-walker flags like the smallest batches.
+static __global__ __launch_bounds__(256) void k_stage_in(const double* __restrict__ src, int64_t ld_src, int64_t W, int n_rows, double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * n_rows) return;
+    const int64_t r = i / W, w = i - r * W;
+    dst[w * n_rows + r] = src[r * ld_src + w];
+}
+
 // `hip_stream` of the *_device entry points: OCTO_STREAM_CTX = the context's own stream; anything else is handed to HIP as
 // it is, so NULL is HIP's NULL stream (the legacy default stream — what torch.cuda.current_stream().cuda_stream is when no
 // torch stream is active). Orders the scratch across a change of stream.
@@ -213,7 +224,11 @@ int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
 // crossover at W·P ≈ 400-1000 (tools/latency_vs_w.py, tools/latency_multi.py). An HGCA table adds blocks to the same launch
 // (one input direction per wave) for W <= 16, the k_hgca launch ahead of it otherwise.
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
-    return W * ds->n_planets <= ctx->small_w && W <= SMALL_W;
+    if (!(W * ds->n_planets <= ctx->small_w && W <= SMALL_W)) return false;
+    if (ds->kind_mask & KM_MARG)      // a marginalised-RV table is ONE block's work there (two passes): not for a very long table
+        for (int o = 0; o < ds->n_obs; ++o)
+            if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG && ds->h_obs[o].n > SMALL_MARG_ROWS) return false;
+    return true;
 }
 
 int drain_timing(octo_ctx* ctx) {
@@ -307,6 +322,7 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     std::memset(ctx->h_flags, 0, sizeof(uint64_t) * (SMALL_W + 32));
     if (const char* ev = std::getenv("OCTO_SMALL_W")) ctx->small_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     if (const char* ev = std::getenv("OCTO_MAPPED_W")) ctx->mapped_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
+    if (const char* ev = std::getenv("OCTO_FLAG_W")) ctx->flag_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     *out = ctx;
     return OCTO_OK;
 }
@@ -592,7 +608,7 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
         }
         pd.walker_major = true; pd.ws_out = ws_out;
         ctx->stage_ws_in = ws_in; ctx->stage_ws_out = ws_out;
-        ctx->flag_request = true; ctx->flag_armed = false;
+        ctx->flag_request = W <= ctx->flag_w; ctx->flag_armed = false;
         int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + n_el : nullptr, 1, W, m_out, g_elems ? m_out + 1 : nullptr,
                                    g_nuis ? m_out + 1 + pd.n_el_out : nullptr, st);
         ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
@@ -604,6 +620,30 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
     if (rc) return rc;
     rc = grow(ctx, ctx->d_out, ctx->cap_out, n_out);
     if (rc) return rc;
+    if (small_eligible(ctx, ds, W)) {
+        // k_small beyond the mapped-input range: rows into the mapped buffer as they are, k_stage_in transposes them into device
+        // memory, results come back walker-major through the mapped buffer + flags (no copy engine, no stream synchronisation)
+        if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
+            return fail(ctx, OCTO_ENOMEM, "octo_eval: pinned staging allocation failed");
+        double *m_in = nullptr, *m_out = nullptr;
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
+        const int nn = nuis ? n_nu : 0;
+        const int n_rows_in = n_el + nn;
+        const int64_t ws_out = 1 + pd.n_el_out + pd.n_nu_out;
+        for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
+        for (int r = 0; r < nn; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
+        hipLaunchKernelGGL(k_stage_in, dim3((unsigned)((W * n_rows_in + 255) / 256)), dim3(256), 0, st, m_in, ldd, W, n_rows_in, ctx->d_in);
+        pd.staged = true; pd.walker_major = true; pd.ws_out = ws_out;
+        ctx->stage_ws_in = n_rows_in; ctx->stage_ws_out = ws_out;
+        ctx->flag_request = false; ctx->flag_armed = false;      // completion by stream synchronisation: per-walker system-scope releases cost more than they save beyond ~100 walkers (W = 512: 38 µs with flags, 30 without)
+        int rcz = octo_eval_device(ctx, ds, ctx->d_in, nuis ? ctx->d_in + n_el : nullptr, 1, W, m_out, g_elems ? m_out + 1 : nullptr,
+                                   g_nuis ? m_out + 1 + pd.n_el_out : nullptr, st);
+        ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
+        if (rcz) return rcz;
+        pd.active = true;
+        return OCTO_OK;
+    }
     double* d_nuis = nuis ? ctx->d_in + (int64_t)n_el * ldd : nullptr;
     double* d_ll = ctx->d_out;
     double* d_ge = g_elems ? ctx->d_out + ldd : nullptr;
@@ -946,7 +986,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
         for (int64_t w = 0; w < W; ++w)
             for (int r = 0; r < D; ++r) ctx->h_in[w * D + r] = theta_t[(size_t)r * ld + w];
         ctx->stage_ws_in = D; ctx->stage_ws_out = ws_o;
-        ctx->flag_request = true; ctx->flag_armed = false;
+        ctx->flag_request = W <= ctx->flag_w; ctx->flag_armed = false;
         int rcz = octo_model_logpost_device(ctx, m, m_in, 1, W, m_out, grad_out ? m_out + 1 : nullptr, st);
         ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
         if (rcz) return rcz;
@@ -963,6 +1003,31 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     if (rc) return rc;
     rc = grow(ctx, m->d_res, m->cap_res, (int64_t)(m->D + 1) * ldd);
     if (rc) return rc;
+    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
+        // the fused launch beyond the mapped-input range: k_stage_in brings θ_t walker-major into device memory, [lp | ∇θ_t] come
+        // back through the mapped buffer + flags (see octo_eval)
+        if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
+            return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");
+        double *m_in = nullptr, *m_out = nullptr;
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
+        const int64_t D = m->D, ws_o = grad_out ? D + 1 : 1;
+        for (int r = 0; r < D; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, theta_t + (size_t)r * ld, sizeof(double) * W);
+        hipLaunchKernelGGL(k_stage_in, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, st, m_in, ldd, W, (int)D, m->d_th);
+        ctx->stage_ws_in = D; ctx->stage_ws_out = ws_o;
+        ctx->flag_request = false; ctx->flag_armed = false;
+        int rcz = octo_model_logpost_device(ctx, m, m->d_th, 1, W, m_out, grad_out ? m_out + 1 : nullptr, st);
+        ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
+        if (rcz) return rcz;
+        rcz = wait_small(ctx, st, W);
+        if (rcz) return rcz;
+        for (int64_t w = 0; w < W; ++w) {
+            lp_out[w] = ctx->h_out[w * ws_o];
+            if (grad_out) for (int r = 0; r < D; ++r) grad_out[(size_t)r * ld + w] = ctx->h_out[w * ws_o + 1 + r];
+        }
+        free_retired(ctx);
+        return OCTO_OK;
+    }
     if ((n_in + n_out) * (int64_t)sizeof(double) <= STAGE_DMA_BYTES) {      // mid-size batch: one pinned transfer each way (see octo_eval)
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");

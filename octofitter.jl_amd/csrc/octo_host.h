@@ -101,6 +101,7 @@ struct octo_ctx {
     void* comm = nullptr;                       // ncclComm_t
     int comm_rank = 0, comm_world = 1;
     int small_w = OCTO_SMALL_BATCH_DEFAULT;     // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
+    int flag_w = 128;                           // ... and signal completion through per-walker flags the host spins on (OCTO_FLAG_W: experiments)
     int mapped_w = 128;                         // host-buffer calls up to this size let k_small read/write mapped pinned memory; larger
                                                 // ones cross the link as one DMA each way (OCTO_MAPPED_W: experiments)
     double *d_in = nullptr, *d_out = nullptr;   // staging for octo_eval (host buffers)
@@ -154,6 +155,7 @@ bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);
 template <int P>
 int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st);
 inline bool hgca_in_small(int64_t W) { return W <= 16; }      // k_small computes the HGCA term itself (else k_hgca ahead of it)
+constexpr int64_t SMALL_MARG_ROWS = 16384;      // longest marginalised-RV table k_small takes (one block runs it twice)
 constexpr int64_t SMALL_KEY = (int64_t)1 << 40;   // get_tasks keys at or below −SMALL_KEY: k_small's row partition
 constexpr int64_t STAGE_DMA_BYTES = 1 << 20;   // host-buffer calls up to this size (inputs + outputs) are staged in pinned memory
 

@@ -49,7 +49,7 @@ struct EvalArgs {
     const int32_t* obs_range;     // [n_obs][2] first and one-past-last task of each observation (tasks are grouped by observation)
     const double* obs_const;      // [n_obs] Σ task_const over the observation's tasks, in task order
     int32_t n_obs, n_tasks, n_planets, n_hblocks;      // n_hblocks: k_small only — extra blocks per walker that compute the HGCA term
-    int32_t task0, pad0;                        // first task of this launch (k_main grid.y is relative to it)
+    int32_t task0, n_rblocks;                   // first task of this launch (k_main grid.y is relative to it); k_small: blocks per walker that take row tasks
     int32_t orbit_kind[MAXP];
     int32_t has_mass[MAXP];
     const double* elems;          // [P*9][ld]

@@ -31,6 +31,9 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     if (rc) return rc;
     a.partials = ctx->d_partials;
     a.marg = nullptr; a.marg_out = nullptr; a.extra = nullptr;
+    // row blocks per walker: every task its own block while the walkers are few; with many walkers the blocks fill the chip by
+    // themselves and one block walks several tasks (tables), which saves their setup and, at one block per walker, the counter protocol
+    a.n_rblocks = (int32_t)std::min<int64_t>(std::max(a.n_tasks, 1), target_tasks);
     a.n_hblocks = 0;
     if (ds->n_hgca > 0) {
         // The proper-motion anomaly has no epoch loop. A handful of walkers: extra blocks of the same launch, one input direction
@@ -66,7 +69,7 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     SmallModel sm;
     std::memset(&sm, 0, sizeof(sm));
     if (MODEL) sm = *smp;
-    hipLaunchKernelGGL((k_small<P, GRAD, NUIS, KM, MODEL>), dim3((unsigned)(std::max(a.n_tasks, 1) + a.n_hblocks), (unsigned)a.W), dim3(SMALL_TPB), 0, st, a, sm,
+    hipLaunchKernelGGL((k_small<P, GRAD, NUIS, KM, MODEL>), dim3((unsigned)(a.n_rblocks + a.n_hblocks), (unsigned)a.W), dim3(SMALL_TPB), 0, st, a, sm,
                        ctx->d_counters, flags, ctx->flag_seq);
     if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
     HIPCHK(ctx, hipGetLastError());

@@ -152,8 +152,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     const int64_t w = blockIdx.y;                       // this block's walker (wave-uniform)
     const int64_t wi = w * a.ws_in, wo = w * a.ws_out;  // its offset in the input and the output rows
     const int task = blockIdx.x;
-    const bool has_task = task < a.n_tasks;
-    const int n_base = a.n_tasks > 1 ? a.n_tasks : 1;      // blocks 0 .. n_base−1: row tasks; n_base .. : the HGCA term
+    const int n_base = a.n_rblocks;      // blocks 0 .. n_base−1 take the row tasks (block b: tasks b, b + n_base, …); n_base .. : the HGCA term
 
     // ---- (MODEL) θ_t -> natural θ, priors, elements as one-partial duals: lane d carries ∂/∂θ_t[d]
     LaneTheta T{0.0, 0.0, lane};
@@ -242,11 +241,15 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     };
 
     double acc[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    const int n_tasks = a.n_tasks;
+    const int n_blocks = n_base + a.n_hblocks;      // blocks of this walker
+    const bool multi = n_blocks > 1;                // more than one block works on this walker: counter + last-block finish
+    const bool via_mem = multi || n_tasks > 1;      // the task sums reach the finish through `partials`
     TRACE_POINT();      // setup done
-    if (has_task) {
-        const Task tk = a.tasks[task];
+    for (int tq = task; tq < (task < n_base ? n_tasks : 0); tq += n_base) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+        const Task tk = a.tasks[tq];
         const DevObs ob = a.obs[tk.obs];
         LogProd lp;
         int my_rows = 0;
@@ -303,6 +306,22 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
             if ((KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG) lg = fma((double)my_rows, LOG2PI, lg);
             acc[L::OFF_S] += lg;
         }
+        // ---- lanes -> wave (DPP), waves -> block (LDS), fixed order; one partial per task
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            const double sum = wave_sum(acc[k]);
+            if (lane == 0) red[wv][k] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < NACC) {
+            double x = red[0][threadIdx.x];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) x += red[q][threadIdx.x];
+            tot[threadIdx.x] = x;
+            // device-scope atomic stores are written through, so no L2 write-back fence is needed
+            if (via_mem) __hip_atomic_store(a.partials + ((int64_t)w * n_tasks + tq) * NACC + threadIdx.x, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
     }
     if constexpr (NUIS) {
         if (task >= n_base) {
@@ -367,37 +386,18 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
             }
         }
     }
-    TRACE_POINT();      // rows done
-    // ---- lanes -> wave (DPP), waves -> block (LDS), fixed order
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-        const double sum = wave_sum(acc[k]);
-        if (lane == 0) red[wv][k] = sum;
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-        double x = red[0][threadIdx.x];
-#pragma unroll
-        for (int q = 1; q < NW; ++q) x += red[q][threadIdx.x];
-        tot[threadIdx.x] = x;
-    }
-    __syncthreads();
-    TRACE_POINT();      // block reduction done
-    const int n_tasks = a.n_tasks;
-    const int n_blocks = n_base + a.n_hblocks;      // blocks of this walker
-    const bool multi = n_blocks > 1;
-    if (multi) {
-        // publish this block's partial; device-scope atomic stores are written through, so no L2 write-back fence is needed
-        if (has_task && threadIdx.x < NACC)
-            __hip_atomic_store(a.partials + ((int64_t)w * n_tasks + task) * NACC + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above have completed (s_waitcnt vmcnt(0))
+    TRACE_POINT();      // rows done, block reductions done
+    if (via_mem) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this block's partial stores have completed (s_waitcnt vmcnt(0))
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const int old = __hip_atomic_fetch_add(&counters[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_flag = (old == n_blocks - 1) ? 1 : 0;
+        if (multi) {
+            if (threadIdx.x == 0) {
+                const int old = __hip_atomic_fetch_add(&counters[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_flag = (old == n_blocks - 1) ? 1 : 0;
+            }
+            __syncthreads();
+            if (!last_flag) return;
         }
-        __syncthreads();
-        if (!last_flag) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     // ---- finish (the single / last block). All 256 threads gather the task partials — thread (slot, k) sums tasks slot,
@@ -424,7 +424,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
         const int t0 = a.obs_range[2 * o], t1 = a.obs_range[2 * o + 1];
         if (slot < NTS) {
             double s = 0.0;
-            if (multi) {
+            if (via_mem) {
                 const double* __restrict__ pp = a.partials + (int64_t)w * n_tasks * NACC + kcol;      // [walker][task][NACC]
 #pragma unroll 8
                 for (int t = t0 + slot; t < t1; t += NTS) s += pp[(int64_t)t * NACC];

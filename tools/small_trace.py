@@ -9,7 +9,7 @@ import numpy as np
 from __graft_entry__ import load_package
 import synth
 pkg = load_package(); capi = pkg.capi
-names = ["start", "setup", "rows", "block-reduce", "last-known", "obs-finish", "outputs", "flag"]
+names = ["start", "setup", "rows+block-reduce", "last-known", "obs-finish", "outputs", "flag"]
 for E, W in ((50, 1), (10000, 1), (10000, 32)):
     cfg = synth.config_astrom(n_epochs=E, n_walkers=W, cfg=3)
     obs, planet = synth.to_mirror(pkg, cfg)

@@ -36,6 +36,16 @@ bool grow_pinned(double*& p, int64_t& cap, int64_t need) {
 // (SoA, walker fastest); this kernel reads them over PCIe — coalesced along the walkers — and leaves them walker-major in device
 // memory, where each k_small block finds its walker's inputs contiguous. Two copy-engine transfers of ~40 KB cost ~17 µs per
 // call; this launch ~4 µs, and the results go back through the mapped buffer + per-walker flags like the smallest batches.
+static int64_t stage_bytes() {      // host-buffer calls up to this size (inputs + outputs) are staged in mapped pinned memory (OCTO_STAGE_BYTES: experiments)
+    if (const char* ev = std::getenv("OCTO_STAGE_BYTES")) { const long v = std::atol(ev); if (v > 0) return v; }
+    return STAGE_DMA_BYTES;
+}
+
+static __global__ __launch_bounds__(256) void k_copy_in(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 static __global__ __launch_bounds__(256) void k_stage_in(const double* __restrict__ src, int64_t ld_src, int64_t W, int n_rows, double* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * n_rows) return;
@@ -648,18 +658,22 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
     double* d_ll = ctx->d_out;
     double* d_ge = g_elems ? ctx->d_out + ldd : nullptr;
     double* d_gn = g_nuis ? ctx->d_out + (int64_t)(1 + (g_elems ? n_el : 0)) * ldd : nullptr;
-    if ((n_in + n_out) * (int64_t)sizeof(double) <= STAGE_DMA_BYTES) {
-        // Mid-size batches (an ensemble sampler's 10²-10³ walkers): the rows are packed into ONE pinned buffer and cross the
-        // link as one DMA each way — pageable 2-D copies cost ~8 µs apiece, and a mapped buffer would have every k_main block
-        // fetch its walkers' nuisances over PCIe.
+    if ((n_in + n_out) * (int64_t)sizeof(double) <= stage_bytes()) {
+        // Mid-size batches of the throughput kernels (10³ walkers): the rows are packed into the mapped pinned buffer, a copy KERNEL
+        // brings them into device memory (k_main blocks must not fetch their walkers' nuisances over PCIe one by one) and k_finish
+        // writes the results straight into the mapped buffer — coalesced rows. Pageable 2-D copies cost ~8 µs apiece, and even
+        // two pinned copy-engine transfers cost 11-14 µs more per call than this (W = 1024, 300 epochs: 47 -> 35 µs).
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_eval: pinned staging allocation failed");
         for (int r = 0; r < n_el; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, elems + (size_t)r * ld, sizeof(double) * W);
         if (nuis) for (int r = 0; r < n_nu; ++r) std::memcpy(ctx->h_in + (size_t)(n_el + r) * ldd, nuis + (size_t)r * ld, sizeof(double) * W);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, ctx->h_in, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, st));
-        rc = octo_eval_device(ctx, ds, ctx->d_in, d_nuis, ldd, W, d_ll, d_ge, d_gn, st);
+        double *m_in = nullptr, *m_out = nullptr;
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
+        hipLaunchKernelGGL(k_copy_in, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, m_in, ctx->d_in, n_in);
+        rc = octo_eval_device(ctx, ds, ctx->d_in, d_nuis, ldd, W, m_out, g_elems ? m_out + ldd : nullptr,
+                              g_nuis ? m_out + (int64_t)(1 + (g_elems ? n_el : 0)) * ldd : nullptr, st);
         if (rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, st));
         pd.staged = true; pd.walker_major = false;
         pd.o_ge = ldd; pd.o_gn = (int64_t)(1 + pd.n_el_out) * ldd;
         pd.active = true;
@@ -1028,17 +1042,20 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
         free_retired(ctx);
         return OCTO_OK;
     }
-    if ((n_in + n_out) * (int64_t)sizeof(double) <= STAGE_DMA_BYTES) {      // mid-size batch: one pinned transfer each way (see octo_eval)
+    if ((n_in + n_out) * (int64_t)sizeof(double) <= stage_bytes()) {      // mid-size batch: mapped pinned buffers + a copy kernel (see octo_eval)
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");
         for (int r = 0; r < m->D; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, theta_t + (size_t)r * ld, sizeof(double) * W);
-        HIPCHK(ctx, hipMemcpyAsync(m->d_th, ctx->h_in, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, st));
-        rc = octo_model_logpost_device(ctx, m, m->d_th, ldd, W, m->d_res, grad_out ? m->d_res + ldd : nullptr, st);
+        double *m_in = nullptr, *m_out = nullptr;
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
+        hipLaunchKernelGGL(k_copy_in, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, m_in, m->d_th, n_in);
+        rc = octo_model_logpost_device(ctx, m, m->d_th, ldd, W, m_out, grad_out ? m_out + ldd : nullptr, st);
         if (rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, m->d_res, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         std::memcpy(lp_out, ctx->h_out, sizeof(double) * W);
         if (grad_out) for (int r = 0; r < m->D; ++r) std::memcpy(grad_out + (size_t)r * ld, ctx->h_out + (size_t)(1 + r) * ldd, sizeof(double) * W);
+        free_retired(ctx);
         return OCTO_OK;
     }
     HIPCHK(ctx, hipMemcpy2DAsync(m->d_th, sizeof(double) * ldd, theta_t, sizeof(double) * ld, sizeof(double) * W, m->D, hipMemcpyHostToDevice, st));

@@ -63,7 +63,28 @@ struct PC {   // one planet's constants for one walker, in registers
     double invP, tp, e, beta, eob, cB, cG, cA, cF, K, cw, sw, mu, a;
     double cGb, cFb, cBe, cAe;
     float ef, omef, k1f;
+    // starter constants derived from (ef, omef, k1f) once per walker (set_starter): every multiple the Markley starter
+    // needs is a ready operand of an FMA, so the row loop carries no FP32 scaling instructions
+    float A0, A1;      // α = K0 + k1·(π − |M|) = A0 + A1·|frac|,  A0 = K0 + k1·π,  A1 = −2π·k1   (M = 2π·frac)
+    float o2, no3;     // 2(1−e), −3(1−e)
+    double he;         // e/2
 };
+
+// PIN: after the loop-invariant constants are computed, an empty asm makes them opaque to the compiler, which otherwise
+// rematerialises cheap ones (3·(1−e), e/2) inside the row loop to save a register.
+template <bool PIN = true>
+__device__ __forceinline__ void set_starter(PC& pc, float ef, float omef, float k1f) {
+    pc.ef = ef; pc.omef = omef; pc.k1f = k1f;
+    pc.A0 = fmaf(k1f, (float)PI, (float)MK_K0); pc.A1 = -(float)TWO_PI * k1f;
+    pc.o2 = 2.0f * omef; pc.no3 = -3.0f * omef;
+    pc.he = 0.5 * pc.e;
+    if constexpr (PIN) {
+        asm("" : "+v"(pc.A0), "+v"(pc.A1), "+v"(pc.o2), "+v"(pc.no3));
+#ifndef OCTO_NO_HE_PIN
+        asm("" : "+v"(pc.he));
+#endif
+    }
+}
 
 struct KSol { double sE, cE, invD, dt, E; };
 
@@ -76,7 +97,7 @@ __device__ __forceinline__ void load_pc(PC& pc, const double* __restrict__ wc, i
     pc.cGb = b[WC_CGB * ldw]; pc.cFb = b[WC_CFB * ldw]; pc.cBe = b[WC_CBE * ldw]; pc.cAe = b[WC_CAE * ldw];
     const float2 fa = *reinterpret_cast<const float2*>(&b[WC_F32A * ldw]);
     const float2 fb = *reinterpret_cast<const float2*>(&b[WC_F32B * ldw]);
-    pc.ef = fa.x; pc.omef = fa.y; pc.k1f = fb.x;
+    set_starter(pc, fa.x, fa.y, fb.x);
 }
 
 __device__ __forceinline__ double pack_f32x2(float x, float y) {
@@ -127,37 +148,58 @@ __device__ __forceinline__ void sincos_halfangle(double x, double& s, double& c)
     c = fma(-t, sh, 1.0);
 }
 
-// sin and cos of the FP32-valued starter through a table in LDS: x = k·SCT_STEP + r with k = round(x/SCT_STEP), the grid
+// sin and cos of the FP32-valued starter x through a table in LDS: x = k·SCT_STEP + r with k = round(x/SCT_STEP), the grid
 // point's (sin, cos) read as one ds_read_b128, and a rotation by r (|r| <= 3.1e-3: sin r to r⁵, cos r − 1 to r⁴, error
-// < 1e-17). 13 FP64 instructions + 5 cheap ones instead of 24: the hot loop is FP64-issue bound and LDS is otherwise
-// idle. SCT_STEP is 2π/1024 cut to 37 significant bits, so k·SCT_STEP is exact and the host fills the table with the
-// sin/cos of exactly those grid points (octo_ctx_create). The index is NOT clamped (a clamp costs two more instructions
-// per row): for a valid walker (0 <= e < 1) the starter lies within ±(π + 1e-3), inside the guard entries; an invalid
-// walker (e >= 1, non-finite elements) may produce any index, which reads garbage from the block's LDS or, beyond the
-// allocation, zero (out-of-range DS reads return 0 and never fault) — k_finish discards that walker's sums.
+// < 1e-17). 12 FP64 instructions + 5 cheap ones instead of 24: the hot loop is FP64-issue bound and LDS is otherwise idle.
+//   * SCT_STEP is 2π/1024 rounded to 13 significant bits, so k·SCT_STEP and the remainder r = x − k·SCT_STEP are EXACT in
+//     FP32 (r is a multiple of ulp(x) below 2^24 of them): one v_fma_f32 and one conversion give r, no FP64 subtraction;
+//     the host fills the table with the sin/cos of exactly those grid points (octo_ctx_create).
+//   * k comes from the magic-number trick: x/STEP + 1.5·2^23 leaves k in the low mantissa bits (one v_fma_f32 instead of
+//     mul + rndne + cvt), and those bits shifted left by 4, plus a constant, ARE the byte offset of the table entry.
+// The index is NOT clamped (a clamp costs two more instructions per row): for a valid walker (0 <= e < 1) the starter lies
+// within ±(π + 1e-3), inside the guard entries; an invalid walker (e >= 1, non-finite elements) may produce any offset,
+// which reads garbage from the block's LDS or, beyond the allocation, zero (out-of-range DS reads return 0 and never
+// fault) — k_finish discards that walker's sums.
 constexpr int SCT_HALF = 512;                         // grid steps per π
 constexpr int SCT_PAD = 8;                            // guard steps beyond ±π (the FP32 starter may land a hair outside)
 constexpr int SCT_N = 2 * (SCT_HALF + SCT_PAD) + 1;   // 1041 entries, 16.3 KB
-constexpr double SCT_STEP = 0x1.921fb5444p-8;
-constexpr float SCT_INV_STEP_F = 162.97466f;
+constexpr double SCT_STEP = 0x1.922p-8;               // 0.00613594…; 2π/1024 = 0.00613592…
+constexpr float SCT_STEP_F = 0x1.922p-8f;
+constexpr float SCT_INV_STEP_F = 162.9742f;
+constexpr float SCT_MAGIC_F = 12582912.0f;            // 1.5·2^23 = 0x4B400000
 
 // c5 = 1/120 is carried in a VGPR by the caller: both coefficients of the inner Horner step as SGPRs would exceed the
 // one-scalar-operand limit of a VOP3 and cost a v_mov_b64 per row.
 struct SinCosTab {
     const double2* tab;
     double c5;
+    float inv_step;         // in a VGPR: v_fmaak_f32 takes the magic number as its literal, and a literal excludes a scalar operand
+    uint32_t off0;          // in an SGPR: the third operand of v_lshl_add_u32
 };
 
 __device__ __forceinline__ SinCosTab make_sincos_tab(const double2* lds_tab) {
-    SinCosTab t{lds_tab, OCTO_KT[17]};
+    SinCosTab t{lds_tab, OCTO_KT[17], SCT_INV_STEP_F, (uint32_t)(16u * (SCT_HALF + SCT_PAD) - (0x4B400000u << 4))};
     asm("" : "+v"(t.c5));      // not volatile: a volatile asm counts as a memory clobber and demotes the s_loads of the rows
+#ifndef OCTO_SCT_RPI
+    asm("" : "+v"(t.inv_step));
+    asm("" : "+s"(t.off0));
+#endif
     return t;
 }
 
-__device__ __forceinline__ void sincos_table(float xf, double x, const SinCosTab& T, double& s, double& c) {
-    const int k = (int)__builtin_rintf(xf * SCT_INV_STEP_F);
+__device__ __forceinline__ void sincos_table(float xf, const SinCosTab& T, double& s, double& c) {
+#ifdef OCTO_SCT_RPI
+    int k;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(k) : "v"(xf * SCT_INV_STEP_F));   // floor(x + 0.5): one instruction for round + convert
+    const float kf = (float)k;
     const double2 g = T.tab[k + (SCT_HALF + SCT_PAD)];
-    const double r = fma(-(double)k, SCT_STEP, x);
+#else
+    const float km = fmaf(xf, T.inv_step, SCT_MAGIC_F);
+    const float kf = km - SCT_MAGIC_F;                                   // k, exact
+    const uint32_t off = (__float_as_uint(km) << 4) + T.off0;
+    const double2 g = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(T.tab) + off);
+#endif
+    const double r = (double)fmaf(-kf, SCT_STEP_F, xf);                   // exact
     const double r2 = r * r;
     const double sr = r * fma(r2, fma(r2, T.c5, OCTO_KT[18]), 1.0);
     const double cm1 = r2 * fma(r2, OCTO_KT[20], -0.5);
@@ -246,23 +288,23 @@ struct LogProd {
 // (1 when it only feeds adjoints, 2 when it feeds a model value, -1 when nobody needs it).
 // tab: the block's LDS copy of the sin/cos table, or null for the polynomial sincos (kernels without the table).
 template <int INV_NR, bool TAB = false>
-__device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCosTab& tab = SinCosTab{nullptr, 0.0}) {
+__device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCosTab& tab = SinCosTab{nullptr, 0.0, 0.0f, 0u}) {
     KSol s;
     // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
     s.dt = t - pc.tp;
     const double u = s.dt * pc.invP;
     const double frac = u - rint(u);                  // M = 2π·frac enters f0 through an FMA below
     // ---- Markley (1995) starter, eqs (20),(5),(9),(10),(14),(15), in FP32
-    const float Mf = (float)frac * (float)TWO_PI;     // scale in FP32: one FP64 multiply less per row
-    const float ef = pc.ef, omef = pc.omef;
-    const float alpha = fmaf(pc.k1f, (float)PI - fabsf(Mf), (float)MK_K0);
-    const float d = fmaf(alpha, ef, 3.0f * omef);
+    const float ff = (float)frac;
+    const float Mf = ff * (float)TWO_PI;              // scale in FP32: one FP64 multiply less per row
+    const float alpha = fmaf(pc.A1, fabsf(ff), pc.A0);
+    const float d = fmaf(alpha, pc.ef, -pc.no3);      // 3(1−e) + αe
     const float ad = alpha * d;
     const float M2 = Mf * Mf;
-    const float q = fmaf(2.0f * ad, omef, -M2);
-    const float r = Mf * fmaf(3.0f * ad, d - omef, M2);
+    const float q = fmaf(ad, pc.o2, -M2);             // 2αd(1−e) − M²
+    const float r = Mf * fmaf(ad, fmaf(d, 3.0f, pc.no3), M2);       // 3αd(d − 1 + e)M + M³
     const float q2 = q * q;
-    const float disc = fmaxf(fmaf(q2, q, r * r), 0.0f);
+    const float disc = fmaf(q2, q, r * r);            // > 0 for 0 <= e < 1: r² dominates wherever q < 0 (q >= −M², r² >= 9α⁶M²)
     const float x = fabsf(r) + __builtin_amdgcn_sqrtf(disc);
     const float w = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (2.0f / 3.0f));   // cbrt(x²)
     const float den = fmaf(w, w + q, q2);
@@ -270,11 +312,11 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     const double E1 = (double)E1f;
     // ---- one fifth-order correction, eqs (21)-(29), FP64
     double s1, c1;
-    if constexpr (TAB) sincos_table(E1f, E1, tab, s1, c1);
+    if constexpr (TAB) sincos_table(E1f, tab, s1, c1);
     else sincos_halfangle(E1, s1, c1);
     const double e = pc.e;
     // f2/2, f2/24, f3/6 of Markley's (21)-(27) from the loop-invariant e/2 and e/6 (f2 = e sin E1 itself is not needed)
-    const double hf2 = (0.5 * e) * s1, q24 = hf2 * (1.0 / 12.0);
+    const double hf2 = pc.he * s1, q24 = hf2 * (1.0 / 12.0);
     const double sf3 = (e * (1.0 / 6.0)) * c1;
     const double f1 = fma(-e, c1, 1.0);
     const double f0 = fma(-e, s1, fma(-frac, TWO_PI, E1));           // E1 − e sin E1 − M

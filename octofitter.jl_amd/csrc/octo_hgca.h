@@ -79,7 +79,7 @@ __device__ __forceinline__ void hgca_setup(const double (&elv)[P][OCTO_N_EL], co
         h.fac = -(el[OCTO_EL_MASS] * c.mjup2msol) / Mt;      // q(sol, M_planet) = −M_planet/M_tot · q(sol)
         h.pc = PC{};
         h.pc.invP = 1.0 / P_d.v; h.pc.tp = h.tp.v; h.pc.e = e.v;
-        h.pc.ef = (float)e.v; h.pc.omef = (float)(1.0 - e.v); h.pc.k1f = (float)(MK_K1N / (1.0 + e.v));
+        set_starter<false>(h.pc, (float)e.v, (float)(1.0 - e.v), (float)(MK_K1N / (1.0 + e.v)));
     }
 }
 

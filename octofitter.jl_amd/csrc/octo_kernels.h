@@ -232,7 +232,7 @@ static __global__ __launch_bounds__(256) void k_kepler(const double* __restrict_
     PC pc = {};
     const double e = ecc[i];
     pc.invP = 1.0 / TWO_PI; pc.tp = 0.0; pc.e = e; pc.beta = sqrt(1.0 - e * e); pc.eob = e / pc.beta;
-    pc.ef = (float)e; pc.omef = (float)(1.0 - e); pc.k1f = (float)(MK_K1N / (1.0 + e));
+    set_starter(pc, (float)e, (float)(1.0 - e), (float)(MK_K1N / (1.0 + e)));
     const KSol s = kepler_solve<2>(MA[i], pc);
     const bool ok = (e >= 0.0) && (e < 1.0) && isfinite(MA[i]);
     E[i] = ok ? s.E : NAN;
@@ -567,7 +567,14 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
 template <int P, bool GRAD, bool NUIS, int KM>
 constexpr size_t main_lds_bytes() { return sizeof(double) * (2 * SCT_N + Layout<P, GRAD, NUIS, KM>::NACC * WAVE); }
 
+// Seven waves per SIMD (72 VGPRs) for the nuisance-free single-planet RA/Dec gradient kernels: they need 76 left alone, one
+// allocation granule too many; held to 72 the compiler parks 12 bytes outside the row loop and the loop itself is unchanged
+// (same-box A/B: −1 % step time). Every other variant keeps the register count it wants (forcing them spills in the loop).
 template <int P, bool GRAD, bool NUIS, int KM>
+constexpr unsigned main_min_waves() { return (P == 1 && GRAD && !NUIS && (KM & ~KM_COR) == KM_RADEC) ? 7u : 1u; }
+
+template <int P, bool GRAD, bool NUIS, int KM>
+__attribute__((amdgpu_waves_per_eu(main_min_waves<P, GRAD, NUIS, KM>())))
 static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -997,7 +1004,7 @@ static __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
         const double e = a.nl[0 * a.ld + wl], sma = a.nl[1 * a.ld + wl], tp = a.nl[2 * a.ld + wl], Mt = a.nl[3 * a.ld + wl];
         const double P_d = a.k_yr * sqrt(sma * sma * sma / Mt);      // parameterizations.jl:322
         pc.invP = 1.0 / P_d; pc.tp = tp; pc.e = e; pc.beta = sqrt(1.0 - e * e);   // sqrt1me2, :325
-        pc.ef = (float)e; pc.omef = (float)(1.0 - e); pc.k1f = (float)(MK_K1N / (1.0 + e));
+        set_starter(pc, (float)e, (float)(1.0 - e), (float)(MK_K1N / (1.0 + e)));
     }
     double acc[OFTI_NACC];
 #pragma unroll

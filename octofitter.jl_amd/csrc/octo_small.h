@@ -58,7 +58,7 @@ __device__ __forceinline__ void pc_from_setup(PC& pc, const double (&v)[NWC]) {
     pc.mu = v[WC_MU]; pc.a = v[WC_A]; pc.cGb = v[WC_CGB]; pc.cFb = v[WC_CFB]; pc.cBe = v[WC_CBE]; pc.cAe = v[WC_CAE];
     const float2 fa = *reinterpret_cast<const float2*>(&v[WC_F32A]);
     const float2 fb = *reinterpret_cast<const float2*>(&v[WC_F32B]);
-    pc.ef = fa.x; pc.omef = fa.y; pc.k1f = fb.x;
+    set_starter<false>(pc, fa.x, fa.y, fb.x);      // wave-uniform here: the constants live in SGPRs
 }
 
 // ---- standard parameterisation, lane = partial -------------------------------------------------------------------------

@@ -431,7 +431,26 @@ def main():
                 t1 = time.perf_counter(); fn.lib.octo_eval(*a_); ts.append(time.perf_counter() - t1)
             med = float(np.median(ts))
             res["pcie_inclusive"] = {"value": W * n_rows / med, "unit": "evals/s", "ms_per_call_median": med * 1e3, "calls": len(ts),
-                                     "what": "octo_eval with host buffers: H2D of elems and D2H of ll + gradient inside the call (SURVEY 8d definition); median of 25"}
+                                     "what": "octo_eval with PAGEABLE host buffers: H2D of elems and D2H of ll + gradient inside the call (SURVEY 8d definition); median of 25"}
+            # the same call with the caller's arrays registered once (octo_host_register): copy kernel in, results written in place
+            try:
+                ll_ref = ll_h.copy()
+                fn.host_register(el_h, ll_h, g_h)
+                ll_h[:] = np.nan
+                for _ in range(5):
+                    fn.lib.octo_eval(*a_)
+                ts = []
+                for _ in range(25):
+                    t1 = time.perf_counter(); fn.lib.octo_eval(*a_); ts.append(time.perf_counter() - t1)
+                medr = float(np.median(ts))
+                fn.host_unregister(el_h, ll_h, g_h)
+                res["pcie_inclusive"]["registered"] = {
+                    "value": W * n_rows / medr, "unit": "evals/s", "ms_per_call_median": medr * 1e3, "calls": len(ts),
+                    "bit_identical_to_pageable": bool(np.array_equal(ll_h, ll_ref, equal_nan=True)),
+                    "what": "the same octo_eval call with elems, ll and gradient arrays registered once by the caller (octo_host_register: "
+                            "page-locked + mapped): no copy engine, inputs by a copy kernel over PCIe, outputs written in place"}
+            except Exception as ex:
+                res["pcie_inclusive"]["registered"] = {"error": str(ex)}
         if not args.no_extras and world == 1 and args.workload == "grad":      # before the CPU baseline: its OpenMP team keeps spinning for a while and would disturb a latency measurement
             try:
                 res["config1"] = config1_latency(pkg, dev_index)

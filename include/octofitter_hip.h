@@ -233,6 +233,19 @@ int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* ds,
                          void* hip_stream);
 int32_t octo_sync(octo_ctx* ctx);
 
+/* Pinning the caller's arrays (optional). octo_eval / octo_eval_begin with pageable host buffers stage big batches through
+ * the runtime's pageable copies (~120 µs per call for the 1.4 MB of a 1e4-walker gradient call). A host that keeps its
+ * element / log-likelihood / gradient arrays alive across calls — a sampler's preallocated buffers; in Julia the Arrays the
+ * shim passes to ccall — registers them ONCE: the range is page-locked and mapped into the device's address space
+ * (hipHostRegister), and every later host-buffer call whose buffers ALL lie inside registered ranges skips the copy engine:
+ * one copy kernel reads the inputs over PCIe, the kernels write ll and the gradients straight into the caller's arrays.
+ * Results are bit-identical to the pageable path. Unregister before freeing the memory. The registry is process-wide and
+ * thread-safe; a range is usable by contexts on the device it was registered for. Mirrors nothing in the reference (its
+ * arrays never leave the host): it is the boundary's cost model, next to `octo_eval`
+ * (src/likelihoods/system.jl:206-241 is the call it replaces). */
+int32_t octo_host_register(octo_ctx* ctx, void* ptr, int64_t bytes);
+int32_t octo_host_unregister(octo_ctx* ctx, void* ptr);
+
 /* Batched eccentric-anomaly solve, HOST buffers (blocking): E = kepler_solver(MA, e) for 0 <= e < 1, the
  * call the reference makes at src/parameterizations.jl:340 (PlanetOrbits.kepler_solver, Markley). Runs the same
  * device routine the likelihood kernel uses. sinE_out / cosE_out may be NULL. Invalid inputs give NaN. */

@@ -36,6 +36,24 @@ bool grow_pinned(double*& p, int64_t& cap, int64_t need) {
 // (SoA, walker fastest); this kernel reads them over PCIe — coalesced along the walkers — and leaves them walker-major in device
 // memory, where each k_small block finds its walker's inputs contiguous. Two copy-engine transfers of ~40 KB cost ~17 µs per
 // call; this launch ~4 µs, and the results go back through the mapped buffer + per-walker flags like the smallest batches.
+// ---- caller-registered host ranges (octo_host_register): process-wide, keyed by base address
+struct HostRange { size_t bytes; char* dev; int device; };
+static std::mutex g_reg_mu;
+static std::map<uintptr_t, HostRange> g_reg;
+
+// device-side address of the host range [p, p + bytes) if it lies inside one registered range for this device, else null
+static void* mapped_range(int device, const void* p, size_t bytes) {
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (g_reg.empty()) return nullptr;
+    auto it = g_reg.upper_bound((uintptr_t)p);
+    if (it == g_reg.begin()) return nullptr;
+    --it;
+    const uintptr_t base = it->first;
+    if ((uintptr_t)p + bytes > base + it->second.bytes || it->second.device != device) return nullptr;
+    return it->second.dev + ((uintptr_t)p - base);
+}
+
 static int64_t stage_bytes() {      // host-buffer calls up to this size (inputs + outputs) are staged in mapped pinned memory (OCTO_STAGE_BYTES: experiments)
     if (const char* ev = std::getenv("OCTO_STAGE_BYTES")) { const long v = std::atol(ev); if (v > 0) return v; }
     return STAGE_DMA_BYTES;
@@ -679,6 +697,29 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
         pd.active = true;
         return OCTO_OK;
     }
+    {
+        // Buffers the caller registered (octo_host_register): no copy engine and no staging copy. One copy kernel brings the inputs
+        // into device memory over PCIe (coalesced; k_main blocks must not fetch nuisances from the host one by one), and k_finish
+        // writes ll and the gradients straight into the caller's arrays. Everything keeps the caller's leading dimension.
+        const size_t sp_el = sizeof(double) * ((size_t)(n_el - 1) * ld + W), sp_nu = sizeof(double) * ((size_t)(n_nu > 0 ? n_nu - 1 : 0) * ld + W);
+        double* m_el = (double*)mapped_range(ctx->device, elems, sp_el);
+        double* m_nu = nuis ? (double*)mapped_range(ctx->device, nuis, sp_nu) : nullptr;
+        double* m_ll = (double*)mapped_range(ctx->device, ll_out, sizeof(double) * W);
+        double* m_ge = g_elems ? (double*)mapped_range(ctx->device, g_elems, sp_el) : nullptr;
+        double* m_gn = g_nuis ? (double*)mapped_range(ctx->device, g_nuis, sp_nu) : nullptr;
+        if (m_el && m_ll && (!nuis || m_nu) && (!g_elems || m_ge) && (!g_nuis || m_gn)) {
+            const int64_t n_el_flat = (int64_t)(n_el - 1) * ld + W, n_nu_flat = nuis ? (int64_t)(n_nu - 1) * ld + W : 0;
+            rc = grow(ctx, ctx->d_in, ctx->cap_in, (int64_t)(n_el + (nuis ? n_nu : 0)) * ld);
+            if (rc) return rc;
+            double* z_nuis = nuis ? ctx->d_in + (int64_t)n_el * ld : nullptr;
+            hipLaunchKernelGGL(k_copy_in, dim3((unsigned)((n_el_flat + 255) / 256)), dim3(256), 0, st, m_el, ctx->d_in, n_el_flat);
+            if (nuis) hipLaunchKernelGGL(k_copy_in, dim3((unsigned)((n_nu_flat + 255) / 256)), dim3(256), 0, st, m_nu, z_nuis, n_nu_flat);
+            rc = octo_eval_device(ctx, ds, ctx->d_in, z_nuis, ld, W, m_ll, m_ge, m_gn, st);
+            if (rc) return rc;
+            pd.active = true;      // not staged: octo_eval_end synchronises the stream, the results are already in place
+            return OCTO_OK;
+        }
+    }
     HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_in, sizeof(double) * ldd, elems, sizeof(double) * ld, sizeof(double) * W, n_el,
                                  hipMemcpyHostToDevice, st));
     if (nuis)
@@ -734,6 +775,41 @@ int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, co
     const int rc = octo_eval_begin(ctx, ds, elems, nuis, ld, W, ll_out, g_elems, g_nuis);
     if (rc) { if (ctx) ctx->pending.active = false; return rc; }
     return octo_eval_end(ctx);
+}
+
+int32_t octo_host_register(octo_ctx* ctx, void* ptr, int64_t bytes) {
+    if (!ctx || !ptr || bytes <= 0) return fail(ctx, OCTO_EINVAL, "octo_host_register: null pointer or empty range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (g_reg.count((uintptr_t)ptr)) return fail(ctx, OCTO_EINVAL, "octo_host_register: this address is already registered");
+    }
+    if (hipHostRegister(ptr, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, OCTO_EHIP, "octo_host_register: hipHostRegister failed (range not owned by the process, or already pinned)");
+    }
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess || !dev) {
+        (void)hipGetLastError(); (void)hipHostUnregister(ptr);
+        return fail(ctx, OCTO_EHIP, "octo_host_register: no device mapping for the range");
+    }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_reg[(uintptr_t)ptr] = HostRange{(size_t)bytes, (char*)dev, ctx->device};
+    return OCTO_OK;
+}
+
+int32_t octo_host_unregister(octo_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return fail(ctx, OCTO_EINVAL, "octo_host_unregister: null argument");
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_reg.find((uintptr_t)ptr);
+        if (it == g_reg.end()) return fail(ctx, OCTO_EINVAL, "octo_host_unregister: address was not registered (pass the base address given to octo_host_register)");
+        g_reg.erase(it);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // nothing of this context may still be writing into the range
+    HIPCHK(ctx, hipHostUnregister(ptr));
+    return OCTO_OK;
 }
 
 int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n, double* E_out, double* sinE_out,

@@ -127,6 +127,8 @@ _SIGS = {
     "octo_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "octo_consts_set": (C.c_int32, [C.c_void_p, C.POINTER(OctoConsts)]),
     "octo_ctx_set_small_batch": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "octo_host_register": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "octo_host_unregister": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "octo_last_error": (C.c_char_p, [C.c_void_p]),
     "octo_dataset_create": (C.c_int32, [C.c_void_p, C.POINTER(OctoObsDesc), C.c_int32,
                                         C.POINTER(OctoPlanetDesc), C.c_int32, C.POINTER(C.c_void_p)]),

@@ -259,6 +259,28 @@ class BatchedLnLike:
                                        capi._dptr(ll), capi._dptr(g_el), capi._dptr(g_nu)), "octo_eval")
         return (ll, g_el, g_nu) if grad else ll
 
+    def ln_like_into(self, elems, nuis, ll, g_elems=None, g_nuis=None):
+        """octo_eval into arrays the caller owns (C-contiguous float64, walker index fastest): with all of them registered
+        (`host_register`) a big batch crosses PCIe without the copy engine and lands in place."""
+        W = elems.shape[1]
+        self._check(self.lib.octo_eval(self._ctx, self._ds, capi._dptr(elems), capi._dptr(nuis), W, W,
+                                       capi._dptr(ll), capi._dptr(g_elems), capi._dptr(g_nuis)), "octo_eval")
+        return ll
+
+    def host_register(self, *arrays):
+        """Page-lock and map arrays the caller keeps alive across calls (octo_host_register)."""
+        for a in arrays:
+            if a is None:
+                continue
+            if not (a.flags["C_CONTIGUOUS"] and a.dtype == np.float64):
+                raise ValueError("host_register: C-contiguous float64 arrays only")
+            self._check(self.lib.octo_host_register(self._ctx, a.ctypes.data, a.nbytes), "octo_host_register")
+
+    def host_unregister(self, *arrays):
+        for a in arrays:
+            if a is not None:
+                self._check(self.lib.octo_host_unregister(self._ctx, a.ctypes.data), "octo_host_unregister")
+
     def __call__(self, θ):
         elems, nuis = self.pack(θ)
         return self.ln_like_arrays(elems, nuis)

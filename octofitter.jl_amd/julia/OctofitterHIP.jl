@@ -103,6 +103,10 @@ end
 octo_ctx_destroy(ctx) = ccall((:octo_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), ctx)
 octo_consts_set(ctx, c::OctoConsts) = check(ctx, ccall((:octo_consts_set, LIB), Int32, (Ptr{Cvoid}, Ref{OctoConsts}), ctx, c), "octo_consts_set")
 octo_ctx_set_small_batch(ctx, n::Integer) = check(ctx, ccall((:octo_ctx_set_small_batch, LIB), Int32, (Ptr{Cvoid}, Int32), ctx, n), "octo_ctx_set_small_batch")
+# Page-lock and map an Array the caller keeps alive (elements, log-likelihoods, gradients of a big batch): later host-buffer calls
+# whose buffers are all registered skip the copy engine. `GC.@preserve` the array for as long as it is registered; unregister before it is freed.
+octo_host_register(ctx, a::Array{Float64}) = check(ctx, ccall((:octo_host_register, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), ctx, pointer(a), sizeof(a)), "octo_host_register")
+octo_host_unregister(ctx, a::Array{Float64}) = check(ctx, ccall((:octo_host_unregister, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx, pointer(a)), "octo_host_unregister")
 function octo_dataset_create(ctx, descs::Vector{OctoObsDesc}, planets::Vector{OctoPlanetDesc})
     ds = Ref{Ptr{Cvoid}}(C_NULL)
     check(ctx, ccall((:octo_dataset_create, LIB), Int32, (Ptr{Cvoid}, Ptr{OctoObsDesc}, Int32, Ptr{OctoPlanetDesc}, Int32, Ref{Ptr{Cvoid}}),

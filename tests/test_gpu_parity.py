@@ -601,3 +601,38 @@ def test_hgca_next_to_oneil_and_marginalised_rv(oracle):
     assert np.array_equal(ll, ll_f) and np.all(np.isfinite(ll))
     ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, elems, nuis, grad=True)
     _cmp_oracle("hgca+oneil+marg", ll, g, gn, ll_o, g_o, gn_o, ll_rtol=1e-9, g_rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_registered_host_buffers_match_the_pageable_path(pkg):
+    """octo_host_register: a big host-buffer batch whose arrays are all registered takes the zero-copy route (copy kernel in,
+    results written in place); bit-identical to the pageable route and to a second call; partial registration falls back."""
+    cfg = synth.config_astrom(n_epochs=96, n_walkers=9001, cfg=3, seed=77)      # 9001 x 19 doubles > 1 MiB: beyond the staged range
+    obs, planet = synth.to_mirror(pkg, cfg)
+    fn = pkg.make_ln_like(pkg.System(name="reg", companions=[planet], observations=[]), cfg["theta_example"])
+    el = np.ascontiguousarray(cfg["elems"])
+    ll0, g0, _ = fn.ln_like_arrays(el, None, grad=True)
+    ll = np.full(el.shape[1], np.nan); g = np.full_like(el, np.nan)
+    fn.host_register(el, ll)                       # the gradient array is not registered yet: pageable route
+    fn.ln_like_into(el, None, ll, g)
+    assert np.array_equal(ll, ll0) and np.array_equal(g, g0)
+    fn.host_register(g)
+    ll[:] = np.nan; g[:] = np.nan
+    fn.ln_like_into(el, None, ll, g)
+    assert np.array_equal(ll, ll0, equal_nan=True) and np.array_equal(g, g0, equal_nan=True)
+    ll[:] = np.nan
+    fn.ln_like_into(el, None, ll)                  # forward only
+    assert np.array_equal(ll, ll0, equal_nan=True)
+    # a view into a registered range is found too (interior pointers), and a leading dimension larger than W is honoured
+    W2 = 8000
+    fn._check(fn.lib.octo_eval(fn._ctx, fn._ds, pkg.capi._dptr(el), None, el.shape[1], W2, pkg.capi._dptr(ll), pkg.capi._dptr(g), None), "octo_eval")
+    assert np.array_equal(ll[:W2], ll0[:W2], equal_nan=True) and np.array_equal(g[:, :W2], g0[:, :W2], equal_nan=True)
+    with pytest.raises(pkg.capi.OctoError):
+        fn.host_register(g)                        # twice
+    fn.host_unregister(el, ll, g)
+    with pytest.raises(pkg.capi.OctoError):
+        fn.host_unregister(g)
+    ll[:] = np.nan
+    fn.ln_like_into(el, None, ll, g)               # pageable again
+    assert np.array_equal(ll, ll0, equal_nan=True)
+    fn.close()

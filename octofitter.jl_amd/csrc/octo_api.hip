@@ -629,17 +629,25 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
         pd.staged = true;
         const int nn = nuis ? n_nu : 0;
         const int64_t ws_in = n_el + nn, ws_out = 1 + pd.n_el_out + pd.n_nu_out;
-        for (int64_t w = 0; w < W; ++w) {
-            double* dst = ctx->h_in + w * ws_in;
-            for (int r = 0; r < n_el; ++r) dst[r] = elems[(size_t)r * ld + w];
-            for (int r = 0; r < nn; ++r) dst[n_el + r] = nuis[(size_t)r * ld + w];
+        ctx->inl.n = 0;
+        if (W == 1 && ws_in <= SMALL_INL && ds->n_hgca == 0) {
+            // one parameter set: inside the kernel arguments (device memory) instead of the mapped buffer (a PCIe read at kernel start)
+            ctx->inl.n = (int32_t)ws_in; ctx->inl.pad = 0;
+            for (int r = 0; r < n_el; ++r) ctx->inl.v[r] = elems[(size_t)r * ld];
+            for (int r = 0; r < nn; ++r) { ctx->inl.v[n_el + r] = nuis[(size_t)r * ld]; if (!std::isfinite(nuis[(size_t)r * ld])) ctx->inl.pad = 1; }
+        } else {
+            for (int64_t w = 0; w < W; ++w) {
+                double* dst = ctx->h_in + w * ws_in;
+                for (int r = 0; r < n_el; ++r) dst[r] = elems[(size_t)r * ld + w];
+                for (int r = 0; r < nn; ++r) dst[n_el + r] = nuis[(size_t)r * ld + w];
+            }
         }
         pd.walker_major = true; pd.ws_out = ws_out;
         ctx->stage_ws_in = ws_in; ctx->stage_ws_out = ws_out;
         ctx->flag_request = W <= ctx->flag_w; ctx->flag_armed = false;
         int rcz = octo_eval_device(ctx, ds, m_in, nuis ? m_in + n_el : nullptr, 1, W, m_out, g_elems ? m_out + 1 : nullptr,
                                    g_nuis ? m_out + 1 + pd.n_el_out : nullptr, st);
-        ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
+        ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0; ctx->inl.n = 0;
         if (rcz) return rcz;
         pd.active = true;
         return OCTO_OK;
@@ -1075,10 +1083,15 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
         const int64_t D = m->D, ws_o = grad_out ? D + 1 : 1;
         for (int64_t w = 0; w < W; ++w)
             for (int r = 0; r < D; ++r) ctx->h_in[w * D + r] = theta_t[(size_t)r * ld + w];
+        ctx->inl.n = 0;
+        if (W == 1 && D <= SMALL_INL && m->ds->n_hgca == 0) {      // one θ_t: inside the kernel arguments (see octo_eval)
+            ctx->inl.n = D; ctx->inl.pad = 0;
+            for (int r = 0; r < D; ++r) ctx->inl.v[r] = theta_t[(size_t)r * ld];
+        }
         ctx->stage_ws_in = D; ctx->stage_ws_out = ws_o;
         ctx->flag_request = W <= ctx->flag_w; ctx->flag_armed = false;
         int rcz = octo_model_logpost_device(ctx, m, m_in, 1, W, m_out, grad_out ? m_out + 1 : nullptr, st);
-        ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0;
+        ctx->flag_request = false; ctx->stage_ws_in = ctx->stage_ws_out = 0; ctx->inl.n = 0;
         if (rcz) return rcz;
         rcz = wait_small(ctx, st, W);
         if (rcz) return rcz;

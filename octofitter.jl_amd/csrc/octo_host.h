@@ -90,6 +90,7 @@ struct octo_ctx {
     uint64_t* h_flags = nullptr;                // mapped pinned [SMALL_W]: k_small's finishing block of walker w stores the call's
     uint64_t flag_seq = 0;                      // sequence number here after its outputs; host-buffer calls spin on it
     bool flag_request = false, flag_armed = false;
+    SmallInline inl = {};                       // n > 0 while a one-θ host-buffer call hands k_small its inputs inside the kernel arguments
     int64_t stage_ws_in = 0, stage_ws_out = 0;  // > 0 while octo_eval hands k_small its walker-major staging buffers
     // octo_eval_begin .. octo_eval_end: what is still to be waited for and copied out
     struct Pending {

@@ -70,7 +70,7 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     std::memset(&sm, 0, sizeof(sm));
     if (MODEL) sm = *smp;
     hipLaunchKernelGGL((k_small<P, GRAD, NUIS, KM, MODEL>), dim3((unsigned)(a.n_rblocks + a.n_hblocks), (unsigned)a.W), dim3(SMALL_TPB), 0, st, a, sm,
-                       ctx->d_counters, flags, ctx->flag_seq);
+                       ctx->d_counters, flags, ctx->flag_seq, ctx->inl);
     if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;

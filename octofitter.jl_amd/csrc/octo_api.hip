@@ -630,7 +630,7 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
         const int nn = nuis ? n_nu : 0;
         const int64_t ws_in = n_el + nn, ws_out = 1 + pd.n_el_out + pd.n_nu_out;
         ctx->inl.n = 0;
-        if (W == 1 && ws_in <= SMALL_INL && ds->n_hgca == 0) {
+        if (W == 1 && ws_in <= SMALL_INL) {
             // one parameter set: inside the kernel arguments (device memory) instead of the mapped buffer (a PCIe read at kernel start)
             ctx->inl.n = (int32_t)ws_in; ctx->inl.pad = 0;
             for (int r = 0; r < n_el; ++r) ctx->inl.v[r] = elems[(size_t)r * ld];
@@ -1084,7 +1084,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
         for (int64_t w = 0; w < W; ++w)
             for (int r = 0; r < D; ++r) ctx->h_in[w * D + r] = theta_t[(size_t)r * ld + w];
         ctx->inl.n = 0;
-        if (W == 1 && D <= SMALL_INL && m->ds->n_hgca == 0) {      // one θ_t: inside the kernel arguments (see octo_eval)
+        if (W == 1 && D <= SMALL_INL) {      // one θ_t: inside the kernel arguments (see octo_eval)
             ctx->inl.n = D; ctx->inl.pad = 0;
             for (int r = 0; r < D; ++r) ctx->inl.v[r] = theta_t[(size_t)r * ld];
         }

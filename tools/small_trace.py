@@ -3,7 +3,7 @@ finishing block of walker 0 — where one small call's microseconds go."""
 import ctypes as C, os, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-os.environ["OCTOFITTER_HIP_LIB"] = str(ROOT / "tools" / "liboctofitter_trace.bin")
+os.environ.setdefault("OCTOFITTER_HIP_LIB", str(ROOT / "tools" / "liboctofitter_trace.bin"))
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 from __graft_entry__ import load_package

@@ -90,6 +90,30 @@ def test_config4_full_size(oracle):
     _cmp_oracle("config 4 sample, no nuisances", ll0[idx], g0[:, idx], None, ll0_o, g0_o, None)
 
 
+def test_config4_registered_host_arrays():
+    """Two planets + nuisances through octo_eval with every array registered (octo_host_register): the copy kernel brings elements
+    AND nuisances in, ll / g_elems / g_nuis are written in place — bit-identical to the pageable route."""
+    gb = _gpu()
+    capi = gb.capi
+    c4 = synth.config_two_planet(n_astrom=70, n_rv=50, n_walkers=4096, seed=11)      # 4096 x (18 + 6) x 2 doubles > 1 MiB
+    a, r = c4["astrom"], c4["rv"]
+    obs = [dict(kind=0, planet=1, epoch=a["epoch"], y1=a["ra"], y2=a["dec"], s1=a["σ_ra"], s2=a["σ_dec"], cor=None),
+           dict(kind=2, planet=-1, epoch=r["epoch"], y1=r["rv"], y2=None, s1=r["σ_rv"], s2=None, cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=True), dict(orbit_kind=0, has_mass=True)]
+    with gb.GpuPath(obs, planets) as path:
+        el = np.ascontiguousarray(c4["elems"]); nu = np.ascontiguousarray(c4["nuis"])
+        ll0, g0, gn0 = path.eval(el, nu, grad=True)
+        ll = np.full_like(ll0, np.nan); g = np.full_like(g0, np.nan); gn = np.full_like(gn0, np.nan)
+        bufs = (el, nu, ll, g, gn)
+        for b in bufs:
+            path._chk(path.lib.octo_host_register(path.ctx, b.ctypes.data, b.nbytes))
+        W = el.shape[1]
+        path._chk(path.lib.octo_eval(path.ctx, path.ds, capi._dptr(el), capi._dptr(nu), W, W, capi._dptr(ll), capi._dptr(g), capi._dptr(gn)))
+        assert np.array_equal(ll, ll0) and np.array_equal(g, g0) and np.array_equal(gn, gn0)
+        for b in bufs:
+            path._chk(path.lib.octo_host_unregister(path.ctx, b.ctypes.data))
+
+
 def test_config5_per_gpu_shape(pkg, oracle):
     import torch
     from octofitter_jl_amd.host.tempering import TemperedSwap

@@ -251,6 +251,11 @@ int32_t octo_host_unregister(octo_ctx* ctx, void* ptr);
  * device routine the likelihood kernel uses. sinE_out / cosE_out may be NULL. Invalid inputs give NaN. */
 int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n,
                           double* E_out, double* sinE_out, double* cosE_out);
+/* The same call through the THROUGHPUT kernels' variant of the routine (k_main, k_ofti_main): sin/cos of the FP32 starter from the
+ * 1041-entry table in LDS + a rotation, instead of the half-angle polynomials of the small-batch kernel that octo_kepler_solve runs.
+ * Both variants find the same root to rounding; the parity tests check each over the whole elliptic domain. */
+int32_t octo_kepler_solve_table(octo_ctx* ctx, const double* MA, const double* e, int64_t n,
+                                double* E_out, double* sinE_out, double* cosE_out);
 
 /* OFTI marginal likelihood: batched `ofti_linear_solve(epochs, ra, dec, σ_ra, σ_dec, cor, σ_ABFG,
  * e, a, tp, M, plx)` — src/parameterizations.jl:318-405. The handle holds one RA/Dec table (cor may be NULL = 0) and

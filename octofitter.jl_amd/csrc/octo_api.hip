@@ -820,8 +820,8 @@ int32_t octo_host_unregister(octo_ctx* ctx, void* ptr) {
     return OCTO_OK;
 }
 
-int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n, double* E_out, double* sinE_out,
-                          double* cosE_out) {
+static int32_t kepler_solve_host(octo_ctx* ctx, const double* MA, const double* e, int64_t n, double* E_out, double* sinE_out,
+                                 double* cosE_out, bool table) {
     if (!ctx || !MA || !e || !E_out || n < 0) return fail(ctx, OCTO_EINVAL, "octo_kepler_solve: null argument");
     if (n == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -833,8 +833,12 @@ int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int6
     { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, MA, sizeof(double) * n, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_in + n, e, sizeof(double) * n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_kepler, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx->d_in, ctx->d_in + n, n, ctx->d_out,
-                       ctx->d_out + n, ctx->d_out + 2 * n);
+    if (table)
+        hipLaunchKernelGGL(k_kepler<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), sizeof(double) * 2 * SCT_N, st, ctx->d_in, ctx->d_in + n, n,
+                           ctx->d_out, ctx->d_out + n, ctx->d_out + 2 * n, ctx->d_sctab);
+    else
+        hipLaunchKernelGGL(k_kepler<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx->d_in, ctx->d_in + n, n, ctx->d_out,
+                           ctx->d_out + n, ctx->d_out + 2 * n, nullptr);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(E_out, ctx->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     if (sinE_out) HIPCHK(ctx, hipMemcpyAsync(sinE_out, ctx->d_out + n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
@@ -842,6 +846,16 @@ int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int6
     HIPCHK(ctx, hipStreamSynchronize(st));
     free_retired(ctx);
     return OCTO_OK;
+}
+
+int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n, double* E_out, double* sinE_out,
+                          double* cosE_out) {
+    return kepler_solve_host(ctx, MA, e, n, E_out, sinE_out, cosE_out, false);
+}
+
+int32_t octo_kepler_solve_table(octo_ctx* ctx, const double* MA, const double* e, int64_t n, double* E_out, double* sinE_out,
+                                double* cosE_out) {
+    return kepler_solve_host(ctx, MA, e, n, E_out, sinE_out, cosE_out, true);
 }
 
 int32_t octo_timing_enable(octo_ctx* ctx, int32_t on) {

@@ -225,15 +225,27 @@ static __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
 // ------------------------------------------------------------------------------------ k_kepler
 // Batched PlanetOrbits.kepler_solver(MA, e) (call site src/parameterizations.jl:340) through the same device
 // routine k_main uses; exported as octo_kepler_solve so tests can check the solver itself.
+// TAB: the throughput kernels' variant (sin/cos of the starter from the sin/cos table, copied to LDS by the block exactly as k_main
+// does); otherwise the half-angle polynomials of k_small / k_hgca.
+template <bool TAB>
 static __global__ __launch_bounds__(256) void k_kepler(const double* __restrict__ MA, const double* __restrict__ ecc, int64_t n,
-                                                 double* E, double* sE, double* cE) {
+                                                       double* E, double* sE, double* cE, const double* __restrict__ sctab) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    SinCosTab tab{nullptr, 0.0, 0.0f, 0u};
+    if constexpr (TAB) {
+        tab = make_sincos_tab(reinterpret_cast<const double2*>(lds));
+        const double2* __restrict__ g = reinterpret_cast<const double2*>(sctab);
+        double2* t = reinterpret_cast<double2*>(lds);
+        for (int i = threadIdx.x; i < SCT_N; i += blockDim.x) t[i] = g[i];
+        __syncthreads();
+    }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     PC pc = {};
     const double e = ecc[i];
     pc.invP = 1.0 / TWO_PI; pc.tp = 0.0; pc.e = e; pc.beta = sqrt(1.0 - e * e); pc.eob = e / pc.beta;
     set_starter(pc, (float)e, (float)(1.0 - e), (float)(MK_K1N / (1.0 + e)));
-    const KSol s = kepler_solve<2>(MA[i], pc);
+    const KSol s = kepler_solve<2, TAB>(MA[i], pc, tab);
     const bool ok = (e >= 0.0) && (e < 1.0) && isfinite(MA[i]);
     E[i] = ok ? s.E : NAN;
     if (sE) sE[i] = ok ? s.sE : NAN;

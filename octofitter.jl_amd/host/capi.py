@@ -150,6 +150,7 @@ _SIGS = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "octo_sync": (C.c_int32, [C.c_void_p]),
     "octo_kepler_solve": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "octo_kepler_solve_table": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "octo_ofti_create": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64,
                                      C.c_double, C.POINTER(C.c_void_p)]),
     "octo_ofti_destroy": (C.c_int32, [C.c_void_p]),

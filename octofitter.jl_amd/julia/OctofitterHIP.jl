@@ -148,6 +148,13 @@ function octo_kepler_solve(ctx, MA::Vector{Float64}, e::Vector{Float64})
                      ctx, MA, e, n, E, sE, cE), "octo_kepler_solve")
     return E, sE, cE
 end
+"The same through the throughput kernels' variant of the routine (sin/cos of the starter from the LDS table)."
+function octo_kepler_solve_table(ctx, MA::Vector{Float64}, e::Vector{Float64})
+    n = length(MA); E = similar(MA); sE = similar(MA); cE = similar(MA)
+    check(ctx, ccall((:octo_kepler_solve_table, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                     ctx, MA, e, n, E, sE, cE), "octo_kepler_solve_table")
+    return E, sE, cE
+end
 
 # OFTI marginal likelihood (src/parameterizations.jl:318-405)
 function octo_ofti_create(ctx, epochs, ra, dec, σ_ra, σ_dec, cor, σ_ABFG)

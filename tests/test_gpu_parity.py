@@ -377,22 +377,27 @@ def test_pt_swap_kernel(pkg):
     lib.octo_ctx_destroy(ctx)
 
 
-def _kepler_device(pkg, MA, e):
+def _kepler_device(pkg, MA, e, table=False):
     lib = pkg.capi.load_library()
     ctx = C.c_void_p()
     assert lib.octo_ctx_create(C.byref(ctx), 0) == 0
     MA = np.ascontiguousarray(MA, dtype=np.float64); e = np.ascontiguousarray(e, dtype=np.float64)
     E = np.empty_like(MA); sE = np.empty_like(MA); cE = np.empty_like(MA)
     dp = pkg.capi._dptr
-    assert lib.octo_kepler_solve(ctx, dp(MA), dp(e), MA.size, dp(E), dp(sE), dp(cE)) == 0
+    fn = lib.octo_kepler_solve_table if table else lib.octo_kepler_solve
+    assert fn(ctx, dp(MA), dp(e), MA.size, dp(E), dp(sE), dp(cE)) == 0
     lib.octo_ctx_destroy(ctx)
     return E, sE, cE
 
 
-def test_kepler_device_solver(pkg, oracle):
+@pytest.mark.parametrize("table", [False, True], ids=["polynomial sincos (k_small)", "LDS table (k_main)"])
+def test_kepler_device_solver(pkg, oracle, table):
     """The device Kepler routine (FP32 Markley starter + FP64 fifth-order correction) against Kepler's equation,
     an 80-bit Newton solve, and the reference algorithm in the oracle — over the whole elliptic domain, including
-    e -> 1 − 1e-9, |M| -> 0 and |M| -> π. Error is weighted by 1 − e cos E (the conditioning of the root)."""
+    e -> 1 − 1e-9, |M| -> 0 and |M| -> π. Error is weighted by 1 − e cos E (the conditioning of the root). Both variants of the
+    routine: sin/cos of the starter from the half-angle polynomials (k_small, k_hgca) and from the table in LDS with the
+    magic-number index and the exact FP32 remainder (k_main, k_ofti_main)."""
+    def kd(pkg_, M_, e_): return _kepler_device(pkg_, M_, e_, table=table)
     rng = np.random.default_rng(5)
     n = 400_000
     e = np.concatenate([rng.uniform(0, 1, n // 2), 1 - 10 ** rng.uniform(-9, -1, n // 2)])
@@ -402,7 +407,7 @@ def test_kepler_device_solver(pkg, oracle):
     M = np.clip(M, -np.pi, np.pi)
     rng.shuffle(M)
     M[:8] = [1.0, 1e-9, -1e-9, np.pi, -np.pi, 0.0, 0.0, 0.0]
-    E, sE, cE = _kepler_device(pkg, M, e)
+    E, sE, cE = kd(pkg, M, e)
     assert np.all(np.isfinite(E))
     # 80-bit Newton truth
     Ml = M.astype(np.longdouble); el = e.astype(np.longdouble)
@@ -423,11 +428,11 @@ def test_kepler_device_solver(pkg, oracle):
     assert (np.abs(E[idx] - Eo) * cond[idx]).max() < 2e-15
     # large mean anomalies are reduced like rem2pi(·, RoundNearest)
     big = np.array([40.0, -1234.5, 6.0e3, 2 * np.pi * 7 + 0.25])
-    Eb, _, _ = _kepler_device(pkg, big, np.full(4, 0.4))
+    Eb, _, _ = kd(pkg, big, np.full(4, 0.4))
     Eo = np.array([lib.octo_oracle_kepler_markley(float(m), 0.4) for m in big])
     assert np.abs(Eb - Eo).max() < 1e-12
     # invalid inputs
-    En, _, _ = _kepler_device(pkg, np.array([1.0, 1.0, np.nan]), np.array([1.0, -0.1, 0.3]))
+    En, _, _ = kd(pkg, np.array([1.0, 1.0, np.nan]), np.array([1.0, -0.1, 0.3]))
     assert np.all(np.isnan(En))
 
 

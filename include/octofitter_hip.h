@@ -247,8 +247,8 @@ int32_t octo_host_register(octo_ctx* ctx, void* ptr, int64_t bytes);
 int32_t octo_host_unregister(octo_ctx* ctx, void* ptr);
 
 /* Batched eccentric-anomaly solve, HOST buffers (blocking): E = kepler_solver(MA, e) for 0 <= e < 1, the
- * call the reference makes at src/parameterizations.jl:340 (PlanetOrbits.kepler_solver, Markley). Runs the same
- * device routine the likelihood kernel uses. sinE_out / cosE_out may be NULL. Invalid inputs give NaN. */
+ * call the reference makes at src/parameterizations.jl:340 (PlanetOrbits.kepler_solver, Markley). Runs the device
+ * routine of the small-batch likelihood kernel (half-angle polynomial sin/cos of the starter). sinE_out / cosE_out may be NULL. Invalid inputs give NaN. */
 int32_t octo_kepler_solve(octo_ctx* ctx, const double* MA, const double* e, int64_t n,
                           double* E_out, double* sinE_out, double* cosE_out);
 /* The same call through the THROUGHPUT kernels' variant of the routine (k_main, k_ofti_main): sin/cos of the FP32 starter from the

@@ -1,13 +1,16 @@
-"""Who is off in a Thiele-Innes near-face-on case of the random sweep (tests/stress_parity.py seed 101, system 42)? The worst walker's
-gradient from the device, from the reference-order C restatement and from the 60-digit oracle. Development aid."""
+"""Who is off in a Thiele-Innes near-face-on case of the random sweep (tests/stress_parity.py; default seed 101, system 42)? The worst
+walker's gradient from the device, from the reference-order C restatement and from the 60-digit oracle. Development aid.
+    python tools/check_ti_case.py [seed] [system index]"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "oracle"))
 import numpy as np, mpmath as mp
 import stress_parity as sp, oracle_binding as ob, gpu_binding as gb, mp_oracle as mo
-rng = np.random.default_rng(101)
-for k in range(43):
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 101
+INDEX = int(sys.argv[2]) if len(sys.argv) > 2 else 42
+rng = np.random.default_rng(SEED)
+for k in range(INDEX + 1):
     sysm = sp.draw_system(rng)
 obs, planets, elems, nuis = sysm
 print(sp.describe(sysm))
@@ -31,6 +34,9 @@ nu = [[mp.mpf(float(nuis[o * 3 + k, w])) for k in range(3)] for o in range(len(o
 f0, g_el, g_nu, s_el, s_nu = mo.ln_like_and_grad(mo.DEFAULT_CONSTS, planets, obs_m, el, nu, with_scale=True)
 gm = np.array([float(g_el[p][k]) for p in range(P) for k in range(9)] + [float(g_nu[o][k]) for o in range(len(obs)) for k in range(3)])
 print("60-digit value", gm[r], "| GPU err", abs(G[r, w] - gm[r]) / scale[r, 0], "| C oracle err", abs(Go[r, w] - gm[r]) / scale[r, 0])
-A, B, F, Gc = [elems[9 + k, w] for k in (0, 2, 3, 4)]
-u = 0.5 * (A * A + B * B + F * F + Gc * Gc); v = A * Gc - B * F
-print("Thiele-Innes planet: (u - |v|)/u =", (u - abs(v)) / u, " (0 = face-on: a = alpha/plx loses digits there)")
+for ip, pl in enumerate(planets):
+    if pl["orbit_kind"] != 2:
+        continue
+    A, B, F, Gc = [elems[9 * ip + k, w] for k in (0, 2, 3, 4)]
+    u = 0.5 * (A * A + B * B + F * F + Gc * Gc); v = A * Gc - B * F
+    print(f"Thiele-Innes planet {ip}: (u - |v|)/u =", (u - abs(v)) / u, " (0 = face-on: a = alpha/plx loses digits there)")

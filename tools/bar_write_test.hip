@@ -45,5 +45,21 @@ int main() {
         printf("%s: %.2f us per (write 512 B, launch, flag)\n", mode ? "inputs in DEVICE memory written by the host (BAR)" : "inputs in mapped pinned HOST memory", best);
         fflush(stdout);
     }
+    // host store bandwidth into each kind of memory (is the BAR mapping write-combining?)
+    double* big_d = nullptr; double* big_h = nullptr;
+    if (hipExtMallocWithFlags((void**)&big_d, 1 << 20, hipDeviceMallocFinegrained) != hipSuccess) return 3;
+    hipHostMalloc((void**)&big_h, 1 << 20, hipHostMallocMapped);
+    static double srcbuf[1 << 17];
+    for (int i = 0; i < (1 << 17); ++i) srcbuf[i] = i;
+    for (size_t bytes : {512ul, 4096ul, 16384ul, 131072ul, 1048576ul}) {
+        for (int mode = 0; mode < 2; ++mode) {
+            double* dst = mode ? big_d : big_h;
+            const int N = bytes <= 16384 ? 2000 : 100;
+            auto t0 = std::chrono::steady_clock::now();
+            for (int it = 0; it < N; ++it) { memcpy(dst, srcbuf, bytes); _mm_sfence(); }
+            double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
+            printf("host memcpy of %7zu B into %s: %8.2f us (%.2f GB/s)\n", bytes, mode ? "device memory (BAR)" : "pinned host memory ", us, bytes / us * 1e-3);
+        }
+    }
     return 0;
 }

@@ -150,3 +150,51 @@ def test_pt_step_two_ranks_over_rccl(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_host_threads_with_their_own_contexts_share_one_dataset():
+    """include/octofitter_hip.h: a dataset may be shared, without locking, by any number of contexts and host threads on the same
+    device (the Julia shim keeps a pool of contexts for concurrent callbacks). Four threads, one context each, one dataset: one-θ calls
+    (inputs inside the kernel arguments), a mid-size batch (mapped staging) and a big batch (copies), interleaved, each bit-identical to
+    the result computed alone beforehand."""
+    import threading
+    import gpu_binding as gb
+    capi = gb.capi
+    cfg = synth.config_astrom(n_epochs=300, n_walkers=9000, cfg=3, seed=5)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    with gb.GpuPath(obs, [dict(orbit_kind=0, has_mass=False)]) as path:
+        lib = path.lib
+        shapes = [(0, 1), (1, 1), (100, 300), (0, 9000), (2, 1), (500, 40)]      # (first walker, batch size)
+        el_all = np.ascontiguousarray(cfg["elems"])
+
+        def run(ctx, w0, W):
+            el = np.ascontiguousarray(el_all[:, w0:w0 + W]); ll = np.empty(W); g = np.empty_like(el)
+            st = lib.octo_eval(ctx, path.ds, capi._dptr(el), None, W, W, capi._dptr(ll), capi._dptr(g), None)
+            assert st == 0, (lib.octo_last_error(ctx) or b"").decode()
+            return ll, g
+
+        ref = [run(path.ctx, w0, W) for w0, W in shapes]
+        ctxs = []
+        for _ in range(4):
+            c = C.c_void_p()
+            assert lib.octo_ctx_create(C.byref(c), 0) == 0
+            ctxs.append(c)
+        errors = []
+
+        def worker(k):
+            try:
+                for it in range(40):
+                    j = (it + k) % len(shapes)
+                    ll, g = run(ctxs[k], *shapes[j])
+                    if not (np.array_equal(ll, ref[j][0]) and np.array_equal(g, ref[j][1])):
+                        errors.append((k, it, j))
+            except Exception as ex:      # noqa: BLE001 - reported below
+                errors.append((k, repr(ex)))
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for x in th: x.start()
+        for x in th: x.join()
+        for c in ctxs:
+            lib.octo_ctx_destroy(c)
+        assert not errors, errors[:5]

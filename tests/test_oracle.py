@@ -239,3 +239,20 @@ def test_thiele_innes_semi_major_axis_known_answers(oracle):
     G = a_mas * (-np.sin(O) * np.sin(w) + np.cos(O) * np.cos(w) * np.cos(i))
     assert abs(alpha_from_oracle(A, B, F, G) - a_mas) < 1e-8          # the reference's tolerance
     assert abs(alpha_from_oracle(A, B, F, G) - a_mas) < 1e-12
+
+
+def test_thiele_innes_near_face_on_fixture(oracle):
+    """Fixture F12 (oracle/make_ti_faceon.py, 60 digits): the reference-order restatement reproduces the value, and its gradient only up
+    to the cancellation of the reference's own α² = u + √((u+v)(u−v)) near face-on (src/parameterizations.jl:15-18) — 1e-7 of scale here.
+    The GPU test of the same fixture holds the kernels, which use the cancellation-free form, to the 60-digit gradient."""
+    import json
+    from conftest import case_tables, rel_err
+    case = json.loads((Path(__file__).resolve().parent / "golden" / "ti_faceon.json").read_text())["cases"][0]
+    obs, planets, elems, nuis = case_tables(case)
+    ll, g_el, g_nu = oracle.oracle_eval(obs, planets, elems, nuis, grad=True)
+    assert np.all(rel_err(ll, np.asarray(case["ll"]), 1.0) < 1e-11)
+    ref = np.asarray(case["g_elems"]); sc = np.abs(ref).max(axis=1, keepdims=True)
+    err = (np.abs(g_el - ref) / np.maximum(sc, 1e-300)).ravel()
+    ti_rows = [0, 2, 3, 4]      # A, B, F, G of the Thiele-Innes planet (planet 0): where the cancellation enters
+    assert 1e-7 < err[ti_rows].max() < 1e-3, err[ti_rows]
+    assert np.delete(err, ti_rows).max() < 1e-8, err

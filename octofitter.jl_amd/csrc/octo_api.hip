@@ -906,7 +906,7 @@ struct octo_model {
     int n_circ = 0;
     int32_t* d_circ_pair = nullptr;   // [n_circ][2] (i0, i1) of each slot (k_small<MODEL>: one pair per lane)
     bool all_circ_slotted = true;     // every CIRCULAR / TPERI source has a slot (<= MODEL_MAXCIRC of them): required by the fused launch
-    double* d_logz = nullptr;         // [D] −log(Φ(hi) − Φ(lo)) of each truncated-Normal prior, NaN elsewhere
+    double* d_logz = nullptr;         // [D][PRIOR_NC] constants of each prior (prior_apply)
     double* d_buf = nullptr;   // elems | nuis | J | lpp | glp | ll | g_el | g_nu, all [rows][ldw]
     int64_t cap_w = 0;
     double *d_th = nullptr, *d_res = nullptr;   // staging for host buffers
@@ -977,16 +977,28 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
         pairs.resize(std::max<size_t>(pairs.size(), 2), 0);
         if (hipMalloc((void**)&m->d_circ_pair, sizeof(int32_t) * pairs.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
         if (hipMemcpy(m->d_circ_pair, pairs.data(), sizeof(int32_t) * pairs.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
-        // −log(Φ(hi) − Φ(lo)): the truncated Normal's normalisation, a constant of the model (Distributions.jl: truncated)
-        std::vector<double> logz(D, std::nan(""));
-        for (int k = 0; k < D; ++k)
-            if (priors[k].kind == OCTO_PRIOR_TRUNCNORMAL) {
-                const double lo = std::isfinite(priors[k].lo) ? 0.5 * std::erfc(-((priors[k].lo - priors[k].p0) / priors[k].p1) * 0.70710678118654752440) : 0.0;
-                const double hi = std::isfinite(priors[k].hi) ? 0.5 * std::erfc(-((priors[k].hi - priors[k].p0) / priors[k].p1) * 0.70710678118654752440) : 1.0;
-                logz[k] = -std::log(hi - lo);
+        // constants of each prior (prior_apply): −log(Φ(hi) − Φ(lo)), the truncated Normal's normalisation (Distributions.jl: truncated),
+        // 1/(b − a), −log(b − a) | log(b/a) | −log σ, 1/σ
+        std::vector<double> logz((size_t)D * PRIOR_NC, std::nan(""));
+        for (int k = 0; k < D; ++k) {
+            const octo_prior& pr = priors[k];
+            double* c = &logz[(size_t)k * PRIOR_NC];
+            double a = -INFINITY, b = INFINITY;
+            if (pr.kind == OCTO_PRIOR_UNIFORM || pr.kind == OCTO_PRIOR_LOGUNIFORM) { a = pr.p0; b = pr.p1; }
+            else if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) { a = pr.lo; b = pr.hi; }
+            else if (pr.kind == OCTO_PRIOR_SINE) { a = 0.0 + 2.220446049250313e-16; b = PI - 2.220446049250313e-16; }
+            c[1] = 1.0 / (b - a);
+            if (pr.kind == OCTO_PRIOR_UNIFORM) c[2] = -std::log(b - a);
+            else if (pr.kind == OCTO_PRIOR_LOGUNIFORM) c[2] = std::log(b / a);
+            else if (pr.kind == OCTO_PRIOR_NORMAL || pr.kind == OCTO_PRIOR_TRUNCNORMAL) { c[2] = -std::log(pr.p1); c[3] = 1.0 / pr.p1; }
+            if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) {
+                const double lo = std::isfinite(pr.lo) ? 0.5 * std::erfc(-((pr.lo - pr.p0) / pr.p1) * 0.70710678118654752440) : 0.0;
+                const double hi = std::isfinite(pr.hi) ? 0.5 * std::erfc(-((pr.hi - pr.p0) / pr.p1) * 0.70710678118654752440) : 1.0;
+                c[0] = -std::log(hi - lo);
             }
-        if (hipMalloc((void**)&m->d_logz, sizeof(double) * D) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
-        if (hipMemcpy(m->d_logz, logz.data(), sizeof(double) * D, hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
+        }
+        if (hipMalloc((void**)&m->d_logz, sizeof(double) * logz.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
+        if (hipMemcpy(m->d_logz, logz.data(), sizeof(double) * logz.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
         if (hipMalloc((void**)&m->d_circ, sizeof(int32_t) * slot.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
         if (hipMemcpy(m->d_circ, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
     }

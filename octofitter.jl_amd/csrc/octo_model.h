@@ -57,7 +57,7 @@ constexpr int MODEL_NPART = 4;   // k_model_fwd: partials per thread. The value 
 
 struct ModelArgs {
     const octo_prior* priors;       // [D]
-    const double* prior_logz;       // [D] −log(Φ(hi) − Φ(lo)) of each truncated-Normal prior (a model constant), NaN elsewhere
+    const double* prior_logz;       // [D][PRIOR_NC] constants of each prior (prior_apply)
     const octo_source* esrc;        // [n_el]
     const octo_source* nsrc;        // [n_nu] or null
     const DevObs* obs;
@@ -75,16 +75,19 @@ struct ModelArgs {
 };
 
 // Bijectors.invlink + logpdf_with_trans (TruncatedBijector; Distributions densities) — mirrors oracle/octo_oracle_core.inc
-DT void prior_apply(const octo_prior& pr, const DU& y, DU& x, DU& lp, double trunc_logz = NAN /* −log(Φ(hi) − Φ(lo)) when precomputed */) {
+// pc: four constants of the prior precomputed at model creation (octo_model_create: prior_consts) — {−log(Φ(hi) − Φ(lo)) of a truncated
+// Normal, 1/(b − a), −log(b − a) | log(b/a) | −log σ, 1/σ} — so that the serial chain of a call holds no logarithm or division of constants.
+constexpr int PRIOR_NC = 4;
+DT void prior_apply(const octo_prior& pr, const DU& y, DU& x, DU& lp, const double* __restrict__ pc = nullptr) {
     double a = -INFINITY, b = INFINITY;
     if (pr.kind == OCTO_PRIOR_UNIFORM || pr.kind == OCTO_PRIOR_LOGUNIFORM) { a = pr.p0; b = pr.p1; }
     else if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) { a = pr.lo; b = pr.hi; }
     else if (pr.kind == OCTO_PRIOR_SINE) { a = 0.0 + 2.220446049250313e-16; b = PI - 2.220446049250313e-16; }
     DU ladj;
     if (isfinite(a) && isfinite(b)) {
-        const double sg = 1.0 / (1.0 + exp(-y.v));
+        const double sg = m_div<FAST>(1.0, 1.0 + exp(-y.v));
         x = chain(y, (b - a) * sg + a, (b - a) * sg * (1.0 - sg));
-        ladj = dlog(((x + (-a)) * (dconst<N, FAST>(b) - x)) * (1.0 / (b - a)));
+        ladj = dlog(((x + (-a)) * (dconst<N, FAST>(b) - x)) * (pc ? pc[1] : 1.0 / (b - a)));
     } else if (isfinite(a)) {
         const double ey = exp(y.v);
         x = chain(y, ey + a, ey);
@@ -97,14 +100,14 @@ DT void prior_apply(const octo_prior& pr, const DU& y, DU& x, DU& lp, double tru
         x = y; ladj = dconst<N, FAST>(0.0);
     }
     switch (pr.kind) {
-        case OCTO_PRIOR_UNIFORM: lp = dconst<N, FAST>((x.v >= a && x.v <= b) ? -log(b - a) : -INFINITY); break;
-        case OCTO_PRIOR_LOGUNIFORM: lp = (x.v >= a && x.v <= b) ? dlog(dconst<N, FAST>(1.0) / (x * log(b / a))) : dconst<N, FAST>(-INFINITY); break;
+        case OCTO_PRIOR_UNIFORM: lp = dconst<N, FAST>((x.v >= a && x.v <= b) ? (pc ? pc[2] : -log(b - a)) : -INFINITY); break;
+        case OCTO_PRIOR_LOGUNIFORM: lp = (x.v >= a && x.v <= b) ? dlog(dconst<N, FAST>(1.0) / (x * (pc ? pc[2] : log(b / a)))) : dconst<N, FAST>(-INFINITY); break;
         case OCTO_PRIOR_NORMAL: case OCTO_PRIOR_TRUNCNORMAL: {
-            const DU z = (x + (-pr.p0)) * (1.0 / pr.p1);
-            lp = (-(z * z + LOG2PI)) * 0.5 + (-log(pr.p1));
+            const DU z = (x + (-pr.p0)) * (pc ? pc[3] : 1.0 / pr.p1);
+            lp = (-(z * z + LOG2PI)) * 0.5 + (pc ? pc[2] : -log(pr.p1));
             if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) {
-                double nlz = trunc_logz;                 // a constant of the model: octo_model_create precomputes it for the fused launch
-                if (!FAST && isnan(nlz)) {
+                double nlz = pc ? pc[0] : NAN;
+                if (isnan(nlz)) {
                     const double lo = isfinite(pr.lo) ? 0.5 * erfc(-((pr.lo - pr.p0) / pr.p1) * 0.70710678118654752440) : 0.0;
                     const double hi = isfinite(pr.hi) ? 0.5 * erfc(-((pr.hi - pr.p0) / pr.p1) * 0.70710678118654752440) : 1.0;
                     nlz = -log(hi - lo);
@@ -177,7 +180,7 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
     double* Lx = lds; double* Ldx = lds + (int64_t)D * WAVE; double* Lp = lds + 2 * (int64_t)D * WAVE; double* Ldp = lds + 3 * (int64_t)D * WAVE;
     for (int k = wy; k < D; k += DB) {
         Dual<1, true> xk, p;
-        prior_apply(a.priors[k], dvar<1, true>(a.theta_t[(int64_t)k * a.ld + wl], 0), xk, p, a.prior_logz[k]);
+        prior_apply(a.priors[k], dvar<1, true>(a.theta_t[(int64_t)k * a.ld + wl], 0), xk, p, a.prior_logz + PRIOR_NC * k);
         Lx[k * WAVE + lane] = xk.v; Ldx[k * WAVE + lane] = xk.d[0]; Lp[k * WAVE + lane] = p.v; Ldp[k * WAVE + lane] = p.d[0];
     }
     __syncthreads();

@@ -132,7 +132,7 @@ struct SmallModel {       // the part of ModelArgs k_small<MODEL> reads
     const octo_source* nsrc;       // or null = defaults
     const int32_t* circ_slot;      // [n_el + n_nu] pair-table slot of each CIRCULAR / TPERI source, or -1
     const int32_t* circ_pair;      // [n_circ][2] (i0, i1) of each slot
-    const double* prior_logz;      // [D] −log(Φ(hi) − Φ(lo)) of each truncated-Normal prior (a model constant), NaN elsewhere
+    const double* prior_logz;      // [D][PRIOR_NC] constants of each prior (prior_apply)
     int32_t n_circ, n_el;
     const double* theta_t;         // [W][D] walker-major (ld = 1) or [D][ld]
     int64_t ld_t, ws_t;            // θ_t[d * ld_t + w * ws_t]
@@ -184,7 +184,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
         }
         finite_in = __all(isfinite(y));                                              // logdensitymodel.jl:120-124
         D1 xk, pk;
-        prior_apply(sm.priors[dl], dvar<1, true>(y, 0), xk, pk, sm.prior_logz[dl]);
+        prior_apply(sm.priors[dl], dvar<1, true>(y, 0), xk, pk, sm.prior_logz + PRIOR_NC * dl);
         T.xv = xk.v; T.xd = xk.d[0];
         {   // the model's UniformCircular pairs, one per lane
             CT.n = sm.n_circ < WAVE ? sm.n_circ : WAVE;

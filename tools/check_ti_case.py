@@ -1,6 +1,6 @@
 """Who is off in a Thiele-Innes near-face-on case of the random sweep (tests/stress_parity.py; default seed 101, system 42)? The worst
 walker's gradient from the device, from the reference-order C restatement and from the 60-digit oracle. Development aid.
-    python tools/check_ti_case.py [seed] [system index]"""
+    python tools/check_ti_case.py [seed] [system index] [size scale]"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -9,6 +9,7 @@ import numpy as np, mpmath as mp
 import stress_parity as sp, oracle_binding as ob, gpu_binding as gb, mp_oracle as mo
 SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 101
 INDEX = int(sys.argv[2]) if len(sys.argv) > 2 else 42
+sp.SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rng = np.random.default_rng(SEED)
 for k in range(INDEX + 1):
     sysm = sp.draw_system(rng)
@@ -33,6 +34,15 @@ el = [[mp.mpf(float(elems[p * 9 + k, w])) for k in range(9)] for p in range(P)]
 nu = [[mp.mpf(float(nuis[o * 3 + k, w])) for k in range(3)] for o in range(len(obs))]
 f0, g_el, g_nu, s_el, s_nu = mo.ln_like_and_grad(mo.DEFAULT_CONSTS, planets, obs_m, el, nu, with_scale=True)
 gm = np.array([float(g_el[p][k]) for p in range(P) for k in range(9)] + [float(g_nu[o][k]) for o in range(len(obs)) for k in range(3)])
+ell = np.abs(ll - ll_o) / np.maximum(1, np.abs(ll_o)); ell[~ok] = 0; wl = int(np.argmax(ell))
+if wl != w:
+    el2 = [[mp.mpf(float(elems[p * 9 + k, wl])) for k in range(9)] for p in range(P)]
+    nu2 = [[mp.mpf(float(nuis[o * 3 + k, wl])) for k in range(3)] for o in range(len(obs))]
+    f0l = mo.ln_like(mo.DEFAULT_CONSTS, planets, obs_m, el2, nu2)
+else:
+    f0l = f0
+print("worst ll walker", wl, "GPU", ll[wl], "C oracle", ll_o[wl], "60-digit", float(f0l), "| GPU err", abs(ll[wl] - float(f0l)) / max(1, abs(float(f0l))),
+      "| C oracle err", abs(ll_o[wl] - float(f0l)) / max(1, abs(float(f0l))))
 print("60-digit value", gm[r], "| GPU err", abs(G[r, w] - gm[r]) / scale[r, 0], "| C oracle err", abs(Go[r, w] - gm[r]) / scale[r, 0])
 for ip, pl in enumerate(planets):
     if pl["orbit_kind"] != 2:

@@ -58,9 +58,9 @@ extern "C" {
 /* ---- observation kinds (one per reference AbstractObs type on the path) -- */
 #define OCTO_ASTROM_RADEC 0  /* PlanetRelAstromObs with (ra, dec, σ_ra, σ_dec[, cor])   */
 #define OCTO_ASTROM_SEPPA 1  /* PlanetRelAstromObs with (pa, sep, σ_pa, σ_sep[, cor])   */
-#define OCTO_RV_ABS       2  /* StarAbsoluteRVObs (no GP, zero trend)                    */
-#define OCTO_RV_ABS_MARG  3  /* MarginalizedStarAbsoluteRVObs (zero trend)               */
-#define OCTO_RV_REL       4  /* PlanetRelativeRVObs (no GP, zero trend)                  */
+#define OCTO_RV_ABS       2  /* StarAbsoluteRVObs (no GP; trend: see OCTO_NU_RV_TREND)   */
+#define OCTO_RV_ABS_MARG  3  /* MarginalizedStarAbsoluteRVObs (trend likewise)           */
+#define OCTO_RV_REL       4  /* PlanetRelativeRVObs (no GP; trend likewise)              */
 #define OCTO_ONEIL_RADEC  5  /* ObsPriorAstromONeil2019 wrapping an (ra, dec) table: the wrapped ln_like PLUS the    */
 #define OCTO_ONEIL_SEPPA  6  /*   observable-based prior 2 log(Σ_j |…|·∛P/√(1−e²)), src/likelihoods/prior-observable.jl:78-137 */
 #define OCTO_HGCA         7  /* HGCAInstantaneousObs (src/likelihoods/hgca.jl:28-219): Hipparcos-Gaia proper-motion   */
@@ -115,6 +115,13 @@ extern "C" {
 /* RV kinds */
 #define OCTO_NU_RV_OFFSET  0   /* rv-absolute.jl:139, rv-relative.jl:130 (ignored by RV_ABS_MARG) */
 #define OCTO_NU_RV_JITTER  1   /* rv-absolute.jl:181,197; rv-absolute-margin.jl:149,174           */
+#define OCTO_NU_RV_TREND   2   /* coefficient c of the table's trend: rv_model[j] += c · basis[j], the reference's
+                                * `trend_function(θ_obs, epoch_j)` (rv-absolute.jl:69,143; rv-relative.jl:64,131;
+                                * rv-absolute-margin.jl:52,111) for every trend that is LINEAR IN ONE θ_obs variable:
+                                * the host evaluates the user's closure once per table row with that variable set to 1 and
+                                * uploads the column as the table's `extra` (basis[j] = epoch_j − 57000 for the documented
+                                * `θ_obs.trend_slope * (epoch - 57000)`, rv-absolute.jl:26). Ignored (and its gradient 0) when
+                                * the table was uploaded without a basis column. Any other trend closure is not on this path. */
 #define OCTO_N_NUIS        3
 
 /* Physical constants, supplied by the host from PlanetOrbits.* so that parity
@@ -141,8 +148,8 @@ typedef struct octo_obs_desc {
     const double* s1;      /* σ_ra | σ_pa | σ_rv                                            */
     const double* s2;      /* σ_dec | σ_sep | NULL                                          */
     const double* cor;     /* correlation column or NULL (astrometry only)                  */
-    const double* extra;   /* per-table constants (OCTO_HGCA: [OCTO_HGCA_N_EXTRA]) or NULL  */
-    int64_t n_extra;
+    const double* extra;   /* per-table constants (OCTO_HGCA: [OCTO_HGCA_N_EXTRA]; RV kinds: the trend basis  */
+    int64_t n_extra;       /*   column [n_epochs], see OCTO_NU_RV_TREND) or NULL; n_extra = its length          */
 } octo_obs_desc;
 
 typedef struct octo_planet_desc {

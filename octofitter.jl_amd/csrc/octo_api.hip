@@ -474,6 +474,10 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
         }
         if (astrom && d.cor) ds->kind_mask |= KM_COR;
         const int64_t n = d.n_epochs;
+        // RV kinds: `extra` is the trend basis column, one value per row (OCTO_NU_RV_TREND)
+        const bool has_basis = !astrom && d.extra != nullptr && d.n_extra > 0;
+        if (has_basis && d.n_extra != n) return bail(OCTO_EINVAL, "octo_dataset_create: an RV table's trend basis column (extra) needs n_extra == n_epochs");
+        if (astrom && d.extra != nullptr && d.n_extra > 0) return bail(OCTO_EINVAL, "octo_dataset_create: astrometry tables take no `extra`");
         std::vector<double> raw((size_t)n * ROW_STRIDE, 0.0), pre((size_t)n * ROW_STRIDE, 0.0);
         ds->h_rowconst_pre[o].resize(n); ds->h_rowconst_raw[o].resize(n);
         for (int64_t r = 0; r < n; ++r) {
@@ -497,6 +501,10 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
             } else {
                 const double s = d.s1[r];
                 a[2] = s; b[2] = 1.0 / (s * s);
+                if (has_basis) {
+                    if (!std::isfinite(d.extra[r])) return bail(OCTO_EINVAL, "octo_dataset_create: table " + std::to_string(o) + " row " + std::to_string(r) + ": trend basis must be finite");
+                    a[3] = d.extra[r];      // read by the nuisance path only: without nuisances the trend coefficient is 0
+                }
                 if (d.kind == OCTO_RV_ABS_MARG) {
                     ds->h_rowconst_pre[o][r] = -std::log(TWO_PI * s * s);   // −log(2π var), rv-absolute-margin.jl:179
                     ds->h_rowconst_raw[o][r] = 0.0;

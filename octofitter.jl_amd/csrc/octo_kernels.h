@@ -30,7 +30,7 @@ constexpr int KM_ALL = 127;
 struct DevObs {
     int32_t kind, planet, has_cor, pad;
     int64_t n;
-    const double* raw;   // [n][8]: astrom {t,y1,y2,s1,s2,cor,0,0}; rv {t,rv,σ,0...}
+    const double* raw;   // [n][8]: astrom {t,y1,y2,s1,s2,cor,0,0}; rv {t,rv,σ,trend basis,0...}
     const double* pre;   // [n][8]: astrom {t,y1,y2,p11,p22,p12,0,0} (Σ⁻¹ entries); rv {t,rv,1/σ²,0...}
 };
 
@@ -462,12 +462,13 @@ struct RvCoef {
     double gc[P];                   // coefficient of K_p·V_p in the RV model
     double ib2[P];                  // 1/β² of each planet (the gradient's closed forms)
     double off, jit, j2, mu_hat, iA;
+    double trend;                   // coefficient of the table's trend basis column (OCTO_NU_RV_TREND)
     bool rel, marg;
     int planet;
 };
 
 template <int P, bool GRAD, bool NUIS, int KM>
-__device__ __forceinline__ RvCoef<P> rv_coef_vals(double off, double jit, const double* __restrict__ margp, int64_t ldw,
+__device__ __forceinline__ RvCoef<P> rv_coef_vals(double off, double jit, double trend, const double* __restrict__ margp, int64_t ldw,
                                                   int ob_kind, int ob_planet, int obs_index, const PC (&pc)[P], int64_t wl) {
     RvCoef<P> c;
     // RV_REL: +1 for this planet (rv-relative.jl:143), −m/M for strictly-inner massive companions (:148-156);
@@ -484,11 +485,12 @@ __device__ __forceinline__ RvCoef<P> rv_coef_vals(double off, double jit, const 
 #pragma unroll
     for (int p = 0; p < P; ++p) c.ib2[p] = GRAD ? 1.0 / (pc[p].beta * pc[p].beta) : 0.0;
     c.marg = (KM & KM_MARG) && ob_kind == OCTO_RV_ABS_MARG;
-    c.off = 0.0; c.jit = 0.0; c.j2 = 0.0;
+    c.off = 0.0; c.jit = 0.0; c.j2 = 0.0; c.trend = 0.0;
     if constexpr (NUIS) {
         c.off = c.marg ? 0.0 : off;
         c.jit = jit;
         c.j2 = c.jit * c.jit;
+        c.trend = trend;
     }
     c.mu_hat = 0.0; c.iA = 0.0;
     if (GRAD && c.marg && margp) {
@@ -502,24 +504,26 @@ __device__ __forceinline__ RvCoef<P> rv_coef_vals(double off, double jit, const 
 template <int P, bool GRAD, bool NUIS, int KM>
 __device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, int64_t ld, const double* __restrict__ margp, int64_t ldw,
                                              int ob_kind, int ob_planet, int obs_index, const PC (&pc)[P], int64_t wl) {
-    double off = 0.0, jit = 0.0;
+    double off = 0.0, jit = 0.0, trend = 0.0;
     if constexpr (NUIS) {
         const double* nu = nuis + (int64_t)obs_index * OCTO_N_NUIS * ld + wl;
-        off = nu[OCTO_NU_RV_OFFSET * ld]; jit = nu[OCTO_NU_RV_JITTER * ld];
+        off = nu[OCTO_NU_RV_OFFSET * ld]; jit = nu[OCTO_NU_RV_JITTER * ld]; trend = nu[OCTO_NU_RV_TREND * ld];
     }
-    return rv_coef_vals<P, GRAD, NUIS, KM>(off, jit, margp, ldw, ob_kind, ob_planet, obs_index, pc, wl);
+    return rv_coef_vals<P, GRAD, NUIS, KM>(off, jit, trend, margp, ldw, ob_kind, ob_planet, obs_index, pc, wl);
 }
 
 template <int P, bool GRAD, bool NUIS, int KM, bool TAB>
 __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
-                                       const RvCoef<P>& co, double t, double rv, double c2, const SinCosTab& tab) {
+                                       const RvCoef<P>& co, double t, double rv, double c2, double basis, const SinCosTab& tab) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const double (&gc)[P] = co.gc;
     const bool rel = co.rel, marg = co.marg;
     const double jit = co.jit, j2 = co.j2, mu_hat = co.mu_hat, iA = co.iA;
     KSol s[P];
     double V[P], cnu[P], snu[P];
-    double model = co.off;
+    // offset + trend_function(θ_obs, t) (rv-absolute.jl:143, rv-relative.jl:131, rv-absolute-margin.jl:111): the trend as
+    // coefficient × the row's basis value (include/octofitter_hip.h: OCTO_NU_RV_TREND); without nuisances both are zero
+    double model = NUIS ? fma(co.trend, basis, co.off) : co.off;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
@@ -541,14 +545,17 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
         }
         const double dm = resid - mu_hat;
         rvb = 2.0 * dm * iv;
-        if constexpr (GRAD && NUIS)
+        if constexpr (GRAD && NUIS) {
             acc[L::OFF_NU + OCTO_NU_RV_JITTER] += 2.0 * jit * iv * (dm * dm * iv - 1.0 + iv * iA);
+            acc[L::OFF_NU + OCTO_NU_RV_TREND] = fma(rvb, basis, acc[L::OFF_NU + OCTO_NU_RV_TREND]);
+        }
     } else {
         acc[L::OFF_S] = fma(resid * resid, iv, acc[L::OFF_S]);
         rvb = resid * iv;
         if constexpr (GRAD && NUIS) {
             acc[L::OFF_NU + OCTO_NU_RV_OFFSET] += rvb;
             acc[L::OFF_NU + OCTO_NU_RV_JITTER] += jit * iv * (resid * resid * iv - 1.0);
+            acc[L::OFF_NU + OCTO_NU_RV_TREND] = fma(rvb, basis, acc[L::OFF_NU + OCTO_NU_RV_TREND]);
         }
     }
     if constexpr (GRAD) {
@@ -638,7 +645,7 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE;
         for (int j = 0; j < n_rows; ++j) {
             const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
-            rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], tab);
+            rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, tab);
         }
     }
     if constexpr (NUIS) {
@@ -744,10 +751,9 @@ __device__ __forceinline__ double obs_finish(const DevObs* __restrict__ obs, int
     }
     if constexpr (L::N_NU > 0) {
         if (write) {
-            const bool astrom = kind == OCTO_ASTROM_RADEC || kind == OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA;
             gn[0] = (kind == OCTO_RV_ABS_MARG) ? 0.0 : v[4];
             gn[(int64_t)ld] = v[5];
-            gn[(int64_t)2 * ld] = astrom ? v[6] : 0.0;
+            gn[(int64_t)2 * ld] = v[6];      // northangle | trend coefficient (zero sums for a table without a basis column)
             if (kind == OCTO_HGCA) {      // ∂/∂(pmra, pmdec) from k_hgca
                 const double* x = extra_w + (int64_t)(1 + P * OCTO_N_EL + o * OCTO_N_NUIS) * ldw;
                 gn[0] = x[0]; gn[(int64_t)ld] = x[ldw]; gn[(int64_t)2 * ld] = 0.0;

@@ -295,7 +295,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
             }
         }
         if (L::HAS_RV && !is_astrom) {
-            RvCoef<P> co = rv_coef_vals<P, GRAD, NUIS, KM>(nu[OCTO_NU_RV_OFFSET], nu[OCTO_NU_RV_JITTER], nullptr, a.ldw, ob.kind, ob.planet, tk.obs, pc, 0);
+            RvCoef<P> co = rv_coef_vals<P, GRAD, NUIS, KM>(nu[OCTO_NU_RV_OFFSET], nu[OCTO_NU_RV_JITTER], nu[OCTO_NU_RV_TREND], nullptr, a.ldw, ob.kind, ob.planet, tk.obs, pc, 0);
             if constexpr (GRAD && L::HAS_MARG) {
                 if (co.marg) {      // block-uniform
                     // Marginalised RV (rv-absolute-margin.jl:171-181): the adjoint of a row needs μ̂ = −B/(2A) of the WHOLE table. The
@@ -306,10 +306,10 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
 #pragma unroll
                     for (int k = 0; k < LF::NACC; ++k) accF[k] = 0.0;
                     LogProd lpF;
-                    const RvCoef<P> coF = rv_coef_vals<P, false, NUIS, KM>(nu[OCTO_NU_RV_OFFSET], nu[OCTO_NU_RV_JITTER], nullptr, a.ldw, ob.kind, ob.planet, tk.obs, pc, 0);
+                    const RvCoef<P> coF = rv_coef_vals<P, false, NUIS, KM>(nu[OCTO_NU_RV_OFFSET], nu[OCTO_NU_RV_JITTER], nu[OCTO_NU_RV_TREND], nullptr, a.ldw, ob.kind, ob.planet, tk.obs, pc, 0);
                     for (int r = threadIdx.x; r < tk.nrows; r += SMALL_TPB) {
                         const double* __restrict__ rw = rows + (int64_t)r * ROW_STRIDE;
-                        rv_row<P, false, NUIS, KM, false>(accF, lpF, pc, coF, rw[0], rw[1], rw[2], notab);
+                        rv_row<P, false, NUIS, KM, false>(accF, lpF, pc, coF, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, notab);
                     }
                     const double wA = wave_sum(accF[LF::OFF_MARG + 0]), wB = wave_sum(accF[LF::OFF_MARG + 1]);
                     if (lane == 0) { red[wv][0] = wA; red[wv][1] = wB; }
@@ -324,7 +324,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
             }
             for (int r = threadIdx.x; r < tk.nrows; r += SMALL_TPB) {
                 const double* __restrict__ rw = rows + (int64_t)r * ROW_STRIDE;
-                rv_row<P, GRAD, NUIS, KM, false>(acc, lp, pc, co, rw[0], rw[1], rw[2], notab);
+                rv_row<P, GRAD, NUIS, KM, false>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, notab);
                 ++my_rows;
             }
         }

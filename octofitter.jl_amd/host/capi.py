@@ -25,7 +25,7 @@ ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES, ORBIT_KEP = 0, 1, 2, 3
 N_EL, N_NUIS = 9, 3
 EL_A, EL_E, EL_I, EL_W, EL_O, EL_TP, EL_M, EL_PLX, EL_MASS = range(9)
 NU_JITTER, NU_PLATESCALE, NU_NORTHANGLE = 0, 1, 2
-NU_RV_OFFSET, NU_RV_JITTER = 0, 1
+NU_RV_OFFSET, NU_RV_JITTER, NU_RV_TREND = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)
 STREAM_CTX = C.c_void_p(-1)      # OCTO_STREAM_CTX: the context's own stream (NULL = HIP's NULL stream, e.g. torch's default stream)

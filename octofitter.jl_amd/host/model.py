@@ -90,7 +90,7 @@ class LogDensityModel:
             if obs.kind in capi.ASTROM_KINDS:
                 rows = (("jitter", 0.0), ("platescale", 1.0), ("northangle", 0.0))
             else:
-                rows = (("offset", 0.0), ("jitter", 0.0), (None, 0.0))
+                rows = (("offset", 0.0), ("jitter", 0.0), (getattr(obs, "trend_coef", None), 0.0))      # row 2: OCTO_NU_RV_TREND
             for nm, dv in rows:
                 if nm is not None and nm in ov:
                     nsrc.append(self._source(ov[nm], scope, nm, ov, scope, used_circ))

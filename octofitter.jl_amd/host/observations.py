@@ -153,14 +153,32 @@ class ObsPriorAstromONeil2019(AbstractObs):
         return t
 
 
+class θObs(dict):
+    """θ_obs as a `trend_function(θ_obs, epoch)` receives it: the reference passes a NamedTuple, so the closure reads its
+    variables as fields (`θ_obs.trend_slope`, rv-absolute.jl:26). Item access works too."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+
 class _RVBase(AbstractObs):
     nuisance_names = ("offset", "jitter")
 
     def __init__(self, observations, *, name, variables=None, trend_function=None, gaussian_process=None):
-        if trend_function is not None or gaussian_process is not None:
-            # Those branches (rv-absolute.jl:205-315, user trend closures) are host-side Julia code and
-            # out of scope for the kernel; the Julia shim falls back to the reference closure for them.
-            raise NotImplementedError("trend_function / gaussian_process observations are not on the HIP path")
+        if gaussian_process is not None:
+            # The GP branch (rv-absolute.jl:205-315) is host-side Julia code and out of scope for the kernel; the Julia
+            # shim leaves such an observation on the reference's CPU path.
+            raise NotImplementedError("gaussian_process observations are not on the HIP path")
+        if trend_function is not None and not callable(trend_function):
+            raise TypeError("trend_function must be callable: (θ_obs, epoch) -> m/s")
+        # rv-absolute.jl:69, rv-relative.jl:64, rv-absolute-margin.jl:52: default (θ_obs, epoch) -> 0
+        self.trend_function = trend_function
+        self.trend_coef = None        # the θ_obs variable the trend is linear in      } set by classify_trend, as the Julia shim's
+        self.trend_basis = None       # trend_function(θ_obs with that variable = 1, epoch_j) } `_trend_basis` does (OctofitterHIP.jl)
+        self._trend_checked = trend_function is None
         table = _as_table(observations)
         if not _equal_length_cols(table):
             raise ValueError("The columns in the input data do not all have the same length")
@@ -180,9 +198,44 @@ class _RVBase(AbstractObs):
     def __len__(self):
         return len(self.table["epoch"])
 
+    def classify_trend(self, names, n_probe=3, seed=20260929):
+        """Which device form does `trend_function` have? The closure is arbitrary host code; the kernels carry a trend as ONE θ_obs
+        variable times a per-row basis column (include/octofitter_hip.h: OCTO_NU_RV_TREND). Probed numerically, exactly as the Julia
+        shim does: evaluate the closure at every table epoch for a few draws of θ_obs;
+          * identically zero (the default closure)          -> no trend on the device;
+          * θ_obs[c] · b(epoch) for one variable c           -> coefficient c, basis b = closure at c = 1;
+          * anything else                                    -> NotImplementedError (the Julia shim leaves the observation on the CPU).
+        `names`: the observation's θ_obs variables."""
+        self.trend_coef, self.trend_basis = None, None
+        self._trend_checked = True
+        if self.trend_function is None:
+            return
+        epochs = self.table["epoch"]
+        names = list(names)
+        rng = np.random.default_rng(seed)
+        f = lambda θ: np.array([float(self.trend_function(θObs(θ), float(t))) for t in epochs], dtype=np.float64)
+        draws = [{n: float(rng.uniform(0.5, 2.0)) for n in names} for _ in range(n_probe)]
+        vals = [f(d) for d in draws]
+        if all(not np.any(v) for v in vals):
+            return                                             # the zero trend
+        for c in names:
+            b = f({**draws[0], c: 1.0})
+            z = f({**draws[0], c: 0.0})
+            scale = max(float(np.max(np.abs(b))), 1e-300)
+            if np.any(z) or not np.all(np.isfinite(b)):
+                continue
+            if all(np.all(np.abs(v - d[c] * b) <= 1e-12 * scale * max(1.0, abs(d[c]))) for v, d in zip(vals, draws)):
+                self.trend_coef, self.trend_basis = c, b
+                return
+        raise NotImplementedError(f"{type(self).__name__} {self.name!r}: trend_function is not (one θ_obs variable) × (a function of the "
+                                  "epoch): not on the HIP path — the Julia shim keeps such an observation on the reference's CPU path")
+
     def _c_table(self, planet_index):
         t = self.table
-        return dict(kind=self.kind, planet=planet_index, epoch=t["epoch"], y1=t["rv"], y2=None, s1=t["σ_rv"], s2=None, cor=None)
+        if not self._trend_checked:
+            raise RuntimeError("classify_trend must run before the table is uploaded (make_ln_like does it)")
+        return dict(kind=self.kind, planet=planet_index, epoch=t["epoch"], y1=t["rv"], y2=None, s1=t["σ_rv"], s2=None, cor=None,
+                    extra=self.trend_basis)
 
 
 class StarAbsoluteRVObs(_RVBase):

@@ -120,6 +120,15 @@ class BatchedLnLike:
             for pl, d in zip(system.planets, self.planet_desc):
                 if d["orbit_kind"] == capi.ORBIT_VISUAL_KEP and not d["has_mass"]:
                     raise KeyError(f"planet {pl.name} has no `mass` variable but the system has HGCA data")
+        # RV trend closures: classified against the θ_obs variables the model declares (or the example θ carries)
+        for obs, ip, plname, key in self.obs_entries:
+            if getattr(obs, "trend_function", None) is not None:
+                if ip >= 0:
+                    θobs_ex = planets_ex.get(plname, {}).get("observations", {}).get(key, {})
+                else:
+                    θobs_ex = θ_example.get("observations", {}).get(key, {})
+                names = list(getattr(obs, "variables", None) or {}) or list(θobs_ex)
+                obs.classify_trend(names)
         self.obs_tables = [e[0]._c_table(e[1]) for e in self.obs_entries]
         # ---- C side ------------------------------------------------------------------------------
         self._ctx = C.c_void_p()
@@ -209,11 +218,11 @@ class BatchedLnLike:
             if obs.kind in capi.ASTROM_KINDS:
                 defaults = (("jitter", 0.0), ("platescale", 1.0), ("northangle", 0.0))   # relative-astrometry.jl:170-172
             else:
-                defaults = (("offset", 0.0), ("jitter", 0.0))
+                defaults = (("offset", 0.0), ("jitter", 0.0), (getattr(obs, "trend_coef", None), 0.0))      # row 2: OCTO_NU_RV_TREND
                 if obs.kind == capi.RV_ABS_MARG and "jitter" not in θobs:
                     raise KeyError("MarginalizedStarAbsoluteRVObs requires θ_obs.jitter (rv-absolute-margin.jl:149)")
             for k, (nm, dv) in enumerate(defaults):
-                if nm in θobs:
+                if nm is not None and nm in θobs:
                     any_nuis = True
                     buf[io * capi.N_NUIS + k, :] = θobs[nm]
                 else:
@@ -233,8 +242,8 @@ class BatchedLnLike:
                     out["pmra"] = out.get("pmra", 0.0) + g_nuis[io * capi.N_NUIS]
                     out["pmdec"] = out.get("pmdec", 0.0) + g_nuis[io * capi.N_NUIS + 1]
                     continue
-                names = ("jitter", "platescale", "northangle") if obs.kind in capi.ASTROM_KINDS else ("offset", "jitter")
-                d = {nm: g_nuis[io * capi.N_NUIS + k] for k, nm in enumerate(names)}
+                names = ("jitter", "platescale", "northangle") if obs.kind in capi.ASTROM_KINDS else ("offset", "jitter", getattr(obs, "trend_coef", None))
+                d = {nm: g_nuis[io * capi.N_NUIS + k] for k, nm in enumerate(names) if nm is not None}
                 if ip >= 0:
                     out["planets"][plname]["observations"][key] = d
                 else:

@@ -27,7 +27,7 @@
 #  (3) BATCHES OF STRUCTURED θ             g = OctofitterHIP.GPUBatchedLikelihood(model); ln_like_batch(g, Θ)
 module OctofitterHIP
 
-using Octofitter, PlanetOrbits, ForwardDiff, LogDensityProblems, Random, Distributions
+using Octofitter, PlanetOrbits, ForwardDiff, LogDensityProblems, Random, Distributions, LinearAlgebra
 using Octofitter: PlanetRelAstromObs, System, Planet, AbstractObs, Priors, Derived, normalizename, likelihoodname
 
 const LIB = get(ENV, "OCTOFITTER_HIP_LIB", "liboctofitter_hip.so")
@@ -229,8 +229,52 @@ octo_pt_swap_device(ctx, d_ll_by_replica, d_beta, d_slot2rep, n_temps, n_chains,
 # ---------------------------------------------------------------------------------------------------- tables -> octo_obs_desc
 _f64(x) = collect(Float64, vec(x))
 
-"(kind, 0-based planet or -1, [epoch, y1, y2, s1, s2, cor, extra]) of an observation the kernels implement, or nothing."
-function _table(obs, i_planet)
+"θ_obs of `obs` (attached to planet `ip`, or 0 = a system observation) inside a full θ; `(;)` when it declares no variables (system.jl:91-100)."
+function _θobs(θ, obs, ip)
+    key = Symbol(normalizename(likelihoodname(obs)))
+    src = ip > 0 ? θ.planets[ip].observations : θ.observations
+    return hasproperty(src, key) ? getproperty(src, key) : (;)
+end
+
+"""
+    _trend_basis(obs, θobs_draws) -> (nothing, Float64[]) | (coef::Symbol, basis::Vector{Float64}) | nothing
+
+Every RV observation type carries a `trend_function(θ_obs, epoch)` closure (rv-absolute.jl:63-69,143; rv-relative.jl:57-64,131;
+rv-absolute-margin.jl:46-52,111) — arbitrary user code; the default returns zero. The kernels carry a trend as ONE θ_obs variable times
+a per-row basis column (header: OCTO_NU_RV_TREND). Which case is it? Probed numerically at every table epoch for the given draws of θ_obs:
+  * identically zero                                      -> `(nothing, [])`: no trend on the device;
+  * `θ_obs[c] * b(epoch)` for one variable `c`             -> `(c, b)` with `b[j] = trend_function(θ_obs with c = 1, epoch_j)` — the
+    documented `θ_obs.trend_slope * (epoch - 57000)` (rv-absolute.jl:26) and the reference's own test model (test/runtests.jl:196-201);
+  * anything else                                          -> `nothing`: the observation is NOT eligible and stays on the reference's CPU path.
+"""
+function _trend_basis(obs, θobs_draws)
+    hasproperty(obs, :trend_function) || return (nothing, Float64[])
+    tf = obs.trend_function
+    epochs = _f64(obs.table.epoch)
+    f(θ) = Float64[tf(θ, t) for t in epochs]
+    vals = [f(θ) for θ in θobs_draws]
+    all(v -> all(iszero, v), vals) && return (nothing, Float64[])
+    θ1 = first(θobs_draws)
+    for c in keys(θ1)
+        getproperty(θ1, c) isa Real || continue
+        b = f(merge(θ1, NamedTuple{(c,)}((1.0,))))
+        z = f(merge(θ1, NamedTuple{(c,)}((0.0,))))
+        (all(iszero, z) && all(isfinite, b)) || continue
+        scale = max(maximum(abs, b; init=0.0), floatmin(Float64))
+        linear = all(zip(vals, θobs_draws)) do (v, θ)
+            x = Float64(getproperty(θ, c))
+            all(abs.(v .- x .* b) .<= 1e-12 * scale * max(1.0, abs(x)))
+        end
+        linear && return (c, b)
+    end
+    return nothing
+end
+
+"""
+(kind, 0-based planet or -1, [epoch, y1, y2, s1, s2, cor, extra], trend coefficient or nothing) of an observation the kernels
+implement, or nothing. `θobs_draws`: a few draws of the observation's θ_obs (RV kinds: to classify the trend closure).
+"""
+function _table(obs, i_planet, θobs_draws=[(;)])
     t = obs.table
     if obs isa PlanetRelAstromObs
         if hasproperty(t, :pa) && hasproperty(t, :sep)      # relative-astrometry.jl:53
@@ -239,27 +283,31 @@ function _table(obs, i_planet)
             cols = (_f64(t.epoch), _f64(t.ra), _f64(t.dec), _f64(t.σ_ra), _f64(t.σ_dec)); kind = ASTROM_RADEC
         end
         cor = hasproperty(t, :cor) ? _f64(t.cor) : Float64[]
-        return kind, Int32(i_planet - 1), [cols..., cor, Float64[]]
+        return kind, Int32(i_planet - 1), [cols..., cor, Float64[]], nothing
     end
     T = nameof(typeof(obs))
     if T === :ObsPriorAstromONeil2019 && obs.wrapped_like isa PlanetRelAstromObs      # prior-observable.jl:56-76
-        kind, planet, cols = _table(obs.wrapped_like, i_planet)
-        return (kind == ASTROM_SEPPA ? ONEIL_SEPPA : ONEIL_RADEC), planet, cols
+        kind, planet, cols, _ = _table(obs.wrapped_like, i_planet)
+        return (kind == ASTROM_SEPPA ? ONEIL_SEPPA : ONEIL_RADEC), planet, cols, nothing
     end
     if T === :HGCAInstantaneousObs                                                     # hgca.jl:58-152
         h = obs.hgca
         meas = Float64[m === :ra ? 0 : 1 for m in t.meas]; inst = Float64[i === :hip ? 0 : 1 for i in t.inst]
-        cov(d) = (s = sqrt.(Octofitter.diag(d.Σ)); (s[1], s[2], d.Σ[1, 2] / (s[1] * s[2])))   # includes `factor`
+        cov(d) = (s = sqrt.(diag(d.Σ)); (s[1], s[2], d.Σ[1, 2] / (s[1] * s[2])))   # includes `factor`
         extra = Float64[h.pmra_hip, h.pmdec_hip, cov(h.dist_hip)..., h.pmra_hg, h.pmdec_hg, cov(h.dist_hg)...,
                         h.pmra_gaia, h.pmdec_gaia, cov(h.dist_gaia)...]
-        return HGCA, Int32(-1), [_f64(t.epoch), meas, inst, Float64[], Float64[], Float64[], extra]
+        return HGCA, Int32(-1), [_f64(t.epoch), meas, inst, Float64[], Float64[], Float64[], extra], nothing
     end
     kind = T === :StarAbsoluteRVObs ? RV_ABS : T === :MarginalizedStarAbsoluteRVObs ? RV_ABS_MARG :
            T === :PlanetRelativeRVObs ? RV_REL : nothing
     kind === nothing && return nothing
-    # GP / trend branches are Julia closures: not on the device path (rv-absolute.jl:205-315)
+    # the GP branch is a Julia closure over AbstractGPs: not on the device path (rv-absolute.jl:205-315)
     (hasproperty(obs, :gaussian_process) && !isnothing(obs.gaussian_process)) && return nothing
-    return kind, Int32(kind == RV_REL ? i_planet - 1 : -1), [_f64(t.epoch), _f64(t.rv), Float64[], _f64(t.σ_rv), Float64[], Float64[], Float64[]]
+    # the trend closure: zero, or linear in one θ_obs variable (-> basis column), or the observation is not eligible
+    tb = _trend_basis(obs, θobs_draws)
+    tb === nothing && return nothing
+    coef, basis = tb
+    return kind, Int32(kind == RV_REL ? i_planet - 1 : -1), [_f64(t.epoch), _f64(t.rv), Float64[], _f64(t.σ_rv), Float64[], Float64[], basis], coef
 end
 
 _has_epochs(obs) = hasproperty(obs, :table) && hasproperty(obs.table, :epoch)     # system.jl:39,48
@@ -273,15 +321,23 @@ end
 _consts() = OctoConsts(PlanetOrbits.kepler_year_to_julian_day_conversion_factor, PlanetOrbits.year2day_julian,
                        PlanetOrbits.au2m, PlanetOrbits.sec2year_julian, PlanetOrbits.pc2au, PlanetOrbits.rad2as, Octofitter.mjup2msol)
 
-"Context + dataset for a list of (obs, i_planet or 0) in evaluation order. Returns (ctx, ds, entries, columns)."
-function _upload(system, eligible, θ0; device::Integer=0)
+"A few full parameter sets drawn from the priors: what `_table` classifies an RV trend closure against."
+_θ_draws(system, n=3) = (arr2nt = Octofitter.make_arr2nt(system); sampler = Octofitter.make_prior_sampler(system);
+                         rng = Random.Xoshiro(20260929); [arr2nt(sampler(rng)) for _ in 1:n])
+
+"""
+Context + dataset for a list of (obs, i_planet or 0) in evaluation order. Returns (ctx, ds, entries, columns); an entry is
+(obs, i_planet or 0, θ_obs key, trend coefficient or nothing).
+"""
+function _upload(system, eligible, θs; device::Integer=0)
+    θ0 = first(θs)
     entries = Any[]; descs = OctoObsDesc[]; columns = Vector{Float64}[]
     p(c) = isempty(c) ? Ptr{Float64}(C_NULL) : pointer(c)
     for (obs, ip) in eligible
-        kind, planet, cols = _table(obs, ip)
+        kind, planet, cols, coef = _table(obs, max(ip, 1), [_θobs(θ, obs, ip) for θ in θs])
         append!(columns, cols)
         push!(descs, OctoObsDesc(kind, planet, length(cols[1]), p(cols[1]), p(cols[2]), p(cols[3]), p(cols[4]), p(cols[5]), p(cols[6]), p(cols[7]), length(cols[7])))
-        push!(entries, (obs, ip, normalizename(likelihoodname(obs))))
+        push!(entries, (obs, ip, Symbol(normalizename(likelihoodname(obs))), coef))
     end
     planets = OctoPlanetDesc[]
     for (ip, pl) in enumerate(system.planets)
@@ -306,7 +362,7 @@ function kernel_inputs(system, entries, θ)
         end
     end
     o0 = nP * N_EL
-    for (io, (obs, ip, key)) in enumerate(entries)
+    for (io, (obs, ip, key, trendcoef)) in enumerate(entries)
         src = ip > 0 ? θ.planets[ip].observations : θ.observations
         θobs = hasproperty(src, key) ? getproperty(src, key) : (;)
         T1 = nameof(typeof(obs))
@@ -319,7 +375,7 @@ function kernel_inputs(system, entries, θ)
         else
             x[o0+(io-1)*N_NUIS+1] = hasproperty(θobs, :offset) ? θobs.offset : zero(T)
             x[o0+(io-1)*N_NUIS+2] = hasproperty(θobs, :jitter) ? θobs.jitter : zero(T)
-            x[o0+(io-1)*N_NUIS+3] = zero(T)
+            x[o0+(io-1)*N_NUIS+3] = trendcoef === nothing ? zero(T) : getproperty(θobs, trendcoef)      # OCTO_NU_RV_TREND
         end
     end
     return x
@@ -370,7 +426,7 @@ Octofitter.likelihoodname(obs::HIPObs) = likelihoodname(obs.wrapped_like)
 Octofitter._isprior(::HIPObs) = false
 Octofitter.likeobj_from_epoch_subset(obs::HIPObs, inds) = Octofitter.likeobj_from_epoch_subset(obs.wrapped_like, inds)   # cross-validation falls back to the CPU
 
-_eligible(obs) = _has_epochs(obs) && _table(obs, 1) !== nothing
+_eligible(obs, ip, θs) = _has_epochs(obs) && _table(obs, max(ip, 1), [_θobs(θ, obs, ip) for θ in θs]) !== nothing
 
 """
     accelerate(system::System; device=0) -> System
@@ -381,17 +437,16 @@ IAD, GP RV, images, …) also stays in Julia and the reference keeps solving the
 each `ln_like` method is independent (src/variables.jl:94-102).
 """
 function accelerate(system::System; device::Integer=0, n_contexts::Integer=Threads.nthreads(), verbosity::Integer=1)
-    arr2nt = Octofitter.make_arr2nt(system)
-    θ0 = arr2nt(Octofitter.make_prior_sampler(system)(Random.default_rng()))
+    θs = _θ_draws(system)
     eligible = Any[]
     for (ip, pl) in enumerate(system.planets), obs in pl.observations
-        _eligible(obs) && push!(eligible, (obs, ip))
+        _eligible(obs, ip, θs) && push!(eligible, (obs, ip))
     end
     for obs in system.observations
-        _eligible(obs) && push!(eligible, (obs, 0))
+        _eligible(obs, 0, θs) && push!(eligible, (obs, 0))
     end
     isempty(eligible) && (verbosity >= 1 && @info "OctofitterHIP: no observation of this system is on the HIP path"; return system)
-    ctx, ds, entries, columns = _upload(system, eligible, θ0; device)
+    ctx, ds, entries, columns = _upload(system, eligible, θs; device)
     n_in = length(system.planets) * N_EL + length(entries) * N_NUIS
     slot(c) = HIPSlot(c, Matrix{Float64}(undef, 1, n_in), Matrix{Float64}(undef, 1, n_in), Vector{Float64}(undef, 1))
     slots = [slot(ctx)]
@@ -400,7 +455,7 @@ function accelerate(system::System; device::Integer=0, n_contexts::Integer=Threa
     end
     free = Channel{Int}(length(slots)); foreach(i -> put!(free, i), eachindex(slots))
     nuis_default = Float64[]
-    for (obs, _, _) in entries
+    for (obs, _, _, _) in entries
         T1 = nameof(typeof(obs))
         append!(nuis_default, T1 === :HGCAInstantaneousObs ? (NaN, NaN, 0.0) :
                               (obs isa PlanetRelAstromObs || T1 === :ObsPriorAstromONeil2019) ? (0.0, 1.0, 0.0) : (0.0, 0.0, 0.0))
@@ -410,7 +465,8 @@ function accelerate(system::System; device::Integer=0, n_contexts::Integer=Threa
         octo_dataset_destroy(s.ds); foreach(x -> octo_ctx_destroy(x.ctx), s.slots)
     end
     first_seen = Ref(false)
-    wrap(obs) = _eligible(obs) ? (l = !first_seen[]; first_seen[] = true; HIPObs(obs, obs.priors, obs.derived, shared, l)) : obs
+    wrapped = Set(objectid(e[1]) for e in entries)
+    wrap(obs) = objectid(obs) in wrapped ? (l = !first_seen[]; first_seen[] = true; HIPObs(obs, obs.priors, obs.derived, shared, l)) : obs
     planets = map(system.planets) do pl
         obs2 = map(wrap, pl.observations)
         Planet{Octofitter.orbittype(pl),typeof(pl.priors),typeof(pl.derived),typeof(obs2)}(pl.priors, pl.derived, obs2, pl.name)
@@ -481,14 +537,15 @@ end
 
 function GPUBatchedLikelihood(model; device::Integer=0)
     system = model.system
-    θ0 = model.arr2nt(model.sample_priors(Random.default_rng()))
+    rng = Random.Xoshiro(20260929)
+    θs = [model.arr2nt(model.sample_priors(rng)) for _ in 1:3]
     eligible = Any[]; host_terms = Any[]
     add! = function (obs, ip, ctxkind)
         obs isa HIPObs && (obs = obs.wrapped_like)
         if !_has_epochs(obs)
             push!(host_terms, (obs, ip, ctxkind)); return
         end
-        _table(obs, max(ip, 1)) === nothing && error("observation $(likelihoodname(obs)) is not on the HIP path; keep using model.ℓπcallback")
+        _eligible(obs, ip, θs) || error("observation $(likelihoodname(obs)) is not on the HIP path (GP, or a trend_function that is not one θ_obs variable × a function of the epoch); keep using model.ℓπcallback")
         push!(eligible, (obs, ip))
     end
     # evaluation order of the generated closure: planet observations planet by planet, then system ones (system.jl:229-235)
@@ -498,7 +555,7 @@ function GPUBatchedLikelihood(model; device::Integer=0)
     for obs in system.observations
         add!(obs, 0, :system)
     end
-    ctx, ds, entries, columns = _upload(system, eligible, θ0; device)
+    ctx, ds, entries, columns = _upload(system, eligible, θs; device)
     g = GPUBatchedLikelihood(model, ctx, ds, length(system.planets), entries, host_terms, columns)
     finalizer(g) do x
         octo_dataset_destroy(x.ds); octo_ctx_destroy(x.ctx)

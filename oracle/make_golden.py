@@ -472,9 +472,91 @@ def ti_cases():
     print("wrote", p, p.stat().st_size, "bytes")
 
 
+def trend_cases():
+    """tests/golden/trend.json — F13: RV tables with a `trend_function` (OctofitterRadialVelocity/src/rv-absolute.jl:69,143,
+    rv-relative.jl:64,131, rv-absolute-margin.jl:52,111). The model is the reference's own "PlanetRelativeRV with offset and trend"
+    test (OctofitterRadialVelocity/test/runtests.jl:168-231): P = 80, M = 1, a = ∛(P²·M), circular RadialVelocityOrbit, tp = 50000,
+    20 epochs 50000…50200, σ_rv = 1 m/s, observed = planet + offset 50 + slope 0.1·(epoch − 50000) + noise, trend_function =
+    (θ_obs, epoch) -> θ_obs.trend_slope * (epoch - ref_epoch). On the C ABI the trend is the θ_obs variable it is linear in
+    (nuisance row OCTO_NU_RV_TREND) times the closure evaluated at that variable = 1, one value per row (`extra`)."""
+    rng = np.random.default_rng(20260929 + 71)
+    out = []
+    ref_epoch, P_true, M_true = 50000.0, 80.0, 1.0
+    a_true = float(np.cbrt(P_true ** 2 * M_true))
+    ep = np.linspace(50000.0, 50200.0, 20)
+    orb = mpo._orbit(C, 1, [mp.mpf(x) for x in [a_true, 0.0, 0.0, 0.0, 0.0, ref_epoch, M_true, 0.0, 0.0]])
+    planet_rv = np.array([fl(mpo.solve(orb, t)["rv"]) for t in ep])
+    observed = planet_rv + 50.0 + 0.1 * (ep - ref_epoch) + rng.normal(0, 1.0, 20)
+    basis = ep - ref_epoch                              # trend_function(θ_obs with trend_slope = 1, epoch)
+    def rvt(kind, planet, epoch, rv, s, extra):
+        d = rvtab(kind, planet, epoch, rv, s)
+        d["extra"] = None if extra is None else [float(x) for x in extra]
+        return d
+    W = 6
+    el = np.stack([np.full(W, a_true) * rng.uniform(0.9, 1.1, W), rng.uniform(0, 0.5, W), np.zeros(W), rng.uniform(0, 6.28, W), np.zeros(W),
+                   ref_epoch + rng.uniform(-20, 20, W), rng.normal(1.0, 0.05, W), np.zeros(W), np.zeros(W)])
+    el[:, 0] = [a_true, 0.0, 0.0, 0.0, 0.0, ref_epoch, M_true, 0.0, 0.0]          # the test's fixed orbit (mass = 0.0)
+    nu = col(rng.normal(50, 10, W), np.exp(rng.uniform(np.log(0.01), np.log(50), W)), rng.normal(0.1, 0.05, W))   # offset, jitter, trend_slope
+    nu[:, 0] = [50.0, 1.0, 0.1]                                                    # the truth
+    out.append(run_case("F13_trend_relative_reference_test", [RVO], [rvt("RV_REL", 0, ep, observed, [1.0] * 20, basis)], el, nu,
+                        "OctofitterRadialVelocity/test/runtests.jl:168-231: PlanetRelativeRVObs, offset + linear trend"))
+    # StarAbsoluteRVObs with the documented trend θ_obs.trend_slope * (epoch - 57000) (rv-absolute.jl:26), on a Visual{KepOrbit} with a mass
+    W2 = 5
+    elv = np.stack([rng.uniform(2, 5, W2), rng.uniform(0, 0.6, W2), rng.uniform(0.2, 2.9, W2), rng.uniform(0, 6.28, W2), rng.uniform(0, 6.28, W2),
+                    57000 + rng.uniform(-400, 400, W2), rng.normal(1.1, 0.05, W2), np.full(W2, 40.0), rng.uniform(1, 30, W2)])
+    ep2 = 56800.0 + 23.0 * np.arange(24) + rng.uniform(0, 5, 24)
+    rv2 = rng.normal(0, 30, 24) + 0.02 * (ep2 - 57000.0)
+    nu2 = col(rng.normal(0, 10, W2), np.exp(rng.uniform(np.log(0.1), np.log(20), W2)), rng.normal(0.02, 0.02, W2))
+    out.append(run_case("F13_trend_absolute", [VISM], [rvt("RV_ABS", -1, ep2, rv2, [2.0 + 0.1 * k for k in range(24)], ep2 - 57000.0)], elv, nu2,
+                        "StarAbsoluteRVObs, trend θ_obs.trend_slope * (epoch - 57000) (rv-absolute.jl:26)"))
+    # the marginalised kind: trend, no offset (rv-absolute-margin.jl:111) — and a quadratic basis (any closure linear in one variable)
+    nu3 = nu2.copy(); nu3[0] = 0.0; nu3[2] = rng.normal(1e-4, 1e-4, W2)
+    out.append(run_case("F13_trend_marginalized_quadratic", [VISM], [rvt("RV_ABS_MARG", -1, ep2, rv2, [2.0 + 0.1 * k for k in range(24)], (ep2 - 57000.0) ** 2)], elv, nu3,
+                        "MarginalizedStarAbsoluteRVObs, trend θ_obs.curv * (epoch - 57000)^2"))
+    # two planets: astrometry on the outer one, relative RV WITH a trend on the outer one, absolute RV WITHOUT a basis column whose
+    # third nuisance row is non-zero all the same: ignored, zero gradient
+    W3 = 5
+    e_in = np.stack([rng.uniform(2.5, 3.5, W3), rng.uniform(0, 0.4, W3), np.arccos(rng.uniform(-1, 1, W3)), rng.uniform(0, 6.28, W3), rng.uniform(0, 6.28, W3),
+                     50000 + rng.uniform(0, 1500, W3), np.full(W3, 1.2), np.full(W3, 50.0), 5.0 * rng.uniform(0.5, 2, W3)])
+    e_out = np.stack([rng.uniform(12, 18, W3), rng.uniform(0, 0.5, W3), np.arccos(rng.uniform(-1, 1, W3)), rng.uniform(0, 6.28, W3), rng.uniform(0, 6.28, W3),
+                      50000 + rng.uniform(0, 15000, W3), np.full(W3, 1.2), np.full(W3, 50.0), 10.0 * rng.uniform(0.5, 2, W3)])
+    el6 = np.concatenate([e_in, e_out])
+    ep6 = 50000.0 + 137.0 * np.arange(7)
+    epr = 50010.0 + 91.0 * np.arange(9)
+    rv6 = rng.normal(0, 40, 9)
+    obs6 = [astrom(1, ep6, rng.normal(0, 300, 7), rng.normal(0, 300, 7), [8.0] * 7, [9.0] * 7),
+            rvt("RV_REL", 1, epr, rv6 * 50, [30.0] * 9, epr - 50400.0), rvt("RV_ABS", -1, epr, rv6, [5.0] * 9, None)]
+    nu6 = np.concatenate([col(rng.uniform(0, 5, W3), rng.normal(1, 0.01, W3), rng.normal(0, 0.02, W3)),
+                          col(rng.normal(0, 20, W3), rng.uniform(0.5, 5, W3), rng.normal(0, 0.5, W3)),
+                          col(rng.normal(0, 20, W3), rng.uniform(0.5, 5, W3), rng.normal(0, 0.5, W3))])
+    out.append(run_case("F13_trend_two_planet_mixed", [VISM, VISM], obs6, el6, nu6,
+                        "astrometry + relative RV with a trend on the outer planet + absolute RV without a basis column (its third nuisance row is ignored)"))
+    p = ROOT / "tests" / "golden" / "trend.json"
+    p.write_text(json.dumps(dict(consts=C, cases=out, generator="oracle/make_golden.py trend_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+    # ---- the same model through the whole callback (D = 3: offset ~ Normal(0, 200), jitter ~ LogUniform(0.01, 50), trend_slope ~ Normal(0, 1);
+    # the orbit is fixed, runtests.jl:190-220)
+    P = lambda kind, p0=0.0, p1=0.0, lo=None, hi=None: dict(kind=kind, p0=p0, p1=p1, lo=lo, hi=hi)
+    S = lambda kind, i0=0, i1=0, flags=0, value=0.0: dict(kind=kind, i0=i0, i1=i1, flags=flags, value=value)
+    priors = [P(2, 0.0, 200.0), P(1, 0.01, 50.0), P(2, 0.0, 1.0)]
+    esrc = [S(0, value=a_true), S(0), S(0), S(0), S(0), S(0, value=ref_epoch), S(0, value=M_true), S(0), S(0)]
+    nsrc = [S(1, 0), S(1, 1), S(1, 2)]
+    Wm = 6
+    th = np.stack([rng.normal(50, 20, Wm), rng.normal(0, 1.5, Wm), rng.normal(0.1, 0.1, Wm)])
+    th[:, 0] = [50.0, 0.2, 0.1]
+    obs = [rvt("RV_REL", 0, ep, observed, [1.0] * 20, basis)]
+    res = [mpo.model_logpost_and_grad(C, [RVO], obs, priors, esrc, nsrc, list(th[:, w])) for w in range(Wm)]
+    case = dict(name="D3_relative_rv_offset_trend", planets=[RVO], obs=obs, priors=priors, esrc=esrc, nsrc=nsrc, theta_t=th.tolist(),
+                lp=[fl(r[0]) for r in res], grad=np.array([[fl(v) for v in r[1]] for r in res]).T.tolist())
+    print(f"  D3 trend: lp[0]={case['lp'][0]:.12g}", flush=True)
+    p = ROOT / "tests" / "golden" / "trend_model.json"
+    p.write_text(json.dumps(dict(consts=C, cases=[case], generator="oracle/make_golden.py trend_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(ROOT / "oracle"))
-    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only", "--kep-only") if f in sys.argv]
+    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only", "--kep-only", "--trend-only") if f in sys.argv]
     if not only:
         main()
     if not only or "--ofti-only" in only:
@@ -489,3 +571,5 @@ if __name__ == "__main__":
         config1_case()
     if not only or "--kep-only" in only:
         kep_cases()
+    if not only or "--trend-only" in only:
+        trend_cases()

@@ -212,10 +212,14 @@ def ln_like_terms(c, planets, obs, elems, nuis):
         else:
             offset = nz[0] if (nz is not None and kind != 3) else mp.mpf(0)
             jitter = nz[1] if nz is not None else mp.mpf(0)
+            # trend_function(θ_obs, epoch_j) = (one θ_obs variable) × (the user's closure at that variable = 1): ob["extra"][j]
+            basis = ob.get("extra") if nz is not None else None
             A = B = C = mp.mpf(0)
             for j, t in enumerate(ob["epoch"]):
                 sols = [solve(o, t) for o in orbs]
                 model = offset
+                if basis is not None:
+                    model += nz[2] * mp.mpf(basis[j])
                 if kind == 4:
                     model += sols[ip]["rv"]
                     for p in range(n_pl):

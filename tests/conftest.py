@@ -52,6 +52,8 @@ def golden():
         g["cases"] = g["cases"] + json.load(f)["cases"]
     with open(ROOT / "tests" / "golden" / "kep.json") as f:       # F11: plain KepOrbit basis, RV tables (oracle/make_golden.py --kep-only)
         g["cases"] = g["cases"] + json.load(f)["cases"]
+    with open(ROOT / "tests" / "golden" / "trend.json") as f:     # F13: RV tables with a trend_function (oracle/make_golden.py --trend-only)
+        g["cases"] = g["cases"] + json.load(f)["cases"]
     return g
 
 

@@ -49,7 +49,9 @@ def random_model(rng, obs, planets):
         elif k == 7:
             nsrc += [S_(1, new(P_(2, 4.3, 0.5))), S_(1, new(P_(2, -2.0, 0.5))), S_(0)]
         else:
-            nsrc += [S_(1, new(P_(2, 0.0, 20.0))) if k != 3 else S_(0), S_(1, new(P_(1, 0.1, 10.0))), S_(0)]
+            # third row: the trend coefficient (OCTO_NU_RV_TREND) where the table carries a basis column
+            nsrc += [S_(1, new(P_(2, 0.0, 20.0))) if k != 3 else S_(0), S_(1, new(P_(1, 0.1, 10.0))),
+                     S_(1, new(P_(2, 0.0, 2.0))) if o.get("extra") is not None else S_(0)]
     return priors, esrc, nsrc
 
 

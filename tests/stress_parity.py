@@ -79,6 +79,19 @@ def random_system(rng, invalid=True, P=None, W=None):
         for w_bad, (row, val) in zip(rng.choice(W, 3, replace=False), ((1, 1.2), (6, -1.0), (5, np.nan))):
             elems[int(rng.integers(0, P)) * 9 + row, w_bad] = val
     use_nuis = hgca or rng.random() < 0.6
+    # RV trend_function (include/octofitter_hip.h: OCTO_NU_RV_TREND): about half of the RV tables get a basis column (linear or quadratic
+    # in the epoch) and every RV table a non-zero third nuisance row — ignored, with zero gradient, where there is no column. Drawn from a
+    # generator of its own, seeded by the elements, so that the systems of a given seed are the ones earlier rounds swept.
+    import zlib
+    rng_t = np.random.default_rng(zlib.crc32(np.ascontiguousarray(elems).tobytes()))
+    for io, o in enumerate(obs):
+        if o["kind"] in (2, 3, 4):
+            n = len(o["epoch"])
+            if rng_t.random() < 0.5:
+                o["extra"] = (o["epoch"] - 52000.0) / 100.0 if rng_t.random() < 0.7 else ((o["epoch"] - 52000.0) / 1000.0) ** 2
+                if n == 0:
+                    o["extra"] = None
+            nuis[io * 3 + 2] = rng_t.normal(0, 2.0, W)
     return obs, planets, elems, (nuis if use_nuis else None)
 
 

@@ -311,6 +311,77 @@ def test_mirror_reference_properties(pkg, oracle):
     fn.close()
 
 
+def test_rv_trend_function_reference_test_model(pkg, oracle, golden):
+    """The reference's "PlanetRelativeRV with offset and trend" test (OctofitterRadialVelocity/test/runtests.jl:168-231) through the
+    mirror: PlanetRelativeRVObs(..., trend_function=(θ_obs, epoch) -> θ_obs.trend_slope * (epoch - ref_epoch)), a fixed circular
+    RadialVelocityOrbit, free offset / jitter / trend_slope. The trend reaches the device as coefficient × basis column; checked against
+    the 60-digit fixture F13 (the table is the fixture's), the oracle at a batch size of either kernel family, and the property the
+    reference's test asserts (the posterior sits at offset ≈ 50, slope ≈ 0.1)."""
+    case = next(c for c in golden["cases"] if c["name"] == "F13_trend_relative_reference_test")
+    ob0 = case["obs"][0]
+    ref_epoch = 50000.0
+    rvlike = pkg.PlanetRelativeRVObs([dict(epoch=e, rv=r, σ_rv=1.0) for e, r in zip(ob0["epoch"], ob0["y1"])], name="RelRV",
+                                     trend_function=lambda θ_obs, epoch: θ_obs.trend_slope * (epoch - ref_epoch),
+                                     variables=pkg.variables(offset=pkg.Normal(0, 200), jitter=pkg.LogUniform(0.01, 50), trend_slope=pkg.Normal(0, 1)))
+    b = pkg.Planet(name="b", basis="RadialVelocityOrbit", observations=[rvlike])
+    sys_ = pkg.System(name="RelRVSys", companions=[b])
+    el, nu = np.asarray(case["elems"]), np.asarray(case["nuis"])
+    θ = dict(planets=dict(b=dict(M=el[6], e=el[1], ω=el[3], a=el[0], tp=el[5], mass=el[8],
+                                 observations=dict(RelRV=dict(offset=nu[0], jitter=nu[1], trend_slope=nu[2])))))
+    fn = pkg.make_ln_like(sys_, θ)
+    assert rvlike.trend_coef == "trend_slope" and np.array_equal(fn.obs_tables[0]["extra"], np.asarray(ob0["extra"]))
+    ll, g = fn.ln_like_and_grad(θ)
+    assert np.all(rel_err(ll, case["ll"], 1.0) < LL_RTOL)
+    gobs = g["planets"]["b"]["observations"]["RelRV"]
+    for k, nm in enumerate(("offset", "jitter", "trend_slope")):
+        ok, worst = grad_ok(gobs[nm][None, :], np.asarray(case["g_nuis"])[k][None, :], np.asarray(case["s_nuis"])[k][None, :])
+        assert ok, (nm, worst)
+    # a batch for the throughput kernels (W·P > 512) and one for k_small, against the oracle
+    rng = np.random.default_rng(5)
+    for W in (700, 40):
+        elems = np.stack([el[0, 0] * rng.uniform(0.9, 1.1, W), rng.uniform(0, 0.5, W), np.zeros(W), rng.uniform(0, 6.28, W), np.zeros(W),
+                          ref_epoch + rng.uniform(-20, 20, W), rng.normal(1, 0.05, W), np.zeros(W), np.zeros(W)])
+        nuis = np.stack([rng.normal(50, 10, W), np.exp(rng.uniform(np.log(0.01), np.log(50), W)), rng.normal(0.1, 0.05, W)])
+        llw, gel, gnu = fn.ln_like_arrays(elems, nuis, grad=True)
+        ll_o, g_o, gn_o = oracle.oracle_eval(fn.obs_tables, fn.planet_desc, elems, nuis, grad=True)
+        _cmp_oracle(f"trend W={W}", llw, gel, gnu, ll_o, g_o, gn_o)
+        assert np.any(gnu[2] != 0.0)
+    # the reference's assertions, as a likelihood scan on the fixed orbit: 30 < offset < 70, 0 < slope < 0.3
+    off, slope = np.meshgrid(np.linspace(0, 100, 201), np.linspace(-0.2, 0.4, 241), indexing="ij")
+    W = off.size
+    elems = np.tile(el[:, :1], (1, W))
+    lls = fn.ln_like_arrays(elems, np.stack([off.ravel(), np.ones(W), slope.ravel()]))
+    k = int(np.argmax(lls))
+    assert 45 < off.ravel()[k] < 55 and 0.09 < slope.ravel()[k] < 0.11, (off.ravel()[k], slope.ravel()[k])
+    fn.close()
+    # a closure the device cannot carry is refused, not dropped (VERDICT r2 "boundary defect")
+    bad = pkg.PlanetRelativeRVObs(dict(epoch=ob0["epoch"], rv=ob0["y1"], σ_rv=np.ones(20)), name="RelRV",
+                                  trend_function=lambda θ_obs, epoch: np.sin(θ_obs.trend_slope * epoch))
+    with pytest.raises(NotImplementedError):
+        pkg.make_ln_like(pkg.System(name="s", companions=[pkg.Planet(name="b", basis="RadialVelocityOrbit", observations=[bad])]), θ)
+
+
+def test_rv_trend_basis_validation(pkg):
+    gb = _gpu()
+    ep = np.linspace(50000.0, 50100.0, 6)
+    tab = dict(kind=2, planet=-1, epoch=ep, y1=np.zeros(6), y2=None, s1=np.ones(6), s2=None, cor=None)
+    planets = [dict(orbit_kind=1, has_mass=True)]
+    for extra in (np.ones(5), np.array([1, 2, 3, np.nan, 5, 6.0])):      # wrong length, non-finite
+        with pytest.raises(pkg.capi.OctoError):
+            gb.GpuPath([dict(tab, extra=extra)], planets)
+    with pytest.raises(pkg.capi.OctoError):                              # astrometry tables take no `extra`
+        gb.GpuPath([dict(kind=0, planet=0, epoch=ep, y1=np.zeros(6), y2=np.zeros(6), s1=np.ones(6), s2=np.ones(6), cor=None, extra=np.ones(6))],
+                   [dict(orbit_kind=0, has_mass=False)])
+    # without a nuisance block the trend coefficient is zero whatever the table carries (jitter 0, offset 0 defaults)
+    rng = np.random.default_rng(2)
+    W = 9
+    elems = np.stack([rng.uniform(0.5, 3, W), rng.uniform(0, 0.8, W), np.zeros(W), rng.uniform(0, 6.28, W), np.zeros(W),
+                      50000 + rng.uniform(-100, 100, W), rng.normal(1, 0.05, W), np.zeros(W), rng.uniform(0, 10, W)])
+    a = gb.gpu_eval([dict(tab, extra=ep - 50000.0)], planets, elems, None, grad=False)[0]
+    b = gb.gpu_eval([tab], planets, elems, None, grad=False)[0]
+    assert np.array_equal(a, b)
+
+
 def test_device_resident_api_matches_host_api(pkg):
     import torch
     cfg = synth.config_astrom(n_epochs=200, n_walkers=500, seed=21)

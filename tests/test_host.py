@@ -77,10 +77,68 @@ def test_rv_constructors(pkg):
         assert o.kind == kind and list(o.table["epoch"]) == [50000.0, 50010.0] and list(o.table["rv"]) == [1.0, 3.0]
     with pytest.raises(ValueError):
         pkg.StarAbsoluteRVObs(dict(epoch=[50000.0], rv=[1.0]), name="x")
-    with pytest.raises(NotImplementedError):   # GP / trend branches stay on the reference's Julia path
-        pkg.StarAbsoluteRVObs(rows, name="x", trend_function=lambda θ, t: 0.0)
+    with pytest.raises(NotImplementedError):   # the GP branch stays on the reference's Julia path
+        pkg.StarAbsoluteRVObs(rows, name="x", gaussian_process=lambda θ: None)
+    with pytest.raises(TypeError):
+        pkg.StarAbsoluteRVObs(rows, name="x", trend_function=0.1)
     with pytest.raises(ValueError):
         pkg.StarAbsoluteRVObs(dict(epoch=[1.0, 2.0], rv=[1.0, 2.0], σ_rv=[1.0, 1.0], inst_idx=[1, 2]), name="x")
+
+
+def test_rv_trend_function_classification(pkg):
+    """`trend_function(θ_obs, epoch)` is arbitrary host code (rv-absolute.jl:69,143; rv-relative.jl:64,131; rv-absolute-margin.jl:52,111).
+    The device carries it as (one θ_obs variable) × (a per-row basis column); the mirror finds that form by probing the closure — the same
+    procedure as `_trend_basis` in julia/OctofitterHIP.jl — and refuses every other closure instead of dropping it."""
+    ep = np.linspace(50000.0, 50200.0, 20)
+    rows = dict(epoch=ep, rv=np.zeros(20), σ_rv=np.ones(20))
+    names = ("offset", "jitter", "trend_slope")
+    ref_epoch = 50000.0
+    # the reference's own test model, OctofitterRadialVelocity/test/runtests.jl:196-201 (attribute access on θ_obs, like a NamedTuple)
+    o = pkg.PlanetRelativeRVObs(rows, name="RelRV", trend_function=lambda θ_obs, epoch: θ_obs.trend_slope * (epoch - ref_epoch))
+    with pytest.raises(RuntimeError):
+        o._c_table(0)                                   # not classified yet: the table must not be uploaded without its trend
+    o.classify_trend(names)
+    assert o.trend_coef == "trend_slope" and np.array_equal(o.trend_basis, ep - ref_epoch)
+    assert np.array_equal(o._c_table(0)["extra"], ep - ref_epoch)
+    # the default closure and an explicit zero: no trend on the device
+    for tf in (None, lambda θ, t: 0.0):
+        z = pkg.StarAbsoluteRVObs(rows, name="z", trend_function=tf)
+        z.classify_trend(names)
+        assert z.trend_coef is None and z._c_table(-1)["extra"] is None
+    # any function of the epoch times one variable (the documented rv-absolute.jl:26 form; a quadratic)
+    q = pkg.MarginalizedStarAbsoluteRVObs(rows, name="q", trend_function=lambda θ, t: θ["curv"] * (t - 57000.0) ** 2)
+    q.classify_trend(("jitter", "curv"))
+    assert q.trend_coef == "curv" and np.allclose(q.trend_basis, (ep - 57000.0) ** 2, rtol=1e-15)
+    # not of that form: two variables, a non-linear dependence, a constant that does not vanish with the variable
+    for tf in (lambda θ, t: θ.trend_slope * (t - 5e4) + θ.offset * 1e-3,
+               lambda θ, t: θ.trend_slope ** 2 * (t - 5e4),
+               lambda θ, t: θ.trend_slope * (t - 5e4) + 1.0,
+               lambda θ, t: 3.0):
+        bad = pkg.StarAbsoluteRVObs(rows, name="bad", trend_function=tf)
+        with pytest.raises(NotImplementedError):
+            bad.classify_trend(names)
+
+
+def test_rv_trend_reaches_pack_and_model_sources(pkg):
+    """The trend coefficient travels in the RV table's third nuisance row (OCTO_NU_RV_TREND) — through θ packing, the gradient's
+    unpacking and the standard-parameterisation sources. Host logic only (no device call): `pack` on a hand-made BatchedLnLike."""
+    from octofitter_jl_amd.host.system import BatchedLnLike
+    ep = np.linspace(50000.0, 50200.0, 5)
+    o = pkg.PlanetRelativeRVObs(dict(epoch=ep, rv=np.zeros(5), σ_rv=np.ones(5)), name="RelRV",
+                                trend_function=lambda θ_obs, epoch: θ_obs.trend_slope * (epoch - 50000.0))
+    o.classify_trend(("offset", "jitter", "trend_slope"))
+    b = pkg.Planet(name="b", basis="RadialVelocityOrbit", observations=[o])
+    fn = BatchedLnLike.__new__(BatchedLnLike)
+    fn.system = pkg.System(name="s", companions=[b]); fn.n_planets = 1; fn.n_obs = 1
+    fn.planet_desc = [dict(orbit_kind=pkg.capi.ORBIT_RADVEL, has_mass=True)]
+    fn.obs_entries = [(o, 0, "b", "RelRV")]
+    θ = dict(M=1.0, planets=dict(b=dict(a=18.0, e=0.0, ω=0.0, tp=50000.0, mass=0.0,
+                                        observations=dict(RelRV=dict(offset=[50.0, 49.0], jitter=1.0, trend_slope=[0.1, 0.2])))))
+    elems, nuis = fn.pack(θ)
+    assert nuis.shape == (3, 2) and nuis[pkg.capi.NU_RV_TREND].tolist() == [0.1, 0.2] and nuis[0].tolist() == [50.0, 49.0]
+    g = fn.unpack_grad(np.zeros((9, 2)), np.arange(6.0).reshape(3, 2))
+    assert g["planets"]["b"]["observations"]["RelRV"]["trend_slope"].tolist() == [4.0, 5.0]
+    fn._ds = fn._ctx = None
 
 
 def test_normalizename(pkg):

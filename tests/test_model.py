@@ -18,12 +18,13 @@ ROOT = Path(__file__).resolve().parent.parent
 @pytest.fixture(scope="module")
 def model_golden():
     return (json.loads((ROOT / "tests" / "golden" / "model.json").read_text())["cases"]
-            + json.loads((ROOT / "tests" / "golden" / "ti_model.json").read_text())["cases"])      # [2]: Thiele-Innes tutorial model
+            + json.loads((ROOT / "tests" / "golden" / "ti_model.json").read_text())["cases"]       # [2]: Thiele-Innes tutorial model
+            + json.loads((ROOT / "tests" / "golden" / "trend_model.json").read_text())["cases"])   # [3]: relative RV with offset + trend (D = 3)
 
 
 def _tables(case):
     obs = [dict(kind=KIND_IDS[o["kind"]], planet=o["planet"],
-                **{k: (None if o[k] is None else np.asarray(o[k], dtype=np.float64)) for k in ("epoch", "y1", "y2", "s1", "s2", "cor")}) for o in case["obs"]]
+                **{k: (None if o.get(k) is None else np.asarray(o[k], dtype=np.float64)) for k in ("epoch", "y1", "y2", "s1", "s2", "cor", "extra")}) for o in case["obs"]]
     return obs, case["planets"]
 
 
@@ -431,4 +432,42 @@ def test_gpu_model_thiele_innes_tutorial(pkg, oracle, model_golden):
         ref = g_c["planets"]["b"][key]
         assert np.all(np.abs(g_ti["planets"]["b"][key] - ref) <= 1e-9 * np.abs(ref).max()), key
     assert set(g_ti["planets"]["b"]) >= {"A", "B", "F", "G"}
+    model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_relative_rv_trend(pkg, oracle, model_golden):
+    """The model of OctofitterRadialVelocity/test/runtests.jl:168-231 through the whole callback: D = 3 (offset ~ Normal(0, 200),
+    jitter ~ LogUniform(0.01, 50), trend_slope ~ Normal(0, 1)), fixed circular orbit, trend_function = θ_obs.trend_slope * (epoch − 50000).
+    One θ_t per call (the fused k_small<MODEL> launch) and a batch, against the 60-digit fixture and the oracle."""
+    case = model_golden[3]
+    assert case["name"] == "D3_relative_rv_offset_trend"
+    ob0 = case["obs"][0]
+    rvlike = pkg.PlanetRelativeRVObs(dict(epoch=ob0["epoch"], rv=ob0["y1"], σ_rv=ob0["s1"]), name="RelRV",
+                                     trend_function=lambda θ_obs, epoch: θ_obs.trend_slope * (epoch - 50000.0),
+                                     variables=pkg.variables(offset=pkg.Normal(0, 200), jitter=pkg.LogUniform(0.01, 50), trend_slope=pkg.Normal(0, 1)))
+    true_P, true_M = 80.0, 1.0
+    b = pkg.Planet(name="b", basis="RadialVelocityOrbit", observations=[rvlike],
+                   variables=pkg.variables(M=true_M, e=0.0, ω=0.0, a=float(np.cbrt(true_P ** 2 * true_M)), tp=50000.0, mass=0.0))
+    model = pkg.LogDensityModel(pkg.System(name="RelRVSys", companions=[b]))
+    assert model.D == 3 and model.names == ["b_RelRV_offset", "b_RelRV_jitter", "b_RelRV_trend_slope"]      # runtests.jl:229-230 reads chain[:b_RelRV_offset]
+    for k, s_ in enumerate(case["nsrc"]):
+        c = model._c_nsrc[k]
+        assert (c.kind, c.i0, c.value) == (s_["kind"], s_["i0"], s_["value"])
+    for k, s_ in enumerate(case["esrc"]):
+        c = model._c_esrc[k]
+        assert (c.kind, c.value) == (s_["kind"], s_["value"]), k
+    th = np.asarray(case["theta_t"])
+    lp, g = model.logdensity_and_gradient(th)
+    _check(lp, g, case)
+    for w in range(th.shape[1]):                                            # one θ_t per call
+        lp1, g1 = model.logdensity_and_gradient(th[:, w])
+        _check(np.array([lp1]), g1[:, None], dict(lp=[case["lp"][w]], grad=np.asarray(case["grad"])[:, w:w + 1].tolist()))
+    rng = np.random.default_rng(3)
+    thb = np.stack([rng.normal(50, 20, 2000), rng.normal(0, 1.5, 2000), rng.normal(0.1, 0.1, 2000)])      # the throughput kernels
+    lpb, gb_ = model.logdensity_and_gradient(thb)
+    obs, planets = _tables(case)
+    lp_o, g_o = oracle.oracle_model_logpost(obs, planets, model._c_priors, model._c_esrc, model._c_nsrc, thb, n_threads=0)
+    assert np.all(np.abs(lpb - lp_o) <= 1e-12 * np.maximum(1, np.abs(lp_o)))
+    assert np.all(np.abs(gb_ - g_o) <= 1e-9 * np.abs(g_o).max(axis=1, keepdims=True))
     model.close()

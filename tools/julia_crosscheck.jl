@@ -14,7 +14,8 @@
 #                              O'Neil wrapper, at the committed elements, through `Octofitter.ln_like(obs, ctx)` with solutions from
 #                              `orbitsolve`;
 #   fixtures.json F5, kep.json StarAbsoluteRVObs / MarginalizedStarAbsoluteRVObs / PlanetRelativeRVObs on RadialVelocityOrbit,
-#                              Visual{KepOrbit} and KepOrbit planets.
+#                              Visual{KepOrbit} and KepOrbit planets;
+#   trend.json F13             the same three RV types with a `trend_function` (the model of OctofitterRadialVelocity/test/runtests.jl:168-231).
 # HGCA (needs the catalogue download) and the two-planet cases are left to the restatement; extend `run_case` the same way.
 using Octofitter, OctofitterRadialVelocity, PlanetOrbits, TypedTables, ForwardDiff, JSON, Distributions
 
@@ -73,9 +74,15 @@ function make_obs(ob)
         return startswith(k, "ONEIL") ? ObsPriorAstromONeil2019(o) : o
     end
     tab = Table(epoch=col(ob, "epoch"), rv=col(ob, "y1"), σ_rv=col(ob, "s1"))
-    k == "RV_ABS" && return StarAbsoluteRVObs(tab, name="rv")
-    k == "RV_ABS_MARG" && return MarginalizedStarAbsoluteRVObs(tab, name="rv")
-    k == "RV_REL" && return PlanetRelativeRVObs(tab, name="rv")
+    # F13 (trend.json): the fixture's `extra` column is trend_function(θ_obs with the coefficient = 1, epoch_j); rebuilt here as a closure
+    # over (epoch -> basis) so that the REAL trend_function code path of the reference is what gets evaluated (rv-absolute.jl:143 etc.)
+    basis = get(ob, "extra", nothing)
+    kw = basis === nothing ? (;) : (; trend_function=let d = Dict(zip(col(ob, "epoch"), Float64[x for x in basis]))
+        (θ_obs, epoch) -> θ_obs.trend_coef * d[epoch]
+    end)
+    k == "RV_ABS" && return StarAbsoluteRVObs(tab; name="rv", kw...)
+    k == "RV_ABS_MARG" && return MarginalizedStarAbsoluteRVObs(tab; name="rv", kw...)
+    k == "RV_REL" && return PlanetRelativeRVObs(tab; name="rv", kw...)
     return nothing
 end
 
@@ -101,11 +108,11 @@ function run_case(case)
                 θsys = (M=el[7], plx=el[8], planets=(b=merge(θpl, (observations=(astrom=θobs,),)),), observations=(;))
                 tot += Octofitter.ln_like(o, Octofitter.PlanetObservationContext(θsys, θsys.planets.b, θobs, (orbit,), (sols,), 1, 0))
             elseif o isa PlanetRelativeRVObs
-                θobs = nu === nothing ? (offset=0.0, jitter=0.0) : (offset=nu[1], jitter=nu[2])
+                θobs = nu === nothing ? (offset=0.0, jitter=0.0, trend_coef=0.0) : (offset=nu[1], jitter=nu[2], trend_coef=nu[3])
                 θsys = (M=el[7], plx=el[8], planets=(b=merge(θpl, (observations=(rv=θobs,),)),), observations=(;))
                 tot += Octofitter.ln_like(o, Octofitter.PlanetObservationContext(θsys, θsys.planets.b, θobs, (orbit,), (sols,), 1, 0))
             else
-                θobs = nu === nothing ? (offset=0.0, jitter=0.0) : (offset=nu[1], jitter=nu[2])
+                θobs = nu === nothing ? (offset=0.0, jitter=0.0, trend_coef=0.0) : (offset=nu[1], jitter=nu[2], trend_coef=nu[3])
                 θsys = (M=el[7], plx=el[8], planets=(b=θpl,), observations=(rv=θobs,))
                 tot += Octofitter.ln_like(o, Octofitter.SystemObservationContext(θsys, θobs, (orbit,), (sols,), 0))
             end
@@ -129,7 +136,7 @@ out = Dict{String,Any}("octofitter_version" => string(pkgversion(Octofitter)), "
                                            "rad2as" => PlanetOrbits.rad2as, "mjup2msol" => Octofitter.mjup2msol))
 out["model.json/D11_reference_test_model"] = model_dump(golden("model.json")["cases"][1])
 out["config1.json/config1_D11_50_epochs"] = model_dump(golden("config1.json")["cases"][1])
-for file in ("fixtures.json", "kep.json"), case in golden(file)["cases"]
+for file in ("fixtures.json", "kep.json", "trend.json"), case in golden(file)["cases"]
     r = try run_case(case) catch err; @warn "case failed" case["name"] err; nothing end
     r === nothing || (out["$file/$(case["name"])"] = r)
 end

@@ -216,6 +216,8 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds,
                         const double* elems, const double* nuis, int64_t ld, int64_t W,
                         double* ll_out, double* g_elems, double* g_nuis);
 int32_t octo_eval_end(octo_ctx* ctx);
+/* Between octo_eval_begin and octo_eval_end the context's other HOST-buffer entry points (octo_eval, octo_model_logpost,
+ * octo_ofti_eval, octo_kepler_solve*) return OCTO_EINVAL: they share its staging buffers. */
 
 /* One host batch over n_dev devices from ONE host thread: walkers are split contiguously and evenly (device i gets
  * [i·W/n, (i+1)·W/n) up to rounding), every device's work is enqueued before any is waited for, and the outputs land in
@@ -247,7 +249,9 @@ int32_t octo_sync(octo_ctx* ctx);
  * (hipHostRegister), and every later host-buffer call whose buffers ALL lie inside registered ranges skips the copy engine:
  * one copy kernel reads the inputs over PCIe, the kernels write ll and the gradients straight into the caller's arrays.
  * Results are bit-identical to the pageable path. Unregister before freeing the memory. The registry is process-wide and
- * thread-safe; a range is usable by contexts on the device it was registered for. Mirrors nothing in the reference (its
+ * thread-safe; a range is usable by contexts on the device it was registered for. octo_host_unregister waits for ALL work on that
+ * device (any context, any stream) and then unmaps the range; no evaluation that uses the range may be started concurrently
+ * with it. Mirrors nothing in the reference (its
  * arrays never leave the host): it is the boundary's cost model, next to `octo_eval`
  * (src/likelihoods/system.jl:206-241 is the call it replaces). */
 int32_t octo_host_register(octo_ctx* ctx, void* ptr, int64_t bytes);

@@ -14,6 +14,13 @@ int fail(octo_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// The host-buffer entry points share the context's staging buffers (h_in / h_out, d_in / d_out) and completion flags with an
+// outstanding octo_eval_begin: none of them may run until the matching octo_eval_end.
+int busy(octo_ctx* ctx, const char* what) {
+    if (ctx->pending.active) return fail(ctx, OCTO_EINVAL, std::string(what) + ": an octo_eval_begin of this context has not been ended");
+    return OCTO_OK;
+}
+
 
 DevConsts dev_consts(const octo_consts& c) {
     DevConsts d;
@@ -54,9 +61,15 @@ static void* mapped_range(int device, const void* p, size_t bytes) {
     return it->second.dev + ((uintptr_t)p - base);
 }
 
-static int64_t stage_bytes() {      // host-buffer calls up to this size (inputs + outputs) are staged in mapped pinned memory (OCTO_STAGE_BYTES: experiments)
-    if (const char* ev = std::getenv("OCTO_STAGE_BYTES")) { const long v = std::atol(ev); if (v > 0) return v; }
-    return STAGE_DMA_BYTES;
+static int64_t stage_bytes(const octo_ctx* ctx) {      // host-buffer calls up to this size (inputs + outputs) are staged in mapped pinned memory (OCTO_STAGE_BYTES: experiments)
+    return ctx->env_stage_bytes > 0 ? ctx->env_stage_bytes : STAGE_DMA_BYTES;
+}
+
+static int64_t env_int(const char* name) {
+    const char* ev = std::getenv(name);
+    if (!ev) return 0;
+    const long long v = std::atoll(ev);
+    return v > 0 ? (int64_t)v : 0;
 }
 
 static __global__ __launch_bounds__(256) void k_copy_in(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
@@ -233,17 +246,15 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
 // (A persistent kernel pulling (task, tile) items from an atomic queue, with and without a tapered item size, was
 // measured against this grid-mapped launch in the same run and was not faster at any batch size: the hardware
 // dispatcher already backfills freed slots fast enough for an FP64-issue-bound kernel.)
-int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus) {
-    if (const char* ev = std::getenv("OCTO_CHUNK")) {   // tuning knob for experiments: uniform rows per wave
-        const int v = std::atoi(ev);
-        if (v > 0) return -(int64_t)v;
-    }
+int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu) {
+    const int n_cus = ctx->n_cus;
+    if (ctx->env_chunk > 0) return -ctx->env_chunk;      // OCTO_CHUNK, tuning knob for experiments: uniform rows per wave
     const int64_t cols = (W + WAVE - 1) / WAVE;
     const int64_t capacity = std::max<int64_t>((int64_t)blocks_per_cu * n_cus, 256);
     int64_t rounds = std::min<int64_t>(std::max<int64_t>(std::llround(blocks_per_cu * 3.0 / 7.0), 1), 3);
     // few walker tiles: fewer rounds rather than blocks shorter than ~48 rows per wave (W = 4096: 166 µs at 1 round, 177 at 3)
     while (rounds > 1 && n_rows * cols < 48 * WPB * rounds * capacity) --rounds;
-    if (const char* ev = std::getenv("OCTO_ROUNDS")) { const int v = std::atoi(ev); if (v > 0) rounds = v; }   // experiments
+    if (ctx->env_rounds > 0) rounds = ctx->env_rounds;      // OCTO_ROUNDS: experiments
     return std::max<int64_t>(1, rounds * capacity / cols);
 }
 
@@ -351,6 +362,8 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     if (const char* ev = std::getenv("OCTO_SMALL_W")) ctx->small_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     if (const char* ev = std::getenv("OCTO_MAPPED_W")) ctx->mapped_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     if (const char* ev = std::getenv("OCTO_FLAG_W")) ctx->flag_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
+    ctx->env_small_blocks = env_int("OCTO_SMALL_BLOCKS"); ctx->env_small_min_span = env_int("OCTO_SMALL_MIN_SPAN");
+    ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS");
     *out = ctx;
     return OCTO_OK;
 }
@@ -692,7 +705,7 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
     double* d_ll = ctx->d_out;
     double* d_ge = g_elems ? ctx->d_out + ldd : nullptr;
     double* d_gn = g_nuis ? ctx->d_out + (int64_t)(1 + (g_elems ? n_el : 0)) * ldd : nullptr;
-    if ((n_in + n_out) * (int64_t)sizeof(double) <= stage_bytes()) {
+    if ((n_in + n_out) * (int64_t)sizeof(double) <= stage_bytes(ctx)) {
         // Mid-size batches of the throughput kernels (10³ walkers): the rows are packed into the mapped pinned buffer, a copy KERNEL
         // brings them into device memory (k_main blocks must not fetch their walkers' nuisances over PCIe one by one) and k_finish
         // writes the results straight into the mapped buffer — coalesced rows. Pageable 2-D copies cost ~8 µs apiece, and even
@@ -823,7 +836,11 @@ int32_t octo_host_unregister(octo_ctx* ctx, void* ptr) {
         g_reg.erase(it);
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // nothing of this context may still be writing into the range
+    // The registry is process-wide: another context of this device (a second slot of the Julia pool, octo_eval_multi) or a
+    // caller-owned stream may still have a copy kernel reading from, or k_finish writing into, the range. Wait for the whole
+    // device, not just this context's stream, before the mapping goes away. (The caller must not START an evaluation on the
+    // range concurrently with this call — see the header.)
+    HIPCHK(ctx, hipDeviceSynchronize());
     HIPCHK(ctx, hipHostUnregister(ptr));
     return OCTO_OK;
 }
@@ -831,6 +848,7 @@ int32_t octo_host_unregister(octo_ctx* ctx, void* ptr) {
 static int32_t kepler_solve_host(octo_ctx* ctx, const double* MA, const double* e, int64_t n, double* E_out, double* sinE_out,
                                  double* cosE_out, bool table) {
     if (!ctx || !MA || !e || !E_out || n < 0) return fail(ctx, OCTO_EINVAL, "octo_kepler_solve: null argument");
+    { int rcb = busy(ctx, "octo_kepler_solve"); if (rcb) return rcb; }
     if (n == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = grow(ctx, ctx->d_in, ctx->cap_in, 2 * n);
@@ -1100,6 +1118,7 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
 int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, int64_t ld, int64_t W, double* lp_out, double* grad_out) {
     if (!ctx || !m || !theta_t || !lp_out) return fail(ctx, OCTO_EINVAL, "octo_model_logpost: null argument");
     if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_model_logpost: need 0 <= W <= ld");
+    { int rcb = busy(ctx, "octo_model_logpost"); if (rcb) return rcb; }
     if (W == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t ldd = (W + 63) / 64 * 64;
@@ -1165,7 +1184,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
         free_retired(ctx);
         return OCTO_OK;
     }
-    if ((n_in + n_out) * (int64_t)sizeof(double) <= stage_bytes()) {      // mid-size batch: mapped pinned buffers + a copy kernel (see octo_eval)
+    if ((n_in + n_out) * (int64_t)sizeof(double) <= stage_bytes(ctx)) {      // mid-size batch: mapped pinned buffers + a copy kernel (see octo_eval)
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
             return fail(ctx, OCTO_ENOMEM, "octo_model_logpost: pinned staging allocation failed");
         for (int r = 0; r < m->D; ++r) std::memcpy(ctx->h_in + (size_t)r * ldd, theta_t + (size_t)r * ld, sizeof(double) * W);
@@ -1265,7 +1284,7 @@ int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ofti_main, WAVE * WPB, sizeof(double) * (2 * SCT_N + OFTI_NACC * WAVE)) != hipSuccess || nb < 1) nb = 2;
             blocks_per_cu = nb;
         }
-        const int64_t key = plan_key(W, h->n, blocks_per_cu, ctx->n_cus);
+        const int64_t key = plan_key(ctx, W, h->n, blocks_per_cu);
         if (key < 0) chunk = (int)-key;
         else {
             const int64_t t_o = std::min<int64_t>(std::max<int64_t>(key, 1), std::max<int64_t>(1, h->n / (32 * WPB)));
@@ -1291,6 +1310,7 @@ int32_t octo_ofti_eval_device(octo_ctx* ctx, const octo_ofti* h, const double* d
 int32_t octo_ofti_eval(octo_ctx* ctx, const octo_ofti* h, const double* nl, int64_t ld, int64_t W, double* abfg_out, double* logml_out) {
     if (!ctx || !h || !nl || !logml_out) return fail(ctx, OCTO_EINVAL, "octo_ofti_eval: null argument");
     if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_ofti_eval: need 0 <= W <= ld");
+    { int rcb = busy(ctx, "octo_ofti_eval"); if (rcb) return rcb; }
     if (W == 0) return OCTO_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t ldd = (W + 63) / 64 * 64;

@@ -9,6 +9,8 @@
 // ncclCommInitRank :220, ncclCommDestroy :260, ncclAllGather :678; ncclFloat64 = 8).
 #include <dlfcn.h>
 
+#include <functional>
+
 #include "octo_host.h"
 
 using namespace octo;
@@ -34,23 +36,31 @@ struct Rccl {
     std::string err;
 };
 
-Rccl& rccl() {
-    static Rccl r;
-    if (r.handle || !r.err.empty()) return r;
+void rccl_load(Rccl& r) {
     const char* cands[] = {std::getenv("OCTO_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);      // the copy this process already maps, if any
     for (const char* c : cands) {
         if (h) break;
         if (c && *c) h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
     }
-    if (!h) { r.err = std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "not found"); return r; }
+    if (!h) {
+        const char* e = dlerror();      // one call: dlerror() clears the message it returns
+        r.err = std::string("cannot load librccl.so.1: ") + (e ? e : "not found");
+        return;
+    }
     r.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
     r.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
     r.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
     r.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
     r.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
-    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather) { r.err = "librccl.so.1 lacks the NCCL API"; return r; }
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather) { r.err = "librccl.so.1 lacks the NCCL API"; return; }
     r.handle = h;
+}
+
+Rccl& rccl() {      // bound once, whichever host thread asks first
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, rccl_load, std::ref(r));
     return r;
 }
 
@@ -138,17 +148,26 @@ int32_t octo_eval_multi(octo_ctx* const* ctxs, const octo_dataset* const* dss, i
     std::vector<int64_t> lo(n_dev + 1, 0);
     for (int i = 0; i < n_dev; ++i) lo[i + 1] = lo[i] + W / n_dev + (i < W % n_dev ? 1 : 0);
     int rc_first = OCTO_OK;
+    std::vector<char> began(n_dev, 0);      // only a begin of OURS is ended: a context that refused (e.g. somebody else's begin is
+                                             // still outstanding on it) keeps that other evaluation untouched
     for (int i = 0; i < n_dev; ++i) {
         const int64_t w0 = lo[i], n = lo[i + 1] - lo[i];
         if (n == 0) continue;
         const int rc = octo_eval_begin(ctxs[i], dss[i], elems + w0, nuis ? nuis + w0 : nullptr, ld, n, ll_out + w0, g_elems ? g_elems + w0 : nullptr,
                                        g_nuis ? g_nuis + w0 : nullptr);
-        if (rc && !rc_first) rc_first = rc;
+        began[i] = rc == OCTO_OK;
+        if (rc && !rc_first) {
+            rc_first = rc;
+            if (i > 0) ctxs[0]->err = "octo_eval_multi: device " + std::to_string(i) + ": " + ctxs[i]->err;      // the caller reads ctxs[0]'s message
+        }
     }
     for (int i = 0; i < n_dev; ++i) {
-        if (lo[i + 1] == lo[i]) continue;
+        if (!began[i]) continue;
         const int rc = octo_eval_end(ctxs[i]);
-        if (rc && !rc_first) rc_first = rc;
+        if (rc && !rc_first) {
+            rc_first = rc;
+            if (i > 0) ctxs[0]->err = "octo_eval_multi: device " + std::to_string(i) + ": " + ctxs[i]->err;
+        }
     }
     return rc_first;
 }

@@ -103,6 +103,9 @@ struct octo_ctx {
     void* comm = nullptr;                       // ncclComm_t
     int comm_rank = 0, comm_world = 1;
     int small_w = OCTO_SMALL_BATCH_DEFAULT;     // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
+    // experiment knobs, read from the environment ONCE at context creation (0 = not set): a getenv per call is a linear scan of the
+    // environment on a 12 µs path
+    int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0;
     int flag_w = 128;                           // ... and signal completion through per-walker flags the host spins on (OCTO_FLAG_W: experiments)
     int mapped_w = 128;                         // host-buffer calls up to this size let k_small read/write mapped pinned memory; larger
                                                 // ones cross the link as one DMA each way (OCTO_MAPPED_W: experiments)
@@ -150,7 +153,8 @@ int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
 }
 
 int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out);
-int64_t plan_key(int64_t W, int64_t n_rows, int blocks_per_cu, int n_cus);
+int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu);
+int busy(octo_ctx* ctx, const char* what);      // OCTO_EINVAL while an octo_eval_begin of this context is outstanding
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);
 
 // Launch of one evaluation for a dataset with P planets (octo_launch.h; instantiated in octo_inst_p<P>.hip).

@@ -15,11 +15,11 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     // requests); a few hundred of those in flight is what the link sustains without queueing (measured: 448 blocks x 9
     // scattered reads made W = 32 twice as slow as W = 1), so the block count is capped there.
     int64_t total_blocks = ctx->stage_ws_in > 0 ? 160 : 2 * (int64_t)ctx->n_cus;
-    if (const char* ev = std::getenv("OCTO_SMALL_BLOCKS")) { const int v = std::atoi(ev); if (v > 0) total_blocks = v; }   // experiments
+    if (ctx->env_small_blocks > 0) total_blocks = ctx->env_small_blocks;      // OCTO_SMALL_BLOCKS: experiments
     const int64_t target_tasks = std::max<int64_t>(1, total_blocks / a.W);
     int64_t span = (ds->n_rows + target_tasks - 1) / target_tasks;
     int64_t min_span = a.W < 64 ? SMALL_TPB : 4 * SMALL_TPB;      // many walkers fill the chip by themselves: split a walker's rows only when each part is worth a block
-    if (const char* ev = std::getenv("OCTO_SMALL_MIN_SPAN")) { const int v = std::atoi(ev); if (v > 0) min_span = v; }   // experiments
+    if (ctx->env_small_min_span > 0) min_span = ctx->env_small_min_span;      // OCTO_SMALL_MIN_SPAN: experiments
     span = std::max<int64_t>(min_span, (span + SMALL_TPB - 1) / SMALL_TPB * SMALL_TPB);
     TaskTable* tt = nullptr;
     int rc = get_tasks(ctx, ds, -(span / WPB) - SMALL_KEY, &tt);
@@ -97,7 +97,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         blocks_per_cu = nb;
     }
     TaskTable* tt = nullptr;
-    int rc0 = get_tasks(ctx, ds, plan_key(a.W, ds->n_rows, blocks_per_cu, ctx->n_cus), &tt);
+    int rc0 = get_tasks(ctx, ds, plan_key(ctx, a.W, ds->n_rows, blocks_per_cu), &tt);
     if (rc0) return rc0;
     const Task* tt_tasks = tt->h_tasks.data();
     a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;

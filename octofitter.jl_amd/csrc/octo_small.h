@@ -415,7 +415,19 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     }
     TRACE_POINT();      // rows done, block reductions done
     if (via_mem) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this block's partial stores have completed (s_waitcnt vmcnt(0))
+        // Every storing thread waits for its stores to be acknowledged BEFORE the barrier (the __threadfence() pattern): the partial /
+        // HGCA stores above and the counter atomic below go to different L2 channels, and a workgroup-scope release does not wait
+        // for vmcnt on gfx950 — without this the block that sees the last count could read another block's partials of the
+        // PREVIOUS call (`partials` is reused). ISA: s_waitcnt vmcnt(0) ahead of s_barrier and global_atomic_add
+        // (OCTO_SMALL_FULL_FENCE: the formal agent-scope release, buffer_wbl2 sc1 + the same wait).
+#ifdef OCTO_SMALL_FULL_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+        // Everything this protocol publishes is an agent-scope ATOMIC store (sc1: written through, never left dirty in L2), so the
+        // L2 write-back half of the fence has nothing to do — and costs 1-6 µs per call on the multi-block latency path (same-box
+        // A/B, profiles/r3_small_fence_ab.txt). What the release needs from the hardware is the wait for those stores' acknowledgements.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __syncthreads();
         if (multi) {
             if (threadIdx.x == 0) {

@@ -87,6 +87,7 @@ struct octo_ctx {
     int64_t cap_extra = 0;
     double* d_sctab = nullptr;                  // sin/cos grid of sincos_table, [SCT_N][2]
     int32_t* d_counters = nullptr;              // k_small: finished-block counter per walker, [SMALL_W], zero between launches
+    int64_t fused_w = (int64_t)1 << 40;         // batches up to this many walkers derive the orbit constants inside k_main (OCTO_FUSED_W: experiments; 0 = k_setup launch)
     uint64_t* h_flags = nullptr;                // mapped pinned [SMALL_W]: k_small's finishing block of walker w stores the call's
     uint64_t flag_seq = 0;                      // sequence number here after its outputs; host-buffer calls spin on it
     bool flag_request = false, flag_armed = false;

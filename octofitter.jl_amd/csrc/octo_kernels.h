@@ -108,22 +108,21 @@ struct SetupOut {
     bool ok;
 };
 
-// sin/cos for the latency path: reduce to [−π, π] with a two-term 2π (exact for the |x| a sampler produces; beyond 1e5 the
-// library routine), then the half-angle polynomials — ~35 instructions instead of ocml's ~180 per angle.
-// (the library routine behind a call: inlined, its Payne-Hanek reduction would put ~400 instructions at each of the dozen call sites
-// of the latency kernels, whose cold code has to be fetched on every one-block launch)
-__device__ __attribute__((noinline)) static double2 sincos_library(double x) { double s, c; sincos(x, &s, &c); return make_double2(s, c); }
-
+// sin/cos of an angle given in radians, call-free: reduce to [−π, π] with a two-term 2π (k = rint(x/2π) is exact, x − k·2π_hi is ONE
+// rounding of a number of size π, the second term adds k·2π_lo: absolute error ~4e-16 for |x| < 2^40, where k is still right to
+// ±0 and k·|2π − hi − lo| < 1e-20), then the half-angle polynomials — ~35 instructions instead of ocml's ~180 per angle, and no
+// function call: a call in a kernel clobbers memory for the compiler (the observation rows then stop being scalar loads) and costs
+// the callee-save registers of the calling convention. An angle of 2^40 rad (1.1e12; its own rounding is already 1e-4 rad) or more,
+// or a non-finite one, gives NaN: the walker is invalid (-Inf), like a non-finite element (deliberate deviations).
+constexpr double SINCOS_MAX_ANGLE = 0x1p40;
 __device__ __forceinline__ void sincos_reduced(double x, double& s, double& c) {
-    if (fabs(x) < 1.0e5) {
-        const double k = rint(x * (1.0 / TWO_PI));
-        double r = fma(-k, 0x1.921fb54442d18p+2, x);      // 2π hi
-        r = fma(-k, 0x1.1a62633145c07p-52, r);            // 2π lo
-        sincos_halfangle(r, s, c);
-    } else {
-        const double2 sc = sincos_library(x);
-        s = sc.x; c = sc.y;
-    }
+    const double k = rint(x * (1.0 / TWO_PI));
+    double r = fma(-k, 0x1.921fb54442d18p+2, x);      // 2π hi
+    r = fma(-k, 0x1.1a62633145c07p-52, r);            // 2π lo
+    sincos_halfangle(r, s, c);
+    const bool in_range = fabs(x) < SINCOS_MAX_ANGLE; // false for NaN too
+    s = in_range ? s : NAN;
+    c = in_range ? c : NAN;
 }
 
 // √x from v_rsq_f64 + Newton (rsqrt_nr), with one correction step on the product: ≤ 1 ulp, 14 instructions (ocml: ~25).
@@ -155,6 +154,7 @@ __device__ __forceinline__ SetupOut setup_planet_vals(const double (&elv)[OCTO_N
     const double mass = has_mass ? elv[OCTO_EL_MASS] : 0.0;
     bool ok = isfinite(sma) && isfinite(e) && isfinite(inc) && isfinite(om) && isfinite(Om) && isfinite(tp) &&
               isfinite(Mt) && isfinite(plx) && isfinite(mass);
+    if (FAST && !ti) ok = ok && fabs(om) < SINCOS_MAX_ANGLE && fabs(inc) < SINCOS_MAX_ANGLE && fabs(Om) < SINCOS_MAX_ANGLE;   // sincos_reduced's domain
     double T, A, B, F, G, si, ci, sw, cw, sO, cO;
     if (ti) {
         // ThieleInnesOrbit: rows a, i, ω, Ω carry A, B, F, G [mas]; a = α/plx   (src/parameterizations.jl:14-19).
@@ -583,8 +583,29 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
 }
 
 // ------------------------------------------------------------------------------------ k_main
+// The observation rows are immutable while a kernel runs (a dataset never changes after octo_dataset_create), so k_main reads them
+// through the CONSTANT address space: a wave-uniform load from it is always a scalar load (s_load into SGPRs), whatever else the
+// kernel contains. Left in the global address space the compiler issues scalar loads only while it can prove that nothing in the
+// function may have written the memory — a call (the library sincos of the fused prologue), an argument struct passed by reference
+// or a volatile asm silently demotes every row to per-lane vector loads (+45 % step time, measured).
+typedef const double __attribute__((address_space(4))) * crow_t;
+__device__ __forceinline__ crow_t constant_rows(const double* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (crow_t)p;
+#pragma clang diagnostic pop
+}
+
+constexpr int NPC = WC_CAE + 1;     // the per-walker constants the row loop reads (PC): WC_INVP … WC_CAE; the rest of `wc` is the finish's
+
 template <int P, bool GRAD, bool NUIS, int KM>
 constexpr size_t main_lds_bytes() { return sizeof(double) * (2 * SCT_N + Layout<P, GRAD, NUIS, KM>::NACC * WAVE); }
+// the fused-setup launch also stages the block's per-walker constants (P × NPC × 64 doubles, before the table is written) in the same allocation
+template <int P, bool GRAD, bool NUIS, int KM>
+constexpr size_t fused_lds_bytes() {
+    const size_t b = main_lds_bytes<P, GRAD, NUIS, KM>(), c = sizeof(double) * (size_t)P * NPC * WAVE;
+    return b > c ? b : c;
+}
 
 // Seven waves per SIMD (72 VGPRs) for the nuisance-free single-planet RA/Dec gradient kernels: they need 76 left alone, one
 // allocation granule too many; held to 72 the compiler parks 12 bytes outside the row loop and the loop itself is unchanged
@@ -592,7 +613,13 @@ constexpr size_t main_lds_bytes() { return sizeof(double) * (2 * SCT_N + Layout<
 template <int P, bool GRAD, bool NUIS, int KM>
 constexpr unsigned main_min_waves() { return (P == 1 && GRAD && !NUIS && (KM & ~KM_COR) == KM_RADEC) ? 7u : 1u; }
 
-template <int P, bool GRAD, bool NUIS, int KM>
+// FUSED: the orbit constructors inside the launch — wave 0 of every block derives its tile's constants (what k_setup stores in `wc`) and
+// hands them to the other waves through LDS while those fetch the sin/cos table. No k_setup launch, no `wc` round trip: one stream
+// dependency less per evaluation (~3 µs of a 60 µs call at 1 250 walkers, SURVEY §8d's strong-scaling share; 17 -> 14 µs at 300 epochs);
+// k_finish<FROM_WC = false> derives the handful of constants the finish needs again. Measured and NOT kept (profiles/r3_fused_ab.txt):
+// the finish inside the same launch (last block of a tile, counter + write-through partials) — its tail, one block gathering 87 tasks'
+// partials with the loop's register budget, is longer than the launch gap it saves, at every batch size.
+template <int P, bool GRAD, bool NUIS, int KM, bool FUSED = false>
 __attribute__((amdgpu_waves_per_eu(main_min_waves<P, GRAD, NUIS, KM>())))
 static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
@@ -613,15 +640,58 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     // LDS: [sin/cos table: SCT_N double2][combine buffer: NACC × 64 doubles]
     const SinCosTab tab = make_sincos_tab(reinterpret_cast<const double2*>(lds));
     double* const comb = lds + 2 * SCT_N;
-    {
-        const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
-        double2* t = reinterpret_cast<double2*>(lds);
-        for (int i = threadIdx.x; i < SCT_N; i += WAVE * WPB) t[i] = g[i];
-    }
-
     PC pc[P];
+    if constexpr (!FUSED) {
+        {
+            const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
+            double2* t = reinterpret_cast<double2*>(lds);
+            for (int i = threadIdx.x; i < SCT_N; i += WAVE * WPB) t[i] = g[i];
+        }
 #pragma unroll
-    for (int p = 0; p < P; ++p) load_pc(pc[p], a.wc, a.ldw, p, wl);
+        for (int p = 0; p < P; ++p) load_pc(pc[p], a.wc, a.ldw, p, wl);
+    } else {
+        // wave 0 derives the tile's constants; meanwhile waves 1.. fetch the sin/cos table into registers (one memory round trip,
+        // overlapped with the setup; the registers are live in the branch that does not run the setup)
+        constexpr int TPT = (SCT_N + WAVE * (WPB - 1) - 1) / (WAVE * (WPB - 1));
+        double2 tr[TPT];
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) tr[k] = make_double2(0.0, 0.0);      // defined on both paths: the array stays in registers (left
+                                                                           // undefined on wave 0's path it was demoted to scratch memory)
+        if (wv == 0) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const SetupOut so = setup_planet<true>(a, p, wl);
+#pragma unroll
+                for (int k = 0; k < NPC; ++k) lds[(p * NPC + k) * WAVE + lane] = so.v[k];
+            }
+        } else {
+            const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
+#pragma unroll
+            for (int k = 0; k < TPT; ++k) { const int i = (int)threadIdx.x - WAVE + k * WAVE * (WPB - 1); tr[k] = g[i < SCT_N ? i : SCT_N - 1]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double v[NWC];
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) v[k] = lds[(p * NPC + k) * WAVE + lane];
+#pragma unroll
+            for (int k = NPC; k < NWC; ++k) v[k] = 0.0;
+            pc[p].invP = v[WC_INVP]; pc[p].tp = v[WC_TP]; pc[p].e = v[WC_E]; pc[p].beta = v[WC_BETA]; pc[p].eob = v[WC_EOB];
+            pc[p].cB = v[WC_CB]; pc[p].cG = v[WC_CG]; pc[p].cA = v[WC_CA]; pc[p].cF = v[WC_CF]; pc[p].K = v[WC_K]; pc[p].cw = v[WC_COSW];
+            pc[p].sw = v[WC_SINW]; pc[p].mu = v[WC_MU]; pc[p].a = v[WC_A]; pc[p].cGb = v[WC_CGB]; pc[p].cFb = v[WC_CFB]; pc[p].cBe = v[WC_CBE];
+            pc[p].cAe = v[WC_CAE];
+            const float2 fa = *reinterpret_cast<const float2*>(&v[WC_F32A]);
+            const float2 fb = *reinterpret_cast<const float2*>(&v[WC_F32B]);
+            set_starter(pc[p], fa.x, fa.y, fb.x);
+        }
+        __syncthreads();                                // every wave has its constants: the table may overwrite them
+        if (wv != 0) {
+            double2* t = reinterpret_cast<double2*>(lds);
+#pragma unroll
+            for (int k = 0; k < TPT; ++k) { const int i = (int)threadIdx.x - WAVE + k * WAVE * (WPB - 1); if (i < SCT_N) t[i] = tr[k]; }
+        }
+    }
 
     double acc[L::NACC];
 #pragma unroll
@@ -634,17 +704,17 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
 
     if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
         const AstromCoef<P> co = astrom_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, ob.kind, ob.planet, ob.has_cor, tk.obs, pc, wl);
-        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE;
+        const crow_t rows = constant_rows((NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE);
         for (int j = 0; j < n_rows; ++j) {
-            const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
+            const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
             astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab);
         }
     }
     if (L::HAS_RV && !is_astrom) {
         const RvCoef<P> co = rv_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, a.marg, a.ldw, ob.kind, ob.planet, tk.obs, pc, wl);
-        const double* __restrict__ rows = (NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE;
+        const crow_t rows = constant_rows((NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE);
         for (int j = 0; j < n_rows; ++j) {
-            const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
+            const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
             rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, tab);
         }
     }
@@ -851,24 +921,42 @@ __device__ __forceinline__ void planet_finish(const double (&el)[OCTO_N_EL] /* t
     }
 }
 
-// ------------------------------------------------------------------------------------ k_finish
-// block = 64 walkers × FIN_G task groups: group g sums tasks g, g+FIN_G, … of each observation (more loads in
-// flight than one thread per walker), groups are combined through LDS in a fixed order, group 0 finishes.
-template <int P, bool GRAD, bool NUIS, int KM>
-static __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
+// ------------------------------------------------------------------------------------ finish_tile / k_finish
+// The per-walker tail for one tile of 64 walkers, run by NG waves: wave g sums tasks g, g+NG, … of each observation (more loads in
+// flight than one thread per walker), the waves' sums are combined through LDS in a fixed order, wave 0 finishes.
+//   FROM_WC = true   k_finish (big batches): the per-walker constants and validity flags come from k_setup's `wc` / `valid`;
+//   FROM_WC = false  the last block of a tile inside the fused k_main launch: wave 0 derives them again from the elements
+//                    (once per tile; no k_setup launch, no `wc` round trip).
+// LDS scratch: CH rows × NG × 64 doubles; sums are combined CH rows at a time (two barriers per chunk).
+template <int N, int NG, int CH>
+__device__ __forceinline__ void combine_rows(double (&v)[N], double* lds, int grp, int lane) {
+#pragma unroll
+    for (int c0 = 0; c0 < N; c0 += CH) {
+#pragma unroll
+        for (int k = c0; k < (c0 + CH < N ? c0 + CH : N); ++k) lds[((k - c0) * NG + grp) * WAVE + lane] = v[k];
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int k = c0; k < (c0 + CH < N ? c0 + CH : N); ++k) {
+                double x = 0.0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) x += lds[((k - c0) * NG + g) * WAVE + lane];
+                v[k] = x;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int P, bool GRAD, bool NUIS, int KM, int NG, int CH, bool FROM_WC>
+__device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int grp, int lane, double* lds) {
     using L = Layout<P, GRAD, NUIS, KM>;
     constexpr int NPL = P * L::PL_N;
-    constexpr int LDS_ROWS = NOBS_ACC > L::PL_N ? NOBS_ACC : L::PL_N;
-    static_assert(LDS_ROWS <= 12, "k_finish LDS scratch is sized for 12 rows");
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
+    const int64_t w = tile * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;
     double gp[NPL > 0 ? NPL : 1];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) gp[k] = 0.0;
-    // LDS scratch: [max(NOBS_ACC, PL_N)][FIN_G][64], reused per observation and per planet (two barriers each)
     double ll = 0.0;
     double oneil_g[oneil_slots<P, GRAD, NUIS, KM>()];     // per planet: ΔGE, ΔGM, ΔGT, Δā, ΔM̄tot, Δē from O'Neil terms
 #pragma unroll
@@ -876,37 +964,37 @@ static __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     double sma_p[P], e_p[P], M_p[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        sma_p[p] = L::HAS_ONEIL ? a.wc[((int64_t)p * NWC + WC_A) * a.ldw + wl] : 0.0;
+        if constexpr (FROM_WC) sma_p[p] = L::HAS_ONEIL ? a.wc[((int64_t)p * NWC + WC_A) * a.ldw + wl] : 0.0;
+        else sma_p[p] = L::HAS_ONEIL ? setup_planet<true>(a, p, wl).v[WC_A] : 0.0;
         e_p[p] = L::HAS_ONEIL ? a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wl] : 0.0;
         M_p[p] = L::HAS_ONEIL ? a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wl] : 1.0;
     }
-    int t = 0;
     for (int o = 0; o < a.n_obs; ++o) {
-        double S = 0.0, mA = 0.0, mB = 0.0, mC = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0, cst = 0.0;
-        double on0 = 0.0, on1 = 0.0, on2 = 0.0, on3 = 0.0;
-        t = a.obs_range[2 * o];
-        const int t_end = a.obs_range[2 * o + 1];
-        cst = a.obs_const[o];
+        double v[NOBS_ACC];      // S, margA, margB, margC, nu0, nu1, nu2, on0..on3
+#pragma unroll
+        for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
+        const int t0 = a.obs_range[2 * o], t_end = a.obs_range[2 * o + 1];
+        const double cst = a.obs_const[o];
 #pragma unroll 2
-        for (int tt = t + grp; tt < t_end; tt += FIN_G) {
+        for (int tt = t0 + grp; tt < t_end; tt += NG) {
             const double* pt = a.partials + (int64_t)tt * L::NACC * a.ldw + wl;
-            S += pt[(int64_t)L::OFF_S * a.ldw];
+            v[0] += pt[(int64_t)L::OFF_S * a.ldw];
             if constexpr (L::HAS_MARG) {
-                mA += pt[(int64_t)(L::OFF_MARG + 0) * a.ldw];
-                mB += pt[(int64_t)(L::OFF_MARG + 1) * a.ldw];
-                mC += pt[(int64_t)(L::OFF_MARG + 2) * a.ldw];
+                v[1] += pt[(int64_t)(L::OFF_MARG + 0) * a.ldw];
+                v[2] += pt[(int64_t)(L::OFF_MARG + 1) * a.ldw];
+                v[3] += pt[(int64_t)(L::OFF_MARG + 2) * a.ldw];
             }
             if constexpr (L::N_NU > 0) {
-                nu0 += pt[(int64_t)(L::OFF_NU + 0) * a.ldw];
-                nu1 += pt[(int64_t)(L::OFF_NU + 1) * a.ldw];
-                nu2 += pt[(int64_t)(L::OFF_NU + 2) * a.ldw];
+                v[4] += pt[(int64_t)(L::OFF_NU + 0) * a.ldw];
+                v[5] += pt[(int64_t)(L::OFF_NU + 1) * a.ldw];
+                v[6] += pt[(int64_t)(L::OFF_NU + 2) * a.ldw];
             }
             if constexpr (L::HAS_ONEIL) {
-                on0 += pt[(int64_t)(L::OFF_ONEIL + 0) * a.ldw];
+                v[7] += pt[(int64_t)(L::OFF_ONEIL + 0) * a.ldw];
                 if constexpr (GRAD) {
-                    on1 += pt[(int64_t)(L::OFF_ONEIL + 1) * a.ldw];
-                    on2 += pt[(int64_t)(L::OFF_ONEIL + 2) * a.ldw];
-                    on3 += pt[(int64_t)(L::OFF_ONEIL + 3) * a.ldw];
+                    v[8] += pt[(int64_t)(L::OFF_ONEIL + 1) * a.ldw];
+                    v[9] += pt[(int64_t)(L::OFF_ONEIL + 2) * a.ldw];
+                    v[10] += pt[(int64_t)(L::OFF_ONEIL + 3) * a.ldw];
                 }
             }
             // all of the task's planet sums in flight, then the adds (left to itself the compiler reused one register pair for the
@@ -917,49 +1005,37 @@ static __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) gp[k] += tmp[k];
         }
-        double* lo = lds + grp * WAVE + lane;
-        lo[0 * FIN_G * WAVE] = S; lo[1 * FIN_G * WAVE] = mA; lo[2 * FIN_G * WAVE] = mB; lo[3 * FIN_G * WAVE] = mC;
-        lo[4 * FIN_G * WAVE] = nu0; lo[5 * FIN_G * WAVE] = nu1; lo[6 * FIN_G * WAVE] = nu2;
-        lo[7 * FIN_G * WAVE] = on0; lo[8 * FIN_G * WAVE] = on1; lo[9 * FIN_G * WAVE] = on2; lo[10 * FIN_G * WAVE] = on3;
-        __syncthreads();
+        combine_rows<NOBS_ACC, NG, (CH < NOBS_ACC ? CH : NOBS_ACC)>(v, lds, grp, lane);
         if (grp == 0) {
-            double v[NOBS_ACC];
-#pragma unroll
-            for (int k = 0; k < NOBS_ACC; ++k) {
-                double x = 0.0;
-#pragma unroll
-                for (int g = 0; g < FIN_G; ++g) x += lds[(k * FIN_G + g) * WAVE + lane];
-                v[k] = x;
-            }
             // observations are summed in the order given (system.jl:93,186)
             ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + w : nullptr,
                                                 a.ldw, a.c.k_yr, o, v, cst, sma_p, e_p, M_p, w < a.W, oneil_g);
         }
-        __syncthreads();
     }
+    if constexpr (NPL > 0) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if constexpr (L::PL_N > 0) {
+        for (int p = 0; p < P; ++p) {
+            double vp[L::PL_N];
 #pragma unroll
-            for (int k = 0; k < L::PL_N; ++k) lds[(k * FIN_G + grp) * WAVE + lane] = gp[p * L::PL_N + k];
-            __syncthreads();
-            if (grp == 0) {
+            for (int k = 0; k < L::PL_N; ++k) vp[k] = gp[p * L::PL_N + k];
+            combine_rows<L::PL_N, NG, (CH < L::PL_N ? CH : L::PL_N)>(vp, lds, grp, lane);
 #pragma unroll
-                for (int k = 0; k < L::PL_N; ++k) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int g = 0; g < FIN_G; ++g) v += lds[(k * FIN_G + g) * WAVE + lane];
-                    gp[p * L::PL_N + k] = v;
-                }
-            }
-            __syncthreads();
+            for (int k = 0; k < L::PL_N; ++k) gp[p * L::PL_N + k] = vp[k];
         }
     }
     if (grp != 0 || w >= a.W) return;
     if (a.extra) ll += a.extra[w];
     bool ok = isfinite(ll);
+    if constexpr (FROM_WC) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) ok = ok && a.valid[(int64_t)p * a.ldw + w] != 0;
+        for (int p = 0; p < P; ++p) ok = ok && a.valid[(int64_t)p * a.ldw + w] != 0;
+    } else {
+        // what k_setup records in `valid`: every planet's elements inside the domain, every nuisance finite
+#pragma unroll
+        for (int p = 0; p < P; ++p) ok = ok && setup_planet<true>(a, p, w).ok;
+        if (a.nuis)
+            for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok = ok && isfinite(a.nuis[(int64_t)k * a.ld + w]);
+    }
     a.ll_out[w] = ok ? ll : -INFINITY;
     if constexpr (GRAD) {
         if (!ok && L::N_NU > 0) {
@@ -967,18 +1043,36 @@ static __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const double* wc = a.wc + (int64_t)p * NWC * a.ldw + w;
             FinPC fp;
-            fp.sma = wc[WC_A * a.ldw]; fp.P_d = 1.0 / wc[WC_INVP * a.ldw]; fp.beta = wc[WC_BETA * a.ldw];
-            fp.si = wc[WC_SINI * a.ldw]; fp.ci = wc[WC_COSI * a.ldw]; fp.sO = wc[WC_SINO * a.ldw]; fp.cO = wc[WC_COSO * a.ldw];
-            fp.sw = wc[WC_SINW * a.ldw]; fp.cw = wc[WC_COSW * a.ldw];
             double elv[OCTO_N_EL];
+            if constexpr (FROM_WC) {
+                const double* wc = a.wc + (int64_t)p * NWC * a.ldw + w;
+                fp.sma = wc[WC_A * a.ldw]; fp.P_d = 1.0 / wc[WC_INVP * a.ldw]; fp.beta = wc[WC_BETA * a.ldw];
+                fp.si = wc[WC_SINI * a.ldw]; fp.ci = wc[WC_COSI * a.ldw]; fp.sO = wc[WC_SINO * a.ldw]; fp.cO = wc[WC_COSO * a.ldw];
+                fp.sw = wc[WC_SINW * a.ldw]; fp.cw = wc[WC_COSW * a.ldw];
 #pragma unroll
-            for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + w];
+                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + w];
+            } else {
+                const SetupOut so = setup_planet<true>(a, p, w);      // the same routine, the same values k_setup would have stored
+                fp.sma = so.v[WC_A]; fp.P_d = 1.0 / so.v[WC_INVP]; fp.beta = so.v[WC_BETA];
+                fp.si = so.v[WC_SINI]; fp.ci = so.v[WC_COSI]; fp.sO = so.v[WC_SINO]; fp.cO = so.v[WC_COSO];
+                fp.sw = so.v[WC_SINW]; fp.cw = so.v[WC_COSW];
+#pragma unroll
+                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = so.el[k];
+            }
             planet_finish<P, GRAD, NUIS, KM>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
                                              a.orbit_kind[p], a.has_mass[p], p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
         }
     }
+}
+
+// block = 64 walkers × FIN_G waves, one block per tile. FROM_WC = false: after a k_main launch that derived the constants itself.
+template <int P, bool GRAD, bool NUIS, int KM, bool FROM_WC = true>
+static __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    finish_tile<P, GRAD, NUIS, KM, FIN_G, 12, FROM_WC>(a, (int64_t)blockIdx.x, grp, lane, lds);
 }
 
 // ==================================================================================== OFTI
@@ -1028,9 +1122,9 @@ static __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
 #pragma unroll
     for (int k = 0; k < OFTI_NACC; ++k) acc[k] = 0.0;
     __syncthreads();                                    // table filled
-    const double* __restrict__ rows = a.rows + (int64_t)(row0 + r_lo) * ROW_STRIDE;
+    const crow_t rows = constant_rows(a.rows + (int64_t)(row0 + r_lo) * ROW_STRIDE);
     for (int j = 0; j < r_hi - r_lo; ++j) {
-        const double* __restrict__ rw = rows + (int64_t)j * ROW_STRIDE;
+        const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
         const double t = rw[0], wrr = rw[1], wdd = rw[2], wrd = rw[3], pp = rw[4], qq = rw[5];
         const KSol s = kepler_solve<-1, true>(t, pc, tab);
         const double x = s.cE - pc.e, y = s.sE * pc.beta;            // :343-345

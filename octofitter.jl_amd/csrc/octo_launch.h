@@ -107,6 +107,39 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     int rc = grow(ctx, ctx->d_partials, ctx->cap_part, need);
     if (rc) return rc;
     a.partials = ctx->d_partials;
+    // Two launches: the orbit constructors in k_main's prologue (octo_kernels.h: k_main<FUSED>), then k_finish. Not with a
+    // marginalised-RV gradient (its forward pre-pass and k_marg read `wc`) and not without row tasks: those keep k_setup.
+    if (a.W <= ctx->fused_w && a.n_tasks > 0 && !(GRAD && L::HAS_MARG && (ds->kind_mask & KM_MARG))) {
+        a.extra = nullptr; a.marg = nullptr; a.marg_out = nullptr;
+        if (ds->n_hgca > 0) {      // the proper-motion anomaly term: k_finish adds it
+            if constexpr (NUIS) {
+                const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
+                rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
+                if (rc) return rc;
+                a.extra = ctx->d_extra;
+                hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)cols, (unsigned)n_dir), dim3(WAVE), 0, st, a);
+            } else {
+                return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
+            }
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
+        if (timed) {
+            if (ctx->ev_used == ctx->ev_pool.size()) {
+                hipEvent_t x, y;
+                HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
+                ctx->ev_pool.emplace_back(x, y);
+            }
+            e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
+            HIPCHK(ctx, hipEventRecord(e0, st));
+        }
+        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                           (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+        if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
+        hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * FIN_G), sizeof(double) * 12 * FIN_G * WAVE, st, a);
+        HIPCHK(ctx, hipGetLastError());
+        return OCTO_OK;
+    }
     const dim3 gsetup((unsigned)((a.W + 255) / 256));
     hipLaunchKernelGGL(k_setup, dim3(gsetup.x, (unsigned)a.n_planets), dim3(256), 0, st, a);
     if (a.n_tasks > 0) {

@@ -7,12 +7,18 @@ bench.py — throughput of the epoch-loop likelihood hot path on MI355X.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the hot path (k_setup -> k_main -> k_finish through octo_eval_device) over one batch of synthetic
-input that is already resident in HBM: BASELINE.json config 3 — 1 planet, 1e4 RA/Dec epochs x 1e4 prior-drawn walkers,
-forward log-likelihood + reverse gradient w.r.t. the orbital elements. Metric: epoch-likelihood evaluations per second =
-walkers x rows x steps / wall time, whole job. Multi-GPU: walkers are independent -> each rank owns its own 1e4 walkers
-(weak scaling), the dataset is replicated, and there is NO collective on the data path (the only collective of the path is
-the parallel-tempering swap step, exercised with --workload pt).
+A "step" is ONE pass of the hot path (k_main with the orbit constructors in its prologue -> k_finish, through octo_eval_device) over
+one batch of synthetic input that is already resident in HBM: BASELINE.json config 3 — 1 planet, 1e4 RA/Dec epochs x 1e4 prior-drawn
+walkers, forward log-likelihood + reverse gradient w.r.t. the orbital elements. Metric: epoch-likelihood evaluations per second =
+walkers x rows x steps / wall time, whole job. `value` is that HBM-resident rate (the bench contract); SURVEY.md §8(d) defines the
+metric with the H2D of the elements and the D2H of ll + gradient inside the timed call: that rate travels on the same line as
+`value_pcie_inclusive` (octo_eval on host arrays the caller registered once), with its breakdown in `pcie_inclusive`.
+Multi-GPU: walkers are independent, the dataset is replicated, and there is NO collective on the data path (the only collective of the
+path is the parallel-tempering swap step, exercised with --workload pt).
+  --scaling weak    (default, the bench contract's mode for a path that shards by independent units): every rank owns its own 1e4 walkers;
+  --scaling strong  SURVEY §8(d) "Scaling runs": the SAME 1e4 walkers split evenly over the ranks (1 250 per GPU at 8).
+At N = 1 the line also carries `strong_scaling_projection`: the per-GPU shares of a strong-scaled run (W/2, W/4, W/8 walkers) measured
+on this one GPU — shards are independent, so N x rate(W/N) / rate(W) is what N GPUs deliver short of launch jitter.
 
 Timed region: W warm-up steps, then an untimed spin-up until the device has been busy for >= 0.3 s (clocks ramped, so that a
 20-step run measures the same thing as a 200-step run), barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over
@@ -69,6 +75,8 @@ def parse():
     ap.add_argument("--epochs", type=int, default=10_000)
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default 10000; 8192 = 8 temperatures x 1024 for --workload pt)")
     ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti", "logpost"], default="grad")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --walkers per GPU (default); strong: --walkers in total, split evenly over the ranks (SURVEY 8d)")
     ap.add_argument("--pt-comm", choices=["c_abi", "torch"], default="c_abi",
                     help="--workload pt: all-gather inside the library (octo_pt_step_device, RCCL bound by the C ABI) or through torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,28 +110,43 @@ def kernel_source_hash():
 
 
 def cpu_baseline(cfg, obs_tables, planets, seconds):
-    """Oracle (reference-order restatement, forward-mode duals = ForwardDiff chunk) on all host cores, on a bounded
-    sample of the same workload: whole passes over a subset of the walkers until ~`seconds` of CPU work."""
+    """SURVEY §8(d) "CPU baseline beside it": the C restatement of the reference path (oracle/, kind "port"; forward-mode duals = a
+    ForwardDiff chunk of 8) on a bounded sample of the same workload — (a) single thread and (b) OpenMP over walkers on all host cores,
+    forward-only and fwd+gradient each. `value` is (b) fwd+grad, the metric's definition; the other three travel beside it. The
+    reference's own remarks for scale: 32-200 ns per orbit solve (src/likelihoods/system.jl:244-249)."""
     import oracle_binding as ob
     import synth
     cores = os.cpu_count() or 1
     E = cfg["n_epochs"]
     mask = synth.active_mask(1, 1, mass=False, nuis=False)
-    probe = min(cfg["n_walkers"], 4 * cores)
-    ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :probe], None, grad=True, active=mask, n_threads=0)   # warm
-    t0 = time.perf_counter()
-    ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :probe], None, grad=True, active=mask, n_threads=0)
-    rate = probe * E / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(cfg["n_walkers"], max(cores, rate * seconds / E)))
-    n = max(cores, n // cores * cores)
-    reps = max(1, int(round(rate * seconds / (n * E))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :n], None, grad=True, active=mask, n_threads=0)
-    dt = time.perf_counter() - t0
-    return {"value": reps * n * E / dt, "unit": "epoch-likelihood evals/s (fwd+grad)", "cores": cores, "kind": "port",
-            "sample": f"{reps} pass(es) over {n} walkers x {E} epochs of the same workload, oracle/liboctooracle.so "
-                      f"(gcc -O3 -march=native, OpenMP over walkers, 8 forward-mode partials per dual), {dt:.1f} s"}
+
+    def timed(n_threads, grad, budget):
+        width = cores if n_threads == 0 else 1
+        probe = min(cfg["n_walkers"], 4 * width)
+        ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :probe], None, grad=grad, active=mask, n_threads=n_threads)   # warm
+        t0 = time.perf_counter()
+        ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :probe], None, grad=grad, active=mask, n_threads=n_threads)
+        rate = probe * E / max(time.perf_counter() - t0, 1e-6)
+        n = int(min(cfg["n_walkers"], max(width, rate * budget / E)))
+        n = max(width, n // width * width)
+        reps = max(1, int(round(rate * budget / (n * E))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :n], None, grad=grad, active=mask, n_threads=n_threads)
+        dt = time.perf_counter() - t0
+        return reps * n * E / dt, f"{reps} pass(es) over {n} walkers x {E} epochs, {dt:.1f} s"
+
+    v_all, s_all = timed(0, True, 0.40 * seconds)
+    v_all_f, s_all_f = timed(0, False, 0.15 * seconds)
+    v_one, s_one = timed(1, True, 0.30 * seconds)
+    v_one_f, s_one_f = timed(1, False, 0.15 * seconds)
+    return {"value": v_all, "unit": "epoch-likelihood evals/s (fwd+grad)", "cores": cores, "kind": "port",
+            "sample": f"{s_all} of the same workload, oracle/liboctooracle.so (gcc -O3 -march=native, OpenMP over walkers, 8 forward-mode partials per dual)",
+            "forward_only": {"value": v_all_f, "unit": "evals/s (fwd)", "cores": cores, "sample": s_all_f},
+            "single_thread": {"value": v_one, "unit": "evals/s (fwd+grad)", "cores": 1, "ns_per_eval": 1e9 / v_one, "sample": s_one},
+            "single_thread_forward_only": {"value": v_one_f, "unit": "evals/s (fwd)", "cores": 1, "ns_per_eval": 1e9 / v_one_f, "sample": s_one_f},
+            "reference_remarks": "the reference's own comment puts one Kepler solve at ~200 ns on a CPU core (src/likelihoods/system.jl:245-246; "
+                                 "SURVEY.md section 6 infers 32-200 ns); one evaluation here = one solve + projection + density (+ 8 partials with the gradient)"}
 
 
 def parity_sample(fn, cfg, ll_dev, g_dev, n=8):
@@ -263,7 +286,7 @@ def main():
                 "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median_events": float(np.median(per_step)),
                 "ms_per_step_min_events": float(per_step.min()), "step_events_every": int(os.environ.get("OCTO_BENCH_EVENTS_EVERY", str(STEP_EVENTS_EVERY))),
                 "spinup_steps_untimed": n_spin,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfgd}
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfgd}
 
     grad = args.workload in ("grad", "two_planet")
     if args.workload == "ofti":
@@ -314,14 +337,23 @@ def main():
         bytes_per_launch = W * (2500 * 40.0 + 2500 * 24.0) + W * 8.0 * (18 + 6 + 1 + 18 + 6)
         cfg = None
     else:
-        cfg = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2,
-                                  seed=None if world == 1 else 20260929 + 3 + 1000 * rank)
+        if args.scaling == "strong":
+            # SURVEY §8(d) "Scaling runs": the SAME --walkers split evenly over the ranks (contiguous shards, host/sharding.py:shard_range —
+            # what octo_eval_multi does inside one process); every rank draws the whole batch with the one seed and keeps its slice
+            cfg = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2)
+            lo, hi = pkg.shard_range(args.walkers, rank, world)
+            cfg = dict(cfg, elems=np.ascontiguousarray(cfg["elems"][:, lo:hi]), n_walkers=hi - lo)
+        else:
+            cfg = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2,
+                                      seed=None if world == 1 else 20260929 + 3 + 1000 * rank)
         obs, planet = synth.to_mirror(pkg, cfg)
         system = pkg.System(name="bench", companions=[planet], observations=[])
         fn = pkg.make_ln_like(system, cfg["theta_example"], device=dev_index)
         elems_h, nuis_h = cfg["elems"], None
         n_rows, W = cfg["n_epochs"], cfg["n_walkers"]
-        workload = f"config{'3' if grad else '2'}: 1 planet, {n_rows} RA/Dec epochs x {W} walkers/GPU, {'fwd+reverse-grad' if grad else 'fwd only'}"
+        workload = (f"config{'3' if grad else '2'}: 1 planet, {n_rows} RA/Dec epochs x {W} walkers/GPU"
+                    + (f" ({args.walkers} walkers split over {world} GPUs)" if args.scaling == "strong" else "")
+                    + f", {'fwd+reverse-grad' if grad else 'fwd only'}, inputs and outputs resident in HBM (PCIe-inclusive rate: value_pcie_inclusive)")
         bytes_per_launch = W * n_rows * BYTES_PER_ROW + W * (BYTES_PER_WALKER if grad else 72.0)
 
     elems = torch.tensor(elems_h, device=dev)
@@ -356,16 +388,66 @@ def main():
         if pt is not None:
             pt.swap_step(out[0], i)
 
+    def swap_latency(n=200):
+        """SURVEY §8(d) config 5 "swap-step latency": the all-gather (N > 1) + swap kernel alone, one step at a time, host-synchronised."""
+        for i in range(20):
+            pt.swap_step(out[0], 10_000 + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ts = []
+        for i in range(n):
+            t1 = time.perf_counter(); pt.swap_step(out[0], 20_000 + i); torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+        t = torch.tensor([float(np.median(ts))], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e6
+
+    def strong_projection():
+        """Per-GPU shares of a strong-scaled run of THIS workload (W/N walkers, N = 2, 4, 8) measured on this one GPU, device-resident,
+        back-to-back like the timed region: speed-up N GPUs would deliver = N x rate(W/N) / rate(W) (shards are independent)."""
+        outp = {}
+        base = None
+        for N in (1, 2, 4, 8):
+            Wn = W // N
+            el_n = elems[:, :Wn].contiguous()
+            out_n = (torch.empty(Wn, dtype=torch.float64, device=dev), torch.empty_like(el_n) if grad else None, None)
+            for _ in range(30):
+                fn.ln_like_device(el_n, None, grad=grad, out=out_n)
+            best = 1e9
+            for _ in range(3):
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(100):
+                    fn.ln_like_device(el_n, None, grad=grad, out=out_n)
+                torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t1) / 100)
+            rate = Wn * n_rows / best
+            base = base or rate
+            outp[str(N)] = {"walkers_per_gpu": Wn, "us_per_step": best * 1e6, "evals_per_s_per_gpu": rate, "projected_speedup": N * rate / base}
+        return {"what": "strong scaling of this workload (SURVEY 8d: walkers split evenly, dataset replicated) projected from the per-GPU share "
+                        "measured on one GPU: N x rate(W/N) / rate(W); no collective on this path, so the only thing a real N-GPU run adds is launch jitter",
+                "by_n_gpus": outp}
+
     fn.timing_enable(TIMED_EVERY)      # HIP events around k_main of every TIMED_EVERY-th evaluation, on its launch stream
     dt, per_step, n_spin = timed_loop(run_step, on_timed_start=lambda: fn.timing_read(reset=True))
     kern_med, kern_min, kern_max, kern_n = fn.timing_stats()
     kern_ms, _ = fn.timing_read(reset=True)
     fn.timing_enable(False)
 
-    evals = float(W) * n_rows * args.steps * world
+    if args.scaling == "strong" and cfg is not None:      # ranks may differ by one walker: count what every rank really did
+        tw = torch.tensor([float(W)], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tw, op=dist.ReduceOp.SUM)
+        evals = float(tw.item()) * n_rows * args.steps
+    else:
+        evals = float(W) * n_rows * args.steps * world
     value = evals / dt
     metric = "epoch-likelihood evals/sec (fwd+grad), 1e4 epochs x 1e4 walkers" if args.workload == "grad" else f"epoch-likelihood evals/sec ({args.workload})"
     res = base_line(metric, value, dt, per_step, n_spin, workload, {"walkers_per_gpu": W, "rows": n_rows, "parallelism": parallelism})
+    if pt is not None:
+        lat = swap_latency()
+        res["swap_step_latency_us"] = lat
+        res["swap_step_what"] = ("median over 200 steps, max over ranks: " + ("ncclAllGather of the local replicas' log-likelihoods + " if world > 1 else "")
+                                 + "deterministic neighbour-swap kernel, host-synchronised per step")
     if rank == 0:
         is_cfg3 = args.workload == "grad" and (n_rows, W) == (10_000, 10_000)
         pmc, pmc_ok, pmc_note = None, False, None
@@ -430,6 +512,7 @@ def main():
             for _ in range(25):
                 t1 = time.perf_counter(); fn.lib.octo_eval(*a_); ts.append(time.perf_counter() - t1)
             med = float(np.median(ts))
+            res["value_pcie_inclusive"] = W * n_rows / med      # replaced below by the registered-arrays rate when that leg succeeds
             res["pcie_inclusive"] = {"value": W * n_rows / med, "unit": "evals/s", "ms_per_call_median": med * 1e3, "calls": len(ts),
                                      "what": "octo_eval with PAGEABLE host buffers: H2D of elems and D2H of ll + gradient inside the call (SURVEY 8d definition); median of 25"}
             # the same call with the caller's arrays registered once (octo_host_register): copy kernel in, results written in place
@@ -444,6 +527,9 @@ def main():
                     t1 = time.perf_counter(); fn.lib.octo_eval(*a_); ts.append(time.perf_counter() - t1)
                 medr = float(np.median(ts))
                 fn.host_unregister(el_h, ll_h, g_h)
+                res["value_pcie_inclusive"] = W * n_rows / medr
+                res["value_pcie_inclusive_what"] = ("SURVEY.md 8(d)'s definition of the metric: octo_eval on host arrays (registered once by the caller), H2D of the "
+                                                    "elements and D2H of ll + gradient inside the timed call; median of 25 blocking calls")
                 res["pcie_inclusive"]["registered"] = {
                     "value": W * n_rows / medr, "unit": "evals/s", "ms_per_call_median": medr * 1e3, "calls": len(ts),
                     "bit_identical_to_pageable": bool(np.array_equal(ll_h, ll_ref, equal_nan=True)),
@@ -452,6 +538,10 @@ def main():
             except Exception as ex:
                 res["pcie_inclusive"]["registered"] = {"error": str(ex)}
         if not args.no_extras and world == 1 and args.workload == "grad":      # before the CPU baseline: its OpenMP team keeps spinning for a while and would disturb a latency measurement
+            try:
+                res["strong_scaling_projection"] = strong_projection()
+            except Exception as ex:
+                res["strong_scaling_projection"] = {"error": str(ex)}
             try:
                 res["config1"] = config1_latency(pkg, dev_index)
             except Exception as ex:

@@ -20,7 +20,16 @@ namespace octo {
 constexpr int MAXP = 4;
 constexpr int ROW_STRIDE = 8;   // doubles per observation row record (64 B = one s_load_dwordx16)
 constexpr int WPB = 4;          // waves per k_main block (row split + LDS combine)
-constexpr int FIN_G = 8;        // task groups per walker in k_finish (block = 64 walkers x 8 groups: more loads in flight)
+#ifndef OCTO_FIN_G
+#define OCTO_FIN_G 16
+#endif
+#ifndef OCTO_FIN_UNROLL
+#define OCTO_FIN_UNROLL 4
+#endif
+constexpr int FIN_G = OCTO_FIN_G;        // task groups per walker in k_finish (block = 64 walkers x FIN_G waves). The kernel is pure memory latency — a
+                                         // tile's partials are tasks x NACC rows of 512 B written by other CUs — so what counts is loads in flight:
+                                         // 16 waves x 4 tasks unrolled (8 x 2 in round 2: 10.7 us at 1 250 walkers x 76 tasks, 9.4 us at 1e4 x 34)
+constexpr int FIN_CH = 6;                // rows of the LDS combine per chunk: 6 x 16 x 512 B = 48 KB
 
 // kind mask bits
 constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16, KM_COR = 32, KM_ONEIL = 64;
@@ -283,7 +292,7 @@ __device__ __forceinline__ AstromCoef<P> astrom_coef_vals(double jit, double ps,
     c.jit = 0.0; c.j2 = 0.0; c.ps = 1.0; c.na = 0.0; c.sn = 0.0; c.cn = 1.0;
     if constexpr (NUIS) {
         c.jit = jit; c.ps = ps; c.na = na;
-        sincos(c.na, &c.sn, &c.cn);
+        sincos_reduced(c.na, c.sn, c.cn);      // call-free, ~35 instructions (ocml: ~180 + a large-argument loop) in every block's prologue
         c.j2 = c.jit * c.jit;
     }
     c.seppa = (KM & KM_SEPPA) && (ob_kind == OCTO_ASTROM_SEPPA || ob_kind == OCTO_ONEIL_SEPPA);
@@ -596,6 +605,34 @@ __device__ __forceinline__ crow_t constant_rows(const double* p) {
 #pragma clang diagnostic pop
 }
 
+// One row record in SGPRs. The row loops fetch row j+1 while row j is computed (the scalar load then has a whole iteration to land):
+// every row is a new 64-byte line of the scalar cache, and a kernel that keeps only two or three waves per SIMD (the multi-planet
+// nuisance variants) cannot hide that latency behind other waves.
+// The loads are inline assembly on purpose: written as C++ loads the compiler sinks them to their first use and waits at once (they are
+// pure), whatever the source order. row_issue starts the scalar loads and returns; row_wait is the s_waitcnt the consumers depend on.
+// Scalar loads return out of order, so the only usable wait is lgkmcnt(0): a row is therefore waited for BEFORE the next one is
+// issued (it was issued a whole row body earlier), and the next one lands behind the body's own LDS wait for the sin/cos table.
+typedef int sgpr8_t __attribute__((ext_vector_type(8)));
+typedef int sgpr4_t __attribute__((ext_vector_type(4)));
+struct RowRegs { sgpr8_t lo; sgpr4_t hi; };      // doubles 0-3 and 4-5 of the record
+__device__ __forceinline__ RowRegs row_issue(crow_t p) {
+    RowRegs r;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(r.lo), "=&s"(r.hi) : "s"(p));
+    return r;
+}
+__device__ __forceinline__ void row_wait(RowRegs& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi)); }
+// wait for `cur`, then start the loads of the following row — one asm block that `cur`'s consumers depend on, so that the compiler
+// cannot schedule the first instructions of the row body ahead of the issue
+__device__ __forceinline__ RowRegs row_wait_issue(RowRegs& cur, crow_t p) {
+    RowRegs r;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x20"
+                 : "=&s"(r.lo), "=&s"(r.hi), "+s"(cur.lo), "+s"(cur.hi) : "s"(p));
+    return r;
+}
+__device__ __forceinline__ double row_get(const RowRegs& r, int k) {      // k: compile-time constant after inlining
+    return k < 4 ? __hiloint2double(r.lo[2 * k + 1], r.lo[2 * k]) : __hiloint2double(r.hi[2 * (k - 4) + 1], r.hi[2 * (k - 4)]);
+}
+
 constexpr int NPC = WC_CAE + 1;     // the per-walker constants the row loop reads (PC): WC_INVP … WC_CAE; the rest of `wc` is the finish's
 
 template <int P, bool GRAD, bool NUIS, int KM>
@@ -705,17 +742,54 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
         const AstromCoef<P> co = astrom_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, ob.kind, ob.planet, ob.has_cor, tk.obs, pc, wl);
         const crow_t rows = constant_rows((NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE);
+        // two rows per trip through two SGPR buffers that swap roles (no copies): B is fetched while A is computed and vice versa
+        auto body = [&](const RowRegs& r) {
+            astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4), row_get(r, 5), tab);
+        };
+#ifdef OCTO_NO_ROW_PREFETCH
         for (int j = 0; j < n_rows; ++j) {
             const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
             astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab);
+        }
+        if (false)
+#else
+        if (n_rows > 0)
+#endif
+        {
+            RowRegs A = row_issue(rows);
+            for (int j = 0; j < n_rows; j += 2) {
+                RowRegs B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);      // past the end: re-read a valid row
+                body(A);
+                if (j + 1 >= n_rows) { row_wait(B); break; }
+                A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
+                body(B);
+            }
         }
     }
     if (L::HAS_RV && !is_astrom) {
         const RvCoef<P> co = rv_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, a.marg, a.ldw, ob.kind, ob.planet, tk.obs, pc, wl);
         const crow_t rows = constant_rows((NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE);
+        auto body = [&](const RowRegs& r) {
+            rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab);
+        };
+#ifdef OCTO_NO_ROW_PREFETCH
         for (int j = 0; j < n_rows; ++j) {
             const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
             rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, tab);
+        }
+        if (false)
+#else
+        if (n_rows > 0)
+#endif
+        {
+            RowRegs A = row_issue(rows);
+            for (int j = 0; j < n_rows; j += 2) {
+                RowRegs B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
+                body(A);
+                if (j + 1 >= n_rows) { row_wait(B); break; }
+                A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
+                body(B);
+            }
         }
     }
     if constexpr (NUIS) {
@@ -975,7 +1049,7 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
         for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
         const int t0 = a.obs_range[2 * o], t_end = a.obs_range[2 * o + 1];
         const double cst = a.obs_const[o];
-#pragma unroll 2
+#pragma unroll OCTO_FIN_UNROLL
         for (int tt = t0 + grp; tt < t_end; tt += NG) {
             const double* pt = a.partials + (int64_t)tt * L::NACC * a.ldw + wl;
             v[0] += pt[(int64_t)L::OFF_S * a.ldw];
@@ -1072,7 +1146,7 @@ static __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    finish_tile<P, GRAD, NUIS, KM, FIN_G, 12, FROM_WC>(a, (int64_t)blockIdx.x, grp, lane, lds);
+    finish_tile<P, GRAD, NUIS, KM, FIN_G, FIN_CH, FROM_WC>(a, (int64_t)blockIdx.x, grp, lane, lds);
 }
 
 // ==================================================================================== OFTI

@@ -136,7 +136,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
                            (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
         if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
-        hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * FIN_G), sizeof(double) * 12 * FIN_G * WAVE, st, a);
+        hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * FIN_G), sizeof(double) * FIN_CH * FIN_G * WAVE, st, a);
         HIPCHK(ctx, hipGetLastError());
         return OCTO_OK;
     }
@@ -193,7 +193,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         }
     }
     hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * FIN_G),
-                       sizeof(double) * 12 * FIN_G * WAVE, st, a);
+                       sizeof(double) * FIN_CH * FIN_G * WAVE, st, a);
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;
 }

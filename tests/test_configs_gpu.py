@@ -211,3 +211,27 @@ def test_bench_line_contract():
     assert 0.5 * d["value"] < d["pcie_inclusive"]["value"] < d["value"]
     assert d["config1"]["gpu_matches_fixture"] is True and 5 < d["config1"]["gpu_us_per_call"] < 200
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 1e5
+    # the CPU restatement single-thread and on all cores, forward-only and fwd+grad
+    cb = d["cpu_baseline"]
+    assert cb["single_thread"]["cores"] == 1 and 1e4 < cb["single_thread"]["value"] <= cb["value"] * 1.01
+    assert cb["forward_only"]["value"] > cb["value"] and cb["single_thread_forward_only"]["value"] > cb["single_thread"]["value"]
+    # the metric as SURVEY §8(d) defines it (H2D + D2H inside the timed call) travels on the same line, below the HBM-resident `value`
+    assert 0.5 * d["value"] < d["value_pcie_inclusive"] < d["value"] and d["value_pcie_inclusive"] == d["pcie_inclusive"]["registered"]["value"]
+    assert "HBM" in d["config"]["workload"]
+    # strong-scaling shares measured on the one GPU: 1e4 / N walkers, projected speed-up N x rate(W/N) / rate(W)
+    sp = d["strong_scaling_projection"]["by_n_gpus"]
+    assert [sp[k]["walkers_per_gpu"] for k in ("1", "2", "4", "8")] == [10000, 5000, 2500, 1250]
+    assert sp["1"]["projected_speedup"] == 1.0 and 1.5 < sp["2"]["projected_speedup"] <= 2.05 and 4.0 < sp["8"]["projected_speedup"] <= 8.2
+
+
+def test_bench_strong_scaling_mode():
+    """`--scaling strong` (SURVEY §8d "Scaling runs": the same walkers split evenly over the ranks) at N = 1 is the same job as weak scaling;
+    the line says which mode it ran and the workload names the split."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "10", "--warmup", "3", "--scaling", "strong", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["walkers_per_gpu"] == 10000
+    assert "10000 walkers split over 1 GPUs" in d["config"]["workload"]
+    assert abs(d["value"] - 1e8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -123,6 +123,52 @@ DT void prior_apply(const octo_prior& pr, const DU& y, DU& x, DU& lp, const doub
     lp = lp + ladj;
 }
 
+// The same for the lane = parameter mapping of k_small<MODEL>: every lane applies ITS OWN prior, so the kinds differ across the wave and the
+// branches above run one after the other (five kinds: ~700 serial instructions, most of them the transcendentals of kinds a lane does
+// not have). Branch-free instead — ONE exp, TWO logs and (only if some lane holds a Sine prior: a wave-uniform test) one sincos for all
+// kinds, everything else selects on per-lane flags. Same formulas, same constants (`pc`, octo_model_create), one-partial fast-math duals:
+//   link       both bounds: x = a + (b − a)·σ(y), dx = (b − a)σ(1 − σ);  lower only: x = a + e^y;  upper only: x = b − e^y;  none: x = y
+//   log|J|     log((x − a)(b − x)/(b − a)) | log(x − a) | log(b − x) | 0                                  — the first log
+//   logpdf     Uniform: −log(b − a) · LogUniform: −log(x·log(b/a)) · Normal: −(z² + log 2π)/2 − log σ (+ truncation constant) · Sine: log(sin x / 2)
+//                                                                                                         — the second log
+__device__ __forceinline__ void prior_apply_lanes(const octo_prior& pr, double y, double& xv, double& xd, double& lpv, double& lpd,
+                                                  const double* __restrict__ pc) {
+    const int kind = pr.kind;
+    const bool is_u = kind == OCTO_PRIOR_UNIFORM, is_lu = kind == OCTO_PRIOR_LOGUNIFORM, is_tn = kind == OCTO_PRIOR_TRUNCNORMAL, is_s = kind == OCTO_PRIOR_SINE;
+    const bool is_n = kind == OCTO_PRIOR_NORMAL || is_tn;
+    const double a = (is_u || is_lu) ? pr.p0 : (is_tn ? pr.lo : (is_s ? 2.220446049250313e-16 : -INFINITY));
+    const double b = (is_u || is_lu) ? pr.p1 : (is_tn ? pr.hi : (is_s ? PI - 2.220446049250313e-16 : INFINITY));
+    const bool fa = isfinite(a), fb = isfinite(b), both = fa && fb;
+    const double em = exp(-fabs(y));                                // in (0, 1]: never overflows, whatever θ_t a sampler tries
+    const double r1 = rcp_nr<2>(1.0 + em);
+    const double sg = y >= 0.0 ? r1 : em * r1;                       // σ(y) = 1/(1 + e^−y)
+    const double ey = y >= 0.0 ? rcp_nr<2>(em) : em;                 // e^y for the one-sided links
+    const double ba = b - a;
+    xv = both ? fma(ba, sg, a) : (fa ? ey + a : (fb ? b - ey : y));
+    xd = both ? ba * sg * (1.0 - sg) : (fa ? ey : (fb ? -ey : 1.0));
+    // log|J| and its derivative d/dθ_t = (d arg/dx · dx/dy)/arg
+    const double xa = xv - a, bx = b - xv;
+    const double jarg = both ? xa * bx * pc[1] : (fa ? xa : (fb ? bx : 1.0));
+    const double jdarg = both ? (bx - xa) * pc[1] : (fa ? 1.0 : (fb ? -1.0 : 0.0));
+    const double ladj = (fa || fb) ? log(jarg) : 0.0;
+    const double ladj_d = (fa || fb) ? jdarg * xd * rcp_nr<2>(jarg) : 0.0;
+    // the density
+    double sx = 0.0, cx = 1.0;
+    if (__any(is_s)) sincos_reduced(xv, sx, cx);
+    const double larg = is_lu ? xv * pc[2] : (is_s ? 0.5 * sx : 1.0);
+    const double ldarg = is_lu ? pc[2] : (is_s ? 0.5 * cx : 0.0);
+    const double lg = (is_lu || is_s) ? log(larg) : 0.0;
+    const double lg_d = (is_lu || is_s) ? ldarg * xd * rcp_nr<2>(larg) : 0.0;
+    const double z = is_n ? (xv - pr.p0) * pc[3] : 0.0;
+    double pv = is_u ? pc[2] : (is_lu ? -lg : (is_s ? lg : fma(-0.5, fma(z, z, LOG2PI), pc[2]) + (is_tn ? pc[0] : 0.0)));
+    double pd = is_lu ? -lg_d : (is_s ? lg_d : (is_n ? -z * pc[3] * xd : 0.0));
+    const bool inside = (is_u || is_lu) ? (xv >= a && xv <= b) : (is_tn ? (xv >= pr.lo && xv <= pr.hi) : (is_s ? (xv > 0.0 && xv < PI) : true));
+    pv = inside ? pv : -INFINITY;
+    pd = inside ? pd : 0.0;
+    lpv = pv + ladj;
+    lpd = pd + ladj_d;
+}
+
 // logpdf(LogNormal(log(1.0), 0.1), sqrt(x² + y²))   src/variables.jl:309-323
 DT DU unit_length(const DU& x, const DU& y) {
     const DU r = dsqrt(x * x + y * y);

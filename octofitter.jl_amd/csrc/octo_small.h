@@ -153,7 +153,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef OCTO_SMALL_TRACE
-    unsigned long long tr[8]; int ntr = 0;
+    unsigned long long tr[12]; int ntr = 0;
 #define TRACE_POINT() tr[ntr++] = __builtin_readcyclecounter()
 #else
 #define TRACE_POINT()
@@ -184,8 +184,9 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
         }
         finite_in = __all(isfinite(y));                                              // logdensitymodel.jl:120-124
         D1 xk, pk;
-        prior_apply(sm.priors[dl], dvar<1, true>(y, 0), xk, pk, sm.prior_logz + PRIOR_NC * dl);
+        prior_apply_lanes(sm.priors[dl], y, xk.v, xk.d[0], pk.v, pk.d[0], sm.prior_logz + PRIOR_NC * dl);
         T.xv = xk.v; T.xd = xk.d[0];
+        TRACE_POINT();      // (MODEL) priors applied
         {   // the model's UniformCircular pairs, one per lane
             CT.n = sm.n_circ < WAVE ? sm.n_circ : WAVE;
             const int j = lane < CT.n ? lane : 0;
@@ -196,6 +197,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 CT.ang = ang.v; CT.ang_x = ang.d[0]; CT.ang_y = ang.d[1]; CT.ul = u2.v; CT.ul_x = u2.d[0]; CT.ul_y = u2.d[1];
             }
         }
+        TRACE_POINT();      // (MODEL) UniformCircular table
         for (int k = 0; k < D; ++k) {                                                // in declaration order, healing as the reference
             const double pv = lane_value(pk.v, k);                                   // does (variables.jl:1229-1236)
             if (!healed) {
@@ -218,6 +220,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
         }
     }
 
+    if constexpr (MODEL) { TRACE_POINT(); }      // (MODEL) elements resolved (θ_at_epoch_to_tperi included)
     // ---- orbit constants of this walker (what k_setup would have written to `wc`)
     PC pc[P];
     FinPC fp[P];

@@ -3,7 +3,7 @@ finishing block of walker 0 — where one small call's microseconds go."""
 import ctypes as C, os, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-os.environ.setdefault("OCTOFITTER_HIP_LIB", str(ROOT / "tools" / "liboctofitter_trace.bin"))
+os.environ.setdefault("OCTOFITTER_HIP_LIB", str(ROOT / "octofitter.jl_amd" / "lib" / "variants" / "liboctofitter_hip_trace.so"))      # python tools/build_variant.py trace -DOCTO_SMALL_TRACE
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 from __graft_entry__ import load_package
@@ -17,12 +17,12 @@ for E, W in ((50, 1), (10000, 1), (10000, 32)):
     fn.lib.octo_debug_small_trace.restype = C.POINTER(C.c_uint64); fn.lib.octo_debug_small_trace.argtypes = [C.c_void_p]
     el = np.ascontiguousarray(cfg["elems"]); ll = np.empty(W); g = np.empty_like(el)
     args = (fn._ctx, fn._ds, capi._dptr(el), None, W, W, capi._dptr(ll), capi._dptr(g), None)
-    acc = np.zeros(8); n = 0
+    acc = np.zeros(7); n = 0
     for it in range(300):
         fn.lib.octo_eval(*args)
         if it >= 100:
             fn.sync()
-            t = np.array([fn.lib.octo_debug_small_trace(fn._ctx)[k] for k in range(8)], dtype=np.float64)
+            t = np.array([fn.lib.octo_debug_small_trace(fn._ctx)[k] for k in range(7)], dtype=np.float64)
             acc += t - t[0]; n += 1
     acc /= n
     print(f"E={E} W={W}: " + "  ".join(f"{nm} {acc[k] / 2400:.2f}us" for k, nm in enumerate(names)), flush=True)
@@ -47,13 +47,14 @@ for E in (50, 10000):
     fn.lib.octo_debug_small_trace.restype = C.POINTER(C.c_uint64); fn.lib.octo_debug_small_trace.argtypes = [C.c_void_p]
     th = np.ascontiguousarray(np.asarray(case["theta_t"])[:, :1]); lp = np.empty(1); g = np.empty_like(th)
     args = (fn._ctx, model._m, capi._dptr(th), 1, 1, capi._dptr(lp), capi._dptr(g))
-    acc = np.zeros(8); n = 0
+    mnames = ["start", "priors", "circ-table", "elements(tperi)", "setup", "rows+block-reduce", "last-known", "obs-finish", "outputs", "flag"]
+    acc = np.zeros(len(mnames)); n = 0
     for it in range(300):
         fn.lib.octo_model_logpost(*args)
         if it >= 100:
             fn.sync()
-            t = np.array([fn.lib.octo_debug_small_trace(fn._ctx)[k] for k in range(8)], dtype=np.float64)
+            t = np.array([fn.lib.octo_debug_small_trace(fn._ctx)[k] for k in range(len(mnames))], dtype=np.float64)
             acc += t - t[0]; n += 1
     acc /= n
-    print(f"model D=11 E={E} W=1: " + "  ".join(f"{nm} {acc[k] / 2400:.2f}us" for k, nm in enumerate(names)), flush=True)
+    print(f"model D=11 E={E} W=1: " + "  ".join(f"{nm} {acc[k] / 2400:.2f}us" for k, nm in enumerate(mnames)), flush=True)
     model.close()

@@ -22,6 +22,20 @@ def main(src, dst):
         except sqlite3.Error as ex:
             out.append(f"(no top_kernels: {ex})")
         try:
+            # the same kernel name can be launched in several shapes by one command (bench.py's strong-scaling legs run k_main at
+            # W, W/2, W/4, W/8): one line per (kernel, grid) so that every average belongs to ONE launch shape
+            rows = cur.execute("select name, grid_x, grid_y, workgroup_x, count(*), avg(duration) / 1e3, min(duration) / 1e3, max(duration) / 1e3 "
+                               "from kernels group by name, grid_x, grid_y, workgroup_x having count(*) >= 5 order by sum(duration) desc").fetchall()
+            names = [r[0] for r in rows]
+            if any(names.count(n) > 1 for n in names):
+                out.append("per launch shape (kernels launched in more than one shape; durations in us):")
+                out.append(f"{'kernel':58s} {'grid (work-items)':>18s} {'wg':>5s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
+                for r in rows:
+                    if names.count(r[0]) > 1:
+                        out.append(f"{r[0][:58]:58s} {str(r[1]) + ' x ' + str(r[2]):>18s} {r[3]:5d} {r[4]:6d} {r[5]:10.3f} {r[6]:10.3f} {r[7]:10.3f}")
+        except sqlite3.Error as ex:
+            out.append(f"(no kernels view: {ex})")
+        try:
             rows = cur.execute("select kernel_name, counter_name, avg(value), count(*), max(vgpr_count), max(sgpr_count), max(grid_size), max(workgroup_size) "
                                "from counters_collection group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
             if rows:

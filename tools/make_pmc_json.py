@@ -30,14 +30,20 @@ def counters(src):
 
 
 def kernel_avg_us(src):
+    """Average duration of the kernel in the kernel-trace run of the default bench command — of the launch shape the counters belong to
+    (grid = ceil(W/64) tiles x tasks): the same command also launches k_main on W/2, W/4, W/8 walkers (strong_scaling_projection), and an
+    average over all four shapes would describe none of them."""
+    cols = (W + 63) // 64
     for db in sorted(glob.glob(f"{src}/stats/**/*.db", recursive=True)):
         con = sqlite3.connect(db)
         try:
-            for name, calls, total, avg, pct in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
-                if KERNEL in name:
-                    return avg, calls
+            rows = con.execute("select name, grid_x, grid_y, count(*), avg(duration) / 1e3 from kernels group by name, grid_x, grid_y").fetchall()
         except sqlite3.Error:
-            pass
+            continue
+        rows = [r for r in rows if KERNEL in r[0] and r[1] == cols * 256]
+        if rows:
+            r = max(rows, key=lambda r: r[3])
+            return r[4], r[3]
     return None, 0
 
 

@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--epochs", type=int, default=10_000)
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default 10000; 8192 = 8 temperatures x 1024 for --workload pt)")
-    ap.add_argument("--workload", choices=["grad", "fwd", "two_planet", "pt", "ofti", "logpost"], default="grad")
+    ap.add_argument("--workload", choices=["grad", "fwd", "nuis", "two_planet", "pt", "ofti", "logpost"], default="grad")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --walkers per GPU (default); strong: --walkers in total, split evenly over the ranks (SURVEY 8d)")
     ap.add_argument("--pt-comm", choices=["c_abi", "torch"], default="c_abi",
@@ -288,7 +288,7 @@ def main():
                 "spinup_steps_untimed": n_spin,
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfgd}
 
-    grad = args.workload in ("grad", "two_planet")
+    grad = args.workload in ("grad", "two_planet", "nuis")
     if args.workload == "ofti":
         # batched ofti_linear_solve (src/parameterizations.jl:318-405), forward marginal likelihood
         cfg0 = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=6)
@@ -351,8 +351,12 @@ def main():
         fn = pkg.make_ln_like(system, cfg["theta_example"], device=dev_index)
         elems_h, nuis_h = cfg["elems"], None
         n_rows, W = cfg["n_epochs"], cfg["n_walkers"]
+        if args.workload == "nuis":      # config 3 with per-walker jitter, platescale and northangle: the raw-σ branch of relative-astrometry.jl:234-252
+            rng = np.random.default_rng(1)
+            nuis_h = np.stack([rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W)])
         workload = (f"config{'3' if grad else '2'}: 1 planet, {n_rows} RA/Dec epochs x {W} walkers/GPU"
                     + (f" ({args.walkers} walkers split over {world} GPUs)" if args.scaling == "strong" else "")
+                    + (", per-walker jitter/platescale/northangle" if args.workload == "nuis" else "")
                     + f", {'fwd+reverse-grad' if grad else 'fwd only'}, inputs and outputs resident in HBM (PCIe-inclusive rate: value_pcie_inclusive)")
         bytes_per_launch = W * n_rows * BYTES_PER_ROW + W * (BYTES_PER_WALKER if grad else 72.0)
 

@@ -136,10 +136,19 @@ void free_table(TaskTable& t) {
 
 // Relative cost of one row of a table (VALU instructions per row, from the ISA of the mixed-kind kernels): used only to
 // balance block durations across tables of different kinds.
-double row_cost(int kind) {
+// Relative issue time of one row of each kind, in units of an RA/Dec row of the same kernel variant: what the planner shares the tasks
+// between the tables by. A one-round launch (the multi-planet kernels: grid = what the chip holds at once) ends with its slowest CU, so
+// the weights decide the step time: config 4 (2 planets, RA/Dec + absolute RV with nuisances) ran 3 astrometry tasks of 834 rows and 5 RV
+// tasks of 500 rows per tile with the single-planet weight 1.35 for an RV row — the CUs holding an astrometry block were busy for 88k
+// instructions per SIMD, the others for 57k. In that kernel an RV row costs LESS than an astrometry row (227 against 287 VALU
+// instructions: the astrometry row carries jitter, platescale and northangle, two sky projections and their adjoints).
+// Calibrated on MI355X with tools/sweep_rv_cost.py (profiles/r3_rv_cost_sweep.txt); OCTO_RV_COST=<percent> overrides it for experiments.
+double row_cost(const octo_ctx* ctx, int kind, int n_planets, bool nuis) {
+    const bool rv = kind == OCTO_RV_ABS || kind == OCTO_RV_ABS_MARG || kind == OCTO_RV_REL;
+    if (rv && ctx->env_rv_cost > 0) return 0.01 * (double)ctx->env_rv_cost;
     switch (kind) {
         case OCTO_ASTROM_SEPPA: case OCTO_ONEIL_SEPPA: return 1.8;
-        case OCTO_RV_ABS: case OCTO_RV_ABS_MARG: case OCTO_RV_REL: return 1.35;
+        case OCTO_RV_ABS: case OCTO_RV_ABS_MARG: case OCTO_RV_REL: return n_planets > 1 ? (nuis ? 0.9 : 1.0) : (nuis ? 1.0 : 1.35);
         case OCTO_ONEIL_RADEC: return 1.1;
         default: return 1.0;
     }
@@ -149,11 +158,11 @@ double row_cost(int kind) {
 // straddle tables and tables keep their order, so k_finish can sum each observation's partials contiguously and in a
 // fixed order. key <= −SMALL_KEY: k_small's partition, −key − SMALL_KEY rows per wave; key > 0: about `key` tasks in total, shared between the tables in proportion to rows × row cost, each
 // table cut into EQUAL tasks (no ragged last task); key < 0: −key rows per wave everywhere (OCTO_CHUNK experiments).
-int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out) {
+int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis) {
     // The cache belongs to the CONTEXT (one owner thread), not to the dataset, which stays immutable and can therefore be
     // shared between contexts and host threads.
     for (auto& t : ctx->tables)
-        if (t.ds_serial == ds->serial && t.key == key) { *out = &t; return OCTO_OK; }
+        if (t.ds_serial == ds->serial && t.key == key && t.nuis == nuis) { *out = &t; return OCTO_OK; }
     if (ctx->tables.size() >= 48) {                           // many datasets / batch sizes: drop the oldest half. hipFree waits
         for (size_t k = 0; k < 24; ++k) free_table(ctx->tables[k]);      // for the device, so no launched kernel still reads them
         ctx->tables.erase(ctx->tables.begin(), ctx->tables.begin() + 24);
@@ -161,10 +170,11 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
     TaskTable tt;
     tt.ds_serial = ds->serial;
     tt.key = key;
+    tt.nuis = nuis;      // the row weights differ between the nuisance and the nuisance-free kernels
     std::vector<double> cpre, craw;
     double wsum = 0.0;
     for (int o = 0; o < ds->n_obs; ++o)
-        if (ds->h_obs[o].kind != OCTO_HGCA) wsum += (double)ds->h_obs[o].n * row_cost(ds->h_obs[o].kind);
+        if (ds->h_obs[o].kind != OCTO_HGCA) wsum += (double)ds->h_obs[o].n * row_cost(ctx, ds->h_obs[o].kind, ds->n_planets, nuis);
     // Rows per wave: at least 32 (short blocks pay their prologue, LDS combine and partial store more often, and k_finish walks every
     // task's partials: 1e4 rows × 1024 walkers 56 µs at 32, 62 at 16) — unless the tables are so short that this leaves a handful of
     // blocks whose waves each grind through 30-50 rows one after the other (a 3-planet row is ~1 µs of dependent issue for a lone
@@ -176,6 +186,23 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
             if (ds->h_obs[o].kind != OCTO_HGCA && ds->h_obs[o].n > 0) { n_all += ds->h_obs[o].n; t32 += std::max<int64_t>(1, ds->h_obs[o].n / (32 * WPB)); }
         if (t32 < 32) rows_min = std::min<int64_t>(32, std::max<int64_t>(8, n_all / (32 * WPB)));
     }
+    // key > 0: `key` tasks shared between the tables in proportion to rows x row cost — largest-remainder apportionment, so that the
+    // shares add up to the target (independent rounding gave 7 or 9 tasks for a target of 8: a one-round grid then leaves CUs idle or
+    // spills into a second round)
+    std::vector<int64_t> t_plan(std::max(ds->n_obs, 1), 0);
+    if (key > 0 && wsum > 0.0) {
+        std::vector<std::pair<double, int>> frac;
+        int64_t given = 0;
+        for (int o = 0; o < ds->n_obs; ++o) {
+            if (ds->h_obs[o].kind == OCTO_HGCA || ds->h_obs[o].n <= 0) continue;
+            const double x = (double)key * (double)ds->h_obs[o].n * row_cost(ctx, ds->h_obs[o].kind, ds->n_planets, nuis) / wsum;
+            t_plan[o] = std::max<int64_t>(1, (int64_t)std::floor(x));
+            given += t_plan[o];
+            frac.emplace_back(x - std::floor(x), o);
+        }
+        std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+        for (size_t k = 0; k < frac.size() && given < key; ++k) { t_plan[frac[k].second] += 1; given += 1; }
+    }
     for (int o = 0; o < ds->n_obs; ++o) {
         if (ds->h_obs[o].kind == OCTO_HGCA) continue;          // no epoch-loop rows (k_hgca)
         const int64_t n = ds->h_obs[o].n;
@@ -184,7 +211,7 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
         if (key <= -SMALL_KEY) chunk = (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) ? (n + WPB - 1) / WPB : -(key + SMALL_KEY);   // k_small: a marginalised-RV table in ONE block (its μ̂)
         else if (key < 0) chunk = -key;
         else {
-            int64_t t_o = std::llround((double)key * (double)n * row_cost(ds->h_obs[o].kind) / wsum);
+            int64_t t_o = t_plan[o];
             t_o = std::min<int64_t>(std::max<int64_t>(t_o, 1), std::max<int64_t>(1, n / (rows_min * WPB)));
             const int64_t rows_per_task = (n + t_o - 1) / t_o;
             chunk = (rows_per_task + WPB - 1) / WPB;
@@ -364,7 +391,7 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     if (const char* ev = std::getenv("OCTO_FLAG_W")) ctx->flag_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     if (const char* ev = std::getenv("OCTO_FUSED_W")) ctx->fused_w = std::max<long long>(std::atoll(ev), 0);
     ctx->env_small_blocks = env_int("OCTO_SMALL_BLOCKS"); ctx->env_small_min_span = env_int("OCTO_SMALL_MIN_SPAN");
-    ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS");
+    ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST");
     *out = ctx;
     return OCTO_OK;
 }

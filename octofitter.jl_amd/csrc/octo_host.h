@@ -27,6 +27,7 @@ namespace octo {
 
 struct TaskTable {
     uint64_t ds_serial = 0;          // the dataset this partition belongs to (octo_dataset::serial)
+    bool nuis = false;               // planned with the nuisance kernels' row weights
     int64_t key = 0;                 // > 0: target number of tasks of the plan; < 0: forced uniform rows-per-wave (OCTO_CHUNK)
     int n_tasks = 0;
     Task* d_tasks = nullptr;
@@ -106,7 +107,7 @@ struct octo_ctx {
     int small_w = OCTO_SMALL_BATCH_DEFAULT;     // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
     // experiment knobs, read from the environment ONCE at context creation (0 = not set): a getenv per call is a linear scan of the
     // environment on a 12 µs path
-    int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0;
+    int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0, env_rv_cost = 0;
     int flag_w = 128;                           // ... and signal completion through per-walker flags the host spins on (OCTO_FLAG_W: experiments)
     int mapped_w = 128;                         // host-buffer calls up to this size let k_small read/write mapped pinned memory; larger
                                                 // ones cross the link as one DMA each way (OCTO_MAPPED_W: experiments)
@@ -153,7 +154,7 @@ int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
     return OCTO_OK;
 }
 
-int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out);
+int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis = false);
 int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu);
 int busy(octo_ctx* ctx, const char* what);      // OCTO_EINVAL while an octo_eval_begin of this context is outstanding
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);

@@ -26,10 +26,19 @@ constexpr int WPB = 4;          // waves per k_main block (row split + LDS combi
 #ifndef OCTO_FIN_UNROLL
 #define OCTO_FIN_UNROLL 4
 #endif
-constexpr int FIN_G = OCTO_FIN_G;        // task groups per walker in k_finish (block = 64 walkers x FIN_G waves). The kernel is pure memory latency — a
+constexpr int FIN_G = OCTO_FIN_G;
+// waves of a k_finish block: FIN_G for one planet; half of it for several planets — a 1024-thread block caps the kernel at 128 VGPRs per
+// lane, which the multi-planet finish (24-48 sums per walker + one planet's constants and element adjoints) does not fit without spilling
+constexpr int fin_g(int n_planets) { return n_planets == 1 ? FIN_G : (FIN_G / 2 > n_planets ? FIN_G / 2 : n_planets + 1); }        // task groups per walker in k_finish (block = 64 walkers x FIN_G waves). The kernel is pure memory latency — a
                                          // tile's partials are tasks x NACC rows of 512 B written by other CUs — so what counts is loads in flight:
                                          // 16 waves x 4 tasks unrolled (8 x 2 in round 2: 10.7 us at 1 250 walkers x 76 tasks, 9.4 us at 1e4 x 34)
-constexpr int FIN_CH = 6;                // rows of the LDS combine per chunk: 6 x 16 x 512 B = 48 KB
+#ifndef OCTO_FIN_CH
+#define OCTO_FIN_CH 6
+#endif
+#ifndef OCTO_FIN_FAST
+#define OCTO_FIN_FAST true
+#endif
+constexpr int FIN_CH = OCTO_FIN_CH;      // rows of the LDS combine per chunk: 6 x 16 x 512 B = 48 KB
 
 // kind mask bits
 constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16, KM_COR = 32, KM_ONEIL = 64;
@@ -996,22 +1005,33 @@ __device__ __forceinline__ void planet_finish(const double (&el)[OCTO_N_EL] /* t
 }
 
 // ------------------------------------------------------------------------------------ finish_tile / k_finish
-// The per-walker tail for one tile of 64 walkers, run by NG waves: wave g sums tasks g, g+NG, … of each observation (more loads in
-// flight than one thread per walker), the waves' sums are combined through LDS in a fixed order, wave 0 finishes.
-//   FROM_WC = true   k_finish (big batches): the per-walker constants and validity flags come from k_setup's `wc` / `valid`;
-//   FROM_WC = false  the last block of a tile inside the fused k_main launch: wave 0 derives them again from the elements
-//                    (once per tile; no k_setup launch, no `wc` round trip).
-// LDS scratch: CH rows × NG × 64 doubles; sums are combined CH rows at a time (two barriers per chunk).
-template <int N, int NG, int CH>
+// The per-walker tail for one tile of 64 walkers, run by NG waves. It is a latency chain (a tile's partials were written by other CUs;
+// what follows them is one wave's dependent arithmetic), so the work is spread over the waves instead of being left to wave 0:
+//   * waves 0 .. NG−P−1 ("loaders"): wave g sums tasks g, g + (NG−P), … of each observation — many loads in flight;
+//   * wave NG−P+p ("finisher" of planet p): derives that planet's constants (the orbit constructor again, or `wc`) WHILE the loaders
+//     wait for their partials, receives the planet's combined sums and maps them to the nine element adjoints;
+//   * wave 0 also receives the per-observation sums: log-likelihood, nuisance adjoints, validity.
+// The loaders' sums are combined through LDS in a fixed order (deterministic). The forward-only instantiation uses the same split of
+// the tasks (its finisher waves idle), so that the value it returns is bit-identical to the value returned with a gradient.
+//   FROM_WC = true   after k_setup (big batches with a marginalised-RV gradient): constants and validity flags from `wc` / `valid`;
+//   FROM_WC = false  after the fused k_main launch: derived again from the elements.
+// LDS scratch: CH rows × NG × 64 doubles; sums are combined CH rows at a time (two barriers per chunk); row k is read by wave READER(k).
+constexpr int largest_divisor(int n, int at_most) {
+    int d = 1;
+    for (int k = 1; k <= at_most && k <= n; ++k) d = (n % k == 0) ? k : d;
+    return d;
+}
+
+template <int N, int NG, int CH, int R0, int RDIV>      // row k is summed (and kept) by wave R0 + k / RDIV
 __device__ __forceinline__ void combine_rows(double (&v)[N], double* lds, int grp, int lane) {
 #pragma unroll
     for (int c0 = 0; c0 < N; c0 += CH) {
 #pragma unroll
         for (int k = c0; k < (c0 + CH < N ? c0 + CH : N); ++k) lds[((k - c0) * NG + grp) * WAVE + lane] = v[k];
         __syncthreads();
-        if (grp == 0) {
 #pragma unroll
-            for (int k = c0; k < (c0 + CH < N ? c0 + CH : N); ++k) {
+        for (int k = c0; k < (c0 + CH < N ? c0 + CH : N); ++k) {
+            if (grp == R0 + k / RDIV) {
                 double x = 0.0;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) x += lds[((k - c0) * NG + g) * WAVE + lane];
@@ -1026,8 +1046,14 @@ template <int P, bool GRAD, bool NUIS, int KM, int NG, int CH, bool FROM_WC>
 __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int grp, int lane, double* lds) {
     using L = Layout<P, GRAD, NUIS, KM>;
     constexpr int NPL = P * L::PL_N;
+    constexpr int NGL = NG - P;                           // loader waves
+    // tasks in flight per loader wave: OCTO_FIN_UNROLL, fewer for the widest layouts (1024 threads leave 128 VGPRs per lane; the
+    // O'Neil variants spilled to scratch memory with four tasks of 20+ sums in flight)
+    constexpr int UNR = (L::OFF_PL + NPL) > 24 ? 1 : (L::OFF_PL + NPL) > 16 ? (OCTO_FIN_UNROLL > 2 ? 2 : OCTO_FIN_UNROLL) : OCTO_FIN_UNROLL;
+    static_assert(NGL >= 1, "finish_tile: more planets than waves");
     const int64_t w = tile * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;
+    const int my_p = grp - NGL;                           // >= 0: this wave finishes planet my_p
     double gp[NPL > 0 ? NPL : 1];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) gp[k] = 0.0;
@@ -1037,116 +1063,173 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
     for (int k = 0; k < oneil_slots<P, GRAD, NUIS, KM>(); ++k) oneil_g[k] = 0.0;
     double sma_p[P], e_p[P], M_p[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if constexpr (FROM_WC) sma_p[p] = L::HAS_ONEIL ? a.wc[((int64_t)p * NWC + WC_A) * a.ldw + wl] : 0.0;
-        else sma_p[p] = L::HAS_ONEIL ? setup_planet<true>(a, p, wl).v[WC_A] : 0.0;
-        e_p[p] = L::HAS_ONEIL ? a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wl] : 0.0;
-        M_p[p] = L::HAS_ONEIL ? a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wl] : 1.0;
-    }
-    for (int o = 0; o < a.n_obs; ++o) {
-        double v[NOBS_ACC];      // S, margA, margB, margC, nu0, nu1, nu2, on0..on3
+    for (int p = 0; p < P; ++p) { sma_p[p] = 0.0; e_p[p] = 0.0; M_p[p] = 1.0; }
+    if constexpr (L::HAS_ONEIL) {
+        if (grp == 0) {
 #pragma unroll
-        for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
+            for (int p = 0; p < P; ++p) {
+                if constexpr (FROM_WC) sma_p[p] = a.wc[((int64_t)p * NWC + WC_A) * a.ldw + wl];
+                else sma_p[p] = setup_planet<true>(a, p, wl).v[WC_A];
+                e_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wl];
+                M_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wl];
+            }
+        }
+    }
+    // ---- finisher waves: this planet's constants — derived EARLY, while the loaders' partials are in flight, unless the layout is so
+    // wide (O'Neil sums in a 1024-thread block: 128 VGPRs per lane) that 18 more live values across the load loop would spill: then
+    // after the combine
+    constexpr bool EARLY = !L::HAS_ONEIL || P > 1;      // (several planets: blocks of fin_g(P) = 8 waves, 256 VGPRs per lane)
+    FinPC fp = {};
+    double elv[OCTO_N_EL];
+#pragma unroll
+    for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = 0.0;
+    bool ok_mine = true;                                  // wave 0: ll and nuisances finite; finisher p: planet p's elements in the domain
+    auto derive = [&]() {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (my_p != p) continue;
+            if constexpr (FROM_WC) {
+                const double* wc = a.wc + (int64_t)p * NWC * a.ldw + wl;
+                fp.sma = wc[WC_A * a.ldw]; fp.P_d = rcp_nr<2>(wc[WC_INVP * a.ldw]); fp.beta = wc[WC_BETA * a.ldw];
+                fp.si = wc[WC_SINI * a.ldw]; fp.ci = wc[WC_COSI * a.ldw]; fp.sO = wc[WC_SINO * a.ldw]; fp.cO = wc[WC_COSO * a.ldw];
+                fp.sw = wc[WC_SINW * a.ldw]; fp.cw = wc[WC_COSW * a.ldw];
+#pragma unroll
+                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl];
+                ok_mine = a.valid[(int64_t)p * a.ldw + wl] != 0;
+            } else {
+                const SetupOut so = setup_planet<true>(a, p, wl);      // the same routine, the same values k_setup would have stored
+                fp.sma = so.v[WC_A]; fp.P_d = rcp_nr<2>(so.v[WC_INVP]); fp.beta = so.v[WC_BETA];
+                fp.si = so.v[WC_SINI]; fp.ci = so.v[WC_COSI]; fp.sO = so.v[WC_SINO]; fp.cO = so.v[WC_COSO];
+                fp.sw = so.v[WC_SINW]; fp.cw = so.v[WC_COSW];
+#pragma unroll
+                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = so.el[k];
+                ok_mine = so.ok;
+            }
+        }
+    };
+    if constexpr (GRAD && EARLY) derive();
+    for (int o = 0; o < a.n_obs; ++o) {
+        // the per-observation sums this layout carries (S [+ nuisance adjoints] [+ marginalised-RV sums] [+ O'Neil sums]): only those
+        // rows go through the loads and the LDS combine (config 3: ONE row, not NOBS_ACC = 11)
+        constexpr int NOB = L::OFF_PL;
+        double vo[NOB];
+#pragma unroll
+        for (int k = 0; k < NOB; ++k) vo[k] = 0.0;
         const int t0 = a.obs_range[2 * o], t_end = a.obs_range[2 * o + 1];
         const double cst = a.obs_const[o];
-#pragma unroll OCTO_FIN_UNROLL
-        for (int tt = t0 + grp; tt < t_end; tt += NG) {
+#pragma clang loop unroll_count(UNR)
+        for (int tt = t0 + grp; tt < (grp < NGL ? t_end : t0); tt += NGL) {
             const double* pt = a.partials + (int64_t)tt * L::NACC * a.ldw + wl;
-            v[0] += pt[(int64_t)L::OFF_S * a.ldw];
-            if constexpr (L::HAS_MARG) {
-                v[1] += pt[(int64_t)(L::OFF_MARG + 0) * a.ldw];
-                v[2] += pt[(int64_t)(L::OFF_MARG + 1) * a.ldw];
-                v[3] += pt[(int64_t)(L::OFF_MARG + 2) * a.ldw];
-            }
-            if constexpr (L::N_NU > 0) {
-                v[4] += pt[(int64_t)(L::OFF_NU + 0) * a.ldw];
-                v[5] += pt[(int64_t)(L::OFF_NU + 1) * a.ldw];
-                v[6] += pt[(int64_t)(L::OFF_NU + 2) * a.ldw];
-            }
-            if constexpr (L::HAS_ONEIL) {
-                v[7] += pt[(int64_t)(L::OFF_ONEIL + 0) * a.ldw];
-                if constexpr (GRAD) {
-                    v[8] += pt[(int64_t)(L::OFF_ONEIL + 1) * a.ldw];
-                    v[9] += pt[(int64_t)(L::OFF_ONEIL + 2) * a.ldw];
-                    v[10] += pt[(int64_t)(L::OFF_ONEIL + 3) * a.ldw];
-                }
-            }
-            // all of the task's planet sums in flight, then the adds (left to itself the compiler reused one register pair for the
+            // all of the task's sums in flight, then the adds (left to itself the compiler reused one register pair for the
             // 36 loads of a 3-planet task and waited for each: 41 µs per launch instead of ~12)
+            double to[NOB];
+#pragma unroll
+            for (int k = 0; k < NOB; ++k) to[k] = pt[(int64_t)k * a.ldw];
             double tmp[NPL > 0 ? NPL : 1];
 #pragma unroll
             for (int k = 0; k < NPL; ++k) tmp[k] = pt[(int64_t)(L::OFF_PL + k) * a.ldw];
 #pragma unroll
+            for (int k = 0; k < NOB; ++k) vo[k] += to[k];
+#pragma unroll
             for (int k = 0; k < NPL; ++k) gp[k] += tmp[k];
         }
-        combine_rows<NOBS_ACC, NG, (CH < NOBS_ACC ? CH : NOBS_ACC)>(v, lds, grp, lane);
+        combine_rows<NOB, NG, (CH < NOB ? CH : NOB), 0, 1 << 20>(vo, lds, grp, lane);
         if (grp == 0) {
+            double v[NOBS_ACC];      // S, margA, margB, margC, nu0, nu1, nu2, on0..on3
+#pragma unroll
+            for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
+            v[0] = vo[L::OFF_S];
+            if constexpr (L::HAS_MARG) { v[1] = vo[L::OFF_MARG + 0]; v[2] = vo[L::OFF_MARG + 1]; v[3] = vo[L::OFF_MARG + 2]; }
+            if constexpr (L::N_NU > 0) { v[4] = vo[L::OFF_NU + 0]; v[5] = vo[L::OFF_NU + 1]; v[6] = vo[L::OFF_NU + 2]; }
+            if constexpr (L::HAS_ONEIL) {
+                v[7] = vo[L::OFF_ONEIL + 0];
+                if constexpr (GRAD) { v[8] = vo[L::OFF_ONEIL + 1]; v[9] = vo[L::OFF_ONEIL + 2]; v[10] = vo[L::OFF_ONEIL + 3]; }
+            }
             // observations are summed in the order given (system.jl:93,186)
             ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + w : nullptr,
                                                 a.ldw, a.c.k_yr, o, v, cst, sma_p, e_p, M_p, w < a.W, oneil_g);
         }
     }
-    if constexpr (NPL > 0) {
+    // every planet's sums in one pass of chunks; planet p's rows are summed by its finisher wave (wave 0 without a gradient: no rows)
+    // (several planets: chunks that do not straddle two planets — with rows of two readers in one chunk the compiler merged the two
+    // readers' code and indexed the sums dynamically, which put them in scratch memory)
+    if constexpr (NPL > 0) combine_rows<NPL, NG, (P == 1 ? (CH < NPL ? CH : NPL) : largest_divisor(L::PL_N, CH)), NGL, (L::PL_N > 0 ? L::PL_N : 1)>(gp, lds, grp, lane);
+    // a finisher wave keeps its own planet's sums only (the other planets' registers are free for the chain that follows)
+    double gmine[L::PL_N > 0 ? L::PL_N : 1];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            double vp[L::PL_N];
+    for (int k = 0; k < L::PL_N; ++k) {
+        double x = 0.0;
 #pragma unroll
-            for (int k = 0; k < L::PL_N; ++k) vp[k] = gp[p * L::PL_N + k];
-            combine_rows<L::PL_N, NG, (CH < L::PL_N ? CH : L::PL_N)>(vp, lds, grp, lane);
-#pragma unroll
-            for (int k = 0; k < L::PL_N; ++k) gp[p * L::PL_N + k] = vp[k];
-        }
+        for (int p = 0; p < P; ++p) x = (my_p == p) ? gp[p * L::PL_N + k] : x;
+        gmine[k] = x;
     }
-    if (grp != 0 || w >= a.W) return;
-    if (a.extra) ll += a.extra[w];
-    bool ok = isfinite(ll);
-    if constexpr (FROM_WC) {
+    if constexpr (GRAD && !EARLY) derive();
+    if (grp == 0) {
+        if (a.extra) ll += a.extra[wl];
+        ok_mine = isfinite(ll);
+        if constexpr (FROM_WC) {
+            if constexpr (!GRAD) {
 #pragma unroll
-        for (int p = 0; p < P; ++p) ok = ok && a.valid[(int64_t)p * a.ldw + w] != 0;
-    } else {
-        // what k_setup records in `valid`: every planet's elements inside the domain, every nuisance finite
-#pragma unroll
-        for (int p = 0; p < P; ++p) ok = ok && setup_planet<true>(a, p, w).ok;
-        if (a.nuis)
-            for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok = ok && isfinite(a.nuis[(int64_t)k * a.ld + w]);
-    }
-    a.ll_out[w] = ok ? ll : -INFINITY;
-    if constexpr (GRAD) {
-        if (!ok && L::N_NU > 0) {
-            for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + w] = 0.0;
-        }
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            FinPC fp;
-            double elv[OCTO_N_EL];
-            if constexpr (FROM_WC) {
-                const double* wc = a.wc + (int64_t)p * NWC * a.ldw + w;
-                fp.sma = wc[WC_A * a.ldw]; fp.P_d = 1.0 / wc[WC_INVP * a.ldw]; fp.beta = wc[WC_BETA * a.ldw];
-                fp.si = wc[WC_SINI * a.ldw]; fp.ci = wc[WC_COSI * a.ldw]; fp.sO = wc[WC_SINO * a.ldw]; fp.cO = wc[WC_COSO * a.ldw];
-                fp.sw = wc[WC_SINW * a.ldw]; fp.cw = wc[WC_COSW * a.ldw];
-#pragma unroll
-                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + w];
-            } else {
-                const SetupOut so = setup_planet<true>(a, p, w);      // the same routine, the same values k_setup would have stored
-                fp.sma = so.v[WC_A]; fp.P_d = 1.0 / so.v[WC_INVP]; fp.beta = so.v[WC_BETA];
-                fp.si = so.v[WC_SINI]; fp.ci = so.v[WC_COSI]; fp.sO = so.v[WC_SINO]; fp.cO = so.v[WC_COSO];
-                fp.sw = so.v[WC_SINW]; fp.cw = so.v[WC_COSW];
-#pragma unroll
-                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = so.el[k];
+                for (int p = 0; p < P; ++p) ok_mine = ok_mine && a.valid[(int64_t)p * a.ldw + wl] != 0;
             }
-            planet_finish<P, GRAD, NUIS, KM>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
-                                             a.orbit_kind[p], a.has_mass[p], p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
+        } else {
+            // what k_setup records in `valid`: every planet's elements inside the domain (with a gradient: reported by the planet's
+            // finisher wave), every nuisance finite
+            if constexpr (!GRAD) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) ok_mine = ok_mine && setup_planet<true>(a, p, wl).ok;
+            }
+            if (a.nuis)
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok_mine = ok_mine && isfinite(a.nuis[(int64_t)k * a.ld + wl]);
+        }
+    }
+    bool ok = ok_mine;
+    if constexpr (GRAD) {
+        // validity flags (and the O'Neil corrections wave 0 accumulated) cross the waves through LDS: rows 0 .. P of the scratch
+        if (grp == 0 || my_p >= 0) lds[(grp == 0 ? 0 : 1 + my_p) * WAVE + lane] = ok_mine ? 1.0 : 0.0;
+        if constexpr (L::HAS_ONEIL) {
+            if (grp == 0) {
+#pragma unroll
+                for (int k = 0; k < P * 6; ++k) lds[(1 + P + k) * WAVE + lane] = oneil_g[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q <= P; ++q) ok = (q == 0 ? true : ok) && lds[q * WAVE + lane] != 0.0;
+        if constexpr (L::HAS_ONEIL) {
+            if (my_p >= 0) {
+#pragma unroll
+                for (int k = 0; k < P * 6; ++k) oneil_g[k] = lds[(1 + P + k) * WAVE + lane];
+            }
+        }
+    }
+    if (w >= a.W) return;
+    if (grp == 0) {
+        a.ll_out[w] = ok ? ll : -INFINITY;
+        if constexpr (GRAD && L::N_NU > 0) {
+            if (!ok)
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + w] = 0.0;
+        }
+    }
+    if constexpr (GRAD) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (my_p != p) continue;
+            // FAST (reciprocal-multiply divisions, as in k_small): the tail of a launch is one wave's dependent chain, and an IEEE
+            // FP64 division is a dozen dependent instructions
+            planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
+                                                            a.orbit_kind[p], a.has_mass[p], p, gmine, L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
         }
     }
 }
 
 // block = 64 walkers × FIN_G waves, one block per tile. FROM_WC = false: after a k_main launch that derived the constants itself.
 template <int P, bool GRAD, bool NUIS, int KM, bool FROM_WC = true>
-static __global__ __launch_bounds__(64 * FIN_G) void k_finish(EvalArgs a) {
+static __global__ __launch_bounds__(64 * fin_g(P)) void k_finish(EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    finish_tile<P, GRAD, NUIS, KM, FIN_G, FIN_CH, FROM_WC>(a, (int64_t)blockIdx.x, grp, lane, lds);
+    finish_tile<P, GRAD, NUIS, KM, fin_g(P), FIN_CH, FROM_WC>(a, (int64_t)blockIdx.x, grp, lane, lds);
 }
 
 // ==================================================================================== OFTI

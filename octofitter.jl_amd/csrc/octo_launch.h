@@ -97,7 +97,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         blocks_per_cu = nb;
     }
     TaskTable* tt = nullptr;
-    int rc0 = get_tasks(ctx, ds, plan_key(ctx, a.W, ds->n_rows, blocks_per_cu), &tt);
+    int rc0 = get_tasks(ctx, ds, plan_key(ctx, a.W, ds->n_rows, blocks_per_cu), &tt, NUIS);
     if (rc0) return rc0;
     const Task* tt_tasks = tt->h_tasks.data();
     a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;
@@ -136,7 +136,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
                            (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
         if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
-        hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * FIN_G), sizeof(double) * FIN_CH * FIN_G * WAVE, st, a);
+        hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * fin_g(P)), sizeof(double) * FIN_CH * fin_g(P) * WAVE, st, a);
         HIPCHK(ctx, hipGetLastError());
         return OCTO_OK;
     }
@@ -192,8 +192,8 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
             return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
         }
     }
-    hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * FIN_G),
-                       sizeof(double) * FIN_CH * FIN_G * WAVE, st, a);
+    hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * fin_g(P)),
+                       sizeof(double) * FIN_CH * fin_g(P) * WAVE, st, a);
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;
 }

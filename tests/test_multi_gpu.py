@@ -56,6 +56,54 @@ def test_eval_multi_splits_a_host_batch(pkg, oracle):
             p.close()
 
 
+def test_eval_multi_strong_split_shares(pkg, oracle):
+    """SURVEY §8(d) "Scaling runs": config 3's 1e4 walkers split evenly over N = 2, 4, 8 devices (5 000 / 2 500 / 1 250 each) through
+    octo_eval_multi — here N contexts on device 0 (and the visible devices when there are that many). Every share must be BIT-equal to the
+    same walkers evaluated alone by one context (the shards are independent, system.jl:206-241: same kernels, same row partition for
+    that batch size), and equal to the unsplit batch to rounding (its row partition differs, so the sums are ordered differently)."""
+    gb = _gpu()
+    capi = pkg.capi
+    lib = capi.load_library()
+    cfg = synth.config_astrom(n_epochs=10000, n_walkers=10000, cfg=3)
+    t = cfg["table"]
+    obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    el = np.ascontiguousarray(cfg["elems"]); W = el.shape[1]
+    single = gb.GpuPath(obs, planets)
+    ll_full, g_full, _ = single.eval(el, None, grad=True)
+    ok = np.isfinite(ll_full)
+    assert ok.sum() > 0.9 * W
+    n_vis = _device_count()
+    for n in (2, 4, 8):
+        devices = list(range(n)) if n_vis >= n else [0] * n
+        paths = [gb.GpuPath(obs, planets, device=d) for d in devices]
+        ctxs = (C.c_void_p * n)(*[p.ctx for p in paths]); dss = (C.c_void_p * n)(*[p.ds for p in paths])
+        ll = np.full(W, np.nan); g = np.full_like(el, np.nan)
+        for rep in range(2):      # run-to-run determinism of the split call
+            ll2 = np.full(W, np.nan); g2 = np.full_like(el, np.nan)
+            assert lib.octo_eval_multi(ctxs, dss, n, capi._dptr(el), None, W, W, capi._dptr(ll2), capi._dptr(g2), None) == 0
+            if rep == 0: ll, g = ll2, g2
+            else: assert np.array_equal(ll, ll2) and np.array_equal(g, g2), n
+        lo = 0
+        for i in range(n):
+            hi = lo + W // n + (1 if i < W % n else 0)
+            ll_s, g_s, _ = single.eval(el[:, lo:hi], None, grad=True)
+            assert np.array_equal(ll[lo:hi], ll_s) and np.array_equal(g[:, lo:hi], g_s), (n, i)
+            lo = hi
+        assert lo == W
+        assert np.array_equal(np.isfinite(ll), ok)
+        assert np.max(np.abs(ll[ok] - ll_full[ok]) / np.maximum(1.0, np.abs(ll_full[ok]))) < 1e-12
+        scale = np.maximum(np.abs(g_full[:8, ok]).max(axis=1, keepdims=True), 1e-300)
+        assert np.max(np.abs(g[:8, ok] - g_full[:8, ok]) / scale) < 1e-11
+        for p in paths:
+            p.close()
+    # the same shares against the oracle on a sample of each
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el[:, ::625], None, grad=True, active=synth.active_mask(1, 0, mass=False))
+    oko = np.isfinite(ll_o)
+    assert np.max(np.abs(ll_full[::625][oko] - ll_o[oko]) / np.maximum(1.0, np.abs(ll_o[oko]))) < 1e-9
+    single.close()
+
+
 def test_eval_begin_end_overlap_two_contexts(pkg):
     """octo_eval_begin on two contexts, then octo_eval_end on both: the two halves the multi-device split is made of."""
     gb = _gpu()

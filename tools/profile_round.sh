@@ -18,4 +18,6 @@ rocprofv3 --kernel-trace --stats --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VA
 cd $ROOT
 python profiles/summarize_rocpd.py gpurun_out/$tag gpurun_out/$tag > /dev/null
 python tools/make_pmc_json.py gpurun_out/$tag gpurun_out/${tag}_pmc_traffic.json > /dev/null
-tail -1 $out/bench_under_rocprof.log | cut -c1-600
+mkdir -p gpurun_out/${tag}_logs && cp $out/*.log gpurun_out/${tag}_logs/
+[ -n "${OCTO_KEEP_DB:-}" ] || rm -rf $out      # the rocpd databases (~45 MB): gpurun merges at most 64 MiB back; the summaries above are what is committed
+tail -1 gpurun_out/${tag}_logs/bench_under_rocprof.log | cut -c1-600

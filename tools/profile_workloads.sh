@@ -10,4 +10,5 @@ for wl in fwd two_planet pt ofti logpost; do
   grep "^{" $out/$wl.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%s\n  value %.4g %s, %.1f us/step' % (d['config']['workload'], d['value'], d['unit'], d['ms_per_step']*1e3))" >> $ROOT/gpurun_out/${tag}_workloads.txt
   (cd $ROOT && python profiles/summarize_rocpd.py gpurun_out/${tag}_wl/$wl /tmp/x_$wl | grep -v "^==" | grep -v copyBuffer >> gpurun_out/${tag}_workloads.txt)
 done
+[ -n "${OCTO_KEEP_DB:-}" ] || rm -rf $out
 cat $ROOT/gpurun_out/${tag}_workloads.txt

@@ -18,7 +18,8 @@ path is the parallel-tempering swap step, exercised with --workload pt).
   --scaling weak    (default, the bench contract's mode for a path that shards by independent units): every rank owns its own 1e4 walkers;
   --scaling strong  SURVEY §8(d) "Scaling runs": the SAME 1e4 walkers split evenly over the ranks (1 250 per GPU at 8).
 At N = 1 the line also carries `strong_scaling_projection`: the per-GPU shares of a strong-scaled run (W/2, W/4, W/8 walkers) measured
-on this one GPU — shards are independent, so N x rate(W/N) / rate(W) is what N GPUs deliver short of launch jitter.
+on this one GPU — shards are independent, so N x rate(W/N) / rate(W) is what N GPUs deliver short of launch jitter. At N > 1 the default
+(weak) run also MEASURES that strong-scaling point (`strong_scaling_measured`: one rank's W walkers split over the N ranks, max over ranks).
 
 Timed region: W warm-up steps, then an untimed spin-up until the device has been busy for >= 0.3 s (clocks ramped, so that a
 20-step run measures the same thing as a 200-step run), barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over
@@ -431,6 +432,30 @@ def main():
                         "measured on one GPU: N x rate(W/N) / rate(W); no collective on this path, so the only thing a real N-GPU run adds is launch jitter",
                 "by_n_gpus": outp}
 
+    def strong_measured():
+        """N > 1, default (weak) run: the SURVEY §8(d) strong-scaling point of this job measured in the same launch — the W walkers of ONE
+        rank's batch split evenly over the N ranks (rank r evaluates columns shard_range(W, r, N) of its own batch: same shapes and launches
+        as a true split), barrier + synchronize around 100 back-to-back steps, MAX over ranks; speed-up against this rank-0 GPU's own
+        full-W step time from the timed region above. No collective on the data path, so the only thing N ranks add is launch jitter."""
+        lo, hi = pkg.shard_range(W, rank, world)
+        el_n = elems[:, lo:hi].contiguous()
+        out_n = (torch.empty(hi - lo, dtype=torch.float64, device=dev), torch.empty_like(el_n) if grad else None, None)
+        for _ in range(30):
+            fn.ln_like_device(el_n, None, grad=grad, out=out_n)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); dist.barrier(); t1 = time.perf_counter()
+            for _ in range(100):
+                fn.ln_like_device(el_n, None, grad=grad, out=out_n)
+            torch.cuda.synchronize(); dist.barrier()
+            tt = torch.tensor([(time.perf_counter() - t1) / 100], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            best = min(best, float(tt.item()))
+        return {"what": "strong scaling measured in this run: one rank's W walkers split evenly over the N ranks (contiguous shards, dataset replicated, "
+                        "no collective), 100 back-to-back steps between barriers, max over ranks, best of 3; speedup = full-W step time of the timed "
+                        "region / this",
+                "n_gpus": world, "walkers_total": W, "walkers_per_gpu": hi - lo, "us_per_step": best * 1e6, "value": W * n_rows / best, "unit": "evals/s"}
+
     fn.timing_enable(TIMED_EVERY)      # HIP events around k_main of every TIMED_EVERY-th evaluation, on its launch stream
     dt, per_step, n_spin = timed_loop(run_step, on_timed_start=lambda: fn.timing_read(reset=True))
     kern_med, kern_min, kern_max, kern_n = fn.timing_stats()
@@ -447,6 +472,14 @@ def main():
     value = evals / dt
     metric = "epoch-likelihood evals/sec (fwd+grad), 1e4 epochs x 1e4 walkers" if args.workload == "grad" else f"epoch-likelihood evals/sec ({args.workload})"
     res = base_line(metric, value, dt, per_step, n_spin, workload, {"walkers_per_gpu": W, "rows": n_rows, "parallelism": parallelism})
+    if world > 1 and args.scaling == "weak" and cfg is not None and args.workload in ("grad", "fwd") and not args.no_extras:
+        try:      # every rank takes part (barriers + a MAX all-reduce); rank 0 reports
+            sm_ = strong_measured()
+            sm_["speedup_vs_one_gpu"] = (dt / args.steps) / (sm_["us_per_step"] * 1e-6)
+            sm_["one_gpu_us_per_step"] = dt / args.steps * 1e6
+            res["strong_scaling_measured"] = sm_
+        except Exception as ex:
+            res["strong_scaling_measured"] = {"error": str(ex)}
     if pt is not None:
         lat = swap_latency()
         res["swap_step_latency_us"] = lat

@@ -961,6 +961,10 @@ struct octo_model {
     int32_t* d_circ_pair = nullptr;   // [n_circ][2] (i0, i1) of each slot (k_small<MODEL>: one pair per lane)
     bool all_circ_slotted = true;     // every CIRCULAR / TPERI source has a slot (<= MODEL_MAXCIRC of them): required by the fused launch
     double* d_logz = nullptr;         // [D][PRIOR_NC] constants of each prior (prior_apply)
+    // the same descriptors as ONE block for the fused small-batch launch (octo_small.h: SmallModel), byte offsets of its sections
+    double* d_blob = nullptr;
+    int32_t blob_n = 0, off_logz = 0, off_esrc = 0, off_nsrc = -1, off_cslot = 0, off_cpair = 0;
+    bool fused_ok = false;            // all_circ_slotted and the block + the nuisance values fit k_small<MODEL>'s LDS staging
     double* d_buf = nullptr;   // elems | nuis | J | lpp | glp | ll | g_el | g_nu, all [rows][ldw]
     int64_t cap_w = 0;
     double *d_th = nullptr, *d_res = nullptr;   // staging for host buffers
@@ -1055,6 +1059,25 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
         if (hipMemcpy(m->d_logz, logz.data(), sizeof(double) * logz.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
         if (hipMalloc((void**)&m->d_circ, sizeof(int32_t) * slot.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
         if (hipMemcpy(m->d_circ, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
+        {
+            std::vector<unsigned char> blob;
+            auto put = [&](const void* src, size_t bytes) {
+                const size_t off = blob.size();
+                blob.resize(off + (bytes + 7) / 8 * 8, 0);
+                std::memcpy(blob.data() + off, src, bytes);
+                return (int32_t)off;
+            };
+            put(priors, sizeof(octo_prior) * D);      // at byte 0
+            m->off_logz = put(logz.data(), sizeof(double) * logz.size());
+            m->off_esrc = put(elem_src, sizeof(octo_source) * n_el);
+            m->off_nsrc = (nuis_src && n_nu > 0) ? put(nuis_src, sizeof(octo_source) * n_nu) : -1;
+            m->off_cslot = put(slot.data(), sizeof(int32_t) * slot.size());
+            m->off_cpair = put(pairs.data(), sizeof(int32_t) * pairs.size());
+            m->blob_n = (int32_t)(blob.size() / 8);
+            if (hipMalloc((void**)&m->d_blob, blob.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
+            if (hipMemcpy(m->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
+            m->fused_ok = m->all_circ_slotted && m->blob_n <= SMALL_BLOB_MAX && n_nu <= SMALL_MX_NU;
+        }
     }
     // k_model_fwd shares x, dx, p, dp of every prior and 6 numbers per UniformCircular pair through LDS: 512 B each.
     m->lds_bytes = (int64_t)sizeof(double) * (4 * D + 6 * m->n_circ) * WAVE;
@@ -1072,7 +1095,7 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
 int32_t octo_model_destroy(octo_model* m) {
     if (!m) return OCTO_OK;
     (void)hipSetDevice(m->device);
-    (void)hipFree(m->d_priors); (void)hipFree(m->d_esrc); (void)hipFree(m->d_nsrc); (void)hipFree(m->d_circ); (void)hipFree(m->d_circ_pair); (void)hipFree(m->d_logz); (void)hipFree(m->d_buf);
+    (void)hipFree(m->d_priors); (void)hipFree(m->d_esrc); (void)hipFree(m->d_nsrc); (void)hipFree(m->d_circ); (void)hipFree(m->d_circ_pair); (void)hipFree(m->d_logz); (void)hipFree(m->d_blob); (void)hipFree(m->d_buf);
     (void)hipFree(m->d_th); (void)hipFree(m->d_res);
     delete m;
     return OCTO_OK;
@@ -1087,12 +1110,12 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st;
     { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
-    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
+    if (small_eligible(ctx, m->ds, W) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
         // one launch: θ_t -> priors, elements, likelihood, ∇θ_t inside k_small<MODEL> (octo_small.h)
         SmallModel sm;
         std::memset(&sm, 0, sizeof(sm));
-        sm.priors = m->d_priors; sm.esrc = m->d_esrc; sm.nsrc = m->d_nsrc; sm.D = m->D;
-        sm.circ_slot = m->d_circ; sm.circ_pair = m->d_circ_pair; sm.n_circ = m->n_circ; sm.prior_logz = m->d_logz; sm.n_el = m->n_el;
+        sm.blob = m->d_blob; sm.blob_n = m->blob_n; sm.off_logz = m->off_logz; sm.off_esrc = m->off_esrc; sm.off_nsrc = m->off_nsrc;
+        sm.off_cslot = m->off_cslot; sm.off_cpair = m->off_cpair; sm.n_circ = m->n_circ; sm.n_el = m->n_el; sm.n_nu = m->n_nu; sm.D = m->D;
         sm.theta_t = d_theta_t; sm.lp_out = d_lp; sm.grad_out = d_grad;
         if (ctx->stage_ws_in > 0) { sm.ld_t = 1; sm.ws_t = ctx->stage_ws_in; sm.ld_o = 1; sm.ws_o = ctx->stage_ws_out; }      // walker-major staging
         else { sm.ld_t = ld; sm.ws_t = 1; sm.ld_o = ld; sm.ws_o = 1; }
@@ -1153,7 +1176,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     hipStream_t st;
     { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
     const int64_t n_in = (int64_t)m->D * ldd, n_out = (int64_t)(grad_out ? m->D + 1 : 1) * ldd;
-    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && (m->ds->n_hgca == 0 || hgca_in_small(W)) && W <= ctx->mapped_w) {
+    if (small_eligible(ctx, m->ds, W) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W)) && W <= ctx->mapped_w) {
         // one θ_t per call (NUTS): the fused launch on mapped pinned buffers, no copy engine (see octo_eval) — θ_t of one walker
         // contiguous on the way in, [lp | ∇θ_t] on the way out, completion by flag
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
@@ -1187,7 +1210,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     if (rc) return rc;
     rc = grow(ctx, m->d_res, m->cap_res, (int64_t)(m->D + 1) * ldd);
     if (rc) return rc;
-    if (small_eligible(ctx, m->ds, W) && m->all_circ_slotted && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
+    if (small_eligible(ctx, m->ds, W) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
         // the fused launch beyond the mapped-input range: k_stage_in brings θ_t walker-major into device memory, [lp | ∇θ_t] come
         // back through the mapped buffer + flags (see octo_eval)
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))

@@ -268,6 +268,12 @@ __device__ __forceinline__ double rem_2pi_trunc(double x) {
     return r;
 }
 
+// The value lane `src_lane` holds (src_lane wave-uniform), in every lane.
+__device__ __forceinline__ double lane_value(double x, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 // Σ_rows log(x_row) as log(Π x_row): one multiply and a mantissa/exponent split per row instead of one FP64 log (≈45
 // instructions) per row; one real log per wave at the end. The running mantissa stays in [0.5, 1), so nothing
 // over- or underflows whatever the σ's; 0, Inf and NaN factors propagate to the final log as they would through a sum
@@ -323,14 +329,27 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     // One hardware reciprocal for the three divisions: the denominators are f1·(den4 + O(δ²)), den4, den4 + O(δ³), so
     // each reciprocal is a Newton step away from the previous one (prototype: tools/kepler_proto.py, same error).
     const double r3 = __builtin_amdgcn_rcp(fma(f1, f1, -(f0 * hf2)));                // ≈2^-23
-    double r4 = f1 * r3;                                                             // ≈ 1/den4, and f1·r3 is also Halley's factor:
+    const double r4 = f1 * r3;                                                       // ≈ 1/den4, and f1·r3 is also Halley's factor:
     const double d3 = -f0 * r4;                                                      // δ3 = −f0·f1/(f1² − f0 f2/2)
+#ifdef OCTO_KEPLER_NR_CHAIN
+    // round 1-3 form: refine the reciprocal (one Newton step each), then δ = −f0·r: 3 instructions per division
     const double den4 = fma(d3, fma(d3, sf3, hf2), f1);
-    r4 = fma(fma(-den4, r4, 1.0), r4, r4);
-    const double d4 = -f0 * r4;
+    const double r4b = fma(fma(-den4, r4, 1.0), r4, r4);
+    const double d4 = -f0 * r4b;
     const double den5 = fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1);
-    const double r5 = fma(fma(-den5, r4, 1.0), r4, r4);
+    const double r5 = fma(fma(-den5, r4b, 1.0), r4b, r4b);
     const double d5 = -f0 * r5;
+#else
+    // δ4 = −f0/den4 and δ5 = −f0/den5 as ONE correction step each on the quotient instead of on the reciprocal:
+    // δ' = δ − r·(den·δ + f0) with the crude r = r4 (≈ 1/den to 2^-23 + O(δ²)). The residual den·δ + f0 comes out of one FMA
+    // without rounding before the cancellation, and the previous δ is already right to r4's relative error, so the error of δ' is
+    // that squared — the same 2^-46 the refined reciprocals gave — for 2 instructions per division instead of 3 (tools/kepler_proto.py's
+    // samples: identical 5.13e-16 weighted maximum over 2e6 (M, e) pairs, e -> 1 − 1e-9).
+    const double den4 = fma(d3, fma(d3, sf3, hf2), f1);
+    const double d4 = fma(-r4, fma(den4, d3, f0), d3);
+    const double den5 = fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1);
+    const double d5 = fma(-r4, fma(den5, d4, f0), d4);
+#endif
     s.E = E1 + d5;                                                   // eq. (29); dead code unless a caller reads it
     // ---- sin/cos(E1 + δ5) by rotation; |δ5| < 5e-4: sin δ = δ(1 − δ²/6) (+1e-19), cos δ − 1 = δ²(−1/2 + δ²/24) (+1e-23)
     const double dd = d5 * d5;

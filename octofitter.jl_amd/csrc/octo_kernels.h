@@ -143,6 +143,21 @@ __device__ __forceinline__ void sincos_reduced(double x, double& s, double& c) {
     c = in_range ? c : NAN;
 }
 
+// Several angles at once where the arguments are WAVE-UNIFORM (k_small: one parameter set per block): lane j evaluates angle j and the
+// results are read back with v_readlane — one pass of the reduction + polynomials (~45 instructions) instead of one per angle. Per
+// angle the arithmetic is that of sincos_reduced, so the values are bit-identical to separate calls.
+template <int N>
+__device__ __forceinline__ void sincos_lanes(const double (&x)[N], double (&s)[N], double (&c)[N]) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    double xl = x[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) xl = (lane == k) ? x[k] : xl;
+    double sl, cl;
+    sincos_reduced(xl, sl, cl);
+#pragma unroll
+    for (int k = 0; k < N; ++k) { s[k] = lane_value(sl, k); c[k] = lane_value(cl, k); }
+}
+
 // √x from v_rsq_f64 + Newton (rsqrt_nr), with one correction step on the product: ≤ 1 ulp, 14 instructions (ocml: ~25).
 __device__ __forceinline__ double sqrt_fast(double x) {
     const double y = rsqrt_nr(x);
@@ -153,7 +168,8 @@ __device__ __forceinline__ double sqrt_fast(double x) {
 
 // FAST (k_small): reciprocal-multiply instead of IEEE division, rsqrt-based roots, polynomial sincos. At the clock a
 // mostly-idle GPU runs one short kernel at, every 100 serial FP64 instructions are about a microsecond of latency.
-template <bool FAST = false>
+// LANES (k_small only): the elements are wave-uniform, so the three angles go through sincos_lanes in one pass.
+template <bool FAST = false, bool LANES = false>
 __device__ __forceinline__ SetupOut setup_planet_vals(const double (&elv)[OCTO_N_EL], const DevConsts& cst, int orbit_kind, int has_mass) {
     SetupOut so;
     auto fdiv = [](double x, double y) { return FAST ? x * rcp_nr<2>(y) : x / y; };
@@ -187,7 +203,12 @@ __device__ __forceinline__ SetupOut setup_planet_vals(const double (&elv)[OCTO_N
         // PlanetOrbits KepOrbit ctor invariants: i = rem(i, π, RoundDown), Ω = rem2pi(Ω, RoundDown)
         inc = inc - PI * floor(inc / PI);
         Om = Om - TWO_PI * floor(Om / TWO_PI);
-        if constexpr (FAST) { sincos_reduced(inc, si, ci); sincos_reduced(om, sw, cw); sincos_reduced(Om, sO, cO); }
+        if constexpr (FAST && LANES) {
+            const double xs[3] = {inc, om, Om};
+            double ss[3], cs[3];
+            sincos_lanes<3>(xs, ss, cs);
+            si = ss[0]; ci = cs[0]; sw = ss[1]; cw = cs[1]; sO = ss[2]; cO = cs[2];
+        } else if constexpr (FAST) { sincos_reduced(inc, si, ci); sincos_reduced(om, sw, cw); sincos_reduced(Om, sO, cO); }
         else { sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO); }
         if (radvel) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
         // Thiele-Innes constants (parameterizations.jl:34-37) scaled to mas: T = a · cart2angle

@@ -131,21 +131,42 @@ DT void prior_apply(const octo_prior& pr, const DU& y, DU& x, DU& lp, const doub
 //   log|J|     log((x − a)(b − x)/(b − a)) | log(x − a) | log(b − x) | 0                                  — the first log
 //   logpdf     Uniform: −log(b − a) · LogUniform: −log(x·log(b/a)) · Normal: −(z² + log 2π)/2 − log σ (+ truncation constant) · Sine: log(sin x / 2)
 //                                                                                                         — the second log
-__device__ __forceinline__ void prior_apply_lanes(const octo_prior& pr, double y, double& xv, double& xd, double& lpv, double& lpd,
-                                                  const double* __restrict__ pc) {
+// Split in two because only the LINK is on the critical path of a call (x feeds the elements, the epoch loop and the finish); the
+// density and log|J| are needed at the very end, so k_small<MODEL> lets another wave of the block compute them meanwhile.
+struct PriorBounds {
+    double a, b;
+    bool fa, fb, both;
+};
+__device__ __forceinline__ PriorBounds prior_bounds(const octo_prior& pr) {
     const int kind = pr.kind;
     const bool is_u = kind == OCTO_PRIOR_UNIFORM, is_lu = kind == OCTO_PRIOR_LOGUNIFORM, is_tn = kind == OCTO_PRIOR_TRUNCNORMAL, is_s = kind == OCTO_PRIOR_SINE;
-    const bool is_n = kind == OCTO_PRIOR_NORMAL || is_tn;
-    const double a = (is_u || is_lu) ? pr.p0 : (is_tn ? pr.lo : (is_s ? 2.220446049250313e-16 : -INFINITY));
-    const double b = (is_u || is_lu) ? pr.p1 : (is_tn ? pr.hi : (is_s ? PI - 2.220446049250313e-16 : INFINITY));
-    const bool fa = isfinite(a), fb = isfinite(b), both = fa && fb;
+    PriorBounds B;
+    B.a = (is_u || is_lu) ? pr.p0 : (is_tn ? pr.lo : (is_s ? 2.220446049250313e-16 : -INFINITY));
+    B.b = (is_u || is_lu) ? pr.p1 : (is_tn ? pr.hi : (is_s ? PI - 2.220446049250313e-16 : INFINITY));
+    B.fa = isfinite(B.a); B.fb = isfinite(B.b); B.both = B.fa && B.fb;
+    return B;
+}
+
+// Bijectors.invlink of this lane's prior: x and dx/dθ_t
+__device__ __forceinline__ void prior_link_lanes(const octo_prior& pr, double y, double& xv, double& xd) {
+    const PriorBounds B = prior_bounds(pr);
     const double em = exp(-fabs(y));                                // in (0, 1]: never overflows, whatever θ_t a sampler tries
     const double r1 = rcp_nr<2>(1.0 + em);
     const double sg = y >= 0.0 ? r1 : em * r1;                       // σ(y) = 1/(1 + e^−y)
     const double ey = y >= 0.0 ? rcp_nr<2>(em) : em;                 // e^y for the one-sided links
-    const double ba = b - a;
-    xv = both ? fma(ba, sg, a) : (fa ? ey + a : (fb ? b - ey : y));
-    xd = both ? ba * sg * (1.0 - sg) : (fa ? ey : (fb ? -ey : 1.0));
+    const double ba = B.b - B.a;
+    xv = B.both ? fma(ba, sg, B.a) : (B.fa ? ey + B.a : (B.fb ? B.b - ey : y));
+    xd = B.both ? ba * sg * (1.0 - sg) : (B.fa ? ey : (B.fb ? -ey : 1.0));
+}
+
+// logpdf_with_trans of this lane's prior at the linked x: value and d/dθ_t
+__device__ __forceinline__ void prior_density_lanes(const octo_prior& pr, double xv, double xd, double& lpv, double& lpd, const double* __restrict__ pc) {
+    const int kind = pr.kind;
+    const bool is_u = kind == OCTO_PRIOR_UNIFORM, is_lu = kind == OCTO_PRIOR_LOGUNIFORM, is_tn = kind == OCTO_PRIOR_TRUNCNORMAL, is_s = kind == OCTO_PRIOR_SINE;
+    const bool is_n = kind == OCTO_PRIOR_NORMAL || is_tn;
+    const PriorBounds B = prior_bounds(pr);
+    const double a = B.a, b = B.b;
+    const bool fa = B.fa, fb = B.fb, both = B.both;
     // log|J| and its derivative d/dθ_t = (d arg/dx · dx/dy)/arg
     const double xa = xv - a, bx = b - xv;
     const double jarg = both ? xa * bx * pc[1] : (fa ? xa : (fb ? bx : 1.0));
@@ -178,8 +199,10 @@ DT DU unit_length(const DU& x, const DU& y) {
 
 // θ_at_epoch_to_tperi   src/parameterizations.jl:34-67
 // Thiele-Innes planets (ti): the arguments a, inc, w, O carry A, B, F, G [mas] and a = α/plx (:14-19).
+// pre (k_small<MODEL>, wave-uniform arguments): {sin, cos} of Ω, ω, i and θ computed in one lane-batched pass (sincos_lanes) by the caller.
 DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU& a_in,
-            const DU& inc, const DU& w, const DU& O, double k_yr, double yd, bool ti = false, const DU* plx = nullptr) {
+            const DU& inc, const DU& w, const DU& O, double k_yr, double yd, bool ti = false, const DU* plx = nullptr,
+            const double (*pre)[2] = nullptr) {
     DU A, B, F, G, a = a_in;
     if (ti) {
         A = a_in; B = inc; F = w; G = O;
@@ -187,14 +210,21 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
         const DU pp = ((A + G) * (A + G) + (B - F) * (B - F)) * 0.5, mm = ((A - G) * (A - G) + (B + F) * (B + F)) * 0.5;
         a = ((dsqrt(pp) + dsqrt(mm)) * 0.70710678118654752440) / *plx;
     } else {
-        DU cO, sO, cw, sw;
-        dsincos(O, sO, cO); dsincos(w, sw, cw);
-        const DU ci = dcos(inc);
+        DU cO, sO, cw, sw, ci;
+        if (pre) {
+            sO = chain(O, pre[0][0], pre[0][1]); cO = chain(O, pre[0][1], -pre[0][0]);
+            sw = chain(w, pre[1][0], pre[1][1]); cw = chain(w, pre[1][1], -pre[1][0]);
+            ci = chain(inc, pre[2][1], -pre[2][0]);
+        } else {
+            dsincos(O, sO, cO); dsincos(w, sw, cw);
+            ci = dcos(inc);
+        }
         A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
         F = -(cO * sw) - sO * cw * ci; G = -(sO * sw) + cO * cw * ci;
     }
     DU ct, st;
-    dsincos(th, st, ct);
+    if (pre) { st = chain(th, pre[3][0], pre[3][1]); ct = chain(th, pre[3][1], -pre[3][0]); }
+    else dsincos(th, st, ct);
     const DU det = A * G - F * B;
     const DU xr = (G * ct - F * st) / det, yr = (A * st - B * ct) / det;
     const DU nu = datan2(yr, xr);

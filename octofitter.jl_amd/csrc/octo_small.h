@@ -47,11 +47,6 @@ __device__ __forceinline__ double wave_sum(double x) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double lane_value(double x, int src_lane) {      // src_lane wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
 __device__ __forceinline__ void pc_from_setup(PC& pc, const double (&v)[NWC]) {
     pc.invP = v[WC_INVP]; pc.tp = v[WC_TP]; pc.e = v[WC_E]; pc.beta = v[WC_BETA]; pc.eob = v[WC_EOB];
     pc.cB = v[WC_CB]; pc.cG = v[WC_CG]; pc.cA = v[WC_CA]; pc.cF = v[WC_CF]; pc.K = v[WC_K]; pc.cw = v[WC_COSW]; pc.sw = v[WC_SINW];
@@ -126,20 +121,31 @@ struct SmallInline {
     double v[SMALL_INL];
 };
 
-struct SmallModel {       // the part of ModelArgs k_small<MODEL> reads
-    const octo_prior* priors;
-    const octo_source* esrc;
-    const octo_source* nsrc;       // or null = defaults
-    const int32_t* circ_slot;      // [n_el + n_nu] pair-table slot of each CIRCULAR / TPERI source, or -1
-    const int32_t* circ_pair;      // [n_circ][2] (i0, i1) of each slot
-    const double* prior_logz;      // [D][PRIOR_NC] constants of each prior (prior_apply)
+// The model's descriptors travel as ONE block of device memory (`blob`, built by octo_model_create: priors | prior constants | element
+// sources | nuisance sources | pair slots | pairs) that every block copies into LDS with one load per thread: one memory round trip
+// at the start of the call instead of a chain of a dozen dependent scalar loads through six separate allocations.
+constexpr int SMALL_BLOB_MAX = 1024;      // doubles (8 KB of LDS); a model that needs more takes the throughput path
+constexpr int SMALL_MX_NU = 48;           // nuisance values shared through LDS (16 observations x 3)
+struct SmallModel {       // the part of the model k_small<MODEL> reads
+    const double* blob;            // [blob_n] doubles; the priors (octo_prior[D]) sit at byte 0
+    int32_t blob_n;
+    int32_t off_logz;              // byte offsets inside the blob: [D][PRIOR_NC] constants of each prior (prior_density_lanes)
+    int32_t off_esrc;              //   octo_source[n_el]
+    int32_t off_nsrc;              //   octo_source[n_nu], or -1 = defaults
+    int32_t off_cslot;             //   int32[n_el + n_nu] pair-table slot of each CIRCULAR / TPERI source, or -1
+    int32_t off_cpair;             //   int32[n_circ][2] (i0, i1) of each slot
     int32_t n_circ, n_el;
     const double* theta_t;         // [W][D] walker-major (ld = 1) or [D][ld]
     int64_t ld_t, ws_t;            // θ_t[d * ld_t + w * ws_t]
     double* lp_out; double* grad_out; int64_t ld_o, ws_o;      // lp_out[w * ws_o], grad_out[d * ld_o + w * ws_o]
-    int32_t D, pad;
+    int32_t D, n_nu;
     double k_yr, yd;
 };
+
+// The kernel-argument block as the ABI lays it out (by-value structs in declaration order at their natural alignment; checked against
+// the code object's metadata: offsets 0 / 280 / 416 / 424 / 432 / 440): lane d of the fused model launch loads θ_t[d] straight from
+// it — one vector load next to the blob's, instead of 64 scalar values and a 63-step select chain.
+struct SmallKernargs { EvalArgs a; SmallModel sm; int32_t* counters; uint64_t* done_flags; uint64_t seq; SmallInline inl; };
 
 template <int P, bool GRAD, bool NUIS, int KM, bool MODEL>
 static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallModel sm, int32_t* __restrict__ counters, uint64_t* done_flags, uint64_t seq,
@@ -164,60 +170,146 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     const int task = blockIdx.x;
     const int n_base = a.n_rblocks;      // blocks 0 .. n_base−1 take the row tasks (block b: tasks b, b + n_base, …); n_base .. : the HGCA term
 
-    // ---- (MODEL) θ_t -> natural θ, priors, elements as one-partial duals: lane d carries ∂/∂θ_t[d]
+    // ---- (MODEL) θ_t -> natural θ, priors, elements as one-partial duals: lane d carries ∂/∂θ_t[d].
+    // What a one-θ call pays for is the LENGTH of one wave's instruction chain (~5 ns per serial FP64 instruction), and only part of this
+    // section feeds the rest of the call: x = invlink(θ_t) -> the UniformCircular angles -> θ_at_epoch_to_tperi -> the elements. The
+    // densities of the priors (two logarithms, a sincos) and the UnitLengthPrior terms (a root, two logarithms per pair) are needed at the
+    // very end only. So the block's waves split the work — they run on different SIMDs, truly in parallel:
+    //   every wave   the model's descriptors into LDS (one load per thread), θ_t[lane], the link x[lane], dx/dθ_t[lane]
+    //   wave 0       atan(y, x) of every pair (one pair per lane), the elements, tp; publishes the element VALUES (and the nuisances')
+    //   wave 1       logpdf_with_trans of every prior, their sum in declaration order with the healing rule, ∂/∂θ_t[lane]
+    //   wave 2       the UnitLengthPrior term of every pair and their sum over the sources that carry one, ∂/∂θ_t[lane]
+    // and meet at one barrier; the finishing wave picks the sums up from LDS at the end.
     LaneTheta T{0.0, 0.0, lane};
     D1 elD[P][OCTO_N_EL];
-    D1 ul = dconst<1, true>(0.0);                       // Σ UnitLengthPrior terms (value and this lane's partial)
+    D1 ul = dconst<1, true>(0.0);                       // Σ UnitLengthPrior terms (value and this lane's partial): from wave 2, through LDS
     CircTable CT{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
-    double lpp = 0.0, glp = 0.0;                        // Σ logpdf_with_trans in declaration order, and ∂/∂θ_t[lane]
-    bool healed = false, finite_in = true;
+    double lpp = 0.0, glp = 0.0;                        // Σ logpdf_with_trans in declaration order, and ∂/∂θ_t[lane]: from wave 1, through LDS
+    bool finite_in = true;
+    __shared__ double mblob[MODEL ? SMALL_BLOB_MAX : 1];
+    __shared__ double mx_glp[MODEL ? WAVE : 1], mx_uld[MODEL ? WAVE : 1], mx_s[2];      // wave 1 -> finisher, wave 2 -> finisher, {lpp, Σ ul}
+    __shared__ double mx_el[MODEL ? P * OCTO_N_EL : 1], mx_nu[MODEL ? SMALL_MX_NU : 1];   // wave 0 -> every wave: element and nuisance values
+    const char* const mb = reinterpret_cast<const char*>(mblob);
+    // a source record of the model, wave-uniform (every lane reads the same LDS words; the integers go to SGPRs)
+    auto blob_src = [&](int off, int k) {
+        octo_source sc = *reinterpret_cast<const octo_source*>(mb + off + k * (int)sizeof(octo_source));
+        sc.kind = __builtin_amdgcn_readfirstlane(sc.kind); sc.i0 = __builtin_amdgcn_readfirstlane(sc.i0);
+        sc.i1 = __builtin_amdgcn_readfirstlane(sc.i1); sc.flags = __builtin_amdgcn_readfirstlane(sc.flags);
+        return sc;
+    };
+    auto blob_slot = [&](int k) { return __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int32_t*>(mb + sm.off_cslot + 4 * k)); };
+    auto nuis_src = [&](int o, int r, int obs_kind) {
+        return sm.off_nsrc >= 0 ? blob_src(sm.off_nsrc, o * OCTO_N_NUIS + r) : default_nuis_source(obs_kind, r);
+    };
     if constexpr (MODEL) {
         const int D = sm.D;
         const int dl = lane < D ? lane : D - 1;
+        for (int i = threadIdx.x; i < sm.blob_n; i += SMALL_TPB) mblob[i] = sm.blob[i];
         double y;
-        if (inl.n > 0) {      // θ_t from the kernel arguments: lane d picks entry d (scalar loads + selects, no memory round trip)
-            y = inl.v[0];
-#pragma unroll
-            for (int k = 1; k < SMALL_INL; ++k) y = (dl == k) ? inl.v[k] : y;
+        if (inl.n > 0) {      // θ_t from the kernel arguments: lane d loads entry d from the argument block itself
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+            const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma clang diagnostic pop
+            y = reinterpret_cast<const double*>(ka + offsetof(SmallKernargs, inl) + offsetof(SmallInline, v))[dl];
         } else {
             y = sm.theta_t[(int64_t)dl * sm.ld_t + w * sm.ws_t];
         }
+        __syncthreads();      // the descriptors are in LDS
         finite_in = __all(isfinite(y));                                              // logdensitymodel.jl:120-124
-        D1 xk, pk;
-        prior_apply_lanes(sm.priors[dl], y, xk.v, xk.d[0], pk.v, pk.d[0], sm.prior_logz + PRIOR_NC * dl);
-        T.xv = xk.v; T.xd = xk.d[0];
-        TRACE_POINT();      // (MODEL) priors applied
-        {   // the model's UniformCircular pairs, one per lane
-            CT.n = sm.n_circ < WAVE ? sm.n_circ : WAVE;
-            const int j = lane < CT.n ? lane : 0;
-            const int i0 = CT.n > 0 ? sm.circ_pair[2 * j] : 0, i1 = CT.n > 0 ? sm.circ_pair[2 * j + 1] : 0;
-            const D2 cx = dvar<2, true>(__shfl(T.xv, i0), 0), cy = dvar<2, true>(__shfl(T.xv, i1), 1);
-            if (CT.n > 0) {
-                const D2 ang = datan2(cy, cx), u2 = unit_length(cx, cy);
-                CT.ang = ang.v; CT.ang_x = ang.d[0]; CT.ang_y = ang.d[1]; CT.ul = u2.v; CT.ul_x = u2.d[0]; CT.ul_y = u2.d[1];
+        const octo_prior pr = *reinterpret_cast<const octo_prior*>(mb + dl * (int)sizeof(octo_prior));
+        prior_link_lanes(pr, y, T.xv, T.xd);
+        TRACE_POINT();      // (MODEL) priors linked
+        const int nC = sm.n_circ < WAVE ? sm.n_circ : WAVE;
+        const int jc = lane < nC ? lane : 0;
+        const int32_t* cpair = reinterpret_cast<const int32_t*>(mb + sm.off_cpair);
+        const int ci0 = nC > 0 ? cpair[2 * jc] : 0, ci1 = nC > 0 ? cpair[2 * jc + 1] : 0;
+        if (wv == 1) {
+            // logpdf_with_trans of prior `lane`, then the sum in declaration order, healing as the reference does (variables.jl:1229-1236)
+            D1 pk;
+            prior_density_lanes(pr, T.xv, T.xd, pk.v, pk.d[0], reinterpret_cast<const double*>(mb + sm.off_logz) + PRIOR_NC * dl);
+            bool healed = false;
+            double sum = 0.0;
+            for (int k = 0; k < D; ++k) {
+                const double pv = lane_value(pk.v, k);
+                if (!healed) {
+                    if (!isfinite(pv)) { sum = -1.7976931348623157e308; healed = true; }
+                    else sum += pv;
+                }
             }
-        }
-        TRACE_POINT();      // (MODEL) UniformCircular table
-        for (int k = 0; k < D; ++k) {                                                // in declaration order, healing as the reference
-            const double pv = lane_value(pk.v, k);                                   // does (variables.jl:1229-1236)
-            if (!healed) {
-                if (!isfinite(pv)) { lpp = -1.7976931348623157e308; healed = true; }
-                else lpp += pv;
+            mx_glp[lane] = (healed || lane >= D) ? 0.0 : pk.d[0];
+            if (lane == 0) mx_s[0] = sum;
+        } else if (wv == 2) {
+            // UnitLengthPrior term of pair `lane` (variables.jl:309-323) with both partials, then Σ over the sources that carry one, in the
+            // order the elements are resolved in (a planet's plain sources, then its tp), then the nuisances'
+            D1 acc = dconst<1, true>(0.0);
+            if (nC > 0) {
+                const D2 cx = dvar<2, true>(__shfl(T.xv, ci0), 0), cy = dvar<2, true>(__shfl(T.xv, ci1), 1);
+                const D2 u2 = unit_length(cx, cy);
+                auto add_ul = [&](const octo_source& sc, int k) {
+                    if ((sc.kind == OCTO_SRC_CIRCULAR || sc.kind == OCTO_SRC_TPERI) && (sc.flags & OCTO_SRC_FLAG_UNITLEN)) {
+                        const int slot = blob_slot(k);
+                        const double sx = (sc.i0 == T.lane) ? T.xd : 0.0, sy = (sc.i1 == T.lane) ? T.xd : 0.0;
+                        acc.v += lane_value(u2.v, slot);
+                        acc.d[0] += lane_value(u2.d[0], slot) * sx + lane_value(u2.d[1], slot) * sy;
+                    }
+                };
+                for (int p = 0; p < P; ++p) {
+                    for (int k = 0; k < OCTO_N_EL; ++k) {
+                        const octo_source sc = blob_src(sm.off_esrc, p * OCTO_N_EL + k);
+                        if (sc.kind != OCTO_SRC_TPERI) add_ul(sc, p * OCTO_N_EL + k);
+                    }
+                    const octo_source sc = blob_src(sm.off_esrc, p * OCTO_N_EL + OCTO_EL_TP);
+                    if (sc.kind == OCTO_SRC_TPERI) add_ul(sc, p * OCTO_N_EL + OCTO_EL_TP);
+                }
+                if (sm.off_nsrc >= 0)
+                    for (int k = 0; k < sm.n_nu; ++k) add_ul(blob_src(sm.off_nsrc, k), sm.n_el + k);
             }
-        }
-        glp = (healed || lane >= D) ? 0.0 : pk.d[0];
+            mx_uld[lane] = acc.d[0];
+            if (lane == 0) mx_s[1] = acc.v;
+        } else if (wv == 0) {
+            // atan(y, x) of the model's UniformCircular pairs, one per lane (variables.jl:279-299)
+            CT.n = nC;
+            if (nC > 0) {
+                const D2 cx = dvar<2, true>(__shfl(T.xv, ci0), 0), cy = dvar<2, true>(__shfl(T.xv, ci1), 1);
+                const D2 ang = datan2(cy, cx);
+                CT.ang = ang.v; CT.ang_x = ang.d[0]; CT.ang_y = ang.d[1];
+            }
+            TRACE_POINT();      // (MODEL) UniformCircular angles
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
+            for (int p = 0; p < P; ++p) {
 #pragma unroll
-            for (int k = 0; k < OCTO_N_EL; ++k) {
-                const octo_source sc = sm.esrc[p * OCTO_N_EL + k];
-                elD[p][k] = (sc.kind == OCTO_SRC_TPERI) ? dconst<1, true>(0.0) : src_plain(sc, sm.circ_slot[p * OCTO_N_EL + k], CT, T, ul, true);
+                for (int k = 0; k < OCTO_N_EL; ++k) {
+                    const octo_source sc = blob_src(sm.off_esrc, p * OCTO_N_EL + k);
+                    elD[p][k] = (sc.kind == OCTO_SRC_TPERI) ? dconst<1, true>(0.0) : src_plain(sc, blob_slot(p * OCTO_N_EL + k), CT, T, ul, false);
+                }
+                const octo_source sc = blob_src(sm.off_esrc, p * OCTO_N_EL + OCTO_EL_TP);
+                if (sc.kind == OCTO_SRC_TPERI) {    // tp = θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω | plx, A, B, F, G), parameterizations.jl:6-69
+                    const D1 th = src_angle(sc, blob_slot(p * OCTO_N_EL + OCTO_EL_TP), CT, T, ul, false);
+                    // sin/cos of Ω, ω, i, θ in one pass, lane j taking angle j (the values are wave-uniform here)
+                    const double xs[4] = {elD[p][OCTO_EL_O].v, elD[p][OCTO_EL_W].v, elD[p][OCTO_EL_I].v, th.v};
+                    double ss[4], cs[4];
+                    sincos_lanes<4>(xs, ss, cs);
+                    const double pre[4][2] = {{ss[0], cs[0]}, {ss[1], cs[1]}, {ss[2], cs[2]}, {ss[3], cs[3]}};
+                    elD[p][OCTO_EL_TP] = tperi(th, sc.value, elD[p][OCTO_EL_M], elD[p][OCTO_EL_E], elD[p][OCTO_EL_A], elD[p][OCTO_EL_I],
+                                               elD[p][OCTO_EL_W], elD[p][OCTO_EL_O], sm.k_yr, sm.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &elD[p][OCTO_EL_PLX], pre);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < OCTO_N_EL; ++k) mx_el[p * OCTO_N_EL + k] = elD[p][k].v;
+                }
             }
-            const octo_source sc = sm.esrc[p * OCTO_N_EL + OCTO_EL_TP];
-            if (sc.kind == OCTO_SRC_TPERI)      // tp = θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω | plx, A, B, F, G), parameterizations.jl:6-69
-                elD[p][OCTO_EL_TP] = tperi(src_angle(sc, sm.circ_slot[p * OCTO_N_EL + OCTO_EL_TP], CT, T, ul, true), sc.value, elD[p][OCTO_EL_M], elD[p][OCTO_EL_E], elD[p][OCTO_EL_A], elD[p][OCTO_EL_I],
-                                           elD[p][OCTO_EL_W], elD[p][OCTO_EL_O], sm.k_yr, sm.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &elD[p][OCTO_EL_PLX]);
+            if constexpr (NUIS) {      // the nuisance VALUES, for every wave's row tasks (their partials: the finishing wave, below)
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) {
+                    const octo_source sc = nuis_src(k / OCTO_N_NUIS, k % OCTO_N_NUIS, a.obs[k / OCTO_N_NUIS].kind);
+                    const D1 v = src_plain(sc, sm.off_nsrc >= 0 ? blob_slot(sm.n_el + k) : -1, CT, T, ul, false);
+                    if (lane == 0) mx_nu[k] = v.v;
+                }
+            }
         }
+        __syncthreads();      // elements, nuisances, prior and UnitLength sums are in LDS
+        lpp = mx_s[0]; glp = mx_glp[lane];
+        ul.v = mx_s[1]; ul.d[0] = mx_uld[lane];
     }
 
     if constexpr (MODEL) { TRACE_POINT(); }      // (MODEL) elements resolved (θ_at_epoch_to_tperi included)
@@ -230,7 +322,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     for (int p = 0; p < P; ++p) {
         if constexpr (MODEL) {
 #pragma unroll
-            for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = elD[p][k].v;
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = mx_el[p * OCTO_N_EL + k];      // wave 0's values, through LDS
         } else {
             if (inl.n > 0) {
 #pragma unroll
@@ -241,7 +333,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = el[(int64_t)k * a.ld];
             }
         }
-        const SetupOut so = setup_planet_vals<true>(elv[p], a.c, a.orbit_kind[p], a.has_mass[p]);
+        const SetupOut so = setup_planet_vals<true, true>(elv[p], a.c, a.orbit_kind[p], a.has_mass[p]);      // wave-uniform elements: lane-batched sincos
         pc_from_setup(pc[p], so.v);
         fp[p].sma = so.v[WC_A]; fp[p].P_d = 1.0 / so.v[WC_INVP]; fp[p].beta = so.v[WC_BETA];
         fp[p].si = so.v[WC_SINI]; fp[p].ci = so.v[WC_COSI]; fp[p].sO = so.v[WC_SINO]; fp[p].cO = so.v[WC_COSO];
@@ -251,12 +343,13 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     // nuisance rows of observation o: from memory, or (MODEL) from their sources
     auto nuis_of = [&](int o, int obs_kind, double (&nu)[OCTO_N_NUIS], D1* nuD, bool count_ul) {
         if constexpr (MODEL) {
+            // values: resolved once by wave 0 of this block (above); with partials (nuD: the finishing wave, which is a wave 0): again
+            // from the sources. The UnitLengthPrior terms of circular nuisance sources are in wave 2's sum already.
+            (void)count_ul;
 #pragma unroll
             for (int r = 0; r < OCTO_N_NUIS; ++r) {
-                const octo_source sc = sm.nsrc ? sm.nsrc[o * OCTO_N_NUIS + r] : default_nuis_source(obs_kind, r);
-                const D1 v = src_plain(sc, sm.nsrc ? sm.circ_slot[sm.n_el + o * OCTO_N_NUIS + r] : -1, CT, T, ul, count_ul);
-                nu[r] = v.v;
-                if (nuD) nuD[r] = v;
+                nu[r] = mx_nu[o * OCTO_N_NUIS + r];
+                if (nuD) nuD[r] = src_plain(nuis_src(o, r, obs_kind), sm.off_nsrc >= 0 ? blob_slot(sm.n_el + o * OCTO_N_NUIS + r) : -1, CT, T, ul, false);
             }
         } else {
             if (inl.n > 0) {

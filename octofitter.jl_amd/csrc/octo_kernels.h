@@ -148,10 +148,15 @@ __device__ __forceinline__ void sincos_reduced(double x, double& s, double& c) {
 // angle the arithmetic is that of sincos_reduced, so the values are bit-identical to separate calls.
 template <int N>
 __device__ __forceinline__ void sincos_lanes(const double (&x)[N], double (&s)[N], double (&c)[N]) {
-    const int lane = threadIdx.x & (WAVE - 1);
-    double xl = x[0];
+    // angle k into lane k with v_writelane (a select chain on the lane index is turned into a scratch-memory lookup table by the compiler)
+    int xlo = __double2loint(x[0]), xhi = __double2hiint(x[0]);
 #pragma unroll
-    for (int k = 1; k < N; ++k) xl = (lane == k) ? x[k] : xl;
+    for (int k = 1; k < N; ++k) {
+        const int slo = __builtin_amdgcn_readfirstlane(__double2loint(x[k])), shi = __builtin_amdgcn_readfirstlane(__double2hiint(x[k]));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(xlo) : "s"(slo), "n"(k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(xhi) : "s"(shi), "n"(k));
+    }
+    const double xl = __hiloint2double(xhi, xlo);
     double sl, cl;
     sincos_reduced(xl, sl, cl);
 #pragma unroll

@@ -77,6 +77,23 @@ def refine(M, e, E1, rcp_bits=26, nr=(1, 1, 2)):
     return E, sE, cE, d5
 
 
+def refine_device(M, e, E1, rcp_bits=23):
+    """The correction as octo_device.h: kepler_solve computes it since round 3: ONE hardware reciprocal (Halley's denominator), δ3, then δ4
+    and δ5 as one correction step each on the QUOTIENT, δ' = δ − r·(den·δ + f0), with the same crude r — 2 FMAs per division."""
+    s1 = np.sin(E1); c1 = np.cos(E1)
+    hf2 = 0.5 * e * s1; q24 = hf2 / 12; sf3 = e / 6 * c1; f1 = 1 - e * c1; f0 = (E1 - M) - e * s1
+    den3 = f1 * f1 - f0 * hf2
+    r3 = (1.0 / den3) * (1 + np.random.default_rng(0).uniform(-1, 1, den3.shape) * 2.0**-rcp_bits)
+    r4 = f1 * r3; d3 = -f0 * r4
+    den4 = f1 + d3 * (hf2 + d3 * sf3)
+    d4 = d3 - r4 * (den4 * d3 + f0)
+    den5 = f1 + d4 * (hf2 + d4 * (sf3 - d4 * q24))
+    d5 = d4 - r4 * (den5 * d4 + f0)
+    E = E1 + d5; dd = d5 * d5
+    sd = d5 * (1 + dd * (-1 / 6)); cm1 = dd * (-0.5 + dd / 24)
+    return E, s1 + (c1 * sd + s1 * cm1), c1 + (-s1 * sd + c1 * cm1), d5
+
+
 if __name__ == "__main__":
     rng = np.random.default_rng(1)
     n = 2_000_000
@@ -88,7 +105,7 @@ if __name__ == "__main__":
     Et = truth(M, e)
     E64, d5_64 = markley64(M, e)
     E1 = starter32(M, e)
-    E, sE, cE, d5 = refine(M, e, E1)
+    E, sE, cE, d5 = refine_device(M, e, E1)      # refine(M, e, E1): the reciprocal-refinement form of rounds 1-2
     cond = 1 - e * np.cos(Et.astype(np.float64))
     err64 = np.abs((E64 - Et).astype(np.float64)) * cond
     err = np.abs((E - Et).astype(np.float64)) * cond

@@ -417,8 +417,12 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
             (void)count_ul;
 #pragma unroll
             for (int r = 0; r < OCTO_N_NUIS; ++r) {
-                nu[r] = mx_nu[o * OCTO_N_NUIS + r];
-                if (nuD) nuD[r] = src_plain(nuis_src(o, r, obs_kind), sm.off_nsrc >= 0 ? blob_slot(sm.n_el + o * OCTO_N_NUIS + r) : -1, CT, T, ul, false);
+                if (nuD) {      // (also the only route of a launch compiled without nuisances: wave 0 fills mx_nu only `if constexpr (NUIS)`)
+                    nuD[r] = src_plain(nuis_src(o, r, obs_kind), sm.off_nsrc >= 0 ? blob_slot(sm.n_el + o * OCTO_N_NUIS + r) : -1, CT, T, ul, false);
+                    nu[r] = nuD[r].v;
+                } else {
+                    nu[r] = mx_nu[o * OCTO_N_NUIS + r];
+                }
             }
         } else {
             if (inl.n > 0) {

@@ -49,6 +49,23 @@ def test_random_models_vs_oracle(pkg, oracle, seed):
     assert not fails, fails
 
 
+def test_model_cases_found_by_the_long_sweep(pkg, oracle):
+    """Cases 32 and 53 of `stress_model.py 400 303` (round 3): models on an O'Neil-wrapped table WITHOUT rows and without nuisance
+    variables. The fused model launch is then compiled without nuisances, and its finish read the observation's default nuisance
+    values from an LDS array that only a nuisance launch fills — log-posterior −Inf with the gradient, right without. Both kernel
+    families, value with and without the gradient, against the oracle."""
+    import stress_model as sm
+    rng = np.random.default_rng(303)
+    lib = pkg.capi.load_library()
+    seen = []
+    for k in range(54):
+        r = sm.check_model(rng, lib, evaluate=k in (32, 53))
+        if r is not None:
+            seen.append(k)
+            assert r[0], (k,) + r[1:]
+    assert seen == [32, 53]
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_random_ofti_vs_oracle(oracle, seed):
     import stress_ofti as so

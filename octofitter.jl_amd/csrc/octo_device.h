@@ -15,8 +15,8 @@
 //     below: 13 FP64 instructions); in k_small and k_hgca from one half-angle polynomial pair on |E1|/2 <= 1.59
 //     (sincos_halfangle: 24 instructions, no table fill). Neither needs range reduction, quadrant selects or a
 //     Payne-Hanek slow path: |E1| <= π by construction;
-//   * the three divisions of the correction use v_rcp_f64 (2^-23) with 0/1/1 Newton steps — the sensitivity
-//     of E to δ3, δ4 is O(δ²);
+//   * the three divisions of the correction share ONE v_rcp_f64 (2^-23): δ3 uses it as it is, δ4 and δ5 are one correction step each
+//     on the quotient, δ' = δ − r·(den·δ + f0) (round 3; rounds 1-2 refined the reciprocal instead: OCTO_KEPLER_NR_CHAIN);
 //   * sin/cos(E) follow from (sin E1, cos E1) by a rotation through δ5 (|δ5| < 5e-4: Taylor to δ^6).
 // tools/kepler_proto.py measures this scheme against an 80-bit Newton solve over 2e6 (M, e) pairs incl.
 // e -> 1 − 1e-9 and |M| -> 0, π: residual-weighted error 5.1e-16 max vs 7.1e-16 for the all-FP64 reference

@@ -211,9 +211,10 @@ struct SmallModel {       // the part of the model k_small<MODEL> reads
     double k_yr, yd;
 };
 
-// The kernel-argument block as the ABI lays it out (by-value structs in declaration order at their natural alignment; checked against
-// the code object's metadata: offsets 0 / 280 / 416 / 424 / 432 / 440): lane d of the fused model launch loads θ_t[d] straight from
-// it — one vector load next to the blob's, instead of 64 scalar values and a 63-step select chain.
+// The kernel-argument block as the ABI lays it out: by-value structs in declaration order at their natural alignment, i.e. exactly this
+// C struct (checked against the `.offset` entries of the code object's metadata; the fixtures would fail on a mismatch). Keep it in step
+// with k_small's parameter list. Lane d of the fused model launch loads θ_t[d] straight from it — one vector load next to the blob's,
+// instead of 64 scalar values and a 63-step select chain.
 struct SmallKernargs { EvalArgs a; SmallModel sm; int32_t* counters; uint64_t* done_flags; uint64_t seq; SmallInline inl; };
 
 template <int P, bool GRAD, bool NUIS, int KM, bool MODEL>

@@ -227,10 +227,22 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
     else dsincos(th, st, ct);
     const DU det = A * G - F * B;
     const DU xr = (G * ct - F * st) / det, yr = (A * st - B * ct) / det;
-    const DU nu = datan2(yr, xr);
     const DU s1 = dsqrt(dconst<N, FAST>(1.0) - e * e);
     DU sn, cn;
-    dsincos(nu, sn, cn);
+    if constexpr (FAST) {
+        // The reference takes ν = atan(yr, xr) and then sin ν, cos ν (parameterizations.jl:52-56); ν itself is not used again, and
+        // sin ν = yr/r, cos ν = xr/r with r = hypot(xr, yr) are the same numbers without an arctangent followed by a sincos (~90 serial
+        // instructions of the one-θ callback's chain; the partials follow from dν = (xr·dyr − yr·dxr)/r², as datan2 forms them).
+        const double ih = rsqrt_nr(fma(xr.v, xr.v, yr.v * yr.v));
+        cn.v = xr.v * ih; sn.v = yr.v * ih;
+        DFOR {
+            const double dnu = (xr.v * yr.d[k_] - yr.v * xr.d[k_]) * (ih * ih);
+            sn.d[k_] = cn.v * dnu; cn.d[k_] = -sn.v * dnu;
+        }
+    } else {
+        const DU nu = datan2(yr, xr);
+        dsincos(nu, sn, cn);
+    }
     const DU MA = datan2(-(s1 * sn), -e - cn) + PI - (e * s1 * sn) / (e * cn + 1.0);
     const DU period_yrs = dsqrt(a * a * a / M) * (k_yr / yd);
     const DU n = dconst<N, FAST>(TWO_PI) / period_yrs;

@@ -1076,7 +1076,7 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
             m->blob_n = (int32_t)(blob.size() / 8);
             if (hipMalloc((void**)&m->d_blob, blob.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
             if (hipMemcpy(m->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
-            m->fused_ok = m->all_circ_slotted && m->blob_n <= SMALL_BLOB_MAX && n_nu <= SMALL_MX_NU;
+            m->fused_ok = m->all_circ_slotted && m->blob_n <= SMALL_BLOB_MAX && (!has_nuis || n_nu <= SMALL_MX_NU);
         }
     }
     // k_model_fwd shares x, dx, p, dp of every prior and 6 numbers per UniformCircular pair through LDS: 512 B each.

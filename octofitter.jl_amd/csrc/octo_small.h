@@ -194,7 +194,7 @@ struct SmallInline {
 // sources | nuisance sources | pair slots | pairs) that every block copies into LDS with one load per thread: one memory round trip
 // at the start of the call instead of a chain of a dozen dependent scalar loads through six separate allocations.
 constexpr int SMALL_BLOB_MAX = 1024;      // doubles (8 KB of LDS); a model that needs more takes the throughput path
-constexpr int SMALL_MX_NU = 48;           // nuisance values shared through LDS (16 observations x 3)
+constexpr int SMALL_MX_NU = 192;          // nuisance values shared through LDS (64 observations x 3; only launches compiled with nuisances use them)
 struct SmallModel {       // the part of the model k_small<MODEL> reads
     const double* blob;            // [blob_n] doubles; the priors (octo_prior[D]) sit at byte 0
     int32_t blob_n;

@@ -471,3 +471,31 @@ def test_gpu_model_relative_rv_trend(pkg, oracle, model_golden):
     assert np.all(np.abs(lpb - lp_o) <= 1e-12 * np.maximum(1, np.abs(lp_o)))
     assert np.all(np.abs(gb_ - g_o) <= 1e-9 * np.abs(g_o).max(axis=1, keepdims=True))
     model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_many_observation_tables(pkg):
+    """Seventeen RA/Dec tables on one planet against the same rows as ONE table: the fused one-θ launch stages the model's
+    descriptors (priors, sources, one source triple per observation) as one block in LDS, so the number of observations is part of its
+    shape. Same log-posterior and gradient to rounding (the split changes the order of the row sums only), one θ_t and a batch."""
+    rng = np.random.default_rng(7)
+    n_tab, per = 17, 3
+    ep = np.sort(50000 + rng.uniform(0, 3000, n_tab * per))
+    ra, dec = rng.normal(-480, 30, n_tab * per), rng.normal(40, 60, n_tab * per)
+    one = dict(epoch=ep, ra=ra, dec=dec, σ_ra=np.full(ep.size, 10.0), σ_dec=np.full(ep.size, 12.0))
+    def build(tables):
+        likes = [pkg.PlanetRelAstromLikelihood(t, name=f"t{k}") for k, t in enumerate(tables)]
+        b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=likes,
+                       variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                               Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+        return pkg.LogDensityModel(pkg.System(name="many", companions=[b], observations=[],
+                                   variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))))
+    split = [{k: v[j * per:(j + 1) * per] for k, v in one.items()} for j in range(n_tab)]
+    m1, m17 = build([one]), build(split)
+    θ_t = m1.link(m1.sample_priors(np.random.default_rng(3), 33))
+    for W in (1, 33):
+        lp1, g1 = m1.logdensity_and_gradient(θ_t[:, :W])
+        lp17, g17 = m17.logdensity_and_gradient(θ_t[:, :W])
+        assert np.all(np.isfinite(lp1)) and np.allclose(lp17, lp1, rtol=1e-12, atol=0)
+        assert np.allclose(g17, g1, rtol=1e-9, atol=1e-9 * np.abs(g1).max())
+    m1.close(); m17.close()

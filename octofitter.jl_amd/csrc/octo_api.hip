@@ -422,6 +422,29 @@ int32_t octo_consts_set(octo_ctx* ctx, const octo_consts* c) {
     return OCTO_OK;
 }
 
+// Test hook (not part of the C ABI of include/octofitter_hip.h; tests/test_sweeps_gpu.py binds it by name): fill the LDS of every CU
+// with the bit pattern of `value`. LDS keeps what the last block left there, and a kernel that reads a word it has not written
+// usually finds zeros or stale finite numbers — which is how an uninitialised read in this round's k_small<MODEL> passed every
+// fixture. With NaN (or a huge number) in every word such a read changes the result, deterministically.
+static __global__ __launch_bounds__(256) void k_poison_lds(double value, int n) {
+    extern __shared__ __attribute__((aligned(16))) double pl[];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) pl[i] = value;
+    __syncthreads();
+    if (pl[(threadIdx.x * 37) % n] != value && value == value) __builtin_trap();      // keep the stores
+    // stay resident for a few microseconds so that the launch spreads over every CU instead of reusing the first ones
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 2000) {}      // 100 MHz ticks: 20 µs
+}
+int32_t octo_debug_poison_lds(octo_ctx* ctx, double value) {
+    if (!ctx) return OCTO_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int bytes = 64 * 1024;      // two such blocks fill most of a CU's 160 KB, each starting at the offsets a small kernel's blocks get
+    hipLaunchKernelGGL(k_poison_lds, dim3((unsigned)(ctx->n_cus * 2)), dim3(256), (size_t)bytes, ctx->stream, value, bytes / 8);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return OCTO_OK;
+}
+
 #ifdef OCTO_SMALL_TRACE
 // development build only: cycle stamps of the last k_small launch's walker-0 finishing block (tools/small_trace.py)
 const uint64_t* octo_debug_small_trace(octo_ctx* ctx) { return ctx ? ctx->h_flags + SMALL_W : nullptr; }

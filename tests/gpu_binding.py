@@ -17,6 +17,22 @@ import os
 DEFAULT_SMALL_BATCH = int(os.environ["OCTO_TEST_SMALL_BATCH"]) if os.environ.get("OCTO_TEST_SMALL_BATCH") else None
 
 
+# Set to a number (NaN, 1e300) to fill every CU's LDS with it ahead of each evaluation (octo_debug_poison_lds, a test hook of the
+# library): a kernel that reads an LDS word it has not written then returns something else than with the usual stale zeros.
+POISON_LDS = None
+
+
+def poison(ctx):
+    if POISON_LDS is None:
+        return
+    lib = capi.load_library()
+    lib.octo_debug_poison_lds.restype = C.c_int32
+    lib.octo_debug_poison_lds.argtypes = [C.c_void_p, C.c_double]
+    st = lib.octo_debug_poison_lds(ctx, float(POISON_LDS))
+    if st != 0:
+        raise capi.OctoError(st, "octo_debug_poison_lds")
+
+
 class GpuPath:
     def __init__(self, obs_tables, planets, device=0, consts=None, small_batch=None):
         if small_batch is None:
@@ -47,6 +63,7 @@ class GpuPath:
         ll = np.full(W, np.nan)
         g_el = np.full_like(elems, np.nan) if grad else None
         g_nu = np.full_like(nu, np.nan) if (grad and nu is not None) else None
+        poison(self.ctx)
         self._chk(self.lib.octo_eval(self.ctx, self.ds, capi._dptr(elems), capi._dptr(nu), W, W,
                                      capi._dptr(ll), capi._dptr(g_el), capi._dptr(g_nu)))
         return ll, g_el, g_nu

@@ -77,7 +77,9 @@ def check_model(rng, lib, P=None, W=None, evaluate=True):
     st = lib.octo_model_create(path.ctx, path.ds, pr_c, D, es_c, ns_c, C.byref(m))
     assert st == 0, (st, lib.octo_last_error(path.ctx))
     thc = np.ascontiguousarray(th); lp = np.empty(W); g = np.empty_like(thc); lp0 = np.empty(W)
+    gb.poison(path.ctx)
     assert lib.octo_model_logpost(path.ctx, m, capi._dptr(thc), W, W, capi._dptr(lp), capi._dptr(g)) == 0
+    gb.poison(path.ctx)
     assert lib.octo_model_logpost(path.ctx, m, capi._dptr(thc), W, W, capi._dptr(lp0), None) == 0
     lib.octo_model_destroy(m); path.close()
     lp_o, g_o = ob.oracle_model_logpost(obs, planets, pr_c, es_c, ns_c, thc, n_threads=0)

@@ -49,6 +49,40 @@ def test_random_models_vs_oracle(pkg, oracle, seed):
     assert not fails, fails
 
 
+@pytest.mark.parametrize("value", [float("nan"), 1e300])
+def test_results_do_not_depend_on_stale_lds(pkg, oracle, value):
+    """LDS keeps what the last block left there. With every word of every CU's LDS set to NaN (and to 1e300) ahead of EACH evaluation
+    — `octo_debug_poison_lds`, a test hook of the library — random systems and random models still match the oracle, value with and
+    without the gradient alike: no kernel reads an LDS word it has not written (the round-3 bug of the fused model launch did, and
+    passed every fixture on stale zeros). Both kernel families (the module's fixture)."""
+    import gpu_binding as gb
+    import stress_parity as sp
+    import stress_model as sm
+    lib = pkg.capi.load_library()
+    gb.POISON_LDS = value
+    try:
+        fails = []
+        rng = np.random.default_rng(31)
+        for k in range(12):
+            sysm = sp.draw_system(rng)
+            good, e_ll, e_g, loose = sp.check_system(sysm)
+            if not good:
+                fails.append(("system", k, sp.describe(sysm), e_ll, e_g))
+        rng = np.random.default_rng(32)
+        for k in range(12):
+            r = sm.check_model(rng, lib)
+            if r is not None and not r[0]:
+                fails.append(("model", k) + r[1:])
+        rng = np.random.default_rng(303)      # the two models of the long sweep that hit the uninitialised read
+        for k in range(54):
+            r = sm.check_model(rng, lib, evaluate=k in (32, 53))
+            if r is not None and not r[0]:
+                fails.append(("model 303", k) + r[1:])
+    finally:
+        gb.POISON_LDS = None
+    assert not fails, fails
+
+
 def test_model_cases_found_by_the_long_sweep(pkg, oracle):
     """Cases 32 and 53 of `stress_model.py 400 303` (round 3): models on an O'Neil-wrapped table WITHOUT rows and without nuisance
     variables. The fused model launch is then compiled without nuisances, and its finish read the observation's default nuisance

@@ -1,6 +1,7 @@
 // octo_api.hip — C ABI of include/octofitter_hip.h over the HIP runtime (gfx950 only).
 // Host logic only: uploads, task tables, scratch, kernel dispatch, timing. No CPU compute path:
 // every entry point that evaluates fails with OCTO_ENODEV / OCTO_EHIP when no device is usable.
+#define OCTO_API_TU 1      // this translation unit owns the non-template kernels (octo_model.h, octo_kernels.h)
 #include "octo_host.h"
 
 using namespace octo;
@@ -389,9 +390,8 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     if (const char* ev = std::getenv("OCTO_SMALL_W")) ctx->small_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     if (const char* ev = std::getenv("OCTO_MAPPED_W")) ctx->mapped_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     if (const char* ev = std::getenv("OCTO_FLAG_W")) ctx->flag_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
-    if (const char* ev = std::getenv("OCTO_FUSED_W")) ctx->fused_w = std::max<long long>(std::atoll(ev), 0);
     ctx->env_small_blocks = env_int("OCTO_SMALL_BLOCKS"); ctx->env_small_min_span = env_int("OCTO_SMALL_MIN_SPAN");
-    ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST");
+    ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST"); ctx->env_kind_all = env_int("OCTO_KIND_ALL");
     *out = ctx;
     return OCTO_OK;
 }
@@ -510,6 +510,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
                 return bail(OCTO_EHIP, "octo_dataset_create: upload failed");
             h.raw = dr; h.pre = dx;
             ds->n_hgca += 1;
+            ds->kind_mask |= KM_HGCA;
             continue;
         }
         const bool oneil = d.kind == OCTO_ONEIL_RADEC || d.kind == OCTO_ONEIL_SEPPA;
@@ -852,6 +853,9 @@ int32_t octo_eval_end(octo_ctx* ctx) {
 
 int32_t octo_eval(octo_ctx* ctx, const octo_dataset* ds, const double* elems, const double* nuis, int64_t ld, int64_t W,
                   double* ll_out, double* g_elems, double* g_nuis) {
+    // Refused while an octo_eval_begin of this context is outstanding — and that evaluation stays intact (its octo_eval_end still
+    // waits and copies out): only a begin of THIS call may be rolled back below.
+    if (ctx && ctx->pending.active) return fail(ctx, OCTO_EINVAL, "octo_eval: an octo_eval_begin of this context has not been ended");
     const int rc = octo_eval_begin(ctx, ds, elems, nuis, ld, W, ll_out, g_elems, g_nuis);
     if (rc) { if (ctx) ctx->pending.active = false; return rc; }
     return octo_eval_end(ctx);

@@ -53,25 +53,30 @@ __device__ __forceinline__ void hgca_setup(const double (&elv)[P][OCTO_N_EL], co
         for (int k = 0; k < OCTO_N_EL; ++k) el[k] = (dir == p * OCTO_N_EL + k) ? dvar<1>(elv[p][k], 0) : dconst<1>(elv[p][k]);
         if (!has_mass[p]) el[OCTO_EL_MASS] = dconst<1>(0.0);
         const D e = el[OCTO_EL_E], Mt = el[OCTO_EL_M];
-        HgcaPlanet& h = hp[p];
-        D sma;
+        // The branch below fills LOCALS, and hp[p] is written once, outside of it: with `hp[p].T = …` in both arms the optimizer sinks the
+        // two stores into the join block with a phi of the two ADDRESSES (hp is still indexed by the loop variable at that point), and
+        // after the loop is unrolled that phi keeps every such field in scratch memory (40 bytes per planet in rounds 2-3: the
+        // `.private_segment_fixed_size` of k_hgca<P >= 2> and of every k_small<P >= 2, NUIS> variant).
+        D sma, T, cA, cB, cF, cG;
         if (ti) {
             // constants in mas; a = α/plx   (src/parameterizations.jl:14-19)
-            h.cA = el[OCTO_EL_TI_A]; h.cB = el[OCTO_EL_TI_B]; h.cF = el[OCTO_EL_TI_F]; h.cG = el[OCTO_EL_TI_G];
-            const D pp = ((h.cA + h.cG) * (h.cA + h.cG) + (h.cB - h.cF) * (h.cB - h.cF)) * 0.5;      // u + v, u − v as sums of squares
-            const D mm = ((h.cA - h.cG) * (h.cA - h.cG) + (h.cB + h.cF) * (h.cB + h.cF)) * 0.5;      // (see setup_planet_vals)
+            cA = el[OCTO_EL_TI_A]; cB = el[OCTO_EL_TI_B]; cF = el[OCTO_EL_TI_F]; cG = el[OCTO_EL_TI_G];
+            const D pp = ((cA + cG) * (cA + cG) + (cB - cF) * (cB - cF)) * 0.5;      // u + v, u − v as sums of squares
+            const D mm = ((cA - cG) * (cA - cG) + (cB + cF) * (cB + cF)) * 0.5;      // (see setup_planet_vals)
             sma = ((dsqrt(pp) + dsqrt(mm)) * 0.70710678118654752440) / el[OCTO_EL_PLX];
-            h.T = dconst<1>(1.0);
+            T = dconst<1>(1.0);
         } else {
             D inc = el[OCTO_EL_I], Om = el[OCTO_EL_O];
             inc.v = inc.v - PI * floor(inc.v / PI);                // KepOrbit ctor invariants, as in k_setup
             Om.v = Om.v - TWO_PI * floor(Om.v / TWO_PI);
             sma = el[OCTO_EL_A];
-            h.T = sma * el[OCTO_EL_PLX] * c.mas_per_au_per_plx;   // parameterizations.jl:215-216
+            T = sma * el[OCTO_EL_PLX] * c.mas_per_au_per_plx;     // parameterizations.jl:215-216
             const D ci = dcos(inc), sw = dsin(el[OCTO_EL_W]), cw = dcos(el[OCTO_EL_W]), sO = dsin(Om), cO = dcos(Om);
-            h.cA = cO * cw - sO * sw * ci; h.cB = sO * cw + cO * sw * ci;
-            h.cF = -(cO * sw) - sO * cw * ci; h.cG = -(sO * sw) + cO * cw * ci;
+            cA = cO * cw - sO * sw * ci; cB = sO * cw + cO * sw * ci;
+            cF = -(cO * sw) - sO * cw * ci; cG = -(sO * sw) + cO * cw * ci;
         }
+        HgcaPlanet& h = hp[p];
+        h.T = T; h.cA = cA; h.cB = cB; h.cF = cF; h.cG = cG;
         const D P_d = dsqrt(sma * sma * sma / Mt) * c.k_yr;   // parameterizations.jl:62
         h.e = e; h.tp = el[OCTO_EL_TP];
         h.beta = dsqrt(dconst<1>(1.0) - e * e);

@@ -88,7 +88,6 @@ struct octo_ctx {
     int64_t cap_extra = 0;
     double* d_sctab = nullptr;                  // sin/cos grid of sincos_table, [SCT_N][2]
     int32_t* d_counters = nullptr;              // k_small: finished-block counter per walker, [SMALL_W], zero between launches
-    int64_t fused_w = (int64_t)1 << 40;         // batches up to this many walkers derive the orbit constants inside k_main (OCTO_FUSED_W: experiments; 0 = k_setup launch)
     uint64_t* h_flags = nullptr;                // mapped pinned [SMALL_W]: k_small's finishing block of walker w stores the call's
     uint64_t flag_seq = 0;                      // sequence number here after its outputs; host-buffer calls spin on it
     bool flag_request = false, flag_armed = false;
@@ -107,7 +106,7 @@ struct octo_ctx {
     int small_w = OCTO_SMALL_BATCH_DEFAULT;     // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
     // experiment knobs, read from the environment ONCE at context creation (0 = not set): a getenv per call is a linear scan of the
     // environment on a 12 µs path
-    int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0, env_rv_cost = 0;
+    int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0, env_rv_cost = 0, env_kind_all = 0;
     int flag_w = 128;                           // ... and signal completion through per-walker flags the host spins on (OCTO_FLAG_W: experiments)
     int mapped_w = 128;                         // host-buffer calls up to this size let k_small read/write mapped pinned memory; larger
                                                 // ones cross the link as one DMA each way (OCTO_MAPPED_W: experiments)

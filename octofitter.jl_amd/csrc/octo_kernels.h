@@ -26,12 +26,11 @@ constexpr int WPB = 4;          // waves per k_main block (row split + LDS combi
 #ifndef OCTO_FIN_UNROLL
 #define OCTO_FIN_UNROLL 4
 #endif
-constexpr int FIN_G = OCTO_FIN_G;
-// waves of a k_finish block: FIN_G for one planet; half of it for several planets — a 1024-thread block caps the kernel at 128 VGPRs per
-// lane, which the multi-planet finish (24-48 sums per walker + one planet's constants and element adjoints) does not fit without spilling
-constexpr int fin_g(int n_planets) { return n_planets == 1 ? FIN_G : (FIN_G / 2 > n_planets ? FIN_G / 2 : n_planets + 1); }        // task groups per walker in k_finish (block = 64 walkers x FIN_G waves). The kernel is pure memory latency — a
+constexpr int FIN_G = OCTO_FIN_G;      // waves of a single-planet k_finish block (block = 64 walkers x FIN_G waves). The kernel is pure memory latency — a
                                          // tile's partials are tasks x NACC rows of 512 B written by other CUs — so what counts is loads in flight:
                                          // 16 waves x 4 tasks unrolled (8 x 2 in round 2: 10.7 us at 1 250 walkers x 76 tasks, 9.4 us at 1e4 x 34)
+// several planets (finish_tile_multi): waves per planet that share the planet's tasks; block = 1 + P·fin_nwr(P) waves
+constexpr int fin_nwr(int n_planets) { return n_planets == 2 ? 3 : 2; }
 #ifndef OCTO_FIN_CH
 #define OCTO_FIN_CH 6
 #endif
@@ -43,7 +42,12 @@ constexpr int FIN_CH = OCTO_FIN_CH;      // rows of the LDS combine per chunk: 6
 // kind mask bits
 constexpr int KM_RADEC = 1, KM_SEPPA = 2, KM_RVABS = 4, KM_MARG = 8, KM_RVREL = 16, KM_COR = 32, KM_ONEIL = 64;
 constexpr int KM_RV = KM_RVABS | KM_MARG | KM_RVREL;
-constexpr int KM_ALL = 127;
+constexpr int KM_ALL = 127;      // every ROW kind (the epoch-loop kernels' kind sets)
+// The dataset holds an OCTO_HGCA table (hgca.jl:155-400: no epoch loop). Only k_small looks at this bit — its variants compiled with it
+// carry the proper-motion-anomaly block (extra blocks of the launch, one input direction per wave); k_main / k_finish / k_marg are
+// instantiated with the bit stripped (the term reaches k_finish through `extra`, a run-time pointer). Rounds 2-3 compiled that block into
+// EVERY k_small<NUIS> variant: 20 KB of code, registers and (through hgca_setup) a scratch allocation on calls that have no such table.
+constexpr int KM_HGCA = 128;
 
 struct DevObs {
     int32_t kind, planet, has_cor, pad;
@@ -174,71 +178,136 @@ __device__ __forceinline__ double sqrt_fast(double x) {
 // FAST (k_small): reciprocal-multiply instead of IEEE division, rsqrt-based roots, polynomial sincos. At the clock a
 // mostly-idle GPU runs one short kernel at, every 100 serial FP64 instructions are about a microsecond of latency.
 // LANES (k_small only): the elements are wave-uniform, so the three angles go through sincos_lanes in one pass.
-template <bool FAST = false, bool LANES = false>
-__device__ __forceinline__ SetupOut setup_planet_vals(const double (&elv)[OCTO_N_EL], const DevConsts& cst, int orbit_kind, int has_mass) {
-    SetupOut so;
-    auto fdiv = [](double x, double y) { return FAST ? x * rcp_nr<2>(y) : x / y; };
-    auto fsqrt = [](double x) { return FAST ? sqrt_fast(x) : sqrt(x); };
-#pragma unroll
-    for (int k = 0; k < OCTO_N_EL; ++k) so.el[k] = elv[k];
+//
+// The constructor is written as four independent PIECES + an assembly, so that the fused k_main prologue can hand one piece to each
+// of its four waves (round 4: the ~300-instruction chain ran in wave 0 alone while the block's other three SIMDs waited — ~3.5 µs of a
+// one-round launch): the sin/cos of i, of ω, of Ω, and the scalars (a, period, β, K/sin i, m/M, starter constants). setup_planet_vals
+// is the same pieces in sequence, so every kernel derives bit-identical constants.
+struct SetupScalars { double sma, T, invP, beta, eob, K0, mu, f32a, f32b; };
+
+template <bool FAST> __device__ __forceinline__ double setup_fdiv(double x, double y) { return FAST ? x * rcp_nr<2>(y) : x / y; }
+template <bool FAST> __device__ __forceinline__ double setup_fsqrt(double x) { return FAST ? sqrt_fast(x) : sqrt(x); }
+
+// the angle as the orbit constructor sees it. WHICH: 0 = i (KepOrbit ctor: rem(i, π, RoundDown)), 1 = ω, 2 = Ω (rem2pi(Ω, RoundDown));
+// a RadialVelocityOrbit has neither i nor Ω (0), a ThieleInnesOrbit none of the three (the rows carry A, B, F, G)
+template <int WHICH>
+__device__ __forceinline__ double setup_angle_arg(const double (&elv)[OCTO_N_EL], int orbit_kind) {
+    const bool radvel = orbit_kind == OCTO_ORBIT_RADVEL;
+    if constexpr (WHICH == 0) { const double inc = radvel ? 0.0 : elv[OCTO_EL_I]; return inc - PI * floor(inc / PI); }
+    else if constexpr (WHICH == 1) return elv[OCTO_EL_W];
+    else { const double Om = radvel ? 0.0 : elv[OCTO_EL_O]; return Om - TWO_PI * floor(Om / TWO_PI); }
+}
+// sin and cos of that angle as the constants use them (RadialVelocityOrbit: sin i = 1, cos i = 0, sin Ω = 0, cos Ω = 1; ThieleInnesOrbit: 0)
+template <int WHICH, bool FAST>
+__device__ __forceinline__ void setup_angle(const double (&elv)[OCTO_N_EL], int orbit_kind, double& sn, double& cs) {
+    const bool radvel = orbit_kind == OCTO_ORBIT_RADVEL;
+    if (orbit_kind == OCTO_ORBIT_THIELE_INNES) { sn = 0.0; cs = 0.0; return; }
+    const double x = setup_angle_arg<WHICH>(elv, orbit_kind);
+    if constexpr (FAST) sincos_reduced(x, sn, cs);
+    else sincos(x, &sn, &cs);
+    if (radvel && WHICH == 0) { sn = 1.0; cs = 0.0; }
+    if (radvel && WHICH == 2) { sn = 0.0; cs = 1.0; }
+}
+
+template <bool FAST>
+__device__ __forceinline__ SetupScalars setup_scalars(const double (&elv)[OCTO_N_EL], const DevConsts& cst, int orbit_kind, int has_mass) {
+    SetupScalars q;
     const bool radvel = orbit_kind == OCTO_ORBIT_RADVEL;
     const bool ti = orbit_kind == OCTO_ORBIT_THIELE_INNES;
     const bool kep = orbit_kind == OCTO_ORBIT_KEP;      // plain KepOrbit: no parallax, positions stay in AU (no astrometry tables)
-    const double e = elv[OCTO_EL_E], om = elv[OCTO_EL_W];
-    const double tp = elv[OCTO_EL_TP], Mt = elv[OCTO_EL_M];
-    double sma = elv[OCTO_EL_A];
-    double inc = radvel ? 0.0 : elv[OCTO_EL_I];
-    double Om = radvel ? 0.0 : elv[OCTO_EL_O];
+    const double e = elv[OCTO_EL_E], Mt = elv[OCTO_EL_M];
     const double plx = (radvel || kep) ? 1.0 : elv[OCTO_EL_PLX];
     const double mass = has_mass ? elv[OCTO_EL_MASS] : 0.0;
-    bool ok = isfinite(sma) && isfinite(e) && isfinite(inc) && isfinite(om) && isfinite(Om) && isfinite(tp) &&
-              isfinite(Mt) && isfinite(plx) && isfinite(mass);
-    if (FAST && !ti) ok = ok && fabs(om) < SINCOS_MAX_ANGLE && fabs(inc) < SINCOS_MAX_ANGLE && fabs(Om) < SINCOS_MAX_ANGLE;   // sincos_reduced's domain
-    double T, A, B, F, G, si, ci, sw, cw, sO, cO;
+    double sma = elv[OCTO_EL_A];
     if (ti) {
         // ThieleInnesOrbit: rows a, i, ω, Ω carry A, B, F, G [mas]; a = α/plx   (src/parameterizations.jl:14-19).
         // The reference writes α² = u + √((u+v)(u−v)), u = (A²+B²+F²+G²)/2, v = AG − BF, which cancels in u − v for near-face-on
         // orbits. Same quantity without the cancellation: u ± v are sums of squares, and u + √((u+v)(u−v)) = ½(√(u+v) + √(u−v))².
-        A = sma; B = inc; F = om; G = Om;
+        const double A = elv[OCTO_EL_TI_A], B = elv[OCTO_EL_TI_B], F = elv[OCTO_EL_TI_F], G = elv[OCTO_EL_TI_G];
         const double pp = 0.5 * ((A + G) * (A + G) + (B - F) * (B - F)), mm = 0.5 * ((A - G) * (A - G) + (B + F) * (B + F));
-        sma = fdiv((fsqrt(pp) + fsqrt(mm)) * 0.70710678118654752440, plx);
-        T = 1.0;
-        si = ci = sw = cw = sO = cO = 0.0;
+        sma = setup_fdiv<FAST>((setup_fsqrt<FAST>(pp) + setup_fsqrt<FAST>(mm)) * 0.70710678118654752440, plx);
+        q.T = 1.0;
     } else {
-        // PlanetOrbits KepOrbit ctor invariants: i = rem(i, π, RoundDown), Ω = rem2pi(Ω, RoundDown)
-        inc = inc - PI * floor(inc / PI);
-        Om = Om - TWO_PI * floor(Om / TWO_PI);
-        if constexpr (FAST && LANES) {
-            const double xs[3] = {inc, om, Om};
-            double ss[3], cs[3];
-            sincos_lanes<3>(xs, ss, cs);
-            si = ss[0]; ci = cs[0]; sw = ss[1]; cw = cs[1]; sO = ss[2]; cO = cs[2];
-        } else if constexpr (FAST) { sincos_reduced(inc, si, ci); sincos_reduced(om, sw, cw); sincos_reduced(Om, sO, cO); }
-        else { sincos(inc, &si, &ci); sincos(om, &sw, &cw); sincos(Om, &sO, &cO); }
-        if (radvel) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
         // Thiele-Innes constants (parameterizations.jl:34-37) scaled to mas: T = a · cart2angle
-        T = (radvel || kep) ? 0.0 : sma * plx * cst.mas_per_au_per_plx;   // parameterizations.jl:215-216
+        q.T = (radvel || kep) ? 0.0 : sma * plx * cst.mas_per_au_per_plx;   // parameterizations.jl:215-216
+    }
+    q.sma = sma;
+    const double P_d = cst.k_yr * setup_fsqrt<FAST>(setup_fdiv<FAST>(sma * sma * sma, Mt));       // parameterizations.jl:62
+    const double ome2 = 1.0 - e * e;
+    q.beta = setup_fsqrt<FAST>(ome2);
+    // K = ((2π a)/P_yr)/√(1−e²) · au2m · sec2year · sin i: everything but the sine here
+    q.K0 = setup_fdiv<FAST>(setup_fdiv<FAST>(TWO_PI * sma, setup_fdiv<FAST>(P_d, cst.yd)), q.beta) * cst.au2m * cst.sec2yr;
+    q.invP = setup_fdiv<FAST>(1.0, P_d);
+    q.eob = setup_fdiv<FAST>(e, q.beta);
+    q.f32a = pack_f32x2((float)e, (float)(1.0 - e));
+    q.f32b = pack_f32x2((float)setup_fdiv<FAST>(MK_K1N, 1.0 + e), 0.0f);
+    q.mu = setup_fdiv<FAST>(mass * cst.mjup2msol, Mt);
+    return q;
+}
+
+// validity of one (walker, planet): every element finite and inside the domain (logdensitymodel.jl:120-124, system.jl:214-221)
+template <bool FAST>
+__device__ __forceinline__ bool setup_valid(const double (&elv)[OCTO_N_EL], int orbit_kind, int has_mass, double sma) {
+    const bool radvel = orbit_kind == OCTO_ORBIT_RADVEL;
+    const bool ti = orbit_kind == OCTO_ORBIT_THIELE_INNES;
+    const bool kep = orbit_kind == OCTO_ORBIT_KEP;
+    const double e = elv[OCTO_EL_E], om = elv[OCTO_EL_W], tp = elv[OCTO_EL_TP], Mt = elv[OCTO_EL_M];
+    const double inc = radvel ? 0.0 : elv[OCTO_EL_I], Om = radvel ? 0.0 : elv[OCTO_EL_O];
+    const double plx = (radvel || kep) ? 1.0 : elv[OCTO_EL_PLX];
+    const double mass = has_mass ? elv[OCTO_EL_MASS] : 0.0;
+    bool ok = isfinite(elv[OCTO_EL_A]) && isfinite(e) && isfinite(inc) && isfinite(om) && isfinite(Om) && isfinite(tp) &&
+              isfinite(Mt) && isfinite(plx) && isfinite(mass);
+    if (FAST && !ti) ok = ok && fabs(om) < SINCOS_MAX_ANGLE && fabs(inc) < SINCOS_MAX_ANGLE && fabs(Om) < SINCOS_MAX_ANGLE;   // sincos_reduced's domain
+    return ok && (e >= 0.0) && (e < 1.0) && (sma > 0.0) && (Mt > 0.0) && (plx > 0.0);
+}
+
+// the per-walker constants from the pieces (o: NWC slots; the caller's dead stores fall away after inlining)
+__device__ __forceinline__ void setup_assemble(double* o, const double (&elv)[OCTO_N_EL], int orbit_kind, double si, double ci, double sw, double cw,
+                                               double sO, double cO, const SetupScalars& q) {
+    const bool ti = orbit_kind == OCTO_ORBIT_THIELE_INNES;
+    const double e = elv[OCTO_EL_E], T = q.T, beta = q.beta;
+    double A, B, F, G;
+    if (ti) { A = elv[OCTO_EL_TI_A]; B = elv[OCTO_EL_TI_B]; F = elv[OCTO_EL_TI_F]; G = elv[OCTO_EL_TI_G]; }
+    else {
         A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
         F = -cO * sw - sO * cw * ci; G = -sO * sw + cO * cw * ci;
     }
-    ok = ok && (e >= 0.0) && (e < 1.0) && (sma > 0.0) && (Mt > 0.0) && (plx > 0.0);
-    const double P_d = cst.k_yr * fsqrt(fdiv(sma * sma * sma, Mt));       // parameterizations.jl:62
-    const double ome2 = 1.0 - e * e;
-    const double beta = fsqrt(ome2);
-    // K = ((2π a)/P_yr)/√(1−e²) · au2m · sec2year · sin i
-    const double K = fdiv(fdiv(TWO_PI * sma, fdiv(P_d, cst.yd)), beta) * cst.au2m * cst.sec2yr * si;   // 0 for a ThieleInnesOrbit (no RV tables there)
-    double* o = so.v;
-    o[WC_INVP] = fdiv(1.0, P_d); o[WC_TP] = tp; o[WC_E] = e; o[WC_BETA] = beta;
-    o[WC_EOB] = fdiv(e, beta);
-    o[WC_F32A] = pack_f32x2((float)e, (float)(1.0 - e));
-    o[WC_F32B] = pack_f32x2((float)fdiv(MK_K1N, 1.0 + e), 0.0f);
+    o[WC_INVP] = q.invP; o[WC_TP] = elv[OCTO_EL_TP]; o[WC_E] = e; o[WC_BETA] = beta;
+    o[WC_EOB] = q.eob;
+    o[WC_F32A] = q.f32a;
+    o[WC_F32B] = q.f32b;
     o[WC_CB] = T * B; o[WC_CG] = T * G; o[WC_CA] = T * A; o[WC_CF] = T * F;
     o[WC_CGB] = T * G * beta; o[WC_CFB] = T * F * beta;
     o[WC_CBE] = T * B * e; o[WC_CAE] = T * A * e;
-    o[WC_K] = K; o[WC_COSW] = cw; o[WC_SINW] = sw;
-    o[WC_MU] = fdiv(mass * cst.mjup2msol, Mt); o[WC_A] = sma;
+    o[WC_K] = q.K0 * si;      // 0 for a ThieleInnesOrbit (no RV tables there)
+    o[WC_COSW] = cw; o[WC_SINW] = sw;
+    o[WC_MU] = q.mu; o[WC_A] = q.sma;
     o[WC_SINI] = si; o[WC_COSI] = ci; o[WC_SINO] = sO; o[WC_COSO] = cO;
-    so.ok = ok;
+}
+
+template <bool FAST = false, bool LANES = false>
+__device__ __forceinline__ SetupOut setup_planet_vals(const double (&elv)[OCTO_N_EL], const DevConsts& cst, int orbit_kind, int has_mass) {
+    SetupOut so;
+#pragma unroll
+    for (int k = 0; k < OCTO_N_EL; ++k) so.el[k] = elv[k];
+    double si, ci, sw, cw, sO, cO;
+    if constexpr (FAST && LANES) {
+        if (orbit_kind == OCTO_ORBIT_THIELE_INNES) { si = ci = sw = cw = sO = cO = 0.0; }
+        else {
+            const double xs[3] = {setup_angle_arg<0>(elv, orbit_kind), setup_angle_arg<1>(elv, orbit_kind), setup_angle_arg<2>(elv, orbit_kind)};
+            double ss[3], cs[3];
+            sincos_lanes<3>(xs, ss, cs);
+            si = ss[0]; ci = cs[0]; sw = ss[1]; cw = cs[1]; sO = ss[2]; cO = cs[2];
+            if (orbit_kind == OCTO_ORBIT_RADVEL) { si = 1.0; ci = 0.0; sO = 0.0; cO = 1.0; }
+        }
+    } else {
+        setup_angle<0, FAST>(elv, orbit_kind, si, ci);
+        setup_angle<1, FAST>(elv, orbit_kind, sw, cw);
+        setup_angle<2, FAST>(elv, orbit_kind, sO, cO);
+    }
+    const SetupScalars q = setup_scalars<FAST>(elv, cst, orbit_kind, has_mass);
+    setup_assemble(so.v, elv, orbit_kind, si, ci, sw, cw, sO, cO, q);
+    so.ok = setup_valid<FAST>(elv, orbit_kind, has_mass, q.sma);
     return so;
 }
 
@@ -271,6 +340,7 @@ static __global__ __launch_bounds__(256) void k_setup(EvalArgs a) {
 // routine k_main uses; exported as octo_kepler_solve so tests can check the solver itself.
 // TAB: the throughput kernels' variant (sin/cos of the starter from the sin/cos table, copied to LDS by the block exactly as k_main
 // does); otherwise the half-angle polynomials of k_small / k_hgca.
+#ifdef OCTO_API_TU      // launched from octo_api.hip only
 template <bool TAB>
 static __global__ __launch_bounds__(256) void k_kepler(const double* __restrict__ MA, const double* __restrict__ ecc, int64_t n,
                                                        double* E, double* sE, double* cE, const double* __restrict__ sctab) {
@@ -295,6 +365,8 @@ static __global__ __launch_bounds__(256) void k_kepler(const double* __restrict_
     if (sE) sE[i] = ok ? s.sE : NAN;
     if (cE) cE[i] = ok ? s.cE : NAN;
 }
+
+#endif      // OCTO_API_TU
 
 // ------------------------------------------------------------------------------------ row bodies
 // One observation row for one walker: Kepler solve of every planet, projection, residual, density, and (GRAD) the reverse
@@ -1104,7 +1176,7 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
     // ---- finisher waves: this planet's constants — derived EARLY, while the loaders' partials are in flight, unless the layout is so
     // wide (O'Neil sums in a 1024-thread block: 128 VGPRs per lane) that 18 more live values across the load loop would spill: then
     // after the combine
-    constexpr bool EARLY = !L::HAS_ONEIL || P > 1;      // (several planets: blocks of fin_g(P) = 8 waves, 256 VGPRs per lane)
+    constexpr bool EARLY = true;      // (O'Neil layouts run 8-wave blocks: 256 VGPRs per lane; several planets: finish_tile_multi)
     FinPC fp = {};
     double elv[OCTO_N_EL];
 #pragma unroll
@@ -1249,13 +1321,209 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
     }
 }
 
-// block = 64 walkers × FIN_G waves, one block per tile. FROM_WC = false: after a k_main launch that derived the constants itself.
+// ------------------------------------------------------------------------------------ finish_tile_multi (several planets)
+// The same tail for P >= 2. finish_tile's loaders carry EVERY planet's sums (P·PL_N = 24-48 running sums + as many loads in flight per
+// lane): the 3- and 4-planet instantiations spilled 170-418 VGPRs (round 3). Here a wave only ever holds ONE planet's PL_N sums:
+//   * wave 0 ("observations"): the per-observation columns (S, nuisance adjoints, marginalised-RV and O'Neil sums) of every task, one
+//     observation after the other -> obs_finish, log-likelihood, validity. No other wave touches those columns, so they need no combine.
+//   * waves 1 + p·NWR + j, j < NWR ("planet p"): tasks j, j + NWR, … of ALL tasks, planet p's PL_N columns only. Wave j = 0 of the group
+//     is the planet's finisher: it derives the planet's constants while its first loads are in flight, receives the other waves' sums
+//     through LDS (one barrier, fixed order) and maps them to the nine element adjoints.
+// The forward-only instantiation is wave 0 alone (a 64-thread block): it sums the same columns in the same order as wave 0 of the
+// gradient instantiation, so the value is bit-identical with and without a gradient.
+// LDS: rows 0 .. 7P of 64 doubles (validity flags, O'Neil corrections), then P·(NWR−1)·PL_N rows for the combine.
+template <int P, bool GRAD, bool NUIS, int KM>
+constexpr int fin_waves() {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    if (P == 1) return L::HAS_ONEIL ? FIN_G / 2 : FIN_G;      // (the O'Neil sums next to a planet's in a 1024-thread block: 128 VGPRs per lane, 34 spilled)
+    return GRAD ? 1 + P * fin_nwr(P) : 1;
+}
+template <int P, bool GRAD, bool NUIS, int KM>
+constexpr size_t fin_lds_bytes() {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    if (P == 1) return sizeof(double) * FIN_CH * fin_waves<P, GRAD, NUIS, KM>() * WAVE;
+    return sizeof(double) * WAVE * (size_t)((1 + 7 * P) + (GRAD ? P * (fin_nwr(P) - 1) * L::PL_N : 0));
+}
+
+template <int P, bool GRAD, bool NUIS, int KM, bool FROM_WC>
+__device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t tile, int grp, int lane, double* lds) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    constexpr int NWR = fin_nwr(P);
+    constexpr int PLN = L::PL_N;
+    constexpr int NOB = L::OFF_PL;
+    constexpr int FLAG_ROWS = 1 + 7 * P;
+    constexpr int UNR_O = NOB <= 4 ? 8 : (NOB <= 8 ? 4 : 2);      // tasks in flight: wave 0 (NOB columns each) ...
+    constexpr int UNR_P = P <= 3 ? 4 : (L::HAS_ONEIL ? 2 : 3);     // ... and a planet wave (PL_N columns each; the 9 waves of P = 4 leave 168 VGPRs per lane)
+    const int64_t w = tile * WAVE + lane;
+    const int64_t wl = w < a.W ? w : a.W - 1;
+    const int role_p = grp == 0 ? -1 : (grp - 1) / NWR;           // the planet this wave works for
+    const int sub = grp == 0 ? 0 : (grp - 1) % NWR;
+    const int my_p = (grp > 0 && sub == 0) ? role_p : -1;        // >= 0: this wave finishes planet my_p
+    double gp[PLN > 0 ? PLN : 1];
+#pragma unroll
+    for (int k = 0; k < PLN; ++k) gp[k] = 0.0;
+    double ll = 0.0;
+    double oneil_g[oneil_slots<P, GRAD, NUIS, KM>()];
+#pragma unroll
+    for (int k = 0; k < oneil_slots<P, GRAD, NUIS, KM>(); ++k) oneil_g[k] = 0.0;
+    FinPC fp = {};
+    double elv[OCTO_N_EL];
+#pragma unroll
+    for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = 0.0;
+    bool ok_mine = true;
+    if (grp == 0) {
+        // ---- the observations' own sums -> log-likelihood and nuisance adjoints
+        double sma_p[P], e_p[P], M_p[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) { sma_p[p] = 0.0; e_p[p] = 0.0; M_p[p] = 1.0; }
+        if constexpr (L::HAS_ONEIL) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if constexpr (FROM_WC) sma_p[p] = a.wc[((int64_t)p * NWC + WC_A) * a.ldw + wl];
+                else sma_p[p] = setup_planet<true>(a, p, wl).v[WC_A];
+                e_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wl];
+                M_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wl];
+            }
+        }
+        for (int o = 0; o < a.n_obs; ++o) {
+            double vo[NOB];
+#pragma unroll
+            for (int k = 0; k < NOB; ++k) vo[k] = 0.0;
+            const int t0 = a.obs_range[2 * o], t_end = a.obs_range[2 * o + 1];
+#pragma clang loop unroll_count(UNR_O)
+            for (int tt = t0; tt < t_end; ++tt) {
+                const double* pt = a.partials + (int64_t)tt * L::NACC * a.ldw + wl;
+                double to[NOB];
+#pragma unroll
+                for (int k = 0; k < NOB; ++k) to[k] = pt[(int64_t)k * a.ldw];
+#pragma unroll
+                for (int k = 0; k < NOB; ++k) vo[k] += to[k];
+            }
+            double v[NOBS_ACC];      // S, margA, margB, margC, nu0, nu1, nu2, on0..on3
+#pragma unroll
+            for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
+            v[0] = vo[L::OFF_S];
+            if constexpr (L::HAS_MARG) { v[1] = vo[L::OFF_MARG + 0]; v[2] = vo[L::OFF_MARG + 1]; v[3] = vo[L::OFF_MARG + 2]; }
+            if constexpr (L::N_NU > 0) { v[4] = vo[L::OFF_NU + 0]; v[5] = vo[L::OFF_NU + 1]; v[6] = vo[L::OFF_NU + 2]; }
+            if constexpr (L::HAS_ONEIL) {
+                v[7] = vo[L::OFF_ONEIL + 0];
+                if constexpr (GRAD) { v[8] = vo[L::OFF_ONEIL + 1]; v[9] = vo[L::OFF_ONEIL + 2]; v[10] = vo[L::OFF_ONEIL + 3]; }
+            }
+            // observations are summed in the order given (system.jl:93,186)
+            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + w : nullptr,
+                                                a.ldw, a.c.k_yr, o, v, a.obs_const[o], sma_p, e_p, M_p, w < a.W, oneil_g);
+        }
+        if (a.extra) ll += a.extra[wl];
+        ok_mine = isfinite(ll);
+        if constexpr (FROM_WC) {
+            if constexpr (!GRAD) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) ok_mine = ok_mine && a.valid[(int64_t)p * a.ldw + wl] != 0;
+            }
+        } else {
+            // what k_setup records in `valid`: every planet's elements inside the domain (with a gradient: reported by the planet's
+            // finisher wave), every nuisance finite
+            if constexpr (!GRAD) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) ok_mine = ok_mine && setup_planet<true>(a, p, wl).ok;
+            }
+            if (a.nuis)
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok_mine = ok_mine && isfinite(a.nuis[(int64_t)k * a.ld + wl]);
+        }
+    } else if constexpr (GRAD) {
+        // ---- planet role_p's running sums over every task; the group's first wave derives the planet's constants meanwhile
+        const double* pcol = a.partials + (int64_t)(L::OFF_PL + role_p * PLN) * a.ldw + wl;
+        const int64_t tstride = (int64_t)L::NACC * a.ldw;
+        auto load_sum = [&](int tt) {
+            const double* pt = pcol + (int64_t)tt * tstride;
+            double tmp[PLN];
+#pragma unroll
+            for (int k = 0; k < PLN; ++k) tmp[k] = pt[(int64_t)k * a.ldw];
+#pragma unroll
+            for (int k = 0; k < PLN; ++k) gp[k] += tmp[k];
+        };
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (my_p != p) continue;
+            if constexpr (FROM_WC) {
+                const double* wc = a.wc + (int64_t)p * NWC * a.ldw + wl;
+                fp.sma = wc[WC_A * a.ldw]; fp.P_d = rcp_nr<2>(wc[WC_INVP * a.ldw]); fp.beta = wc[WC_BETA * a.ldw];
+                fp.si = wc[WC_SINI * a.ldw]; fp.ci = wc[WC_COSI * a.ldw]; fp.sO = wc[WC_SINO * a.ldw]; fp.cO = wc[WC_COSO * a.ldw];
+                fp.sw = wc[WC_SINW * a.ldw]; fp.cw = wc[WC_COSW * a.ldw];
+#pragma unroll
+                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl];
+                ok_mine = a.valid[(int64_t)p * a.ldw + wl] != 0;
+            } else {
+                const SetupOut so = setup_planet<true>(a, p, wl);      // the same routine, the same values k_setup would have stored
+                fp.sma = so.v[WC_A]; fp.P_d = rcp_nr<2>(so.v[WC_INVP]); fp.beta = so.v[WC_BETA];
+                fp.si = so.v[WC_SINI]; fp.ci = so.v[WC_COSI]; fp.sO = so.v[WC_SINO]; fp.cO = so.v[WC_COSO];
+                fp.sw = so.v[WC_SINW]; fp.cw = so.v[WC_COSW];
+#pragma unroll
+                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = so.el[k];
+                ok_mine = so.ok;
+            }
+        }
+#pragma clang loop unroll_count(UNR_P)
+        for (int tt = sub; tt < a.n_tasks; tt += NWR) load_sum(tt);
+    }
+    bool ok = ok_mine;
+    if constexpr (GRAD) {
+        double* comb = lds + FLAG_ROWS * WAVE;
+        if (grp > 0 && sub > 0) {
+#pragma unroll
+            for (int k = 0; k < PLN; ++k) comb[((role_p * (NWR - 1) + sub - 1) * PLN + k) * WAVE + lane] = gp[k];
+        }
+        // validity flags (and the O'Neil corrections wave 0 accumulated) cross the waves through LDS rows 0 .. 7P
+        if (grp == 0 || my_p >= 0) lds[(grp == 0 ? 0 : 1 + my_p) * WAVE + lane] = ok_mine ? 1.0 : 0.0;
+        if constexpr (L::HAS_ONEIL) {
+            if (grp == 0) {
+#pragma unroll
+                for (int k = 0; k < P * 6; ++k) lds[(1 + P + k) * WAVE + lane] = oneil_g[k];
+            }
+        }
+        __syncthreads();
+        if (my_p >= 0) {
+#pragma unroll
+            for (int j = 1; j < NWR; ++j) {
+#pragma unroll
+                for (int k = 0; k < PLN; ++k) gp[k] += comb[((my_p * (NWR - 1) + j - 1) * PLN + k) * WAVE + lane];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q <= P; ++q) ok = (q == 0 ? true : ok) && lds[q * WAVE + lane] != 0.0;
+        if constexpr (L::HAS_ONEIL) {
+            if (my_p >= 0) {
+#pragma unroll
+                for (int k = 0; k < P * 6; ++k) oneil_g[k] = lds[(1 + P + k) * WAVE + lane];
+            }
+        }
+    }
+    if (w >= a.W) return;
+    if (grp == 0) {
+        a.ll_out[w] = ok ? ll : -INFINITY;
+        if constexpr (GRAD && L::N_NU > 0) {
+            if (!ok)
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + w] = 0.0;
+        }
+    }
+    if constexpr (GRAD) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (my_p != p) continue;
+            planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
+                                                            a.orbit_kind[p], a.has_mass[p], p, gp, L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
+        }
+    }
+}
+
+// one block per tile of 64 walkers. FROM_WC = false: after a k_main launch that derived the constants itself.
 template <int P, bool GRAD, bool NUIS, int KM, bool FROM_WC = true>
-static __global__ __launch_bounds__(64 * fin_g(P)) void k_finish(EvalArgs a) {
+static __global__ __launch_bounds__((64 * fin_waves<P, GRAD, NUIS, KM>())) void k_finish(EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    finish_tile<P, GRAD, NUIS, KM, fin_g(P), FIN_CH, FROM_WC>(a, (int64_t)blockIdx.x, grp, lane, lds);
+    if constexpr (P == 1) finish_tile<P, GRAD, NUIS, KM, fin_waves<P, GRAD, NUIS, KM>(), FIN_CH, FROM_WC>(a, (int64_t)blockIdx.x, grp, lane, lds);
+    else finish_tile_multi<P, GRAD, NUIS, KM, FROM_WC>(a, (int64_t)blockIdx.x, grp, lane, lds);
 }
 
 // ==================================================================================== OFTI
@@ -1276,6 +1544,7 @@ struct OftiArgs {
     double k_yr, lambda /* 1/σ_ABFG² */, data_quad, log_det_data_cov, log_det_prior_inv, n_log2pi;
 };
 
+#ifdef OCTO_API_TU      // launched from octo_api.hip only
 static __global__ __launch_bounds__(64 * WPB) void k_ofti_main(OftiArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1400,5 +1669,7 @@ static __global__ __launch_bounds__(64) void k_ofti_finish(OftiArgs a) {
         for (int k = 0; k < 4; ++k) a.abfg[(int64_t)k * a.ld + w] = fin ? mu[k] : NAN;
     }
 }
+
+#endif      // OCTO_API_TU
 
 }  // namespace octo

@@ -39,7 +39,7 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
         // The proper-motion anomaly has no epoch loop. A handful of walkers: extra blocks of the same launch, one input direction
         // per wave, lanes over the table's rows (26 µs per call at W = 1 instead of 30 with a launch of its own). More walkers:
         // k_hgca (lane = walker) ahead of k_small — 4-5 more blocks per walker would each fetch the walker's inputs again.
-        if constexpr (NUIS) {
+        if constexpr (NUIS && (KM & KM_HGCA) != 0) {
             const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
             rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
             if (rc) return rc;
@@ -48,7 +48,8 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
             else if constexpr (!MODEL) hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)((a.W + WAVE - 1) / WAVE), (unsigned)n_dir), dim3(WAVE), 0, st, a);
             else return fail(ctx, OCTO_EINVAL, "internal: fused model launch requested for an HGCA dataset beyond hgca_in_small");
         } else {
-            return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
+            return fail(ctx, OCTO_EINVAL, NUIS ? "internal: HGCA dataset dispatched to a kind set without KM_HGCA"
+                                               : "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
         }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -76,30 +77,52 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
     return OCTO_OK;
 }
 
-template <int P, bool GRAD, bool NUIS, int KM>
+// The kind set k_small is instantiated for (a subset of the epoch-loop kernels' sets: rows are per LANE there and the branch on the
+// table's kind is block-uniform, so a wider set costs a one-θ call nothing it can measure — profiles/r4_small_kindsets_ab.txt — while
+// every set costs 1-2 MB of code per planet count): RA/Dec alone; + sep/PA and cor; + O'Neil; + absolute / relative RV; everything.
+constexpr int small_kind_set(int km_rows) {
+    if (km_rows == KM_RADEC) return KM_RADEC;
+    if ((km_rows & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return KM_RADEC | KM_SEPPA | KM_COR;
+    if ((km_rows & ~(KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL)) == 0) return KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL;
+    if ((km_rows & (KM_MARG | KM_ONEIL)) == 0) return KM_ALL & ~KM_MARG & ~KM_ONEIL;
+    return KM_ALL;
+}
+
+template <int P, bool GRAD, bool NUIS, int KMD>
 int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallModel* sm, hipStream_t st) {
+    // KMD: the dataset's kind set, possibly with KM_HGCA. The epoch-loop kernels never see that bit (KM below); k_small does, when it is
+    // compiled with nuisances (an HGCA table without `nuis` is refused at run time, so the nuisance-free variants need no HGCA twin).
+    constexpr int KM = KMD & ~KM_HGCA;
+    constexpr int KS = small_kind_set(KM) | (NUIS ? (KMD & KM_HGCA) : 0);
     using L = Layout<P, GRAD, NUIS, KM>;
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
     const octo_dataset* ds = cds;
     {
-        if (sm) return launch_small<P, GRAD, NUIS, KM, true>(ctx, ds, a, sm, st);      // the caller checked small_eligible
-        if (small_eligible(ctx, ds, a.W)) return launch_small<P, GRAD, NUIS, KM, false>(ctx, ds, a, nullptr, st);
+        if (sm) return launch_small<P, GRAD, NUIS, KS, true>(ctx, ds, a, sm, st);      // the caller checked small_eligible
+        if (small_eligible(ctx, ds, a.W)) return launch_small<P, GRAD, NUIS, KS, false>(ctx, ds, a, nullptr, st);
     }
     if (sm) return fail(ctx, OCTO_EINVAL, "internal: fused model launch requested for an ineligible dataset");
-    // Occupancy of the GRADIENT variant, also for forward-only launches: both then use the same row partition, so the
-    // forward value and the value returned with a gradient are the same sum in the same order — bit-identical, like the
-    // primal of a ForwardDiff dual. Cached per context (= per device) and variant.
-    int& blocks_per_cu = ctx->occupancy[(uint32_t)((P << 16) | ((NUIS ? 1 : 0) << 15) | KM)];
+    // Two launches: the orbit constructors in k_main's prologue (octo_kernels.h: k_main<FUSED>), then k_finish. A marginalised-RV GRADIENT
+    // keeps the round-2 shape (k_setup -> forward pre-pass -> k_marg -> k_main -> k_finish: the pre-pass and k_marg read `wc`); that path,
+    // its non-fused k_main and the k_finish that reads `wc` are compiled for the kind sets with marginalised RV only.
+    const bool marg_ds = L::HAS_MARG && (ds->kind_mask & KM_MARG);
+    // Occupancy of the GRADIENT variant that is launched (FUSED: more registers, and for several planets more LDS), also for forward-only
+    // launches: both then use the same row partition, so the forward value and the value returned with a gradient are the same sum in
+    // the same order — bit-identical, like the primal of a ForwardDiff dual. Cached per context (= per device) and variant.
+    int& blocks_per_cu = ctx->occupancy[(uint32_t)((P << 16) | ((NUIS ? 1 : 0) << 15) | ((marg_ds ? 1 : 0) << 14) | KM)];
     if (blocks_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM>, WAVE * WPB, (main_lds_bytes<P, true, NUIS, KM>())) != hipSuccess || nb < 1)
-            nb = 2;
+        hipError_t qe = hipErrorUnknown;
+        if constexpr (L::HAS_MARG) {
+            if (marg_ds) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM, false>, WAVE * WPB, (main_lds_bytes<P, true, NUIS, KM>()));
+        }
+        if (!marg_ds) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM, true>, WAVE * WPB, (fused_lds_bytes<P, true, NUIS, KM>()));
+        if (qe != hipSuccess || nb < 1) nb = 2;
         blocks_per_cu = nb;
     }
     TaskTable* tt = nullptr;
     int rc0 = get_tasks(ctx, ds, plan_key(ctx, a.W, ds->n_rows, blocks_per_cu), &tt, NUIS);
     if (rc0) return rc0;
-    const Task* tt_tasks = tt->h_tasks.data();
     a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;
     a.obs_range = tt->d_obs_range; a.obs_const = NUIS ? tt->d_obs_const_raw : tt->d_obs_const_pre;
     a.n_tasks = tt->n_tasks;
@@ -107,43 +130,51 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     int rc = grow(ctx, ctx->d_partials, ctx->cap_part, need);
     if (rc) return rc;
     a.partials = ctx->d_partials;
-    // Two launches: the orbit constructors in k_main's prologue (octo_kernels.h: k_main<FUSED>), then k_finish. Not with a
-    // marginalised-RV gradient (its forward pre-pass and k_marg read `wc`) and not without row tasks: those keep k_setup.
-    if (a.W <= ctx->fused_w && a.n_tasks > 0 && !(GRAD && L::HAS_MARG && (ds->kind_mask & KM_MARG))) {
-        a.extra = nullptr; a.marg = nullptr; a.marg_out = nullptr;
-        if (ds->n_hgca > 0) {      // the proper-motion anomaly term: k_finish adds it
-            if constexpr (NUIS) {
-                const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
-                rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
-                if (rc) return rc;
-                a.extra = ctx->d_extra;
-                hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)cols, (unsigned)n_dir), dim3(WAVE), 0, st, a);
-            } else {
-                return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
-            }
+    a.extra = nullptr; a.marg = nullptr; a.marg_out = nullptr;
+    auto hgca_term = [&]() -> int {      // the proper-motion anomaly (no epoch loop): k_hgca ahead of k_finish, which adds it
+        if (ds->n_hgca == 0) return OCTO_OK;
+        if constexpr (NUIS) {
+            const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
+            int rcx = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
+            if (rcx) return rcx;
+            a.extra = ctx->d_extra;
+            hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)cols, (unsigned)n_dir), dim3(WAVE), 0, st, a);
+            return OCTO_OK;
+        } else {
+            return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
         }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
-        if (timed) {
-            if (ctx->ev_used == ctx->ev_pool.size()) {
-                hipEvent_t x, y;
-                HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
-                ctx->ev_pool.emplace_back(x, y);
-            }
-            e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
-            HIPCHK(ctx, hipEventRecord(e0, st));
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto timing_begin = [&]() -> int {      // HIP events around k_main of every timing_every-th evaluation, on its launch stream
+        if (!(ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0)) return OCTO_OK;
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            hipEvent_t x, y;
+            HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
+            ctx->ev_pool.emplace_back(x, y);
         }
-        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
-                           (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
-        if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
-        hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * fin_g(P)), sizeof(double) * FIN_CH * fin_g(P) * WAVE, st, a);
+        e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
+        HIPCHK(ctx, hipEventRecord(e0, st));
+        return OCTO_OK;
+    };
+    if (!(GRAD && marg_ds)) {
+        rc = hgca_term();
+        if (rc) return rc;
+        if (a.n_tasks > 0) {      // (a dataset without rows — an HGCA table alone, empty tables — is k_finish's closed forms only)
+            rc = timing_begin();
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                               (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+            if (e1) HIPCHK(ctx, hipEventRecord(e1, st));
+        }
+        hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * fin_waves<P, GRAD, NUIS, KM>()), (fin_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
         HIPCHK(ctx, hipGetLastError());
         return OCTO_OK;
     }
-    const dim3 gsetup((unsigned)((a.W + 255) / 256));
-    hipLaunchKernelGGL(k_setup, dim3(gsetup.x, (unsigned)a.n_planets), dim3(256), 0, st, a);
-    if (a.n_tasks > 0) {
-        if (GRAD && L::HAS_MARG && (ds->kind_mask & KM_MARG)) {
+    if constexpr (GRAD && L::HAS_MARG) {
+        const Task* tt_tasks = tt->h_tasks.data();
+        const dim3 gsetup((unsigned)((a.W + 255) / 256));
+        hipLaunchKernelGGL(k_setup, dim3(gsetup.x, (unsigned)a.n_planets), dim3(256), 0, st, a);
+        if (a.n_tasks > 0) {
             // marginalised RV: forward pre-pass over those tables' tasks for μ̂ and A, then the gradient pass
             using L0 = Layout<P, false, NUIS, KM>;
             static_assert(L0::NACC <= L::NACC, "forward partials fit in the gradient buffer");
@@ -156,7 +187,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
                 while (t1 < a.n_tasks && tt_tasks[t1].obs == o) ++t1;
                 if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) {
                     a.task0 = t0;
-                    hipLaunchKernelGGL((k_main<P, false, NUIS, KM>), dim3((unsigned)cols, (unsigned)(t1 - t0)), dim3(WAVE * WPB),
+                    hipLaunchKernelGGL((k_main<P, false, NUIS, KM, false>), dim3((unsigned)cols, (unsigned)(t1 - t0)), dim3(WAVE * WPB),
                                        (main_lds_bytes<P, false, NUIS, KM>()), st, a);
                 }
                 t0 = t1;
@@ -164,37 +195,17 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
             a.task0 = 0;
             hipLaunchKernelGGL((k_marg<P, NUIS, KM>), gsetup, dim3(256), 0, st, a);
             a.marg = ctx->d_marg;
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0;
-        if (timed) {
-            if (ctx->ev_used == ctx->ev_pool.size()) {
-                hipEvent_t x, y;
-                HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
-                ctx->ev_pool.emplace_back(x, y);
-            }
-            e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
-            HIPCHK(ctx, hipEventRecord(e0, st));
-        }
-        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
-                           (main_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
-        if (timed) HIPCHK(ctx, hipEventRecord(e1, st));
-    }
-    a.extra = nullptr;
-    if (ds->n_hgca > 0) {
-        if constexpr (NUIS) {
-            const int n_dir = P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS;
-            rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
+            rc = timing_begin();
             if (rc) return rc;
-            a.extra = ctx->d_extra;
-            hipLaunchKernelGGL((k_hgca<P>), dim3((unsigned)cols, (unsigned)n_dir), dim3(WAVE), 0, st, a);
-        } else {
-            return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
+            hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                               (main_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+            if (e1) HIPCHK(ctx, hipEventRecord(e1, st));
         }
+        rc = hgca_term();
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols), dim3(WAVE * fin_waves<P, GRAD, NUIS, KM>()), (fin_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+        HIPCHK(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM>), dim3((unsigned)cols), dim3(WAVE * fin_g(P)),
-                       sizeof(double) * FIN_CH * fin_g(P) * WAVE, st, a);
-    HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;
 }
 
@@ -207,7 +218,14 @@ int dispatch2(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, boo
 template <int P>
 int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st) {
     // The smallest compiled kind set that covers the dataset: registers and occupancy are not paid for code it never runs.
-    const int km = ds->kind_mask;
+    const int km = ctx->env_kind_all ? KM_ALL : (ds->kind_mask & ~KM_HGCA);      // OCTO_KIND_ALL: experiments (what the narrower kind sets buy)
+    if (ds->kind_mask & KM_HGCA) {
+        // an HGCA table next to the rows: three kind sets carry k_small's proper-motion-anomaly block (the usual companions of an HGCA
+        // term are relative astrometry and RVs); the epoch-loop kernels behind them are the same instantiations as without the table
+        if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR | KM_HGCA>(ctx, ds, a, grad, nuis, sm, st);
+        if ((km & (KM_MARG | KM_ONEIL)) == 0) return dispatch2<P, (KM_ALL & ~KM_MARG & ~KM_ONEIL) | KM_HGCA>(ctx, ds, a, grad, nuis, sm, st);
+        return dispatch2<P, KM_ALL | KM_HGCA>(ctx, ds, a, grad, nuis, sm, st);
+    }
     if ((km & ~KM_RADEC) == 0) return dispatch2<P, KM_RADEC>(ctx, ds, a, grad, nuis, sm, st);
     if ((km & ~(KM_RADEC | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_COR>(ctx, ds, a, grad, nuis, sm, st);
     if ((km & ~(KM_RADEC | KM_RVABS)) == 0) return dispatch2<P, KM_RADEC | KM_RVABS>(ctx, ds, a, grad, nuis, sm, st);      // BASELINE config 4

@@ -249,6 +249,7 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
     return dconst<N, FAST>(theta_epoch) - (MA / n) * yd;
 }
 
+#ifdef OCTO_API_TU      // the non-template kernels are launched from octo_api.hip only: one copy in the library, not one per translation unit
 // block = 64 walkers × DB partials (DB = min(D, 8) waves), grid = (walker tiles, ⌈D/DB⌉). Thread (w, d) carries the
 // value and ONE partial (∂/∂θ_t[d]) of every quantity, so a wave is 64 walkers × one partial: uniform control flow,
 // coalesced Jacobian rows, D× the parallelism of a thread-per-walker layout. The diagonal part — invlink and
@@ -411,6 +412,7 @@ static __global__ __launch_bounds__(256) void k_model_bwd(ModelArgs a) {
     }
     a.grad_out[(int64_t)d * a.ld + w] = ok ? g : 0.0;
 }
+#endif      // OCTO_API_TU
 #undef DFOR
 #undef DT
 #undef DU

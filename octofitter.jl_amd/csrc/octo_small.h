@@ -23,6 +23,9 @@
 namespace octo {
 
 constexpr int SMALL_W = OCTO_SMALL_BATCH_MAX;
+#ifndef OCTO_SMALL_WAVE_SETUP
+#define OCTO_SMALL_WAVE_SETUP 1      // several planets: wave p derives planet p's orbit constants (0: every wave derives all of them, rounds 2-3)
+#endif
 constexpr int SMALL_TPB = 256;
 
 template <int CTRL, int ROW_MASK>
@@ -251,11 +254,15 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     //   wave 2       the UnitLengthPrior term of every pair and their sum over the sources that carry one, ∂/∂θ_t[lane]
     // and meet at one barrier; the finishing wave picks the sums up from LDS at the end.
     LaneTheta T{0.0, 0.0, lane};
-    D1 elD[P][OCTO_N_EL];
-    D1 ul = dconst<1, true>(0.0);                       // Σ UnitLengthPrior terms (value and this lane's partial): from wave 2, through LDS
+    D1 ul = dconst<1, true>(0.0);                       // Σ UnitLengthPrior terms (value and this lane's partial): from wave 2, through LDS — read at the finish
     CircTable CT{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
-    double lpp = 0.0, glp = 0.0;                        // Σ logpdf_with_trans in declaration order, and ∂/∂θ_t[lane]: from wave 1, through LDS
     bool finite_in = true;
+    // What only the FINISH needs again is parked in LDS across the row loop instead of being held in registers (the 3- and 4-planet model
+    // launches spilled up to 262 VGPRs in round 3): ∂(element)/∂θ_t[lane] of every element (wave 0 of a block computes them; the finishing
+    // wave is a wave 0), and per planet the element values + the nine constants planet_finish takes (wave-uniform: one word each).
+    constexpr int PARK_N = OCTO_N_EL + 9;
+    __shared__ double park_fin[P][PARK_N];
+    __shared__ double park_eld[(MODEL && GRAD) ? P * OCTO_N_EL * WAVE : 1];
     __shared__ double mblob[MODEL ? SMALL_BLOB_MAX : 1];
     __shared__ double mx_glp[MODEL ? WAVE : 1], mx_uld[MODEL ? WAVE : 1], mx_s[2];      // wave 1 -> finisher, wave 2 -> finisher, {lpp, Σ ul}
     __shared__ double mx_el[MODEL ? P * OCTO_N_EL : 1], mx_nu[MODEL ? SMALL_MX_NU : 1];   // wave 0 -> every wave: element and nuisance values
@@ -348,25 +355,30 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
             TRACE_POINT();      // (MODEL) UniformCircular angles
 #pragma unroll
             for (int p = 0; p < P; ++p) {
+                D1 elD[OCTO_N_EL];
 #pragma unroll
                 for (int k = 0; k < OCTO_N_EL; ++k) {
                     const octo_source sc = blob_src(sm.off_esrc, p * OCTO_N_EL + k);
-                    elD[p][k] = (sc.kind == OCTO_SRC_TPERI) ? dconst<1, true>(0.0) : src_plain(sc, blob_slot(p * OCTO_N_EL + k), CT, T, ul, false);
+                    elD[k] = (sc.kind == OCTO_SRC_TPERI) ? dconst<1, true>(0.0) : src_plain(sc, blob_slot(p * OCTO_N_EL + k), CT, T, ul, false);
                 }
                 const octo_source sc = blob_src(sm.off_esrc, p * OCTO_N_EL + OCTO_EL_TP);
                 if (sc.kind == OCTO_SRC_TPERI) {    // tp = θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω | plx, A, B, F, G), parameterizations.jl:6-69
                     const D1 th = src_angle(sc, blob_slot(p * OCTO_N_EL + OCTO_EL_TP), CT, T, ul, false);
                     // sin/cos of Ω, ω, i, θ in one pass, lane j taking angle j (the values are wave-uniform here)
-                    const double xs[4] = {elD[p][OCTO_EL_O].v, elD[p][OCTO_EL_W].v, elD[p][OCTO_EL_I].v, th.v};
+                    const double xs[4] = {elD[OCTO_EL_O].v, elD[OCTO_EL_W].v, elD[OCTO_EL_I].v, th.v};
                     double ss[4], cs[4];
                     sincos_lanes<4>(xs, ss, cs);
                     const double pre[4][2] = {{ss[0], cs[0]}, {ss[1], cs[1]}, {ss[2], cs[2]}, {ss[3], cs[3]}};
-                    elD[p][OCTO_EL_TP] = tperi(th, sc.value, elD[p][OCTO_EL_M], elD[p][OCTO_EL_E], elD[p][OCTO_EL_A], elD[p][OCTO_EL_I],
-                                               elD[p][OCTO_EL_W], elD[p][OCTO_EL_O], sm.k_yr, sm.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &elD[p][OCTO_EL_PLX], pre);
+                    elD[OCTO_EL_TP] = tperi(th, sc.value, elD[OCTO_EL_M], elD[OCTO_EL_E], elD[OCTO_EL_A], elD[OCTO_EL_I],
+                                            elD[OCTO_EL_W], elD[OCTO_EL_O], sm.k_yr, sm.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &elD[OCTO_EL_PLX], pre);
                 }
                 if (lane == 0) {
 #pragma unroll
-                    for (int k = 0; k < OCTO_N_EL; ++k) mx_el[p * OCTO_N_EL + k] = elD[p][k].v;
+                    for (int k = 0; k < OCTO_N_EL; ++k) mx_el[p * OCTO_N_EL + k] = elD[k].v;
+                }
+                if constexpr (GRAD) {      // this lane's partial of every element: parked for the finish (which a wave 0 runs)
+#pragma unroll
+                    for (int k = 0; k < OCTO_N_EL; ++k) park_eld[(p * OCTO_N_EL + k) * WAVE + lane] = elD[k].d[0];
                 }
             }
             if constexpr (NUIS) {      // the nuisance VALUES, for every wave's row tasks (their partials: the finishing wave, below)
@@ -377,39 +389,97 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 }
             }
         }
-        __syncthreads();      // elements, nuisances, prior and UnitLength sums are in LDS
-        lpp = mx_s[0]; glp = mx_glp[lane];
-        ul.v = mx_s[1]; ul.d[0] = mx_uld[lane];
+        __syncthreads();      // elements, nuisances, prior and UnitLength sums are in LDS (the sums are picked up at the finish)
     }
 
     if constexpr (MODEL) { TRACE_POINT(); }      // (MODEL) elements resolved (θ_at_epoch_to_tperi included)
     // ---- orbit constants of this walker (what k_setup would have written to `wc`)
+    // One planet: every wave derives them itself (no exchange). Several planets: WAVE p derives planet p — the waves run on different
+    // SIMDs, so the P orbit constructors (~300 dependent instructions each) run side by side instead of one after the other in every
+    // wave — and lane 0 publishes the planet's NWC constants, validity flag and the finish's parked values through LDS; after ONE barrier
+    // every wave reads all P sets back (wave-uniform LDS reads). Everything a wave reads of another planet comes out of LDS after that
+    // barrier — nothing per-planet stays in a register array that only one wave has filled (the round-3 attempt).
     PC pc[P];
-    FinPC fp[P];
-    double elv[P][OCTO_N_EL];
     bool ok = true;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
+    constexpr bool WAVE_SETUP = (P > 1) && OCTO_SMALL_WAVE_SETUP;
+    __shared__ double park_pc[WAVE_SETUP ? P : 1][NWC];
+    __shared__ int park_ok[WAVE_SETUP ? P : 1];
+    static_assert(P <= SMALL_TPB / WAVE, "k_small: one wave per planet for the orbit constants");
+    auto load_elv = [&](int p, double (&elv)[OCTO_N_EL]) {      // p: compile-time constant or wave-uniform
         if constexpr (MODEL) {
 #pragma unroll
-            for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = mx_el[p * OCTO_N_EL + k];      // wave 0's values, through LDS
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = mx_el[p * OCTO_N_EL + k];      // wave 0's values, through LDS
         } else {
             if (inl.n > 0) {
+                if constexpr (WAVE_SETUP) {      // (p is this wave's index: the values come from the argument block with a run-time offset)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+                    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma clang diagnostic pop
+                    const double* iv = reinterpret_cast<const double*>(ka + offsetof(SmallKernargs, inl) + offsetof(SmallInline, v)) + p * OCTO_N_EL;
 #pragma unroll
-                for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = inl.v[p * OCTO_N_EL + k];
+                    for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = iv[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = inl.v[p * OCTO_N_EL + k];
+                }
             } else {
                 const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + wi;
 #pragma unroll
-                for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = el[(int64_t)k * a.ld];
+                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = el[(int64_t)k * a.ld];
             }
         }
-        const SetupOut so = setup_planet_vals<true, true>(elv[p], a.c, a.orbit_kind[p], a.has_mass[p]);      // wave-uniform elements: lane-batched sincos
-        pc_from_setup(pc[p], so.v);
-        fp[p].sma = so.v[WC_A]; fp[p].P_d = 1.0 / so.v[WC_INVP]; fp[p].beta = so.v[WC_BETA];
-        fp[p].si = so.v[WC_SINI]; fp[p].ci = so.v[WC_COSI]; fp[p].sO = so.v[WC_SINO]; fp[p].cO = so.v[WC_COSO];
-        fp[p].sw = so.v[WC_SINW]; fp[p].cw = so.v[WC_COSW];
-        ok = ok && so.ok;
+    };
+    auto park_planet = [&](int p, const double (&elv)[OCTO_N_EL], const SetupOut& so) {
+        // for the finish (and the HGCA block): [elements | sma, P_d, β, sin i, cos i, sin Ω, cos Ω, sin ω, cos ω]
+#pragma unroll
+        for (int k = 0; k < OCTO_N_EL; ++k) park_fin[p][k] = elv[k];
+        double* q = &park_fin[p][OCTO_N_EL];
+        q[0] = so.v[WC_A]; q[1] = 1.0 / so.v[WC_INVP]; q[2] = so.v[WC_BETA]; q[3] = so.v[WC_SINI]; q[4] = so.v[WC_COSI];
+        q[5] = so.v[WC_SINO]; q[6] = so.v[WC_COSO]; q[7] = so.v[WC_SINW]; q[8] = so.v[WC_COSW];
+    };
+    if constexpr (WAVE_SETUP) {
+        if (wv < P) {
+            double elv[OCTO_N_EL];
+            load_elv(wv, elv);
+            int okind = a.orbit_kind[0], hmass = a.has_mass[0];      // select chains on the wave index: no run-time index into the argument arrays
+#pragma unroll
+            for (int p = 1; p < P; ++p) { okind = (wv == p) ? a.orbit_kind[p] : okind; hmass = (wv == p) ? a.has_mass[p] : hmass; }
+            const SetupOut so = setup_planet_vals<true, true>(elv, a.c, okind, hmass);      // wave-uniform elements: lane-batched sincos
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < NWC; ++k) park_pc[wv][k] = so.v[k];
+                park_ok[wv] = so.ok ? 1 : 0;
+                park_planet(wv, elv, so);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double v[NWC];
+#pragma unroll
+            for (int k = 0; k < NWC; ++k) v[k] = park_pc[p][k];
+            pc_from_setup(pc[p], v);
+            ok = ok && park_ok[p] != 0;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double elv[OCTO_N_EL];
+            load_elv(p, elv);
+            const SetupOut so = setup_planet_vals<true, true>(elv, a.c, a.orbit_kind[p], a.has_mass[p]);      // wave-uniform elements: lane-batched sincos
+            pc_from_setup(pc[p], so.v);
+            if (threadIdx.x == 0) park_planet(p, elv, so);
+            ok = ok && so.ok;
+        }
     }
+    __syncthreads();      // the parked values are visible to every wave (the HGCA block's waves read them)
+    auto parked_fp = [&](int p) {
+        FinPC f;
+        const double* q = &park_fin[p][OCTO_N_EL];
+        f.sma = q[0]; f.P_d = q[1]; f.beta = q[2]; f.si = q[3]; f.ci = q[4]; f.sO = q[5]; f.cO = q[6]; f.sw = q[7]; f.cw = q[8];
+        return f;
+    };
     // nuisance rows of observation o: from memory, or (MODEL) from their sources
     auto nuis_of = [&](int o, int obs_kind, double (&nu)[OCTO_N_NUIS], D1* nuD, bool count_ul) {
         if constexpr (MODEL) {
@@ -520,7 +590,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
         }
         __syncthreads();
     }
-    if constexpr (NUIS) {
+    if constexpr (NUIS && (KM & KM_HGCA) != 0) {
         if (task >= n_base) {
             // ---- HGCAInstantaneousObs (octo_hgca.h): wave wv of this block carries input direction d as a one-partial dual (what
             // k_hgca does with one thread per (walker, direction)); its lanes take the table's rows. The forward-only launch needs
@@ -532,6 +602,11 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 const int dir = GRAD ? d : -1;
                 HgcaPlanet hp[P];
                 bool visual[P];
+                double elv[P][OCTO_N_EL];      // (thread 0 parked them; the barrier below the setup made them visible)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = park_fin[p][k];
                 hgca_setup<P>(elv, a.orbit_kind, a.has_mass, a.c, dir, hp, visual);
                 DH llh = dconst<1>(0.0);
                 for (int o = 0; o < a.n_obs; ++o) {
@@ -629,7 +704,7 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
     for (int k = 0; k < oneil_slots<P, GRAD, NUIS, KM>(); ++k) oneil_g[k] = 0.0;
     double sma_p[P], e_p[P], M_p[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) { sma_p[p] = fp[p].sma; e_p[p] = elv[p][OCTO_EL_E]; M_p[p] = elv[p][OCTO_EL_M]; }
+    for (int p = 0; p < P; ++p) { sma_p[p] = park_fin[p][OCTO_N_EL]; e_p[p] = park_fin[p][OCTO_EL_E]; M_p[p] = park_fin[p][OCTO_EL_M]; }
     for (int o = 0; o < a.n_obs; ++o) {
         const int t0 = a.obs_range[2 * o], t1 = a.obs_range[2 * o + 1];
         if (slot < NTS) {
@@ -685,30 +760,91 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
         }
         __syncthreads();
     }
-    if (wv != 0) return;
     TRACE_POINT();      // observations finished
-    double gp[P * L::PL_N > 0 ? P * L::PL_N : 1];
+    // ---- element adjoints. One planet: wave 0 alone. Several planets (WAVE_FIN): wave p maps planet p's running sums to its nine element
+    // adjoints — planet_finish is ~250 dependent instructions, and P of them one after the other in wave 0 were most of the finish; the
+    // sums, the O'Neil corrections and the validity verdict reach the waves through LDS (one barrier), and for the fused model launch
+    // each wave's share of Σ_k J[k][lane]·ḡ[k] goes back to wave 0 the same way (summed in planet order: deterministic).
+    constexpr bool WAVE_FIN = GRAD && WAVE_SETUP;
+    constexpr int FX_OK = NACC, FX_ONEIL = NACC + 1, FX_N = NACC + 1 + oneil_slots<P, GRAD, NUIS, KM>();
+    __shared__ double fin_x[WAVE_FIN ? FX_N : 1];
+    __shared__ double fin_gth[(WAVE_FIN && MODEL) ? P * WAVE : 1];
+    if (wv == 0) {
+        if (multi && lane == 0) __hip_atomic_store(&counters[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        if (a.extra) ll += a.extra[w];      // the HGCA term (this walker's extra blocks)
+        ok = ok && isfinite(ll);
+        if constexpr (WAVE_FIN) {
+            if (lane < NACC) fin_x[lane] = gp_acc;
+            if (lane == 0) {
+                fin_x[FX_OK] = ok ? 1.0 : 0.0;
+                if constexpr (L::HAS_ONEIL) {
 #pragma unroll
-    for (int k = 0; k < P * L::PL_N; ++k) gp[k] = lane_value(gp_acc, L::OFF_PL + k);
-    if (multi && lane == 0) __hip_atomic_store(&counters[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-    if (a.extra) ll += a.extra[w];      // the HGCA term (this walker's extra blocks)
-    ok = ok && isfinite(ll);
+                    for (int k = 0; k < P * 6; ++k) fin_x[FX_ONEIL + k] = oneil_g[k];
+                }
+            }
+        }
+    }
+    if constexpr (WAVE_FIN) {
+        __syncthreads();
+        if (wv < P) {
+            const int pm = wv;      // this wave's planet (wave-uniform, run time)
+            const bool okf = fin_x[FX_OK] != 0.0;
+            double gpl[L::PL_N], ogl[6], elv[OCTO_N_EL];
+#pragma unroll
+            for (int k = 0; k < L::PL_N; ++k) gpl[k] = fin_x[L::OFF_PL + pm * L::PL_N + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ogl[k] = L::HAS_ONEIL ? fin_x[FX_ONEIL + pm * 6 + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = park_fin[pm][k];
+            int okind = a.orbit_kind[0], hmass = a.has_mass[0];
+#pragma unroll
+            for (int p = 1; p < P; ++p) { okind = (pm == p) ? a.orbit_kind[p] : okind; hmass = (pm == p) ? a.has_mass[p] : hmass; }
+            if constexpr (MODEL) {
+                double gel[OCTO_N_EL];
+                planet_finish<P, GRAD, NUIS, KM, true>(elv, gel, 1, a.extra ? a.extra + w : nullptr, a.ldw, a.c, okind, hmass, pm, gpl, L::HAS_ONEIL ? ogl : nullptr, parked_fp(pm), okf);
+                double g = 0.0;
+#pragma unroll
+                for (int k = 0; k < OCTO_N_EL; ++k) g = fma(park_eld[(pm * OCTO_N_EL + k) * WAVE + lane], gel[k], g);
+                fin_gth[pm * WAVE + lane] = g;
+            } else {
+                if (lane == 0)
+                    planet_finish<P, GRAD, NUIS, KM, true>(elv, a.g_elems + (int64_t)pm * OCTO_N_EL * a.ld + wo, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c, okind, hmass,
+                                                           pm, gpl, L::HAS_ONEIL ? ogl : nullptr, parked_fp(pm), okf);
+                // the adjoints of planets 1.. are stored by waves 1..: acknowledged before the barrier that precedes wave 0's completion flag
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+    }
+    if (wv != 0) return;
     if constexpr (MODEL) {
         // ℓπcallback: non-finite θ_t -> -Inf; non-finite prior -> returned without the likelihood (logdensitymodel.jl:120-133);
         // the UnitLengthPrior terms are likelihood terms of the reference (variables.jl:309-323): part of ll, never healed
+        const double lpp = mx_s[0], glp = mx_glp[lane];      // wave 1's and wave 2's sums of THIS block (the prologue's barrier published them)
+        ul.v = mx_s[1]; ul.d[0] = mx_uld[lane];
         const double llk = ok ? ll + ul.v : -INFINITY;
         const double lpr = finite_in ? lpp : -INFINITY;
         double lp = isfinite(lpr) ? lpr + llk : lpr;
         if (isnan(lp)) lp = -INFINITY;
         const bool fin = isfinite(lp);
         if constexpr (GRAD) {
+            if constexpr (WAVE_FIN) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                double gel[OCTO_N_EL];
-                planet_finish<P, GRAD, NUIS, KM, true>(elv[p], gel, 1, a.extra ? a.extra + w : nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p], p, &gp[p * L::PL_N],
-                                                       L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp[p], ok);
+                for (int p = 0; p < P; ++p) gth += fin_gth[p * WAVE + lane];
+            } else {
+                double gp[P * L::PL_N > 0 ? P * L::PL_N : 1];
 #pragma unroll
-                for (int k = 0; k < OCTO_N_EL; ++k) gth = fma(elD[p][k].d[0], gel[k], gth);
+                for (int k = 0; k < P * L::PL_N; ++k) gp[k] = lane_value(gp_acc, L::OFF_PL + k);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double gel[OCTO_N_EL], elv[OCTO_N_EL];
+#pragma unroll
+                    for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = park_fin[p][k];
+                    planet_finish<P, GRAD, NUIS, KM, true>(elv, gel, 1, a.extra ? a.extra + w : nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p], p, &gp[p * L::PL_N],
+                                                           L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, parked_fp(p), ok);
+#pragma unroll
+                    for (int k = 0; k < OCTO_N_EL; ++k) gth = fma(park_eld[(p * OCTO_N_EL + k) * WAVE + lane], gel[k], gth);
+                }
             }
             if (lane < sm.D) sm.grad_out[(int64_t)lane * sm.ld_o + w * sm.ws_o] = fin ? glp + ul.d[0] + gth : 0.0;
         }
@@ -720,10 +856,19 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 if (!ok && L::N_NU > 0) {
                     for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + wo] = 0.0;
                 }
+                if constexpr (!WAVE_FIN) {
+                    double gp[P * L::PL_N > 0 ? P * L::PL_N : 1];
 #pragma unroll
-                for (int p = 0; p < P; ++p)
-                    planet_finish<P, GRAD, NUIS, KM, true>(elv[p], a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p],
-                                                           p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp[p], ok);
+                    for (int k = 0; k < P * L::PL_N; ++k) gp[k] = lane_value(gp_acc, L::OFF_PL + k);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        double elv[OCTO_N_EL];
+#pragma unroll
+                        for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = park_fin[p][k];
+                        planet_finish<P, GRAD, NUIS, KM, true>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c, a.orbit_kind[p], a.has_mass[p],
+                                                               p, &gp[p * L::PL_N], L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, parked_fp(p), ok);
+                    }
+                }
             }
         }
     }

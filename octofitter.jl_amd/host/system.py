@@ -243,7 +243,10 @@ class BatchedLnLike:
                     out["pmdec"] = out.get("pmdec", 0.0) + g_nuis[io * capi.N_NUIS + 1]
                     continue
                 names = ("jitter", "platescale", "northangle") if obs.kind in capi.ASTROM_KINDS else ("offset", "jitter", getattr(obs, "trend_coef", None))
-                d = {nm: g_nuis[io * capi.N_NUIS + k] for k, nm in enumerate(names) if nm is not None}
+                d = {}
+                for k, nm in enumerate(names):      # summed per NAME: a trend coefficient may be the variable that is also `offset` or `jitter`
+                    if nm is not None:
+                        d[nm] = d.get(nm, 0.0) + g_nuis[io * capi.N_NUIS + k]
                 if ip >= 0:
                     out["planets"][plname]["observations"][key] = d
                 else:

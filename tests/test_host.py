@@ -138,6 +138,12 @@ def test_rv_trend_reaches_pack_and_model_sources(pkg):
     assert nuis.shape == (3, 2) and nuis[pkg.capi.NU_RV_TREND].tolist() == [0.1, 0.2] and nuis[0].tolist() == [50.0, 49.0]
     g = fn.unpack_grad(np.zeros((9, 2)), np.arange(6.0).reshape(3, 2))
     assert g["planets"]["b"]["observations"]["RelRV"]["trend_slope"].tolist() == [4.0, 5.0]
+    # a trend whose coefficient is the variable that is also the table's offset (trend_function = θ.offset·b(t)): the two rows' adjoints
+    # belong to ONE variable and are summed (the later dict key used to overwrite the earlier one)
+    o.trend_coef = "offset"
+    g = fn.unpack_grad(np.zeros((9, 2)), np.arange(6.0).reshape(3, 2))
+    assert g["planets"]["b"]["observations"]["RelRV"]["offset"].tolist() == [0.0 + 4.0, 1.0 + 5.0]
+    assert g["planets"]["b"]["observations"]["RelRV"]["jitter"].tolist() == [2.0, 3.0]
     fn._ds = fn._ctx = None
 
 

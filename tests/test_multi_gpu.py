@@ -120,6 +120,11 @@ def test_eval_begin_end_overlap_two_contexts(pkg):
     for p, (ll, g) in zip((a, b), outs):
         assert lib.octo_eval_begin(p.ctx, p.ds, capi._dptr(el), None, W, W, capi._dptr(ll), capi._dptr(g), None) == 0
     assert lib.octo_eval_begin(a.ctx, a.ds, capi._dptr(el), None, W, W, capi._dptr(outs[0][0]), None, None) == capi.OCTO_EINVAL   # one outstanding begin per context
+    # a blocking octo_eval in between is refused too — and must leave the outstanding evaluation intact (its error path
+    # cleared `pending`, so the later octo_eval_end returned OK without waiting or copying the results out)
+    scratch_ll = np.full(W, np.nan)
+    assert lib.octo_eval(a.ctx, a.ds, capi._dptr(el), None, W, W, capi._dptr(scratch_ll), None, None) == capi.OCTO_EINVAL
+    assert np.isnan(scratch_ll).all()
     for p in (a, b):
         assert lib.octo_eval_end(p.ctx) == 0
     for ll, g in outs:

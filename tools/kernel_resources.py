@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""Scratch memory, register spills and code size of every compiled kernel, read from the code objects' own metadata
+(the .note section of the gfx950 ELF inside each csrc/build/*.o — what the loader sees, not a compiler remark):
+
+    python tools/kernel_resources.py                 # table of every kernel that uses scratch or spills + totals
+    python tools/kernel_resources.py --all [filter]  # every kernel (optionally: demangled name contains `filter`)
+    python tools/kernel_resources.py --json out.json
+
+`resources()` is imported by tests/test_kernel_resources.py, which holds the build to the budget below: the latency kernels
+(k_small, k_hgca) carry NO scratch allocation unless they spill, and the spill counts stay under the per-family limits.
+"""
+from __future__ import annotations
+
+import json
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+BUILD = ROOT / "octofitter.jl_amd" / "csrc" / "build"
+LLVM = Path("/opt/rocm/lib/llvm/bin")
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+FIELDS = ("vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
+          "group_segment_fixed_size", "kernarg_segment_size", "max_flat_workgroup_size")
+
+
+def code_object(obj: Path, tmp: Path) -> Path | None:
+    """The gfx950 ELF bundled in a host object's .hip_fatbin section."""
+    fat = tmp / (obj.stem + ".fatbin")
+    co = tmp / (obj.stem + ".co")
+    r = subprocess.run([str(LLVM / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(obj)], capture_output=True, text=True)
+    if r.returncode != 0 or not fat.exists() or fat.stat().st_size == 0:
+        return None
+    r = subprocess.run([str(LLVM / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", f"--targets={TARGET}", f"--output={co}"],
+                       capture_output=True, text=True)
+    return co if r.returncode == 0 and co.exists() else None
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    return dict(zip(names, out))
+
+
+def kernel_text_sizes(co: Path):
+    """bytes of machine code per kernel symbol (FUNC symbols of the code object)."""
+    out = subprocess.run([str(LLVM / "llvm-readelf"), "-s", "--wide", str(co)], capture_output=True, text=True).stdout
+    sizes = {}
+    for line in out.splitlines():
+        p = line.split()
+        if len(p) >= 8 and p[3] == "FUNC":
+            sizes[p[7]] = int(p[2])
+    return sizes
+
+
+def scratch_instruction_counts(co: Path):
+    """scratch_load / scratch_store instructions per kernel symbol, from the disassembly: a kernel may carry a private segment without
+    touching it (a dead SGPR spill slot the compiler forgot to drop: every such spill went to VGPR lanes)."""
+    out = subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--no-show-raw-insn", str(co)], capture_output=True, text=True).stdout
+    counts, cur = {}, None
+    for line in out.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1); counts.setdefault(cur, 0)
+        elif cur is not None and "scratch_" in line:
+            counts[cur] += 1
+    return counts
+
+
+def resources(build_dir: Path = BUILD, disassemble: bool = True):
+    """[{name (demangled), object, vgpr_count, ..., code_bytes, scratch_instructions}] for every kernel of every csrc/build/*.o"""
+    rows = []
+    with tempfile.TemporaryDirectory() as td:
+        tmp = Path(td)
+        for obj in sorted(build_dir.glob("*.o")):
+            co = code_object(obj, tmp)
+            if co is None:
+                continue
+            notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], capture_output=True, text=True).stdout
+            sizes = kernel_text_sizes(co)
+            scr = scratch_instruction_counts(co) if disassemble else {}
+            for blk in re.split(r"\n  - \.agpr_count:", "\n" + notes)[1:]:
+                blk = ".agpr_count:" + blk
+                m = re.search(r"^\s*\.name:\s+(\S+)", blk, re.M)
+                if not m:
+                    continue
+                row = {"symbol": m.group(1), "object": obj.name}
+                for f in FIELDS:
+                    mm = re.search(rf"^\s*\.{f}:\s+(\d+)", blk, re.M)
+                    row[f] = int(mm.group(1)) if mm else 0
+                row["code_bytes"] = sizes.get(row["symbol"], 0)
+                row["scratch_instructions"] = scr.get(row["symbol"], 0) if disassemble else None
+                rows.append(row)
+    dm = demangle([r["symbol"] for r in rows])
+    for r in rows:
+        d = dm.get(r["symbol"], r["symbol"])
+        r["name"] = re.sub(r"^void octo::|\(octo::.*$|\(anonymous namespace\)::", "", d).strip()
+    return rows
+
+
+def family(name: str) -> str:
+    return re.match(r"[\w:]+", name).group(0)
+
+
+def main():
+    args = sys.argv[1:]
+    rows = resources()
+    if not rows:
+        raise SystemExit("no code objects under csrc/build/: run `python __graft_entry__.py` first")
+    if "--json" in args:
+        Path(args[args.index("--json") + 1]).write_text(json.dumps(rows, indent=1))
+        return
+    show_all = "--all" in args
+    filt = [a for a in args if not a.startswith("--")]
+    filt = filt[0] if filt else ""
+    print(f"{'kernel':78s} {'vgpr':>5s} {'sgpr':>5s} {'vspill':>6s} {'sspill':>6s} {'scratch B':>9s} {'scr.ins':>7s} {'LDS B':>7s} {'code B':>8s}")
+    for r in sorted(rows, key=lambda r: (family(r["name"]), r["name"])):
+        interesting = r["private_segment_fixed_size"] or r["vgpr_spill_count"]      # (SGPR spills go to VGPR lanes: --all shows them)
+        if (show_all or interesting) and filt in r["name"]:
+            print(f"{r['name'][:78]:78s} {r['vgpr_count']:5d} {r['sgpr_count']:5d} {r['vgpr_spill_count']:6d} {r['sgpr_spill_count']:6d} "
+                  f"{r['private_segment_fixed_size']:9d} {r['scratch_instructions']:7d} {r['group_segment_fixed_size']:7d} {r['code_bytes']:8d}")
+    fams = {}
+    for r in rows:
+        f = fams.setdefault(family(r["name"]), {"n": 0, "code": 0, "scratch": 0, "used": 0, "spill": 0})
+        f["n"] += 1; f["code"] += r["code_bytes"]
+        f["scratch"] += 1 if r["private_segment_fixed_size"] else 0
+        f["used"] += 1 if r["scratch_instructions"] else 0
+        f["spill"] += 1 if r["vgpr_spill_count"] else 0
+    print(f"\n{'family':18s} {'kernels':>7s} {'code MB':>8s} {'private segment':>15s} {'... accessed':>12s} {'VGPR spills':>11s}")
+    for k, f in sorted(fams.items()):
+        print(f"{k:18s} {f['n']:7d} {f['code'] / 1e6:8.2f} {f['scratch']:15d} {f['used']:12d} {f['spill']:11d}")
+    print(f"{'total':18s} {len(rows):7d} {sum(r['code_bytes'] for r in rows) / 1e6:8.2f}")
+
+
+if __name__ == "__main__":
+    main()

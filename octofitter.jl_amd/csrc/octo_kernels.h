@@ -794,33 +794,53 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
 #pragma unroll
         for (int p = 0; p < P; ++p) load_pc(pc[p], a.wc, a.ldw, p, wl);
     } else {
-        // wave 0 derives the tile's constants; meanwhile waves 1.. fetch the sin/cos table into registers (one memory round trip,
-        // overlapped with the setup; the registers are live in the branch that does not run the setup)
-        constexpr int TPT = (SCT_N + WAVE * (WPB - 1) - 1) / (WAVE * (WPB - 1));
-        double2 tr[TPT];
-#pragma unroll
-        for (int k = 0; k < TPT; ++k) tr[k] = make_double2(0.0, 0.0);      // defined on both paths: the array stays in registers (left
-                                                                           // undefined on wave 0's path it was demoted to scratch memory)
-        if (wv == 0) {
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const SetupOut so = setup_planet<true>(a, p, wl);
-#pragma unroll
-                for (int k = 0; k < NPC; ++k) lds[(p * NPC + k) * WAVE + lane] = so.v[k];
-            }
-        } else {
+        // The orbit constructors of the tile, one PIECE per wave (setup_planet_vals' four pieces: sin/cos of i, of ω, of Ω, the scalars):
+        // in a one-round launch every block of the chip runs this prologue at the same moment, and as one wave's ~300-instruction
+        // chain it left three of the four SIMDs idle for its duration (rounds 3: ~8.5 µs of fixed cost per launch, most of it here).
+        // The pieces meet in LDS, and every wave assembles the constants it keeps in registers from them. The sin/cos table travels
+        // global -> registers (issued first: one memory round trip under the pieces) -> LDS once the pieces have been read.
+        static_assert(WPB == 4, "k_main<FUSED>: one setup piece per wave");
+        constexpr int TPT = (SCT_N + WAVE * WPB - 1) / (WAVE * WPB);
+        constexpr int NRAW = 15;      // si ci | sw cw | sO cO | sma T invP beta eob K0 mu f32a f32b
+        static_assert(NRAW <= NPC, "the pieces fit in the LDS the fused launch allocates");
+        double trs[TPT], trc[TPT];      // (scalars, not double2[]: the aggregate copies kept the array in scratch memory)
+        {
             const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
 #pragma unroll
-            for (int k = 0; k < TPT; ++k) { const int i = (int)threadIdx.x - WAVE + k * WAVE * (WPB - 1); tr[k] = g[i < SCT_N ? i : SCT_N - 1]; }
+            for (int k = 0; k < TPT; ++k) {
+                const int i = (int)threadIdx.x + k * WAVE * WPB;
+                const double2 v = g[i < SCT_N ? i : SCT_N - 1];
+                trs[k] = v.x; trc[k] = v.y;
+            }
+        }
+        double elv[P][OCTO_N_EL];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + wl;
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = el[(int64_t)k * a.ld];
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double* raw = lds + (p * NRAW) * WAVE + lane;
+            if (wv == 0) { double sn, cs; setup_angle<0, true>(elv[p], a.orbit_kind[p], sn, cs); raw[0 * WAVE] = sn; raw[1 * WAVE] = cs; }
+            else if (wv == 1) { double sn, cs; setup_angle<1, true>(elv[p], a.orbit_kind[p], sn, cs); raw[2 * WAVE] = sn; raw[3 * WAVE] = cs; }
+            else if (wv == 2) { double sn, cs; setup_angle<2, true>(elv[p], a.orbit_kind[p], sn, cs); raw[4 * WAVE] = sn; raw[5 * WAVE] = cs; }
+            else {
+                const SetupScalars q = setup_scalars<true>(elv[p], a.c, a.orbit_kind[p], a.has_mass[p]);
+                raw[6 * WAVE] = q.sma; raw[7 * WAVE] = q.T; raw[8 * WAVE] = q.invP; raw[9 * WAVE] = q.beta; raw[10 * WAVE] = q.eob;
+                raw[11 * WAVE] = q.K0; raw[12 * WAVE] = q.mu; raw[13 * WAVE] = q.f32a; raw[14 * WAVE] = q.f32b;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < P; ++p) {
+            const double* raw = lds + (p * NRAW) * WAVE + lane;
+            SetupScalars q;
+            q.sma = raw[6 * WAVE]; q.T = raw[7 * WAVE]; q.invP = raw[8 * WAVE]; q.beta = raw[9 * WAVE]; q.eob = raw[10 * WAVE];
+            q.K0 = raw[11 * WAVE]; q.mu = raw[12 * WAVE]; q.f32a = raw[13 * WAVE]; q.f32b = raw[14 * WAVE];
             double v[NWC];
-#pragma unroll
-            for (int k = 0; k < NPC; ++k) v[k] = lds[(p * NPC + k) * WAVE + lane];
-#pragma unroll
-            for (int k = NPC; k < NWC; ++k) v[k] = 0.0;
+            setup_assemble(v, elv[p], a.orbit_kind[p], raw[0 * WAVE], raw[1 * WAVE], raw[2 * WAVE], raw[3 * WAVE], raw[4 * WAVE], raw[5 * WAVE], q);
             pc[p].invP = v[WC_INVP]; pc[p].tp = v[WC_TP]; pc[p].e = v[WC_E]; pc[p].beta = v[WC_BETA]; pc[p].eob = v[WC_EOB];
             pc[p].cB = v[WC_CB]; pc[p].cG = v[WC_CG]; pc[p].cA = v[WC_CA]; pc[p].cF = v[WC_CF]; pc[p].K = v[WC_K]; pc[p].cw = v[WC_COSW];
             pc[p].sw = v[WC_SINW]; pc[p].mu = v[WC_MU]; pc[p].a = v[WC_A]; pc[p].cGb = v[WC_CGB]; pc[p].cFb = v[WC_CFB]; pc[p].cBe = v[WC_CBE];
@@ -829,11 +849,11 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
             const float2 fb = *reinterpret_cast<const float2*>(&v[WC_F32B]);
             set_starter(pc[p], fa.x, fa.y, fb.x);
         }
-        __syncthreads();                                // every wave has its constants: the table may overwrite them
-        if (wv != 0) {
+        __syncthreads();                                // every wave has read the pieces: the table may overwrite them
+        {
             double2* t = reinterpret_cast<double2*>(lds);
 #pragma unroll
-            for (int k = 0; k < TPT; ++k) { const int i = (int)threadIdx.x - WAVE + k * WAVE * (WPB - 1); if (i < SCT_N) t[i] = tr[k]; }
+            for (int k = 0; k < TPT; ++k) { const int i = (int)threadIdx.x + k * WAVE * WPB; if (i < SCT_N) t[i] = make_double2(trs[k], trc[k]); }
         }
     }
 

@@ -283,7 +283,29 @@ int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_
     // few walker tiles: fewer rounds rather than blocks shorter than ~48 rows per wave (W = 4096: 166 µs at 1 round, 177 at 3)
     while (rounds > 1 && n_rows * cols < 48 * WPB * rounds * capacity) --rounds;
     if (ctx->env_rounds > 0) rounds = ctx->env_rounds;      // OCTO_ROUNDS: experiments
-    return std::max<int64_t>(1, rounds * capacity / cols);
+    const int64_t key0 = std::max<int64_t>(1, rounds * capacity / cols);
+    if (rounds != 1 || ctx->env_rounds > 0 || n_rows < 32 * WPB * 8) return key0;      // (short tables: get_tasks' own rule, calibrated on them)
+    // One round (few walker tiles — a strong-scaled shard): every block of the grid is resident at once, each block puts one
+    // wave on each SIMD of its CU, so the launch lasts (waves on the fullest SIMD) x (rows per wave), and the task count decides both
+    // factors in steps. Filling every slot (1 250 walkers: 76 tasks x 20 tiles, 6 waves per SIMD x 33 rows) is no faster than 38 tasks (3
+    // waves x 66 rows) — three waves nearly saturate the FP64 issue port — while every task costs k_finish a partial to fetch:
+    // 55.2 -> 53.1 µs per step (tools/step_probe.py, profiles/r4_chunk_sweep_1250.txt); two waves per SIMD are NOT enough (100 rows per
+    // wave: 51.9 µs of k_main against 48.3), one wave even less. Cost model fitted to that sweep, in units of one row of one wave on a
+    // SIMD that holds seven: n waves on a SIMD take n·g(n) per row, g = 1.59, 1.13, 1.045, 1.03, 1.015, 1.005, 1 for n = 1 … 7;
+    // a block's prologue + combine ~ 2.7 rows; a task costs k_finish ~ 0.34.
+    const int64_t t_max = std::max<int64_t>(1, n_rows / (32 * WPB));
+    int64_t best_t = key0;
+    double best_cost = 1e300;
+    for (int wps = 1; wps <= blocks_per_cu; ++wps) {
+        int64_t t = std::min<int64_t>((int64_t)wps * n_cus / cols, t_max);
+        if (t < 1) continue;
+        const double chunk = std::ceil((double)n_rows / (double)(t * WPB));
+        const double n = std::ceil((double)(cols * t) / (double)n_cus);
+        static const double g[8] = {1.59, 1.59, 1.13, 1.045, 1.03, 1.015, 1.005, 1.0};
+        const double cost = n * g[(int)std::min(n, 7.0)] * (chunk + 2.7) + 0.34 * (double)t;
+        if (cost < best_cost) { best_cost = cost; best_t = t; }
+    }
+    return best_t;
 }
 
 // Small and mid-size batches: one fused launch, lane = epoch (octo_small.h: k_small). Its cost grows with the number of blocks

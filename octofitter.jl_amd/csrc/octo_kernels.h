@@ -926,19 +926,29 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         acc[L::OFF_S] += lg;
     }
     // ---- combine the block's waves through LDS in a fixed order (deterministic), one partial per (tile, task).
-    // Waves take turns through one NACC×64 buffer, so the footprint stays <= 28 KB (+ the table) for the widest layout.
+    // The sin/cos table is dead once every wave has left its row loop, so the waves' sums go through the WHOLE allocation (table +
+    // the NACC×64 buffer behind it), as many waves per round as fit: all three at once for the narrow layouts (config 3: one round, two
+    // barriers, where rounds 1-3 took turns through the buffer alone: three rounds, six barriers at the tail of every block). Wave 0
+    // adds them in wave order, as before: bit-identical sums.
+    constexpr int LDS_DOUBLES = (int)((FUSED ? fused_lds_bytes<P, GRAD, NUIS, KM>() : main_lds_bytes<P, GRAD, NUIS, KM>()) / sizeof(double));
+    constexpr int WPR = (LDS_DOUBLES / (L::NACC * WAVE)) < (WPB - 1) ? (LDS_DOUBLES / (L::NACC * WAVE)) : (WPB - 1);      // waves per round
+    static_assert(WPR >= 1, "k_main: the combine buffer holds one wave's sums");
+    (void)comb;
 #pragma unroll 1
-    for (int q = 1; q < WPB; ++q) {
-        if (wv == q) {
+    for (int q0 = 1; q0 < WPB; q0 += WPR) {
+        __syncthreads();                                // table (first round) / previous round's sums no longer needed
+        if (wv >= q0 && wv < q0 + WPR) {
 #pragma unroll
-            for (int k = 0; k < L::NACC; ++k) comb[k * WAVE + lane] = acc[k];
+            for (int k = 0; k < L::NACC; ++k) lds[((wv - q0) * L::NACC + k) * WAVE + lane] = acc[k];
         }
         __syncthreads();
         if (wv == 0) {
+#pragma unroll 1
+            for (int q = q0; q < (q0 + WPR < WPB ? q0 + WPR : WPB); ++q) {
 #pragma unroll
-            for (int k = 0; k < L::NACC; ++k) acc[k] += comb[k * WAVE + lane];
+                for (int k = 0; k < L::NACC; ++k) acc[k] += lds[((q - q0) * L::NACC + k) * WAVE + lane];
+            }
         }
-        __syncthreads();
     }
     if (wv == 0 && w < a.W) {
         double* out = a.partials + (int64_t)task * L::NACC * a.ldw + w;

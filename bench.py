@@ -201,7 +201,14 @@ def config1_latency(pkg, dev_index):
         ob.oracle_model_logpost(obs, case["planets"], model._c_priors, model._c_esrc, None, th)
     cpu_us = (time.perf_counter() - t0) / m * 1e6
     model.close()
-    return {"workload": "config1: D=11 model (test/integration/sampling.jl:29-64), 50 RA/Dec epochs, one theta_t per call, value + gradient",
+    first = None
+    try:      # cold start of the library in a fresh process (module load + first call): tools/first_call.py
+        r = subprocess.run([sys.executable, str(ROOT / "tools" / "first_call.py")], capture_output=True, text=True, timeout=300)
+        first = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as ex:
+        first = {"error": str(ex)}
+    return {"first_call": first, "first_call_ms": (first or {}).get("first_call_ms"), "lib_bytes": (first or {}).get("lib_bytes"),
+            "workload": "config1: D=11 model (test/integration/sampling.jl:29-64), 50 RA/Dec epochs, one theta_t per call, value + gradient",
             "gpu_us_per_call": gpu_us, "gpu_entry": "octo_model_logpost (host buffers, blocking)", "gpu_matches_fixture": bool(ok),
             "cpu_us_per_call": cpu_us, "cpu_entry": "oracle/ octo_oracle_model_logpost, 1 thread, forward-mode duals (includes ~10 us of ctypes marshalling)"}
 

@@ -664,6 +664,10 @@ static int eval_impl(octo_ctx* ctx, const octo_dataset* ds, const double* d_elem
     if (ctx->stage_ws_in > 0) { a.ws_in = ctx->stage_ws_in; a.ws_out = ctx->stage_ws_out; }      // octo_eval's walker-major staging (k_small only)
     a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w; a.sctab = ctx->d_sctab;
     a.ll_out = d_ll; a.g_elems = d_g_elems; a.g_nuis = d_g_nuis;
+    if (ctx->mt_req) {
+        a.mt_J = ctx->mt.J; a.mt_glp = ctx->mt.glp; a.mt_lpp = ctx->mt.lpp; a.mt_lp = ctx->mt.lp; a.mt_grad = ctx->mt.grad;
+        a.mt_ld = ctx->mt.ld; a.mt_ldo = ctx->mt.ldo; a.mt_D = ctx->mt.D; a.mt_n_nu = ctx->mt.n_nu;
+    }
     a.c = dev_consts(ctx->consts);
     switch (ds->n_planets) {
         case 1: return dispatch1<1>(ctx, ds, a, grad, nuis, sm, st);
@@ -1133,7 +1137,8 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
     if (m->lds_bytes > ctx->max_lds)
         return bail(OCTO_EINVAL, "octo_model_create: the model needs more LDS per block than this device has ((4·D + 6·n_circular)·512 B)");
     if (m->lds_bytes > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)k_model_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess) {
+        (hipFuncSetAttribute((const void*)k_model_fwd<MODEL_NPART>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
+         hipFuncSetAttribute((const void*)k_model_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess)) {
         (void)hipGetLastError();
         if (m->lds_bytes > 64 * 1024) return bail(OCTO_EINVAL, "octo_model_create: cannot raise k_model_fwd's dynamic LDS limit for this model");
     }
@@ -1198,18 +1203,33 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     a.ll = d_ll; a.g_el = d_gel; a.g_nu = m->has_nuis ? d_gnu : nullptr;
     a.lp_out = d_lp; a.grad_out = d_grad;
     a.k_yr = ctx->consts.kepler_year_to_julian_day; a.yd = ctx->consts.year2day_julian;
-    {
+    // θ_t -> kernel inputs, priors (+ Jacobian with a gradient). A forward-only callback launches the VALUES alone (k_model_fwd<0>: half the
+    // chain). Tried and not kept (profiles/r4_model_streams_ab.txt): values on the caller's stream + the Jacobian launch on a second stream
+    // beside k_main — k_main is undisturbed and the Jacobian fully hidden, but the values launch is still 13.6 of the 26 µs, k_finish
+    // slows down by 3.7 µs next to the Jacobian's tail and the fork / join events cost the rest: 0.364 ms per step against 0.351.
+    const bool grad = d_grad != nullptr;
+    a.circ_slot = m->d_circ; a.n_circ = m->n_circ; a.write_values = 1;
+    if (!grad) {
+        const int DB0 = std::max(1, std::min(m->D, 8));      // the priors are shared out over all DB waves; one wave resolves the sources
+        a.src_waves = 1;
+        hipLaunchKernelGGL(k_model_fwd<0>, dim3((unsigned)((W + 63) / 64), 1u), dim3(64, DB0), (size_t)m->lds_bytes, st, a);
+    } else {
         const int n_thr = (m->D + MODEL_NPART - 1) / MODEL_NPART;      // threads per walker, MODEL_NPART partials each
         const int DBs = std::min(n_thr, 8), DB = std::max(DBs, std::min(m->D, 8));      // the priors are shared out over all DB waves
-        a.src_waves = DBs; a.circ_slot = m->d_circ; a.n_circ = m->n_circ;
-        hipLaunchKernelGGL(k_model_fwd, dim3((unsigned)((W + 63) / 64), (unsigned)((n_thr + DBs - 1) / DBs)), dim3(64, DB),
+        a.src_waves = DBs;
+        hipLaunchKernelGGL(k_model_fwd<MODEL_NPART>, dim3((unsigned)((W + 63) / 64), (unsigned)((n_thr + DBs - 1) / DBs)), dim3(64, DB),
                            (size_t)m->lds_bytes, st, a);
     }
     HIPCHK(ctx, hipGetLastError());
-    const bool grad = d_grad != nullptr;
+    // lp = prior + ll and ∇θ_t = Jᵀḡ + ∇prior: inside k_finish (model_tail), tile by tile as the adjoints become known
+    ctx->mt.J = a.J; ctx->mt.glp = a.glp; ctx->mt.lpp = a.lpp; ctx->mt.lp = d_lp; ctx->mt.grad = d_grad;
+    ctx->mt.ld = L; ctx->mt.ldo = ld; ctx->mt.D = m->D; ctx->mt.n_nu = m->has_nuis ? m->n_nu : 0;
+    ctx->mt_req = true; ctx->mt_applied = false;
     int rc = eval_impl(ctx, m->ds, a.elems, m->has_nuis ? a.nuis : nullptr, L, W, d_ll, grad ? d_gel : nullptr,
                        (grad && m->has_nuis) ? d_gnu : nullptr, st, nullptr, grad, m->has_nuis);
+    ctx->mt_req = false;
     if (rc) return rc;
+    if (ctx->mt_applied) return OCTO_OK;
     hipLaunchKernelGGL(k_model_bwd, dim3((unsigned)((W + 255) / 256), (unsigned)(d_grad ? m->D : 1)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;

@@ -16,7 +16,7 @@
 //     (sincos_halfangle: 24 instructions, no table fill). Neither needs range reduction, quadrant selects or a
 //     Payne-Hanek slow path: |E1| <= π by construction;
 //   * the three divisions of the correction share ONE v_rcp_f64 (2^-23): δ3 uses it as it is, δ4 and δ5 are one correction step each
-//     on the quotient, δ' = δ − r·(den·δ + f0) (round 3; rounds 1-2 refined the reciprocal instead: OCTO_KEPLER_NR_CHAIN);
+//     on the quotient, δ' = δ − r·(den·δ + f0) (round 3; rounds 1-2 refined the reciprocal instead: 3 instructions per division);
 //   * sin/cos(E) follow from (sin E1, cos E1) by a rotation through δ5 (|δ5| < 5e-4: Taylor to δ^6).
 // tools/kepler_proto.py measures this scheme against an 80-bit Newton solve over 2e6 (M, e) pairs incl.
 // e -> 1 − 1e-9 and |M| -> 0, π: residual-weighted error 5.1e-16 max vs 7.1e-16 for the all-FP64 reference
@@ -80,9 +80,7 @@ __device__ __forceinline__ void set_starter(PC& pc, float ef, float omef, float 
     pc.he = 0.5 * pc.e;
     if constexpr (PIN) {
         asm("" : "+v"(pc.A0), "+v"(pc.A1), "+v"(pc.o2), "+v"(pc.no3));
-#ifndef OCTO_NO_HE_PIN
         asm("" : "+v"(pc.he));
-#endif
     }
 }
 
@@ -180,25 +178,16 @@ struct SinCosTab {
 __device__ __forceinline__ SinCosTab make_sincos_tab(const double2* lds_tab) {
     SinCosTab t{lds_tab, OCTO_KT[17], SCT_INV_STEP_F, (uint32_t)(16u * (SCT_HALF + SCT_PAD) - (0x4B400000u << 4))};
     asm("" : "+v"(t.c5));      // not volatile: a volatile asm counts as a memory clobber and demotes the s_loads of the rows
-#ifndef OCTO_SCT_RPI
     asm("" : "+v"(t.inv_step));
     asm("" : "+s"(t.off0));
-#endif
     return t;
 }
 
 __device__ __forceinline__ void sincos_table(float xf, const SinCosTab& T, double& s, double& c) {
-#ifdef OCTO_SCT_RPI
-    int k;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(k) : "v"(xf * SCT_INV_STEP_F));   // floor(x + 0.5): one instruction for round + convert
-    const float kf = (float)k;
-    const double2 g = T.tab[k + (SCT_HALF + SCT_PAD)];
-#else
     const float km = fmaf(xf, T.inv_step, SCT_MAGIC_F);
     const float kf = km - SCT_MAGIC_F;                                   // k, exact
     const uint32_t off = (__float_as_uint(km) << 4) + T.off0;
     const double2 g = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(T.tab) + off);
-#endif
     const double r = (double)fmaf(-kf, SCT_STEP_F, xf);                   // exact
     const double r2 = r * r;
     const double sr = r * fma(r2, fma(r2, T.c5, OCTO_KT[18]), 1.0);
@@ -331,15 +320,6 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     const double r3 = __builtin_amdgcn_rcp(fma(f1, f1, -(f0 * hf2)));                // ≈2^-23
     const double r4 = f1 * r3;                                                       // ≈ 1/den4, and f1·r3 is also Halley's factor:
     const double d3 = -f0 * r4;                                                      // δ3 = −f0·f1/(f1² − f0 f2/2)
-#ifdef OCTO_KEPLER_NR_CHAIN
-    // round 1-3 form: refine the reciprocal (one Newton step each), then δ = −f0·r: 3 instructions per division
-    const double den4 = fma(d3, fma(d3, sf3, hf2), f1);
-    const double r4b = fma(fma(-den4, r4, 1.0), r4, r4);
-    const double d4 = -f0 * r4b;
-    const double den5 = fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1);
-    const double r5 = fma(fma(-den5, r4b, 1.0), r4b, r4b);
-    const double d5 = -f0 * r5;
-#else
     // δ4 = −f0/den4 and δ5 = −f0/den5 as ONE correction step each on the quotient instead of on the reciprocal:
     // δ' = δ − r·(den·δ + f0) with the crude r = r4 (≈ 1/den to 2^-23 + O(δ²)). The residual den·δ + f0 comes out of one FMA
     // without rounding before the cancellation, and the previous δ is already right to r4's relative error, so the error of δ' is
@@ -349,7 +329,6 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     const double d4 = fma(-r4, fma(den4, d3, f0), d3);
     const double den5 = fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1);
     const double d5 = fma(-r4, fma(den5, d4, f0), d4);
-#endif
     s.E = E1 + d5;                                                   // eq. (29); dead code unless a caller reads it
     // ---- sin/cos(E1 + δ5) by rotation; |δ5| < 5e-4: sin δ = δ(1 − δ²/6) (+1e-19), cos δ − 1 = δ²(−1/2 + δ²/24) (+1e-23)
     const double dd = d5 * d5;

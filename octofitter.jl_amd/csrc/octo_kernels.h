@@ -30,7 +30,7 @@ constexpr int FIN_G = OCTO_FIN_G;      // waves of a single-planet k_finish bloc
                                          // tile's partials are tasks x NACC rows of 512 B written by other CUs — so what counts is loads in flight:
                                          // 16 waves x 4 tasks unrolled (8 x 2 in round 2: 10.7 us at 1 250 walkers x 76 tasks, 9.4 us at 1e4 x 34)
 // several planets (finish_tile_multi): waves per planet that share the planet's tasks; block = 1 + P·fin_nwr(P) waves
-constexpr int fin_nwr(int n_planets) { return n_planets == 2 ? 3 : 2; }
+constexpr int fin_nwr(int n_planets) { return n_planets == 2 ? 3 : (n_planets == 3 ? 2 : 1); }      // (four planets: 5 waves — a ninth wave would cap the block at 168 VGPRs per lane, which the O'Neil layouts spill)
 #ifndef OCTO_FIN_CH
 #define OCTO_FIN_CH 6
 #endif
@@ -90,6 +90,15 @@ struct EvalArgs {
     const double* sctab;          // [SCT_N][2] sin/cos grid (octo_device.h: sincos_table), copied to LDS by every k_main block
     int64_t ldw;
     double* ll_out; double* g_elems; double* g_nuis;
+    // The tail of the standard parameterisation (octo_model.h; src/logdensitymodel.jl:110-146,169-177) for big batches, run by k_finish right
+    // after a tile's adjoints are known: lp = prior + ll with the callback's rules, ∇θ_t[d] = ∂prior/∂θ_t[d] + Σ_k J[k][d]·ḡ[k]. Null mt_lpp:
+    // a plain likelihood evaluation. (Rounds 1-3: a kernel of its own, k_model_bwd, behind k_finish: 7 µs + a launch boundary per callback.)
+    const double* mt_J;           // [(n_in·D)][mt_ld]   Jacobian of the kernel inputs (elements, then nuisances) w.r.t. θ_t, from k_model_fwd
+    const double* mt_glp;         // [D][mt_ld]          ∂(prior + UnitLength terms)/∂θ_t
+    const double* mt_lpp;         // [mt_ld]             prior + UnitLength terms (−Inf for a non-finite θ_t)
+    double* mt_lp; double* mt_grad;      // outputs: lp[W]; grad[D][mt_ldo] or null
+    int64_t mt_ld, mt_ldo;
+    int32_t mt_D, mt_n_nu;        // θ_t dimension; nuisance rows that have a Jacobian (0: the model has no nuisance variables)
     DevConsts c;
 };
 
@@ -727,7 +736,11 @@ __device__ __forceinline__ RowRegs row_issue(crow_t p) {
     asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(r.lo), "=&s"(r.hi) : "s"(p));
     return r;
 }
-__device__ __forceinline__ void row_wait(RowRegs& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi)); }
+// the last load issued (into `r`) has landed, with everything before it. `r` is an INPUT of the wait, so its registers stay allocated to
+// it until the load has written them (a tuple that is dead in the program is free for the register allocator at once); an in/out
+// operand made the compiler copy the in-flight registers ahead of the wait (round 3). That no instruction touches a load's destination
+// before the wait is checked on the ISA of every k_main variant — tools/kernel_resources.py: scalar_load_hazards.
+__device__ __forceinline__ void row_drain(const RowRegs& r) { asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(r.lo), "s"(r.hi)); }
 // wait for `cur`, then start the loads of the following row — one asm block that `cur`'s consumers depend on, so that the compiler
 // cannot schedule the first instructions of the row body ahead of the issue
 __device__ __forceinline__ RowRegs row_wait_issue(RowRegs& cur, crow_t p) {
@@ -767,6 +780,11 @@ template <int P, bool GRAD, bool NUIS, int KM, bool FUSED = false>
 __attribute__((amdgpu_waves_per_eu(main_min_waves<P, GRAD, NUIS, KM>())))
 static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
+    // The hand-scheduled row prefetch (row_issue / row_wait_issue below) is used where the ISA check passes: the multi-planet variants of
+    // the k_setup route (a marginalised-RV gradient and its forward pre-pass) run out of SGPRs, and the compiler spilled the prefetched
+    // tuple to VGPR lanes WHILE the load was in flight (tools/kernel_resources.py: scalar_load_hazards found it) — they read their rows
+    // with plain scalar loads the compiler waits for itself.
+    constexpr bool ROW_PREFETCH = FUSED || P == 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction; make it an SGPR
@@ -873,24 +891,25 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         auto body = [&](const RowRegs& r) {
             astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4), row_get(r, 5), tab);
         };
-#ifdef OCTO_NO_ROW_PREFETCH
-        for (int j = 0; j < n_rows; ++j) {
-            const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
-            astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab);
-        }
-        if (false)
-#else
-        if (n_rows > 0)
-#endif
-        {
+        if constexpr (!ROW_PREFETCH) {
+            for (int j = 0; j < n_rows; ++j) {
+                const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
+                astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab);
+            }
+        } else if (n_rows > 0) {
+            // Two rows per trip through two SGPR buffers that swap roles (no copies): B is fetched while A is computed and vice versa. Either
+            // exit leaves ONE load in flight (the spare re-read of the last row) and waits for it (row_drain). (Rounds 2-3 waited on the early
+            // exit only, and with the tuple as an in/out operand: copies of the in-flight registers ahead of the wait — dead values, but
+            // reads of a load in flight — while the normal exit did not wait at all.)
             RowRegs A = row_issue(rows);
             for (int j = 0; j < n_rows; j += 2) {
-                RowRegs B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);      // past the end: re-read a valid row
+                RowRegs B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
                 body(A);
-                if (j + 1 >= n_rows) { row_wait(B); break; }
+                if (j + 1 >= n_rows) { row_drain(B); break; }
                 A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                 body(B);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)");      // the normal exit's spare prefetch (of the shapes tried, this one keeps the loop's registers: 105 VALU per row)
         }
     }
     if (L::HAS_RV && !is_astrom) {
@@ -899,24 +918,21 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         auto body = [&](const RowRegs& r) {
             rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab);
         };
-#ifdef OCTO_NO_ROW_PREFETCH
-        for (int j = 0; j < n_rows; ++j) {
-            const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
-            rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, tab);
-        }
-        if (false)
-#else
-        if (n_rows > 0)
-#endif
-        {
+        if constexpr (!ROW_PREFETCH) {
+            for (int j = 0; j < n_rows; ++j) {
+                const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
+                rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, tab);
+            }
+        } else if (n_rows > 0) {
             RowRegs A = row_issue(rows);
             for (int j = 0; j < n_rows; j += 2) {
                 RowRegs B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
                 body(A);
-                if (j + 1 >= n_rows) { row_wait(B); break; }
+                if (j + 1 >= n_rows) { row_drain(B); break; }
                 A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                 body(B);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)");
         }
     }
     if constexpr (NUIS) {
@@ -1132,6 +1148,30 @@ __device__ __forceinline__ void planet_finish(const double (&el)[OCTO_N_EL] /* t
     }
 }
 
+// ------------------------------------------------------------------------------------ model tail (k_finish, big-batch callbacks)
+// Called by every thread of a k_finish block once the tile's ll, ḡ_elems and ḡ_nuis are in memory (written by other waves of the SAME
+// block: a block-scope fence + barrier make them visible). Wave g forms the gradient rows d = g, g + NG, … for its lane's walker.
+template <int P>
+__device__ __forceinline__ void model_tail(const EvalArgs& a, int64_t w, int grp, int n_waves) {
+    __threadfence_block();
+    __syncthreads();
+    if (w >= a.W) return;
+    const double lpp = a.mt_lpp[w], ll = a.ll_out[w];
+    // ℓπcallback: non-finite θ_t or prior -> returned without the likelihood (logdensitymodel.jl:120-133)
+    double lp = isfinite(lpp) ? lpp + ll : lpp;
+    if (isnan(lp)) lp = -INFINITY;
+    if (grp == 0) a.mt_lp[w] = lp;
+    if (!a.mt_grad) return;
+    const bool ok = isfinite(lp);
+    const int D = a.mt_D, n_el = P * OCTO_N_EL, n_nu = a.g_nuis ? a.mt_n_nu : 0;
+    for (int d = grp; d < D; d += n_waves) {
+        double g = a.mt_glp[(int64_t)d * a.mt_ld + w];
+        for (int k = 0; k < n_el; ++k) g = fma(a.mt_J[((int64_t)k * D + d) * a.mt_ld + w], a.g_elems[(int64_t)k * a.ld + w], g);
+        for (int k = 0; k < n_nu; ++k) g = fma(a.mt_J[((int64_t)(n_el + k) * D + d) * a.mt_ld + w], a.g_nuis[(int64_t)k * a.ld + w], g);
+        a.mt_grad[(int64_t)d * a.mt_ldo + w] = ok ? g : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------ finish_tile / k_finish
 // The per-walker tail for one tile of 64 walkers, run by NG waves. It is a latency chain (a tile's partials were written by other CUs;
 // what follows them is one wave's dependent arithmetic), so the work is spread over the waves instead of being left to wave 0:
@@ -1331,8 +1371,8 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
             }
         }
     }
-    if (w >= a.W) return;
-    if (grp == 0) {
+    const bool live = w < a.W;      // (the tile's tail lanes recomputed the last walker: they store nothing)
+    if (live && grp == 0) {
         a.ll_out[w] = ok ? ll : -INFINITY;
         if constexpr (GRAD && L::N_NU > 0) {
             if (!ok)
@@ -1342,13 +1382,14 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
     if constexpr (GRAD) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            if (my_p != p) continue;
+            if (my_p != p || !live) continue;
             // FAST (reciprocal-multiply divisions, as in k_small): the tail of a launch is one wave's dependent chain, and an IEEE
             // FP64 division is a dozen dependent instructions
             planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
                                                             a.orbit_kind[p], a.has_mass[p], p, gmine, L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
         }
     }
+    if (a.mt_lpp) model_tail<P>(a, w, grp, NG);      // block-uniform (a kernel argument)
 }
 
 // ------------------------------------------------------------------------------------ finish_tile_multi (several planets)
@@ -1383,7 +1424,7 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
     constexpr int NOB = L::OFF_PL;
     constexpr int FLAG_ROWS = 1 + 7 * P;
     constexpr int UNR_O = NOB <= 4 ? 8 : (NOB <= 8 ? 4 : 2);      // tasks in flight: wave 0 (NOB columns each) ...
-    constexpr int UNR_P = P <= 3 ? 4 : (L::HAS_ONEIL ? 2 : 3);     // ... and a planet wave (PL_N columns each; the 9 waves of P = 4 leave 168 VGPRs per lane)
+    constexpr int UNR_P = 4;                                       // ... and a planet wave (PL_N columns each)
     const int64_t w = tile * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;
     const int role_p = grp == 0 ? -1 : (grp - 1) / NWR;           // the planet this wave works for
@@ -1528,8 +1569,8 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
             }
         }
     }
-    if (w >= a.W) return;
-    if (grp == 0) {
+    const bool live = w < a.W;
+    if (live && grp == 0) {
         a.ll_out[w] = ok ? ll : -INFINITY;
         if constexpr (GRAD && L::N_NU > 0) {
             if (!ok)
@@ -1539,11 +1580,12 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
     if constexpr (GRAD) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            if (my_p != p) continue;
+            if (my_p != p || !live) continue;
             planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
                                                             a.orbit_kind[p], a.has_mass[p], p, gp, L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
         }
     }
+    if (a.mt_lpp) model_tail<P>(a, w, grp, (fin_waves<P, GRAD, NUIS, KM>()));
 }
 
 // one block per tile of 64 walkers. FROM_WC = false: after a k_main launch that derived the constants itself.

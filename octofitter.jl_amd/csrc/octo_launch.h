@@ -79,11 +79,11 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
 
 // The kind set k_small is instantiated for (a subset of the epoch-loop kernels' sets: rows are per LANE there and the branch on the
 // table's kind is block-uniform, so a wider set costs a one-θ call nothing it can measure — profiles/r4_small_kindsets_ab.txt — while
-// every set costs 1-2 MB of code per planet count): RA/Dec alone; + sep/PA and cor; + O'Neil; + absolute / relative RV; everything.
+// every set costs ~1 MB of code over the four planet counts): RA/Dec alone; + sep/PA and cor; + absolute / relative RV; everything
+// (O'Neil priors and marginalised RV).
 constexpr int small_kind_set(int km_rows) {
     if (km_rows == KM_RADEC) return KM_RADEC;
     if ((km_rows & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return KM_RADEC | KM_SEPPA | KM_COR;
-    if ((km_rows & ~(KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL)) == 0) return KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL;
     if ((km_rows & (KM_MARG | KM_ONEIL)) == 0) return KM_ALL & ~KM_MARG & ~KM_ONEIL;
     return KM_ALL;
 }
@@ -93,7 +93,9 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     // KMD: the dataset's kind set, possibly with KM_HGCA. The epoch-loop kernels never see that bit (KM below); k_small does, when it is
     // compiled with nuisances (an HGCA table without `nuis` is refused at run time, so the nuisance-free variants need no HGCA twin).
     constexpr int KM = KMD & ~KM_HGCA;
-    constexpr int KS = small_kind_set(KM) | (NUIS ? (KMD & KM_HGCA) : 0);
+    constexpr int KSR = small_kind_set(KM);
+    constexpr int KS = !(NUIS && (KMD & KM_HGCA)) ? KSR      // with an HGCA table: relative astrometry alone, or everything
+                       : ((KSR & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0 ? (KM_RADEC | KM_SEPPA | KM_COR | KM_HGCA) : (KM_ALL | KM_HGCA));
     using L = Layout<P, GRAD, NUIS, KM>;
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
     const octo_dataset* ds = cds;
@@ -168,6 +170,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         }
         hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * fin_waves<P, GRAD, NUIS, KM>()), (fin_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
         HIPCHK(ctx, hipGetLastError());
+        ctx->mt_applied = a.mt_lpp != nullptr;
         return OCTO_OK;
     }
     if constexpr (GRAD && L::HAS_MARG) {
@@ -205,6 +208,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         if (rc) return rc;
         hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols), dim3(WAVE * fin_waves<P, GRAD, NUIS, KM>()), (fin_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
         HIPCHK(ctx, hipGetLastError());
+        ctx->mt_applied = a.mt_lpp != nullptr;
     }
     return OCTO_OK;
 }
@@ -220,9 +224,10 @@ int dispatch1(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, boo
     // The smallest compiled kind set that covers the dataset: registers and occupancy are not paid for code it never runs.
     const int km = ctx->env_kind_all ? KM_ALL : (ds->kind_mask & ~KM_HGCA);      // OCTO_KIND_ALL: experiments (what the narrower kind sets buy)
     if (ds->kind_mask & KM_HGCA) {
-        // an HGCA table next to the rows: three kind sets carry k_small's proper-motion-anomaly block (the usual companions of an HGCA
-        // term are relative astrometry and RVs); the epoch-loop kernels behind them are the same instantiations as without the table
+        // an HGCA table next to the rows: two kind sets carry k_small's proper-motion-anomaly block — relative astrometry alone (the
+        // usual joint fit) and everything; the epoch-loop kernels behind them are the same instantiations as without the table
         if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR | KM_HGCA>(ctx, ds, a, grad, nuis, sm, st);
+        if ((km & ~(KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL)) == 0) return dispatch2<P, KM_RADEC | KM_SEPPA | KM_COR | KM_ONEIL | KM_HGCA>(ctx, ds, a, grad, nuis, sm, st);
         if ((km & (KM_MARG | KM_ONEIL)) == 0) return dispatch2<P, (KM_ALL & ~KM_MARG & ~KM_ONEIL) | KM_HGCA>(ctx, ds, a, grad, nuis, sm, st);
         return dispatch2<P, KM_ALL | KM_HGCA>(ctx, ds, a, grad, nuis, sm, st);
     }

@@ -64,6 +64,8 @@ struct ModelArgs {
     int32_t D, n_el, n_nu, n_planets;
     int32_t src_waves, n_circ;      // k_model_fwd: waves per block that resolve sources (the block may hold more, for the priors);
                                     // number of UniformCircular pairs precomputed through LDS
+    int32_t write_values, pad_wv;   // k_model_fwd<N > 0>: also store the kernel inputs and the prior sum (0: a k_model_fwd<0> launch does — the
+                                    // Jacobian launch then runs beside the likelihood kernels, which read those values)
     const int32_t* circ_slot;       // [n_el + n_nu] LDS slot of a CIRCULAR / TPERI source's (atan2, UnitLength) values, or -1
     const double* theta_t; int64_t ld, W, ldw;
     double* elems; double* nuis;    // [n_el][ldw], [n_nu][ldw]   (kernel inputs)
@@ -256,8 +258,10 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
 // logpdf_with_trans of every prior — is computed once per walker by the block's waves (prior k by wave k mod DB) and
 // shared through LDS: x[k], dx/dθ_t[k], p[k], dp/dθ_t[k]. Fast-math duals as in k_small<MODEL> (polynomial sincos / atan2,
 // reciprocal-multiply divisions): the chain is a few thousand serial instructions per wave, 30 µs at 1e4 walkers with the ocml routines.
+// N = MODEL_NPART: values and Jacobian; N = 0: the VALUES alone (kernel inputs, prior sum) — all a forward-only callback needs, and what the
+// likelihood kernels of a gradient callback wait for (the Jacobian launch runs beside them on a second stream, octo_model_logpost_device).
+template <int N>
 static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
-    constexpr int N = MODEL_NPART;      // partials carried per thread
     extern __shared__ __attribute__((aligned(16))) double lds[];      // [4][D][64]
     const int lane = threadIdx.x;
     const int wy = threadIdx.y, DB = blockDim.y;
@@ -341,8 +345,9 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         if (sc.kind == OCTO_SRC_THETA) return nat(sc.i0);
         return circ_angle(sc, k) * (sc.value / TWO_PI);               // atan(y, x) / 2π * domain, variables.jl:284
     };
+    const bool store_values = (N == 0) || a.write_values != 0;
     auto emit = [&](int k, const Dual<N, true>& val) {
-        if (d0 == 0) {
+        if (d0 == 0 && store_values) {
             double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
             *dst = val.v;
         }
@@ -386,7 +391,7 @@ static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
         }
         emit(a.n_el + k, plain(sc, a.n_el + k));
     }
-    if (d0 == 0) a.lpp[w] = finite_in ? lp.v + ulp.v : -INFINITY;
+    if (d0 == 0 && store_values) a.lpp[w] = finite_in ? lp.v + ulp.v : -INFINITY;
 #pragma unroll
     for (int j = 0; j < N; ++j)
         if (d0 + j < D) a.glp[(int64_t)(d0 + j) * a.ldw + w] = (healed ? 0.0 : lp.d[j]) + ulp.d[j];

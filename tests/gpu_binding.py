@@ -19,7 +19,7 @@ DEFAULT_SMALL_BATCH = int(os.environ["OCTO_TEST_SMALL_BATCH"]) if os.environ.get
 
 # Set to a number (NaN, 1e300) to fill every CU's LDS with it ahead of each evaluation (octo_debug_poison_lds, a test hook of the
 # library): a kernel that reads an LDS word it has not written then returns something else than with the usual stale zeros.
-POISON_LDS = None
+POISON_LDS = float(os.environ["OCTO_TEST_POISON_LDS"]) if os.environ.get("OCTO_TEST_POISON_LDS") else None      # the stand-alone sweeps: nan / 1e300
 
 
 def poison(ctx):

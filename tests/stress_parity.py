@@ -4,6 +4,7 @@ without the nuisance block, random table and batch sizes (ragged tiles). Run on 
     python tests/stress_parity.py [n_systems] [seed]
 Prints the worst errors; exits non-zero if a case breaks the bars of tests/test_gpu_parity.py. tests/test_sweeps_gpu.py runs a
 fixed-seed slice of the same sweep under pytest -m gpu."""
+import os
 import sys
 from pathlib import Path
 import numpy as np
@@ -29,7 +30,7 @@ SCALE = 1      # argv[3]: multiplies table sizes and batch sizes (partition plan
 
 
 def random_system(rng, invalid=True, P=None, W=None):
-    P = int(rng.integers(1, 4)) if P is None else P
+    P = int(rng.integers(1, 1 + int(os.environ.get("OCTO_TEST_MAX_P", "3")))) if P is None else P      # (OCTO_TEST_MAX_P=4: four-planet systems too)
     W = int(rng.choice([1, 7, 64, 65, 130, 200, 333])) * (1 if SCALE == 1 else int(rng.integers(1, SCALE + 1))) if W is None else W
     kinds_pl = [int(rng.choice([0, 0, 2, 1])) for _ in range(P)]
     has_rv_basis = any(k == 1 for k in kinds_pl)
@@ -64,7 +65,7 @@ def random_system(rng, invalid=True, P=None, W=None):
         for d in np.linspace(-500, 500, N): rows += [(57408.0 + d, 0, 1), (57470.0 + d, 1, 1)]
         rows = np.array(rows)
         obs.append(dict(kind=7, planet=-1, epoch=rows[:, 0], y1=rows[:, 1], y2=rows[:, 2], s1=None, s2=None, cor=None, extra=HG))
-    if not obs:
+    if not obs or P * 9 + len(obs) * 3 > 64:      # (the checker carries at most 64 forward-mode partials: four planets with ten tables exceed it)
         return None
     nuis = np.zeros((len(obs) * 3, W))
     for io, o in enumerate(obs):

@@ -45,7 +45,7 @@ def test_latency_kernels_have_no_scratch_and_no_vgpr_spills(rows):
 
 
 # The nuisance-free single-planet RA/Dec gradient kernels are held to 72 VGPRs (seven waves per SIMD, octo_kernels.h: main_min_waves): the
-# compiler parks 12 bytes OUTSIDE the row loop (two scratch instructions per wave, measured -1 % step time in round 2). Deliberate.
+# compiler parks 12-16 bytes OUTSIDE the row loop (two to four scratch instructions per wave, measured -1 % step time in round 2). Deliberate.
 SEVEN_WAVES = re.compile(r"k_main<1, true, false, (1|33), (true|false)>")
 
 
@@ -76,5 +76,15 @@ def test_private_segments_are_dead_spill_slots_or_listed(rows):
 def test_code_size_budget(rows):
     total = sum(r["code_bytes"] for r in rows)
     lib = ROOT / "octofitter.jl_amd" / "lib" / "liboctofitter_hip.so"
-    assert total < 14.0e6, f"device code {total / 1e6:.1f} MB"
-    assert lib.stat().st_size < 17.0e6, f"liboctofitter_hip.so {lib.stat().st_size / 1e6:.1f} MB (VERDICT r3 item 7: < 15 MB)"
+    assert total < 12.0e6, f"device code {total / 1e6:.1f} MB"
+    assert lib.stat().st_size < 15.0e6, f"liboctofitter_hip.so {lib.stat().st_size / 1e6:.1f} MB (VERDICT r3 item 7: < 15 MB)"
+
+
+def test_no_scalar_load_is_read_before_its_wait():
+    """k_main's row prefetch issues s_load_dwordx8 / x4 from inline assembly and waits in a later asm block — the compiler's
+    own s_waitcnt insertion does not see them. The contract is checked on the ISA of EVERY k_main variant: on no path of the kernel's
+    control-flow graph does an instruction name a destination register of a scalar load before an `s_waitcnt … lgkmcnt(0)`.
+    (Round 3's loop failed this check on its early exit: copies of the in-flight tuple ahead of the wait, values that happened to be dead.)"""
+    import kernel_resources as kr
+    bad = kr.scalar_load_hazards()
+    assert not bad, bad[:10]

@@ -134,5 +134,86 @@ def main():
     print(f"{'total':18s} {len(rows):7d} {sum(r['code_bytes'] for r in rows) / 1e6:8.2f}")
 
 
+
+
+# ---- scalar-load hazard check (ADVICE r3): k_main's row prefetch issues s_load_dwordx8/x4 from inline assembly and waits for them in a LATER
+# asm block, which the compiler's own s_waitcnt insertion does not track. The contract is checked on the final ISA instead: between a
+# scalar load and the next `s_waitcnt … lgkmcnt(0)` no instruction may name a register of the load's destination.
+def _sregs(tok):
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def scalar_load_hazards(build_dir: Path = BUILD, name_filter: str = "k_main"):
+    """[(kernel symbol, address, instruction text)] for every instruction that names a register of a scalar load's destination while that load
+    may still be in flight — a forward data-flow over the kernel's control-flow graph (blocks cut at branches and branch targets; a load is
+    pending from its issue to the next `s_waitcnt … lgkmcnt(0)` on every path)."""
+    bad = []
+    with tempfile.TemporaryDirectory() as td:
+        for obj in sorted(build_dir.glob("*.o")):
+            co = code_object(obj, Path(td))
+            if co is None:
+                continue
+            out = subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--no-show-raw-insn", str(co)], capture_output=True, text=True).stdout
+            kernels, cur = {}, None
+            for line in out.splitlines():
+                m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)
+                if m:
+                    cur = m.group(2) if name_filter in m.group(2) else None
+                    if cur:
+                        kernels[cur] = (int(m.group(1), 16), [])
+                    continue
+                if cur is None or "//" not in line:
+                    continue
+                txt, com = line.split("//", 1)
+                txt = txt.strip()
+                ma = re.match(r"\s*([0-9A-Fa-f]+):", com)
+                if not txt or not ma:
+                    continue
+                tgt = re.search(r"<\S+?\+0x([0-9a-fA-F]+)>", com)
+                kernels[cur][1].append((int(ma.group(1), 16), txt, int(tgt.group(1), 16) if tgt else None))
+            for sym, (base, ins) in kernels.items():
+                addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
+                succ = []
+                for i, (a, txt, tgt) in enumerate(ins):
+                    op = txt.split()[0]
+                    nxt = [i + 1] if i + 1 < len(ins) else []
+                    if op == "s_endpgm":
+                        succ.append([])
+                    elif op == "s_branch":
+                        succ.append([addr_index[base + tgt]] if tgt is not None and base + tgt in addr_index else [])
+                    elif op.startswith("s_cbranch"):
+                        succ.append(nxt + ([addr_index[base + tgt]] if tgt is not None and base + tgt in addr_index else []))
+                    else:
+                        succ.append(nxt)
+                state = [None] * len(ins)      # pending registers on entry
+                state[0] = frozenset()
+                work = [0]
+                flagged = set()
+                while work:
+                    i = work.pop()
+                    pend = set(state[i])
+                    a, txt, _ = ins[i]
+                    parts = re.split(r"[ ,]+", txt)
+                    op, args = parts[0], parts[1:]
+                    if op.startswith("s_waitcnt"):
+                        if "lgkmcnt(0)" in txt:
+                            pend = set()
+                    else:
+                        used = set().union(*[_sregs(t) for t in args]) if args else set()
+                        if pend & used and i not in flagged:
+                            flagged.add(i); bad.append((sym, a, txt))
+                        if op.startswith(("s_load_", "s_buffer_load_")) and args:
+                            pend |= _sregs(args[0])
+                    out_state = frozenset(pend)
+                    for j in succ[i]:
+                        merged = out_state if state[j] is None else (state[j] | out_state)
+                        if state[j] is None or merged != state[j]:
+                            state[j] = merged; work.append(j)
+    return bad
+
 if __name__ == "__main__":
     main()

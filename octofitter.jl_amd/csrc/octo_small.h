@@ -668,6 +668,11 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
 #ifdef OCTO_SMALL_FULL_FENCE
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #else
+        // The published stores of this protocol — ALL of them must stay agent-scope atomic (write-through) stores for the shortcut below:
+        //   (1) a.partials[(w·n_tasks + task)·NACC + k]   this block's task sums           (__hip_atomic_store above, after the block reduction)
+        //   (2) a.extra[w], a.extra[(1 + d)·ldw + w]       the HGCA term and its partials   (__hip_atomic_store in the HGCA block)
+        //   (3) counters[w]                                 the finished-block count        (__hip_atomic_fetch_add below)
+        // A PLAIN store added to this set would need the full agent-scope release (OCTO_SMALL_FULL_FENCE) again.
         // Everything this protocol publishes is an agent-scope ATOMIC store (sc1: written through, never left dirty in L2), so the
         // L2 write-back half of the fence has nothing to do — and costs 1-6 µs per call on the multi-block latency path (same-box
         // A/B, profiles/r3_small_fence_ab.txt). What the release needs from the hardware is the wait for those stores' acknowledgements.

@@ -210,6 +210,8 @@ def test_bench_line_contract():
     assert d["parity"]["ok"] is True and d["max_rel_err"] < 1e-8
     assert 0.5 * d["value"] < d["pcie_inclusive"]["value"] < d["value"]
     assert d["config1"]["gpu_matches_fixture"] is True and 5 < d["config1"]["gpu_us_per_call"] < 200
+    # cold start in a fresh process (tools/first_call.py): module load + first call, and the library's size
+    assert 0.05 < d["config1"]["first_call_ms"] < 2000 and d["config1"]["first_call"]["finite"] is True and d["config1"]["lib_bytes"] < 15e6
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 1e5
     # the CPU restatement single-thread and on all cores, forward-only and fwd+grad
     cb = d["cpu_baseline"]

@@ -171,6 +171,61 @@ def test_gpu_model_two_planet_rv(pkg, oracle, model_golden):
     model.close()
 
 
+def _two_planet_model(pkg, case):
+    o_a, o_r = case["obs"]
+    astrom = pkg.PlanetRelAstromObs(dict(epoch=o_a["epoch"], ra=o_a["y1"], dec=o_a["y2"], σ_ra=o_a["s1"], σ_dec=o_a["s2"], cor=o_a["cor"]), name="GPI astrom",
+                                    variables=pkg.variables(jitter=pkg.LogUniform(0.1, 20.0), northangle=pkg.Normal(0.0, 0.05)))
+    rv = pkg.StarAbsoluteRVObs(dict(epoch=o_r["epoch"], rv=o_r["y1"], σ_rv=o_r["s1"]), name="HARPS",
+                               variables=pkg.variables(offset=pkg.Normal(0.0, 30.0), jitter=pkg.LogUniform(0.1, 50.0)))
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[],
+                   variables=pkg.variables(a=pkg.LogUniform(1.0, 5.0), e=pkg.Uniform(0.0, 0.9), i=pkg.Sine(), ω=pkg.UniformCircular(), Ω=pkg.UniformCircular(),
+                                           tp=pkg.Uniform(49000.0, 51000.0), mass=pkg.LogUniform(0.5, 50.0)))
+    c = pkg.Planet(name="c", basis="Visual{KepOrbit}", observations=[astrom],
+                   variables=pkg.variables(a=pkg.LogUniform(8.0, 40.0), e=pkg.Uniform(0.0, 0.9), i=pkg.Sine(), ω=pkg.UniformCircular(), Ω=pkg.UniformCircular(),
+                                           θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000.0), mass=pkg.Uniform(0.0, 30.0)))
+    return pkg.System(name="two", companions=[b, c], observations=[rv],
+                      variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.5, upper=2.0), plx=pkg.Normal(50.0, 0.5)))
+
+
+@pytest.mark.gpu
+def test_gpu_model_tail_inside_k_finish(pkg, oracle, model_golden):
+    """Round 4: for batches on the throughput kernels the tail of the callback — lp = prior + ll with the callback's rules, ∇θ_t = Jᵀḡ +
+    ∇prior (src/logdensitymodel.jl:110-146, 169-177) — runs inside k_finish (model_tail), for one planet (finish_tile) and for several
+    (finish_tile_multi, with nuisance variables). Same θ_t through the fused small-batch launch and through the throughput route must
+    agree to rounding and with the oracle; the forward-only callback (k_model_fwd<0>) returns the value the gradient callback returns;
+    a non-finite θ_t gives -Inf and a zero gradient on both routes."""
+    rng = np.random.default_rng(44)
+    for case, build in ((model_golden[0], lambda: _reference_test_model(pkg)), (model_golden[1], lambda: _two_planet_model(pkg, model_golden[1]))):
+        base = np.asarray(case["theta_t"])
+        D = base.shape[0]
+        W = 150                                    # 3 walker tiles, the last one ragged
+        th = base[:, rng.integers(0, base.shape[1], W)] + 0.02 * rng.normal(size=(D, W))
+        th[2, 5] = np.inf                          # logdensitymodel.jl:120-124
+        out = {}
+        for route in ("small", "throughput"):
+            model = pkg.LogDensityModel(build())
+            if route == "throughput":
+                model.ln_like._check(model.ln_like.lib.octo_ctx_set_small_batch(model.ln_like._ctx, 0), "set")
+            lp, g = model.logdensity_and_gradient(th)
+            lpf = model.ℓπcallback(th)
+            out[route] = (lp, g, lpf)
+            if route == "throughput":
+                obs, planets = _tables(case)
+                nsrc = getattr(model, "_c_nsrc", None)
+                lp_o, g_o = oracle.oracle_model_logpost(obs, planets, model._c_priors, model._c_esrc, nsrc, th)
+            model.close()
+        (lp_s, g_s, lpf_s), (lp_t, g_t, lpf_t) = out["small"], out["throughput"]
+        assert np.isneginf(lp_t[5]) and np.isneginf(lp_s[5]) and np.all(g_t[:, 5] == 0.0) and np.all(g_s[:, 5] == 0.0)
+        assert np.array_equal(lpf_t, lp_t), "forward-only callback != value returned with the gradient (throughput route)"
+        ok = np.isfinite(lp_o)
+        assert ok.sum() >= W - 1 and np.array_equal(np.isfinite(lp_t), ok)
+        assert np.max(np.abs(lp_t[ok] - lp_s[ok]) / np.maximum(1.0, np.abs(lp_s[ok]))) < 1e-12
+        assert np.max(np.abs(lp_t[ok] - lp_o[ok]) / np.maximum(1.0, np.abs(lp_o[ok]))) < 1e-11
+        sc = np.maximum(np.abs(g_o[:, ok]).max(axis=1, keepdims=True), 1e-300)
+        assert np.max(np.abs(g_t[:, ok] - g_s[:, ok]) / sc) < 1e-10
+        assert np.max(np.abs(g_t[:, ok] - g_o[:, ok]) / sc) < 1e-9
+
+
 @pytest.mark.gpu
 def test_gpu_model_reference_style(pkg):
     """test/integration/sampling.jl:136-192 ("Autodiff Gradient Comparison") and :70-76 re-expressed: the device

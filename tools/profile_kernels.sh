@@ -25,6 +25,8 @@ run nuis $B --workload nuis
 run fwd $B --workload fwd
 run ofti $B --workload ofti
 run logpost $B --workload logpost
+run three_planet python $ROOT/tools/multi_planet_steps.py 3 60
+run four_planet python $ROOT/tools/multi_planet_steps.py 4 60
 run small_w1 python $ROOT/tools/small_batch_one.py 10000 1 600
 run small_w512 python $ROOT/tools/small_batch_one.py 10000 512 300
 cd $ROOT

@@ -11,8 +11,9 @@ A "step" is ONE pass of the hot path (k_main with the orbit constructors in its 
 one batch of synthetic input that is already resident in HBM: BASELINE.json config 3 — 1 planet, 1e4 RA/Dec epochs x 1e4 prior-drawn
 walkers, forward log-likelihood + reverse gradient w.r.t. the orbital elements. Metric: epoch-likelihood evaluations per second =
 walkers x rows x steps / wall time, whole job. `value` is that HBM-resident rate (the bench contract); SURVEY.md §8(d) defines the
-metric with the H2D of the elements and the D2H of ll + gradient inside the timed call: that rate travels on the same line as
-`value_pcie_inclusive` (octo_eval on host arrays the caller registered once), with its breakdown in `pcie_inclusive`.
+metric with the H2D of the elements and the D2H of ll + gradient inside the timed call, on the DEVICE's clock (hipEvent): that rate travels on
+the same line as `value_pcie_inclusive` (octo_eval on host arrays the caller registered once, events around the whole call inside the library),
+next to `value_pcie_inclusive_blocking_call` (the same calls by the host's clock) and the breakdown in `pcie_inclusive`.
 Multi-GPU: walkers are independent, the dataset is replicated, and there is NO collective on the data path (the only collective of the
 path is the parallel-tempering swap step, exercised with --workload pt).
   --scaling weak    (default, the bench contract's mode for a path that shards by independent units): every rank owns its own 1e4 walkers;
@@ -570,12 +571,24 @@ def main():
                 for _ in range(25):
                     t1 = time.perf_counter(); fn.lib.octo_eval(*a_); ts.append(time.perf_counter() - t1)
                 medr = float(np.median(ts))
+                # SURVEY 8(d)'s clock: DEVICE time of the call by HIP events, from ahead of the copy-in to behind k_finish's stores into the
+                # caller's arrays (octo_timing_enable(ctx, -1)); the blocking call's wall time adds the launch + synchronisation of one call
+                fn.timing_read(reset=True)
+                fn.timing_enable(-1)
+                for _ in range(25):
+                    fn.lib.octo_eval(*a_)
+                dev_med, dev_min, dev_max, dev_n = fn.timing_stats()
+                fn.timing_read(reset=True)
+                fn.timing_enable(0)
                 fn.host_unregister(el_h, ll_h, g_h)
-                res["value_pcie_inclusive"] = W * n_rows / medr
-                res["value_pcie_inclusive_what"] = ("SURVEY.md 8(d)'s definition of the metric: octo_eval on host arrays (registered once by the caller), H2D of the "
-                                                    "elements and D2H of ll + gradient inside the timed call; median of 25 blocking calls")
+                res["value_pcie_inclusive"] = W * n_rows / (dev_med * 1e-3)
+                res["value_pcie_inclusive_what"] = ("SURVEY.md 8(d)'s definition of the metric: device time (HIP events on the call's stream) of octo_eval on host arrays "
+                                                    "registered once by the caller, H2D of the elements and D2H of ll + gradient inside; median of 25 calls. "
+                                                    "value_pcie_inclusive_blocking_call: the same calls by the host's clock (adds one launch + synchronisation per call)")
+                res["value_pcie_inclusive_blocking_call"] = W * n_rows / medr
                 res["pcie_inclusive"]["registered"] = {
-                    "value": W * n_rows / medr, "unit": "evals/s", "ms_per_call_median": medr * 1e3, "calls": len(ts),
+                    "value": W * n_rows / (dev_med * 1e-3), "unit": "evals/s", "device_ms_per_call_median": dev_med, "device_ms_min": dev_min, "device_ms_max": dev_max,
+                    "calls_timed": int(dev_n), "blocking_call_value": W * n_rows / medr, "ms_per_call_median": medr * 1e3, "calls": len(ts),
                     "bit_identical_to_pageable": bool(np.array_equal(ll_h, ll_ref, equal_nan=True)),
                     "what": "the same octo_eval call with elems, ll and gradient arrays registered once by the caller (octo_host_register: "
                             "page-locked + mapped): no copy engine, inputs by a copy kernel over PCIe, outputs written in place"}

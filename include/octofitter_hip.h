@@ -331,7 +331,9 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
 /* Measurement hook used by bench.py: average duration in milliseconds of the
  * dominant (epoch-loop) kernel over the launches since the last reset, from
  * hipEvents recorded on the launch stream. octo_timing_enable(ctx, n): n = 0 off, n >= 1 bracket the kernel of every
- * n-th evaluation (an event pair costs a few µs of stream time, so a timed region samples rather than brackets all). */
+ * n-th evaluation (an event pair costs a few µs of stream time, so a timed region samples rather than brackets all);
+ * n = -1: bracket every HOST-BUFFER evaluation (octo_eval / octo_eval_begin) whole, from ahead of its first copy to behind
+ * its last kernel or copy — the device time of the call with the PCIe transfers inside (SURVEY.md 8d's clock). */
 int32_t octo_timing_enable(octo_ctx* ctx, int32_t every_n);
 int32_t octo_timing_read(octo_ctx* ctx, double* avg_ms, int64_t* n_launches, int32_t reset);
 /* Median / min / max over the individual timed launches since the last reset (does not reset). */

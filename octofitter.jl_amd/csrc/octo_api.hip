@@ -699,8 +699,8 @@ int32_t octo_sync(octo_ctx* ctx) {
     return OCTO_OK;
 }
 
-int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* elems, const double* nuis, int64_t ld, int64_t W,
-                        double* ll_out, double* g_elems, double* g_nuis) {
+static int32_t eval_begin_impl(octo_ctx* ctx, const octo_dataset* ds, const double* elems, const double* nuis, int64_t ld, int64_t W,
+                               double* ll_out, double* g_elems, double* g_nuis) {
     if (!ctx || !ds || !elems || !ll_out) return fail(ctx, OCTO_EINVAL, "octo_eval: null argument");
     if (W < 0 || ld < W) return fail(ctx, OCTO_EINVAL, "octo_eval: need 0 <= W <= ld");
     if (ctx->pending.active) return fail(ctx, OCTO_EINVAL, "octo_eval_begin: the previous octo_eval_begin of this context has not been ended");
@@ -845,6 +845,28 @@ int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* ele
     return OCTO_OK;
 }
 
+int32_t octo_eval_begin(octo_ctx* ctx, const octo_dataset* ds, const double* elems, const double* nuis, int64_t ld, int64_t W,
+                        double* ll_out, double* g_elems, double* g_nuis) {
+    // octo_timing_enable(ctx, -1): the DEVICE time of the whole host-buffer evaluation — SURVEY §8(d)'s clock for the metric ("device time of
+    // the octo_eval call (hipEvent), H2D of elems and D2H of ll/grad included") — between an event ahead of the first copy and one behind
+    // the last kernel / copy on the context's stream
+    if (!ctx || !ctx->timing_whole || ctx->pending.active || W <= 0) return eval_begin_impl(ctx, ds, elems, nuis, ld, W, ll_out, g_elems, g_nuis);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->ev_used >= 4096) { int rcd = drain_timing(ctx); if (rcd) return rcd; }
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t x, y;
+        HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
+        ctx->ev_pool.emplace_back(x, y);
+    }
+    hipEvent_t e0 = ctx->ev_pool[ctx->ev_used].first, e1 = ctx->ev_pool[ctx->ev_used].second;
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    const int32_t rc = eval_begin_impl(ctx, ds, elems, nuis, ld, W, ll_out, g_elems, g_nuis);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->ev_used++;
+    return OCTO_OK;
+}
+
 int32_t octo_eval_end(octo_ctx* ctx) {
     if (!ctx) return OCTO_EINVAL;
     octo_ctx::Pending& pd = ctx->pending;
@@ -968,6 +990,7 @@ int32_t octo_kepler_solve_table(octo_ctx* ctx, const double* MA, const double* e
 int32_t octo_timing_enable(octo_ctx* ctx, int32_t on) {
     if (!ctx) return OCTO_EINVAL;
     ctx->timing_every = on > 0 ? on : 0;
+    ctx->timing_whole = on < 0;
     ctx->timing_seq = 0;
     return OCTO_OK;
 }

@@ -126,6 +126,7 @@ struct octo_ctx {
     std::map<uint32_t, int> occupancy;          // resident blocks per CU of each k_main variant (P, NUIS, KM) on THIS device
     // timing
     int timing_every = 0;                       // 0 = off, n = bracket every n-th evaluation's k_main with events
+    bool timing_whole = false;                  // octo_timing_enable(ctx, -1): bracket every host-buffer evaluation WHOLE (copy-in .. last store)
     int64_t timing_seq = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;

@@ -13,7 +13,7 @@ W, E = 10000, 10000
 cfg = synth.config_astrom(n_epochs=E, n_walkers=W, cfg=3)
 obs, planet = synth.to_mirror(pkg, cfg)
 fn = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
-el_h = np.ascontiguousarray(cfg["elems"]); el = torch.tensor(el_h, device="cuda")
+el_h = np.array(cfg["elems"], order="C", copy=True); el = torch.tensor(el_h, device="cuda")      # a COPY: the timed calls perturb el_h[0, 0]
 out = (torch.empty(W, dtype=torch.float64, device="cuda"), torch.empty_like(el), None)
 for _ in range(100): fn.ln_like_device(el, None, grad=True, out=out)
 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -35,10 +35,21 @@ for _ in range(100):
     el_h[0, 0] += 1e-9      # the inputs change from call to call (a stale cached copy would show)
     t1 = time.perf_counter(); fn.lib.octo_eval(*a_); ts.append(time.perf_counter() - t1)
 reg = float(np.median(ts))
+fn.timing_read(reset=True); fn.timing_enable(-1)      # SURVEY 8(d)'s clock: device time of the whole call (HIP events inside the library)
+for _ in range(100):
+    el_h[0, 0] += 1e-9
+    fn.lib.octo_eval(*a_)
+dev_med, dev_min, dev_max, dev_n = fn.timing_stats()
+fn.timing_read(reset=True); fn.timing_enable(0)
 el_h[:] = cfg["elems"]; ll_h[:] = np.nan
 fn.lib.octo_eval(*a_)
 same = bool(np.array_equal(ll_h, ll_ref, equal_nan=True) and np.array_equal(g_h, g_ref, equal_nan=True))
+if not same:
+    bad = ~((ll_h == ll_ref) | (np.isnan(ll_h) & np.isnan(ll_ref)))
+    print("ll differs at", int(bad.sum()), "walkers; first:", np.flatnonzero(bad)[:5], ll_h[bad][:3], ll_ref[bad][:3],
+          "| gradient entries that differ:", int((~((g_h == g_ref) | (np.isnan(g_h) & np.isnan(g_ref)))).sum()), flush=True)
 fn.host_unregister(el_h, ll_h, g_h)
-print(f"{tag:>28}: device-resident back-to-back {dev*1e6:7.1f} us, one at a time {lat*1e6:7.1f} us | octo_eval registered {reg*1e6:7.1f} us "
-      f"(ratio to back-to-back {dev/reg:.3f}) bit-identical to the device-resident result: {same}", flush=True)
+tag += " ahead=" + os.environ.get("OCTO_STAGE_AHEAD", "default")
+print(f"{tag:>36}: device-resident back-to-back {dev*1e6:7.1f} us, one at a time {lat*1e6:7.1f} us | octo_eval registered: device clock {dev_med*1e3:7.1f} us "
+      f"(ratio {dev/(dev_med*1e-3):.3f}), blocking call {reg*1e6:7.1f} us (ratio {dev/reg:.3f}) bit-identical to the device-resident result: {same}", flush=True)
 fn.close()

@@ -594,6 +594,38 @@ def main():
                             "page-locked + mapped): no copy engine, inputs by a copy kernel over PCIe, outputs written in place"}
             except Exception as ex:
                 res["pcie_inclusive"]["registered"] = {"error": str(ex)}
+            # ---- the same host-buffer evaluations PIPELINED: two contexts (two streams), octo_eval_begin on one while the other's batch is in
+            # flight — how a driver that holds two walker batches (or two Julia threads, src/initialization.jl:33-48) hides the PCIe legs and
+            # the launch + synchronisation of a blocking call: copy-in and write-back of one batch run under the epoch loop of the other
+            try:
+                fn2 = pkg.make_ln_like(system, cfg["theta_example"], device=dev_index)
+                bufs = []
+                for f_ in (fn, fn2):
+                    e_, l_, g_ = np.array(elems_h, order="C", copy=True), np.empty(W), np.empty((elems_h.shape[0], W))
+                    f_.host_register(e_, l_, g_)
+                    bufs.append((f_, e_, l_, g_, (f_._ctx, f_._ds, capi._dptr(e_), None, W, W, capi._dptr(l_), capi._dptr(g_), None)))
+                lib = fn.lib
+                def pipelined(n_calls):
+                    assert lib.octo_eval_begin(*bufs[0][4]) == 0
+                    for k in range(1, n_calls):
+                        assert lib.octo_eval_begin(*bufs[k & 1][4]) == 0
+                        assert lib.octo_eval_end(bufs[(k - 1) & 1][0]._ctx) == 0
+                    assert lib.octo_eval_end(bufs[(n_calls - 1) & 1][0]._ctx) == 0
+                pipelined(6)
+                n_calls = 40
+                t1 = time.perf_counter(); pipelined(n_calls); dt2 = time.perf_counter() - t1
+                same2 = all(bool(np.array_equal(b[2], ll_ref, equal_nan=True)) for b in bufs)
+                for f_, e_, l_, g_, _ in bufs:
+                    f_.host_unregister(e_, l_, g_)
+                fn2.close()
+                res["value_pcie_inclusive_pipelined"] = W * n_rows * n_calls / dt2
+                res["pcie_inclusive"]["two_contexts_pipelined"] = {
+                    "value": W * n_rows * n_calls / dt2, "unit": "evals/s", "ms_per_call": dt2 / n_calls * 1e3, "calls": n_calls,
+                    "bit_identical_to_pageable": same2,
+                    "what": "octo_eval_begin / octo_eval_end on two contexts alternately, registered host arrays, every call a full 1e4-walker "
+                            "batch with its H2D and D2H inside: wall time of 40 calls / 40"}
+            except Exception as ex:
+                res["pcie_inclusive"]["two_contexts_pipelined"] = {"error": str(ex)}
         if not args.no_extras and world == 1 and args.workload == "grad":      # before the CPU baseline: its OpenMP team keeps spinning for a while and would disturb a latency measurement
             try:
                 res["strong_scaling_projection"] = strong_projection()

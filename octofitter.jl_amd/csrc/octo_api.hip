@@ -665,7 +665,7 @@ static int eval_impl(octo_ctx* ctx, const octo_dataset* ds, const double* d_elem
     a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w; a.sctab = ctx->d_sctab;
     a.ll_out = d_ll; a.g_elems = d_g_elems; a.g_nuis = d_g_nuis;
     if (ctx->mt_req) {
-        a.mt_J = ctx->mt.J; a.mt_glp = ctx->mt.glp; a.mt_lpp = ctx->mt.lpp; a.mt_lp = ctx->mt.lp; a.mt_grad = ctx->mt.grad;
+        a.mt_Jc = ctx->mt.Jc; a.mt_gtp = ctx->mt.gtp; a.mt_esrc = ctx->mt.esrc; a.mt_nsrc = ctx->mt.nsrc; a.mt_glp = ctx->mt.glp; a.mt_lpp = ctx->mt.lpp; a.mt_lp = ctx->mt.lp; a.mt_grad = ctx->mt.grad;
         a.mt_ld = ctx->mt.ld; a.mt_ldo = ctx->mt.ldo; a.mt_D = ctx->mt.D; a.mt_n_nu = ctx->mt.n_nu;
     }
     a.c = dev_consts(ctx->consts);
@@ -1040,8 +1040,9 @@ struct octo_model {
     // the same descriptors as ONE block for the fused small-batch launch (octo_small.h: SmallModel), byte offsets of its sections
     double* d_blob = nullptr;
     int32_t blob_n = 0, off_logz = 0, off_esrc = 0, off_nsrc = -1, off_cslot = 0, off_cpair = 0;
+    bool any_ti = false;              // some planet's tp is θ_at_epoch_to_tperi of a Thiele-Innes basis (k_model_fwd<·, TI>)
     bool fused_ok = false;            // all_circ_slotted and the block + the nuisance values fit k_small<MODEL>'s LDS staging
-    double* d_buf = nullptr;   // elems | nuis | J | lpp | glp | ll | g_el | g_nu, all [rows][ldw]
+    double* d_buf = nullptr;   // elems | nuis | Jc | gtp | lpp | glp | ll | g_el | g_nu, all [rows][ldw]
     int64_t cap_w = 0;
     double *d_th = nullptr, *d_res = nullptr;   // staging for host buffers
     int64_t cap_th = 0, cap_res = 0;
@@ -1084,6 +1085,7 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
     octo_model* m = new (std::nothrow) octo_model();
     if (!m) return fail(ctx, OCTO_ENOMEM, "octo_model_create: host allocation failed");
     m->device = ctx->device; m->ds = ds; m->D = D; m->n_el = n_el; m->n_nu = n_nu; m->has_nuis = has_nuis;
+    for (int k = 0; k < n_el; ++k) m->any_ti = m->any_ti || (elem_src[k].kind == OCTO_SRC_TPERI && (elem_src[k].flags & OCTO_SRC_FLAG_TI));
     auto bail = [&](int code, const char* msg) { octo_model_destroy(m); return fail(ctx, code, msg); };
     if (hipMalloc((void**)&m->d_priors, sizeof(octo_prior) * D) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
     if (hipMalloc((void**)&m->d_esrc, sizeof(octo_source) * n_el) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
@@ -1160,8 +1162,10 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
     if (m->lds_bytes > ctx->max_lds)
         return bail(OCTO_EINVAL, "octo_model_create: the model needs more LDS per block than this device has ((4·D + 6·n_circular)·512 B)");
     if (m->lds_bytes > 48 * 1024 &&
-        (hipFuncSetAttribute((const void*)k_model_fwd<MODEL_NPART>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
-         hipFuncSetAttribute((const void*)k_model_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess)) {
+        (hipFuncSetAttribute((const void*)k_model_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
+         hipFuncSetAttribute((const void*)k_model_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
+         hipFuncSetAttribute((const void*)k_model_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
+         hipFuncSetAttribute((const void*)k_model_fwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess)) {
         (void)hipGetLastError();
         if (m->lds_bytes > 64 * 1024) return bail(OCTO_EINVAL, "octo_model_create: cannot raise k_model_fwd's dynamic LDS limit for this model");
     }
@@ -1201,7 +1205,7 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     }
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     const int n_in = m->n_el + m->n_nu;
-    const int64_t rows = (int64_t)n_in + (int64_t)n_in * m->D + 1 + m->D + 1 + n_in;
+    const int64_t rows = (int64_t)n_in + 2 * (int64_t)n_in + m->n_el + 1 + m->D + 1 + n_in;
     if (ldw > m->cap_w) {
         if (m->d_buf) { ctx->retired.push_back(m->d_buf); m->d_buf = nullptr; m->cap_w = 0; }
         const int64_t cap = ldw + ldw / 2;
@@ -1217,7 +1221,8 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     double* p = m->d_buf;
     a.elems = p; p += (int64_t)m->n_el * L;
     a.nuis = p; p += (int64_t)m->n_nu * L;
-    a.J = p; p += (int64_t)n_in * m->D * L;
+    a.Jc = p; p += 2 * (int64_t)n_in * L;
+    a.gtp = p; p += (int64_t)m->n_el * L;
     a.lpp = p; p += L;
     a.glp = p; p += (int64_t)m->D * L;
     double* d_ll = p; p += L;
@@ -1226,26 +1231,25 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     a.ll = d_ll; a.g_el = d_gel; a.g_nu = m->has_nuis ? d_gnu : nullptr;
     a.lp_out = d_lp; a.grad_out = d_grad;
     a.k_yr = ctx->consts.kepler_year_to_julian_day; a.yd = ctx->consts.year2day_julian;
-    // θ_t -> kernel inputs, priors (+ Jacobian with a gradient). A forward-only callback launches the VALUES alone (k_model_fwd<0>: half the
-    // chain). Tried and not kept (profiles/r4_model_streams_ab.txt): values on the caller's stream + the Jacobian launch on a second stream
-    // beside k_main — k_main is undisturbed and the Jacobian fully hidden, but the values launch is still 13.6 of the 26 µs, k_finish
-    // slows down by 3.7 µs next to the Jacobian's tail and the fork / join events cost the rest: 0.364 ms per step against 0.351.
+    // θ_t -> kernel inputs, prior sum (+ the compact Jacobian with a gradient): one block of NW waves per tile of 64 walkers (octo_model.h).
+    // Tried and not kept (profiles/r4_model_streams_ab.txt, with the dense forward-mode kernel of rounds 1-3): values on the caller's stream +
+    // the Jacobian launch on a second stream beside k_main — fork / join events cost more than the hidden half saved.
     const bool grad = d_grad != nullptr;
-    a.circ_slot = m->d_circ; a.n_circ = m->n_circ; a.write_values = 1;
-    if (!grad) {
-        const int DB0 = std::max(1, std::min(m->D, 8));      // the priors are shared out over all DB waves; one wave resolves the sources
-        a.src_waves = 1;
-        hipLaunchKernelGGL(k_model_fwd<0>, dim3((unsigned)((W + 63) / 64), 1u), dim3(64, DB0), (size_t)m->lds_bytes, st, a);
-    } else {
-        const int n_thr = (m->D + MODEL_NPART - 1) / MODEL_NPART;      // threads per walker, MODEL_NPART partials each
-        const int DBs = std::min(n_thr, 8), DB = std::max(DBs, std::min(m->D, 8));      // the priors are shared out over all DB waves
-        a.src_waves = DBs;
-        hipLaunchKernelGGL(k_model_fwd<MODEL_NPART>, dim3((unsigned)((W + 63) / 64), (unsigned)((n_thr + DBs - 1) / DBs)), dim3(64, DB),
-                           (size_t)m->lds_bytes, st, a);
+    a.circ_slot = m->d_circ; a.circ_pair = m->d_circ_pair; a.n_circ = m->n_circ;
+    {
+        const int want = std::max(2 * m->n_circ + m->D, a.n_planets + 2);
+        const dim3 grid((unsigned)((W + 63) / 64)), block(64, (unsigned)std::max(1, std::min(want, m->any_ti ? 8 : 16)));
+        if (m->any_ti) {
+            if (grad) hipLaunchKernelGGL((k_model_fwd<true, true>), grid, block, (size_t)m->lds_bytes, st, a);
+            else hipLaunchKernelGGL((k_model_fwd<false, true>), grid, block, (size_t)m->lds_bytes, st, a);
+        } else {
+            if (grad) hipLaunchKernelGGL((k_model_fwd<true, false>), grid, block, (size_t)m->lds_bytes, st, a);
+            else hipLaunchKernelGGL((k_model_fwd<false, false>), grid, block, (size_t)m->lds_bytes, st, a);
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     // lp = prior + ll and ∇θ_t = Jᵀḡ + ∇prior: inside k_finish (model_tail), tile by tile as the adjoints become known
-    ctx->mt.J = a.J; ctx->mt.glp = a.glp; ctx->mt.lpp = a.lpp; ctx->mt.lp = d_lp; ctx->mt.grad = d_grad;
+    ctx->mt.Jc = a.Jc; ctx->mt.gtp = a.gtp; ctx->mt.esrc = m->d_esrc; ctx->mt.nsrc = m->d_nsrc; ctx->mt.glp = a.glp; ctx->mt.lpp = a.lpp; ctx->mt.lp = d_lp; ctx->mt.grad = d_grad;
     ctx->mt.ld = L; ctx->mt.ldo = ld; ctx->mt.D = m->D; ctx->mt.n_nu = m->has_nuis ? m->n_nu : 0;
     ctx->mt_req = true; ctx->mt_applied = false;
     int rc = eval_impl(ctx, m->ds, a.elems, m->has_nuis ? a.nuis : nullptr, L, W, d_ll, grad ? d_gel : nullptr,

@@ -95,7 +95,7 @@ struct octo_ctx {
     int64_t stage_ws_in = 0, stage_ws_out = 0;  // > 0 while octo_eval hands k_small its walker-major staging buffers
     // octo_model_logpost_device (big batches): the model's tail for k_finish (EvalArgs::mt_*), valid while mt_req; launch_all sets mt_applied
     // when a k_finish launch carried it (a batch that k_small took has no k_finish: the caller then launches k_model_bwd)
-    struct ModelTail { const double *J = nullptr, *glp = nullptr, *lpp = nullptr; double *lp = nullptr, *grad = nullptr; int64_t ld = 0, ldo = 0; int32_t D = 0, n_nu = 0; } mt;
+    struct ModelTail { const double *Jc = nullptr, *gtp = nullptr, *glp = nullptr, *lpp = nullptr; const octo_source *esrc = nullptr, *nsrc = nullptr; double *lp = nullptr, *grad = nullptr; int64_t ld = 0, ldo = 0; int32_t D = 0, n_nu = 0; } mt;
     bool mt_req = false, mt_applied = false;
     // octo_eval_begin .. octo_eval_end: what is still to be waited for and copied out
     struct Pending {

@@ -93,7 +93,11 @@ struct EvalArgs {
     // The tail of the standard parameterisation (octo_model.h; src/logdensitymodel.jl:110-146,169-177) for big batches, run by k_finish right
     // after a tile's adjoints are known: lp = prior + ll with the callback's rules, ∇θ_t[d] = ∂prior/∂θ_t[d] + Σ_k J[k][d]·ḡ[k]. Null mt_lpp:
     // a plain likelihood evaluation. (Rounds 1-3: a kernel of its own, k_model_bwd, behind k_finish: 7 µs + a launch boundary per callback.)
-    const double* mt_J;           // [(n_in·D)][mt_ld]   Jacobian of the kernel inputs (elements, then nuisances) w.r.t. θ_t, from k_model_fwd
+    const double* mt_Jc;          // [2·n_in][mt_ld]     compact Jacobian of the kernel inputs (elements, then nuisances) w.r.t. θ_t, from k_model_fwd:
+                                  //                     ∂input k/∂θ_t[i0_k], ∂input k/∂θ_t[i1_k] (octo_model.h)
+    const double* mt_gtp;         // [n_el][mt_ld]       ∂tp/∂(element) of the element's planet, 0 where tp is not derived from them
+    const octo_source* mt_esrc;   // [n_el]              the model's element and nuisance sources (which θ_t an input reads); mt_nsrc may be null
+    const octo_source* mt_nsrc;
     const double* mt_glp;         // [D][mt_ld]          ∂(prior + UnitLength terms)/∂θ_t
     const double* mt_lpp;         // [mt_ld]             prior + UnitLength terms (−Inf for a non-finite θ_t)
     double* mt_lp; double* mt_grad;      // outputs: lp[W]; grad[D][mt_ldo] or null
@@ -1149,6 +1153,34 @@ __device__ __forceinline__ void planet_finish(const double (&el)[OCTO_N_EL] /* t
 }
 
 // ------------------------------------------------------------------------------------ model tail (k_finish, big-batch callbacks)
+// ∇θ_t[d] = ∂prior/∂θ_t[d] + Σ_k ([i0_k = d]·Jc[2k] + [i1_k = d]·Jc[2k+1])·(ḡ[k] + ḡ[tp]·gtp[k]) for walker w — the tail of the callback
+// (k_finish: model_tail; behind a k_small batch: k_model_bwd). ge / gn: the likelihood kernels' adjoints, [rows][ldg].
+__device__ __forceinline__ double model_grad_row(int d, int64_t w, int n_planets, int n_nu, const octo_source* __restrict__ esrc,
+                                                 const octo_source* __restrict__ nsrc, const double* __restrict__ Jc, const double* __restrict__ gtp,
+                                                 const double* __restrict__ glp, int64_t ldj, const double* __restrict__ ge,
+                                                 const double* __restrict__ gn, int64_t ldg) {
+    double g = glp[(int64_t)d * ldj + w];
+    const int n_el = n_planets * OCTO_N_EL, n_in = n_el + ((nsrc && gn) ? n_nu : 0);
+#pragma unroll 1
+    for (int k = 0; k < n_in; ++k) {
+        const octo_source sc = k < n_el ? esrc[k] : nsrc[k - n_el];      // wave-uniform: scalar loads and scalar branches
+        if (sc.kind == OCTO_SRC_CONST) continue;
+        const bool h0 = sc.i0 == d, h1 = sc.kind != OCTO_SRC_THETA && sc.i1 == d;
+        if (!h0 && !h1) continue;
+        double gk;
+        if (k < n_el) {
+            gk = ge[(int64_t)k * ldg + w];
+            const int ktp = k - k % OCTO_N_EL + OCTO_EL_TP;
+            if (k != ktp && esrc[ktp].kind == OCTO_SRC_TPERI) gk = fma(ge[(int64_t)ktp * ldg + w], gtp[(int64_t)k * ldj + w], gk);
+        } else {
+            gk = gn[(int64_t)(k - n_el) * ldg + w];
+        }
+        if (h0) g = fma(Jc[(int64_t)(2 * k) * ldj + w], gk, g);
+        if (h1) g = fma(Jc[(int64_t)(2 * k + 1) * ldj + w], gk, g);
+    }
+    return g;
+}
+
 // Called by every thread of a k_finish block once the tile's ll, ḡ_elems and ḡ_nuis are in memory (written by other waves of the SAME
 // block: a block-scope fence + barrier make them visible). Wave g forms the gradient rows d = g, g + NG, … for its lane's walker.
 template <int P>
@@ -1163,11 +1195,9 @@ __device__ __forceinline__ void model_tail(const EvalArgs& a, int64_t w, int grp
     if (grp == 0) a.mt_lp[w] = lp;
     if (!a.mt_grad) return;
     const bool ok = isfinite(lp);
-    const int D = a.mt_D, n_el = P * OCTO_N_EL, n_nu = a.g_nuis ? a.mt_n_nu : 0;
+    const int D = a.mt_D, n_nu = a.g_nuis ? a.mt_n_nu : 0;
     for (int d = grp; d < D; d += n_waves) {
-        double g = a.mt_glp[(int64_t)d * a.mt_ld + w];
-        for (int k = 0; k < n_el; ++k) g = fma(a.mt_J[((int64_t)k * D + d) * a.mt_ld + w], a.g_elems[(int64_t)k * a.ld + w], g);
-        for (int k = 0; k < n_nu; ++k) g = fma(a.mt_J[((int64_t)(n_el + k) * D + d) * a.mt_ld + w], a.g_nuis[(int64_t)k * a.ld + w], g);
+        const double g = model_grad_row(d, w, P, n_nu, a.mt_esrc, a.mt_nsrc, a.mt_Jc, a.mt_gtp, a.mt_glp, a.mt_ld, a.g_elems, a.g_nuis, a.ld);
         a.mt_grad[(int64_t)d * a.mt_ldo + w] = ok ? g : 0.0;
     }
 }

@@ -52,8 +52,6 @@ DT DU datan2(const DU& y, const DU& x) {
 }
 
 constexpr int MODEL_MAXCIRC = 12;   // UniformCircular pairs whose atan2 / UnitLengthPrior values are shared through LDS (more: computed in place)
-constexpr int MODEL_NPART = 4;   // k_model_fwd: partials per thread. The value path (sincos, atan2, …) is the expensive part of a dual;
-                                 // 4 partials per thread repeat it D/4 times per walker instead of D times
 
 struct ModelArgs {
     const octo_prior* priors;       // [D]
@@ -62,14 +60,13 @@ struct ModelArgs {
     const octo_source* nsrc;        // [n_nu] or null
     const DevObs* obs;
     int32_t D, n_el, n_nu, n_planets;
-    int32_t src_waves, n_circ;      // k_model_fwd: waves per block that resolve sources (the block may hold more, for the priors);
-                                    // number of UniformCircular pairs precomputed through LDS
-    int32_t write_values, pad_wv;   // k_model_fwd<N > 0>: also store the kernel inputs and the prior sum (0: a k_model_fwd<0> launch does — the
-                                    // Jacobian launch then runs beside the likelihood kernels, which read those values)
+    int32_t n_circ, pad_nc;         // number of UniformCircular pairs precomputed through LDS
     const int32_t* circ_slot;       // [n_el + n_nu] LDS slot of a CIRCULAR / TPERI source's (atan2, UnitLength) values, or -1
+    const int32_t* circ_pair;       // [n_circ][2] (i0, i1) of each slot
     const double* theta_t; int64_t ld, W, ldw;
     double* elems; double* nuis;    // [n_el][ldw], [n_nu][ldw]   (kernel inputs)
-    double* J;                      // [(n_el+n_nu)*D][ldw]
+    double* Jc;                     // [2·(n_el+n_nu)][ldw]  ∂input k/∂θ_t[i0_k], ∂input k/∂θ_t[i1_k] (for tp: through its own θ pair only)
+    double* gtp;                    // [n_el][ldw]           ∂tp/∂(element) of the element's planet (0 where tp is not derived)
     double* lpp; double* glp;       // [ldw], [D][ldw]            (prior + UnitLength terms and their θ_t-gradient)
     const double* ll; const double* g_el; const double* g_nu;     // from the likelihood kernels
     double* lp_out; double* grad_out;
@@ -251,153 +248,256 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
     return dconst<N, FAST>(theta_epoch) - (MA / n) * yd;
 }
 
-#ifdef OCTO_API_TU      // the non-template kernels are launched from octo_api.hip only: one copy in the library, not one per translation unit
-// block = 64 walkers × DB partials (DB = min(D, 8) waves), grid = (walker tiles, ⌈D/DB⌉). Thread (w, d) carries the
-// value and ONE partial (∂/∂θ_t[d]) of every quantity, so a wave is 64 walkers × one partial: uniform control flow,
-// coalesced Jacobian rows, D× the parallelism of a thread-per-walker layout. The diagonal part — invlink and
-// logpdf_with_trans of every prior — is computed once per walker by the block's waves (prior k by wave k mod DB) and
-// shared through LDS: x[k], dx/dθ_t[k], p[k], dp/dθ_t[k]. Fast-math duals as in k_small<MODEL> (polynomial sincos / atan2,
-// reciprocal-multiply divisions): the chain is a few thousand serial instructions per wave, 30 µs at 1e4 walkers with the ocml routines.
-// N = MODEL_NPART: values and Jacobian; N = 0: the VALUES alone (kernel inputs, prior sum) — all a forward-only callback needs, and what the
-// likelihood kernels of a gradient callback wait for (the Jacobian launch runs beside them on a second stream, octo_model_logpost_device).
-template <int N>
-static __global__ __launch_bounds__(512) void k_model_fwd(ModelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];      // [4][D][64]
-    const int lane = threadIdx.x;
-    const int wy = threadIdx.y, DB = blockDim.y;
-    const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
-    const int64_t wl = w < a.W ? w : a.W - 1;
-    const int DBs = min(DB, a.src_waves);           // waves that go on to resolve the sources; all DB waves share the priors
-    const int d0 = (blockIdx.y * DBs + wy) * N;     // this thread's partials: ∂/∂θ_t[d0 .. d0+N)
-    const int D = a.D;
-    double* Lx = lds; double* Ldx = lds + (int64_t)D * WAVE; double* Lp = lds + 2 * (int64_t)D * WAVE; double* Ldp = lds + 3 * (int64_t)D * WAVE;
-    for (int k = wy; k < D; k += DB) {
-        Dual<1, true> xk, p;
-        prior_apply(a.priors[k], dvar<1, true>(a.theta_t[(int64_t)k * a.ld + wl], 0), xk, p, a.prior_logz + PRIOR_NC * k);
-        Lx[k * WAVE + lane] = xk.v; Ldx[k * WAVE + lane] = xk.d[0]; Lp[k * WAVE + lane] = p.v; Ldp[k * WAVE + lane] = p.d[0];
+// θ_at_epoch_to_tperi of a Campbell planet in closed form, WITH its gradient w.r.t. the seven quantities it reads (throughput path,
+// k_model_fwd). The reference inverts the Thiele-Innes matrix T = R(Ω)·diag(1, cos i)·R(ω) (parameterizations.jl:29-47), so
+// (x, y)/r = R(−ω)·diag(1, 1/cos i)·R(−Ω)·(cos θ, sin θ): with c, s = cos, sin(θ − Ω),
+//     cos ν = σ·(c·ci·cω + s·sω)/r',  sin ν = σ·(−c·ci·sω + s·cω)/r',  r'² = c²ci² + s²,  σ = sign(cos i)
+// — three sincos and one rsqrt instead of four sincos, A/B/F/G, a determinant and its division. MA(ν, e) as the reference writes it (:57).
+//     ∂ν/∂θ = −∂ν/∂Ω = ci/r'²   ∂ν/∂ω = −1   ∂ν/∂i = s·c·sin i/r'²
+//     ∂MA/∂ν = (1−e²)^{3/2}/(1+e cos ν)²   ∂MA/∂e = −√(1−e²)·sin ν·(2 + e cos ν)/(1+e cos ν)²
+//     tp = θ_epoch − MA·P_d/2π,  P_d = √(a³/M)·k_yr:  ∂tp/∂a = −MA·P_d/2π·(3/2)/a,  ∂tp/∂M = +MA·P_d/2π·(1/2)/M
+// (checked against the reference's expression and its central differences at 40 digits: oracle/ has the script's twin in tests/test_model.py).
+// g[OCTO_N_EL]: ∂tp/∂(element slot) — zero for tp, plx, mass; g_theta: ∂tp/∂θ.
+template <bool GRAD>
+__device__ __forceinline__ double tperi_campbell(double th, double theta_epoch, double M, double e, double a, double inc, double w, double O,
+                                                 double k_yr, double (&g)[OCTO_N_EL], double& g_theta) {
+    double s, c, si, ci, sw, cw;
+    sincos_reduced(th - O, s, c);
+    sincos_reduced(inc, si, ci);
+    sincos_reduced(w, sw, cw);
+    const double cci = c * ci;
+    const double Xp = fma(cci, cw, s * sw), Yp = fma(s, cw, -(cci * sw));
+    const double r2 = fma(cci, cci, s * s);
+    const double ir = rsqrt_nr(r2);
+    const double sg = ci == 0.0 ? NAN : copysign(ir, ci);      // cos i = 0: T is singular, the reference divides by zero
+    const double cn = Xp * sg, sn = Yp * sg;
+    const double s1 = sqrt_fast(fma(-e, e, 1.0));
+    const double Dn = fma(e, cn, 1.0), iD = rcp_nr<2>(Dn);
+    const double s1sn = s1 * sn;
+    const double MA = atan2_fast(-s1sn, -e - cn) + PI - e * s1sn * iD;
+    const double iM = rcp_nr<2>(M);
+    const double Pd = sqrt_fast(a * a * a * iM) * k_yr;
+    const double K = Pd * (-1.0 / TWO_PI);
+    if constexpr (GRAD) {
+        const double iD2 = iD * iD;
+        const double Kn = K * (s1 * s1 * s1) * iD2;                 // ∂tp/∂ν
+        const double ir2 = ir * ir;
+        const double gth = Kn * ci * ir2;
+        g_theta = gth;
+        g[OCTO_EL_O] = -gth; g[OCTO_EL_W] = -Kn; g[OCTO_EL_I] = Kn * (s * c) * si * ir2;
+        g[OCTO_EL_E] = -K * s1sn * fma(e, cn, 2.0) * iD2;
+        g[OCTO_EL_A] = K * MA * 1.5 * rcp_nr<2>(a);
+        g[OCTO_EL_M] = -K * MA * 0.5 * iM;
+        g[OCTO_EL_TP] = 0.0; g[OCTO_EL_PLX] = 0.0; g[OCTO_EL_MASS] = 0.0;
     }
-    __syncthreads();
-    // UniformCircular pairs (variables.jl:279-323): angle atan(y, x), its two partials, and the UnitLengthPrior term with its two
-    // partials depend on two natural parameters only. One wave computes them per pair, for all the threads of the walker — in
-    // place they were a ~350-instruction serial chain of atan2, sqrt and two logs, repeated by every thread.
-    double* Lc = lds + 4 * (int64_t)D * WAVE;           // [n_circ][6][64]
-    for (int k = wy; k < a.n_el + a.n_nu; k += DB) {
-        const int slot = a.circ_slot[k];
-        if (slot < 0) continue;
-        const octo_source sc = k < a.n_el ? a.esrc[k] : a.nsrc[k - a.n_el];
-        const Dual<2, true> cx = dvar<2, true>(Lx[sc.i0 * WAVE + lane], 0), cy = dvar<2, true>(Lx[sc.i1 * WAVE + lane], 1);
-        const Dual<2, true> ang = datan2(cy, cx), ul = unit_length(cx, cy);
-        double* o = Lc + (int64_t)slot * 6 * WAVE + lane;
-        o[0] = ang.v; o[WAVE] = ang.d[0]; o[2 * WAVE] = ang.d[1]; o[3 * WAVE] = ul.v; o[4 * WAVE] = ul.d[0]; o[5 * WAVE] = ul.d[1];
-    }
-    __syncthreads();
-    if (w >= a.W || wy >= DBs || d0 >= D) return;
-    bool finite_in = true;
-    for (int k = 0; k < D; ++k) finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + w]);   // logdensitymodel.jl:120-124
-    Dual<N, true> lp = dconst<N, true>(0.0);
-    Dual<N, true> ulp = dconst<N, true>(0.0);      // Σ UnitLengthPrior terms: likelihood terms of the reference (variables.jl:309-323), so they and
-                                       // their gradient survive a healed prior (the healed value is a constant, :1229-1236)
-    bool healed = false;
-    for (int k = 0; k < D; ++k) {
-        const double pv = Lp[k * WAVE + lane];
-        if (!healed) {
-            if (!isfinite(pv)) { lp = dconst<N, true>(-1.7976931348623157e308); healed = true; }     // variables.jl:1229-1236
-            else {
-                lp.v += pv;
-#pragma unroll
-                for (int j = 0; j < N; ++j) if (k == d0 + j) lp.d[j] += Ldp[k * WAVE + lane];
-            }
-        }
-    }
-    auto nat = [&](int k) {      // natural-domain θ[k] with this thread's partial
-        Dual<N, true> xk; xk.v = Lx[k * WAVE + lane];
-        const double dx = Ldx[k * WAVE + lane];
-#pragma unroll
-        for (int j = 0; j < N; ++j) xk.d[j] = (k == d0 + j) ? dx : 0.0;
-        return xk;
-    };
-    // Kernel inputs from the natural θ (arr2nt + Derived variables). The nine element rows of a planet are resolved with
-    // compile-time positions so that they live in registers (a dynamically indexed array lands in scratch memory and made
-    // this kernel 3x slower); θ_at_epoch_to_tperi comes last within a planet because it reads the planet's other elements.
-    // atan(θy, θx) of a UniformCircular pair as a dual, adding its UnitLengthPrior term to lp when this source carries it
-    auto circ_angle = [&](const octo_source& sc, int k) {
-        const int slot = a.circ_slot[k];
-        if (slot < 0) {                                               // beyond the LDS budget: in place
-            const Dual<N, true> cx = nat(sc.i0), cy = nat(sc.i1);
-            if (sc.flags & OCTO_SRC_FLAG_UNITLEN) ulp = ulp + unit_length(cx, cy);
-            return datan2(cy, cx);
-        }
-        const double* c = Lc + (int64_t)slot * 6 * WAVE + lane;
-        const double dx = Ldx[sc.i0 * WAVE + lane], dy = Ldx[sc.i1 * WAVE + lane];    // ∂x/∂θ_t, ∂y/∂θ_t (diagonal)
-        Dual<N, true> ang; ang.v = c[0];
-        const bool ul = (sc.flags & OCTO_SRC_FLAG_UNITLEN) != 0;
-        if (ul) ulp.v += c[3 * WAVE];
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const double sx = (sc.i0 == d0 + j) ? dx : 0.0, sy = (sc.i1 == d0 + j) ? dy : 0.0;
-            ang.d[j] = c[WAVE] * sx + c[2 * WAVE] * sy;
-            if (ul) ulp.d[j] += c[4 * WAVE] * sx + c[5 * WAVE] * sy;
-        }
-        return ang;
-    };
-    auto plain = [&](const octo_source& sc, int k) {      // OCTO_SRC_CONST / _THETA / _CIRCULAR
-        if (sc.kind == OCTO_SRC_CONST) return dconst<N, true>(sc.value);
-        if (sc.kind == OCTO_SRC_THETA) return nat(sc.i0);
-        return circ_angle(sc, k) * (sc.value / TWO_PI);               // atan(y, x) / 2π * domain, variables.jl:284
-    };
-    const bool store_values = (N == 0) || a.write_values != 0;
-    auto emit = [&](int k, const Dual<N, true>& val) {
-        if (d0 == 0 && store_values) {
-            double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
-            *dst = val.v;
-        }
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (d0 + j < D) a.J[((int64_t)k * D + d0 + j) * a.ldw + w] = val.d[j];
-    };
-    for (int p = 0; p < a.n_planets; ++p) {
-        Dual<N, true> el[OCTO_N_EL];
-#pragma unroll
-        for (int j = 0; j < OCTO_N_EL; ++j) el[j] = dconst<N, true>(0.0);
-#pragma unroll 1
-        for (int kk = 0; kk < OCTO_N_EL; ++kk) {          // one copy of the code; the store is a select chain, not an indexed write
-            const octo_source sc = a.esrc[p * OCTO_N_EL + kk];
-            if (sc.kind == OCTO_SRC_TPERI) continue;
-            const Dual<N, true> val = plain(sc, p * OCTO_N_EL + kk);
-#pragma unroll
-            for (int j = 0; j < OCTO_N_EL; ++j) {
-                el[j].v = (j == kk) ? val.v : el[j].v;
-#pragma unroll
-                for (int q = 0; q < N; ++q) el[j].d[q] = (j == kk) ? val.d[q] : el[j].d[q];
-            }
-        }
-        {   // tp = θ_at_epoch_to_tperi(...) is the one derived element of the standard parameterisation
-            const octo_source sc = a.esrc[p * OCTO_N_EL + OCTO_EL_TP];
-            if (sc.kind == OCTO_SRC_TPERI) {
-                el[OCTO_EL_TP] = tperi(circ_angle(sc, p * OCTO_N_EL + OCTO_EL_TP), sc.value, el[OCTO_EL_M], el[OCTO_EL_E], el[OCTO_EL_A], el[OCTO_EL_I], el[OCTO_EL_W],
-                                       el[OCTO_EL_O], a.k_yr, a.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &el[OCTO_EL_PLX]);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < OCTO_N_EL; ++kk) emit(p * OCTO_N_EL + kk, el[kk]);
-    }
-    for (int k = 0; k < a.n_nu; ++k) {
-        octo_source sc;
-        if (a.nsrc) sc = a.nsrc[k];
-        else {
-            const int r = k % OCTO_N_NUIS; const int kind = a.obs[k / OCTO_N_NUIS].kind;
-            sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
-            sc.value = ((kind <= OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
-        }
-        emit(a.n_el + k, plain(sc, a.n_el + k));
-    }
-    if (d0 == 0 && store_values) a.lpp[w] = finite_in ? lp.v + ulp.v : -INFINITY;
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (d0 + j < D) a.glp[(int64_t)(d0 + j) * a.ldw + w] = (healed ? 0.0 : lp.d[j]) + ulp.d[j];
+    return fma(K, MA, theta_epoch);
 }
 
-// grid = (walker tiles of 256, D): thread (w, d) produces grad[d][w] = ∂(prior)/∂θ_t[d] + Σ_k J[k][d]·ḡ[k].
+#ifdef OCTO_API_TU      // the non-template kernels are launched from octo_api.hip only: one copy in the library, not one per translation unit
+// k_model_fwd — θ_t -> kernel inputs, prior, and the COMPACT Jacobian of the inputs (round 4; rounds 1-3: dense forward-mode duals, 4 partials
+// per thread, (9P + 3·n_obs)·D Jacobian rows through memory: 26 µs at 1e4 walkers, D = 11).
+// The map θ_t -> inputs is sparse: an input is a constant, ONE natural parameter, the angle of ONE UniformCircular pair, or tp =
+// θ_at_epoch_to_tperi(pair; the planet's own a, e, i, ω, Ω, M) — so its Jacobian is two numbers per input (∂/∂θ_t[i0], ∂/∂θ_t[i1]: Jc)
+// plus tp's gradient w.r.t. the planet's elements (gtp), folded into the element adjoints by the tail (model_tail / k_model_bwd):
+//     ∇θ_t[d] = ∂prior/∂θ_t[d] + Σ_k ([i0_k = d]·Jc[2k] + [i1_k = d]·Jc[2k+1]) · (ḡ[k] + ḡ[tp]·gtp[k]).
+// block = 64 walkers × NW waves (blockDim.y), one block per tile; the work is a short dependent chain per walker, spread over the waves:
+//   phase 1  wave k: x[k] = invlink(θ_t[k]) and dx/dθ_t                                                  -> LDS
+//   phase 2  one task per wave: atan(y, x) of a UniformCircular pair and its two partials | the pair's UnitLengthPrior term and its
+//            partials | logpdf_with_trans of prior k and its derivative (needed only by the sums of phase 3)           -> LDS
+//   phase 3  wave p: planet p's nine inputs, tp in closed form (tperi_campbell) with its gradient; wave P: nuisance inputs and the prior
+//            sum (healing rule, variables.jl:1229-1236); the other waves: the rows of ∂(prior + UnitLength terms)/∂θ_t.
+// TI: the instantiation for models with a Thiele-Innes planet (its tp keeps the dual-number route of `tperi`, two passes of four partials).
+template <bool GRAD, bool TI>
+static __global__ __launch_bounds__(TI ? 512 : 1024) void k_model_fwd(ModelArgs a) {
+    constexpr int N2 = GRAD ? 2 : 0;
+    extern __shared__ __attribute__((aligned(16))) double lds[];      // [4][D][64] x, dx, p, dp | [n_circ][6][64]
+    const int lane = threadIdx.x;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y), NW = blockDim.y;
+    const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
+    const int64_t wl = w < a.W ? w : a.W - 1;
+    const int D = a.D, P = a.n_planets;
+    double* Lx = lds; double* Ldx = lds + (int64_t)D * WAVE; double* Lp = lds + 2 * (int64_t)D * WAVE; double* Ldp = lds + 3 * (int64_t)D * WAVE;
+    double* Lc = lds + 4 * (int64_t)D * WAVE;
+    for (int k = wy; k < D; k += NW) {
+        double xv, xd;
+        prior_link_lanes(a.priors[k], a.theta_t[(int64_t)k * a.ld + wl], xv, xd);
+        Lx[k * WAVE + lane] = xv; Ldx[k * WAVE + lane] = xd;
+    }
+    __syncthreads();
+    // the six numbers of a UniformCircular pair: angle, ∂angle/∂x, ∂angle/∂y, UnitLength term, its two partials (variables.jl:279-323)
+    auto pair_angle = [&](int i0, int i1, double& v, double& vx, double& vy) {
+        const Dual<N2, true> cx = dvar<N2, true>(Lx[i0 * WAVE + lane], 0), cy = dvar<N2, true>(Lx[i1 * WAVE + lane], 1);
+        const Dual<N2, true> ang = datan2(cy, cx);
+        v = ang.v;
+        if constexpr (GRAD) { vx = ang.d[0]; vy = ang.d[1]; }
+    };
+    auto pair_unitlen = [&](int i0, int i1, double& v, double& vx, double& vy) {
+        const Dual<N2, true> cx = dvar<N2, true>(Lx[i0 * WAVE + lane], 0), cy = dvar<N2, true>(Lx[i1 * WAVE + lane], 1);
+        const Dual<N2, true> ul = unit_length(cx, cy);
+        v = ul.v;
+        if constexpr (GRAD) { vx = ul.d[0]; vy = ul.d[1]; }
+    };
+    const int n_circ = a.n_circ, n2 = 2 * n_circ + D;
+    for (int t = wy; t < n2; t += NW) {
+        if (t < 2 * n_circ) {
+            const int slot = t < n_circ ? t : t - n_circ;
+            const int i0 = a.circ_pair[2 * slot], i1 = a.circ_pair[2 * slot + 1];
+            double* o = Lc + ((int64_t)slot * 6 + (t < n_circ ? 0 : 3)) * WAVE + lane;
+            double v = 0.0, vx = 0.0, vy = 0.0;
+            if (t < n_circ) pair_angle(i0, i1, v, vx, vy); else pair_unitlen(i0, i1, v, vx, vy);
+            o[0] = v;
+            if constexpr (GRAD) { o[WAVE] = vx; o[2 * WAVE] = vy; }
+        } else {
+            const int k = t - 2 * n_circ;
+            double lpv, lpd;
+            prior_density_lanes(a.priors[k], Lx[k * WAVE + lane], Ldx[k * WAVE + lane], lpv, lpd, a.prior_logz + PRIOR_NC * k);
+            Lp[k * WAVE + lane] = lpv; Ldp[k * WAVE + lane] = lpd;
+        }
+    }
+    __syncthreads();
+    const bool live = w < a.W;
+    // an input that is not tp: value and its two Jacobian entries
+    auto resolve = [&](const octo_source& sc, int k, double& val, double& ja, double& jb, double (&c6)[6]) {
+        ja = 0.0; jb = 0.0; val = sc.value;                                         // OCTO_SRC_CONST
+        if (sc.kind == OCTO_SRC_THETA) { val = Lx[sc.i0 * WAVE + lane]; if constexpr (GRAD) ja = Ldx[sc.i0 * WAVE + lane]; }
+        else if (sc.kind == OCTO_SRC_CIRCULAR || sc.kind == OCTO_SRC_TPERI) {
+            const int slot = a.circ_slot[k];
+            if (slot >= 0) {
+                const double* c = Lc + (int64_t)slot * 6 * WAVE + lane;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) c6[q] = (GRAD || q == 0 || q == 3) ? c[q * WAVE] : 0.0;
+            } else {                                                                // beyond the LDS budget: in place
+                pair_angle(sc.i0, sc.i1, c6[0], c6[1], c6[2]); pair_unitlen(sc.i0, sc.i1, c6[3], c6[4], c6[5]);
+            }
+            if (sc.kind == OCTO_SRC_CIRCULAR) {                                     // atan(y, x) / 2π · domain, variables.jl:284
+                const double scl = sc.value * (1.0 / TWO_PI);
+                val = c6[0] * scl;
+                if constexpr (GRAD) { ja = scl * c6[1] * Ldx[sc.i0 * WAVE + lane]; jb = scl * c6[2] * Ldx[sc.i1 * WAVE + lane]; }
+            }
+        }
+    };
+    auto put_input = [&](int k, double val, double ja, double jb) {
+        if (!live) return;
+        double* dst = k < a.n_el ? a.elems + (int64_t)k * a.ldw + w : a.nuis + (int64_t)(k - a.n_el) * a.ldw + w;
+        *dst = val;
+        if constexpr (GRAD) { a.Jc[(int64_t)(2 * k) * a.ldw + w] = ja; a.Jc[(int64_t)(2 * k + 1) * a.ldw + w] = jb; }
+    };
+    for (int role = wy; role <= P; role += NW) {
+        if (role < P) {
+            const int p = role;
+            double el[OCTO_N_EL], c6[6];
+#pragma unroll
+            for (int kk = 0; kk < OCTO_N_EL; ++kk) {
+                const int k = p * OCTO_N_EL + kk;
+                const octo_source sc = a.esrc[k];
+                double ja, jb;
+                resolve(sc, k, el[kk], ja, jb, c6);
+                if (sc.kind != OCTO_SRC_TPERI) put_input(k, el[kk], ja, jb);
+            }
+            const int ktp = p * OCTO_N_EL + OCTO_EL_TP;
+            const octo_source sc = a.esrc[ktp];
+            double g[OCTO_N_EL];      // ∂tp/∂(element slot)
+#pragma unroll
+            for (int q = 0; q < OCTO_N_EL; ++q) g[q] = 0.0;
+            if (sc.kind == OCTO_SRC_TPERI) {      // the one derived element of the standard parameterisation; it reads the planet's other elements
+                double ja, jb, dummy, g_theta = 0.0, tp = 0.0;
+                resolve(sc, ktp, dummy, ja, jb, c6);
+                bool done = false;
+                if constexpr (TI) {
+                    if (sc.flags & OCTO_SRC_FLAG_TI) {
+                        // locals: θ, M, e, A, B, F, G, plx — two passes of four partials through the reference-order routine
+                        constexpr int slot_of[8] = {-1, OCTO_EL_M, OCTO_EL_E, OCTO_EL_A, OCTO_EL_I, OCTO_EL_W, OCTO_EL_O, OCTO_EL_PLX};
+#pragma unroll
+                        for (int pass = 0; pass < (GRAD ? 2 : 1); ++pass) {
+                            constexpr int NT = GRAD ? 4 : 0;
+                            auto lv = [&](double v, int idx) { Dual<NT, true> r = dconst<NT, true>(v); if constexpr (GRAD) { if (idx / 4 == pass) r.d[idx % 4] = 1.0; } return r; };
+                            const Dual<NT, true> plx = lv(el[OCTO_EL_PLX], 7);
+                            const Dual<NT, true> r = tperi(lv(c6[0], 0), sc.value, lv(el[OCTO_EL_M], 1), lv(el[OCTO_EL_E], 2), lv(el[OCTO_EL_A], 3), lv(el[OCTO_EL_I], 4),
+                                                           lv(el[OCTO_EL_W], 5), lv(el[OCTO_EL_O], 6), a.k_yr, a.yd, true, &plx);
+                            tp = r.v;
+                            if constexpr (GRAD) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int idx = pass * 4 + j;
+                                    if (idx == 0) g_theta = r.d[j]; else g[slot_of[idx]] = r.d[j];
+                                }
+                            }
+                        }
+                        done = true;
+                    }
+                }
+                if (!done) tp = tperi_campbell<GRAD>(c6[0], sc.value, el[OCTO_EL_M], el[OCTO_EL_E], el[OCTO_EL_A], el[OCTO_EL_I], el[OCTO_EL_W], el[OCTO_EL_O], a.k_yr, g, g_theta);
+                if constexpr (GRAD) { ja = g_theta * c6[1] * Ldx[sc.i0 * WAVE + lane]; jb = g_theta * c6[2] * Ldx[sc.i1 * WAVE + lane]; }
+                put_input(ktp, tp, ja, jb);
+            }
+            if constexpr (GRAD) {
+                if (live) {
+#pragma unroll
+                    for (int q = 0; q < OCTO_N_EL; ++q) a.gtp[(int64_t)(p * OCTO_N_EL + q) * a.ldw + w] = g[q];
+                }
+            }
+        } else {
+            // nuisance inputs, then the prior sum: logdensitymodel.jl:120-133, variables.jl:1205-1236, 309-323
+            double c6[6];
+            for (int k = 0; k < a.n_nu; ++k) {
+                octo_source sc;
+                if (a.nsrc) sc = a.nsrc[k];
+                else {
+                    const int r = k % OCTO_N_NUIS; const int kind = a.obs[k / OCTO_N_NUIS].kind;
+                    sc.kind = OCTO_SRC_CONST; sc.i0 = sc.i1 = sc.flags = 0;
+                    sc.value = ((kind <= OCTO_ASTROM_SEPPA || kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && r == OCTO_NU_PLATESCALE) ? 1.0 : 0.0;
+                }
+                double val, ja, jb;
+                resolve(sc, a.n_el + k, val, ja, jb, c6);
+                put_input(a.n_el + k, val, ja, jb);
+            }
+            bool finite_in = true, healed = false;
+            double lp = 0.0;
+            for (int k = 0; k < D; ++k) {
+                finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + wl]);
+                const double pv = Lp[k * WAVE + lane];
+                healed = healed || !isfinite(pv);
+                lp += pv;
+            }
+            lp = healed ? -1.7976931348623157e308 : lp;
+            // Σ UnitLengthPrior terms: likelihood terms of the reference, so they and their gradient survive a healed prior
+            double ulp = 0.0;
+            for (int k = 0; k < a.n_el + (a.nsrc ? a.n_nu : 0); ++k) {
+                const octo_source sc = k < a.n_el ? a.esrc[k] : a.nsrc[k - a.n_el];
+                if ((sc.kind != OCTO_SRC_CIRCULAR && sc.kind != OCTO_SRC_TPERI) || !(sc.flags & OCTO_SRC_FLAG_UNITLEN)) continue;
+                const int slot = a.circ_slot[k];
+                if (slot >= 0) ulp += Lc[((int64_t)slot * 6 + 3) * WAVE + lane];
+                else { pair_unitlen(sc.i0, sc.i1, c6[3], c6[4], c6[5]); ulp += c6[3]; }
+            }
+            if (live) a.lpp[w] = finite_in ? lp + ulp : -INFINITY;
+        }
+    }
+    if constexpr (GRAD) {
+        // rows of ∂(prior + UnitLength terms)/∂θ_t: by the waves without a role when there are any
+        const int first = NW > P + 1 ? P + 1 : 0, nh = NW > P + 1 ? NW - (P + 1) : NW;
+        if (wy < first) return;
+        bool healed = false;
+        for (int k = 0; k < D; ++k) healed = healed || !isfinite(Lp[k * WAVE + lane]);
+        for (int d = wy - first; d < D; d += nh) {
+            double g = healed ? 0.0 : Ldp[d * WAVE + lane];
+            const double dxd = Ldx[d * WAVE + lane];
+            for (int k = 0; k < a.n_el + (a.nsrc ? a.n_nu : 0); ++k) {
+                const octo_source sc = k < a.n_el ? a.esrc[k] : a.nsrc[k - a.n_el];
+                if ((sc.kind != OCTO_SRC_CIRCULAR && sc.kind != OCTO_SRC_TPERI) || !(sc.flags & OCTO_SRC_FLAG_UNITLEN)) continue;
+                if (sc.i0 != d && sc.i1 != d) continue;
+                const int slot = a.circ_slot[k];
+                double c6[6];
+                if (slot >= 0) { c6[4] = Lc[((int64_t)slot * 6 + 4) * WAVE + lane]; c6[5] = Lc[((int64_t)slot * 6 + 5) * WAVE + lane]; }
+                else pair_unitlen(sc.i0, sc.i1, c6[3], c6[4], c6[5]);
+                if (sc.i0 == d) g = fma(c6[4], dxd, g);
+                if (sc.i1 == d) g = fma(c6[5], dxd, g);
+            }
+            if (live) a.glp[(int64_t)d * a.ldw + w] = g;
+        }
+    }
+}
+
+// grid = (walker tiles of 256, D): thread (w, d) produces grad[d][w]; only behind a batch that k_small evaluated (no k_finish to carry the tail).
 static __global__ __launch_bounds__(256) void k_model_bwd(ModelArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int d = blockIdx.y;
@@ -408,14 +508,8 @@ static __global__ __launch_bounds__(256) void k_model_bwd(ModelArgs a) {
     if (isnan(lp)) lp = -INFINITY;
     if (d == 0) a.lp_out[w] = lp;
     if (!a.grad_out) return;
-    const bool ok = isfinite(lp);
-    const int n_in = a.n_el + a.n_nu;
-    double g = a.glp[(int64_t)d * a.ldw + w];
-    for (int k = 0; k < n_in; ++k) {
-        const double gk = k < a.n_el ? a.g_el[(int64_t)k * a.ldw + w] : (a.g_nu ? a.g_nu[(int64_t)(k - a.n_el) * a.ldw + w] : 0.0);
-        g = fma(a.J[((int64_t)k * a.D + d) * a.ldw + w], gk, g);
-    }
-    a.grad_out[(int64_t)d * a.ld + w] = ok ? g : 0.0;
+    const double g = model_grad_row(d, w, a.n_planets, a.n_nu, a.esrc, a.nsrc, a.Jc, a.gtp, a.glp, a.ldw, a.g_el, a.g_nu, a.ldw);
+    a.grad_out[(int64_t)d * a.ld + w] = isfinite(lp) ? g : 0.0;
 }
 #endif      // OCTO_API_TU
 #undef DFOR

@@ -258,13 +258,17 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
 //     tp = θ_epoch − MA·P_d/2π,  P_d = √(a³/M)·k_yr:  ∂tp/∂a = −MA·P_d/2π·(3/2)/a,  ∂tp/∂M = +MA·P_d/2π·(1/2)/M
 // (checked against the reference's expression and its central differences at 40 digits: oracle/ has the script's twin in tests/test_model.py).
 // g[OCTO_N_EL]: ∂tp/∂(element slot) — zero for tp, plx, mass; g_theta: ∂tp/∂θ.
+// pre (k_small<MODEL>, wave-uniform arguments): {sin, cos} of θ − Ω, i, ω from one lane-batched pass (sincos_lanes) by the caller.
 template <bool GRAD>
 __device__ __forceinline__ double tperi_campbell(double th, double theta_epoch, double M, double e, double a, double inc, double w, double O,
-                                                 double k_yr, double (&g)[OCTO_N_EL], double& g_theta) {
+                                                 double k_yr, double (&g)[OCTO_N_EL], double& g_theta, const double (*pre)[2] = nullptr) {
     double s, c, si, ci, sw, cw;
-    sincos_reduced(th - O, s, c);
-    sincos_reduced(inc, si, ci);
-    sincos_reduced(w, sw, cw);
+    if (pre) { s = pre[0][0]; c = pre[0][1]; si = pre[1][0]; ci = pre[1][1]; sw = pre[2][0]; cw = pre[2][1]; }
+    else {
+        sincos_reduced(th - O, s, c);
+        sincos_reduced(inc, si, ci);
+        sincos_reduced(w, sw, cw);
+    }
     const double cci = c * ci;
     const double Xp = fma(cci, cw, s * sw), Yp = fma(s, cw, -(cci * sw));
     const double r2 = fma(cci, cci, s * s);

@@ -364,13 +364,26 @@ static __global__ __launch_bounds__(SMALL_TPB) void k_small(EvalArgs a, SmallMod
                 const octo_source sc = blob_src(sm.off_esrc, p * OCTO_N_EL + OCTO_EL_TP);
                 if (sc.kind == OCTO_SRC_TPERI) {    // tp = θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω | plx, A, B, F, G), parameterizations.jl:6-69
                     const D1 th = src_angle(sc, blob_slot(p * OCTO_N_EL + OCTO_EL_TP), CT, T, ul, false);
-                    // sin/cos of Ω, ω, i, θ in one pass, lane j taking angle j (the values are wave-uniform here)
-                    const double xs[4] = {elD[OCTO_EL_O].v, elD[OCTO_EL_W].v, elD[OCTO_EL_I].v, th.v};
-                    double ss[4], cs[4];
-                    sincos_lanes<4>(xs, ss, cs);
-                    const double pre[4][2] = {{ss[0], cs[0]}, {ss[1], cs[1]}, {ss[2], cs[2]}, {ss[3], cs[3]}};
-                    elD[OCTO_EL_TP] = tperi(th, sc.value, elD[OCTO_EL_M], elD[OCTO_EL_E], elD[OCTO_EL_A], elD[OCTO_EL_I],
-                                            elD[OCTO_EL_W], elD[OCTO_EL_O], sm.k_yr, sm.yd, (sc.flags & OCTO_SRC_FLAG_TI) != 0, &elD[OCTO_EL_PLX], pre);
+                    if (sc.flags & OCTO_SRC_FLAG_TI) {
+                        elD[OCTO_EL_TP] = tperi(th, sc.value, elD[OCTO_EL_M], elD[OCTO_EL_E], elD[OCTO_EL_A], elD[OCTO_EL_I],
+                                                elD[OCTO_EL_W], elD[OCTO_EL_O], sm.k_yr, sm.yd, true, &elD[OCTO_EL_PLX]);
+                    } else {
+                        // Campbell basis: tp in closed form with its gradient w.r.t. the planet's elements (octo_model.h: tperi_campbell) — the VALUES
+                        // are wave-uniform, lane d only chains its own partials through the seven numbers. sin/cos of θ − Ω, i, ω in one pass,
+                        // lane j taking angle j.
+                        const double xs[3] = {th.v - elD[OCTO_EL_O].v, elD[OCTO_EL_I].v, elD[OCTO_EL_W].v};
+                        double ss[3], cs[3];
+                        sincos_lanes<3>(xs, ss, cs);
+                        const double pre[3][2] = {{ss[0], cs[0]}, {ss[1], cs[1]}, {ss[2], cs[2]}};
+                        double g[OCTO_N_EL], g_theta;
+                        elD[OCTO_EL_TP].v = tperi_campbell<true>(th.v, sc.value, elD[OCTO_EL_M].v, elD[OCTO_EL_E].v, elD[OCTO_EL_A].v, elD[OCTO_EL_I].v,
+                                                                 elD[OCTO_EL_W].v, elD[OCTO_EL_O].v, sm.k_yr, g, g_theta, pre);
+                        double dtp = g_theta * th.d[0];
+                        dtp = fma(g[OCTO_EL_A], elD[OCTO_EL_A].d[0], dtp); dtp = fma(g[OCTO_EL_E], elD[OCTO_EL_E].d[0], dtp);
+                        dtp = fma(g[OCTO_EL_I], elD[OCTO_EL_I].d[0], dtp); dtp = fma(g[OCTO_EL_W], elD[OCTO_EL_W].d[0], dtp);
+                        dtp = fma(g[OCTO_EL_O], elD[OCTO_EL_O].d[0], dtp); dtp = fma(g[OCTO_EL_M], elD[OCTO_EL_M].d[0], dtp);
+                        elD[OCTO_EL_TP].d[0] = dtp;
+                    }
                 }
                 if (lane == 0) {
 #pragma unroll

@@ -227,6 +227,49 @@ def test_gpu_model_tail_inside_k_finish(pkg, oracle, model_golden):
 
 
 @pytest.mark.gpu
+def test_gpu_model_closed_form_tperi_edges(pkg, oracle, model_golden):
+    """Round 4: θ_at_epoch_to_tperi of a Campbell planet is evaluated in closed form on the device (octo_model.h: tperi_campbell — the
+    reference inverts the Thiele-Innes matrix, src/parameterizations.jl:29-57; the device rotates (cos θ, sin θ) back through Ω, i, ω and
+    carries the analytic gradient). The corners of that rewrite: retrograde orbits (cos i < 0, where the sign of the de-projected direction
+    flips), nearly edge-on and nearly face-on orbits, e -> 0 and e -> 0.99, position angles on both sides of the ±π cut of θ − Ω — through
+    the fused small-batch launch and the throughput kernels, against the oracle's reference-order duals."""
+    case = model_golden[0]
+    obs, planets = _tables(case)
+    base = np.asarray(case["theta_t"])[:, 0]
+    model = pkg.LogDensityModel(_reference_test_model(pkg))
+    nat0 = model.invlink(base[:, None])[:, 0]
+    names = model.names
+    cols = []
+    for inc in (0.02, 0.7, 1.5607, 1.5809, 2.4, 3.12):
+        for ecc in (1e-7, 0.3, 0.985):
+            for ang in (0.1, 3.1, -3.1, -1.4):
+                n = nat0.copy()
+                n[names.index("b_i")] = inc; n[names.index("b_e")] = ecc
+                n[names.index("b_θx")], n[names.index("b_θy")] = np.cos(ang) * 1.02, np.sin(ang) * 1.02
+                n[names.index("b_Ωx")], n[names.index("b_Ωy")] = np.cos(ang - 3.0) * 0.97, np.sin(ang - 3.0) * 0.97
+                cols.append(n)
+    th = model.link(np.stack(cols, axis=1))
+    model.close()
+    W = th.shape[1]
+    lp_o, g_o = None, None
+    for route in ("small", "throughput"):
+        model = pkg.LogDensityModel(_reference_test_model(pkg))
+        if route == "throughput":
+            model.ln_like._check(model.ln_like.lib.octo_ctx_set_small_batch(model.ln_like._ctx, 0), "set")
+        lp, g = model.logdensity_and_gradient(th)
+        if lp_o is None:
+            lp_o, g_o = oracle.oracle_model_logpost(obs, planets, model._c_priors, model._c_esrc, None, th)
+        model.close()
+        ok = np.isfinite(lp_o)
+        assert ok.all() and np.all(np.isfinite(lp)), route
+        assert np.max(np.abs(lp - lp_o) / np.maximum(1.0, np.abs(lp_o))) < 1e-10, route
+        # per walker: every component against the walker's largest one (the gradients span 1e0 … 1e12 over this grid)
+        sc = np.maximum(np.abs(g_o).max(axis=0, keepdims=True), 1e-300)
+        assert np.max(np.abs(g - g_o) / sc) < 1e-8, (route, float(np.max(np.abs(g - g_o) / sc)))
+    assert W == 72
+
+
+@pytest.mark.gpu
 def test_gpu_model_reference_style(pkg):
     """test/integration/sampling.jl:136-192 ("Autodiff Gradient Comparison") and :70-76 re-expressed: the device
     gradient w.r.t. θ_t equals a finite-difference gradient of the device value (atol=1e-3, rtol=1e-4 there), prior draws

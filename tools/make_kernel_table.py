@@ -14,7 +14,7 @@ WORK = {
     "nuis": {"k_main<1, true, true, 1, true>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, true, 1, false>": (E4 * E4, None, 1)},
     "fwd": {"k_main<1, false, false, 1, true>": (E4 * E4, E4 * 157, 1), "k_finish<1, false, false, 1, false>": (E4 * E4, None, 1)},
     "ofti": {"k_ofti_main": (E4 * E4, E4 * 157, 1), "k_ofti_finish": (E4 * E4, None, 1)},
-    "logpost": {"k_model_fwd<4>": (E4 * E4, None, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
+    "logpost": {"k_model_fwd<true, false>": (E4 * E4, None, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
     "three_planet": {"k_main<3, true, true, 5, true>": (6250 * 4096, 6250 * 64, 3), "k_finish<3, true, true, 5, false>": (6250 * 4096, None, 3)},
     "four_planet": {"k_main<4, true, true, 5, true>": (7500 * 4096, 7500 * 64, 4), "k_finish<4, true, true, 5, false>": (7500 * 4096, None, 4)},
     "small_w1": {"k_small<1, true, false, 1, false>": (E4 * 1, E4 * 1 / 64.0, 1)},

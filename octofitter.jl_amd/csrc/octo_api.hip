@@ -1036,7 +1036,7 @@ struct octo_model {
     int n_circ = 0;
     int32_t* d_circ_pair = nullptr;   // [n_circ][2] (i0, i1) of each slot (k_small<MODEL>: one pair per lane)
     bool all_circ_slotted = true;     // every CIRCULAR / TPERI source has a slot (<= MODEL_MAXCIRC of them): required by the fused launch
-    double* d_logz = nullptr;         // [D][PRIOR_NC] constants of each prior (prior_apply)
+    double* d_logz = nullptr;         // [D][PRIOR_NC] constants of each prior (prior_density_lanes)
     // the same descriptors as ONE block for the fused small-batch launch (octo_small.h: SmallModel), byte offsets of its sections
     double* d_blob = nullptr;
     int32_t blob_n = 0, off_logz = 0, off_esrc = 0, off_nsrc = -1, off_cslot = 0, off_cpair = 0;
@@ -1113,7 +1113,7 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
         pairs.resize(std::max<size_t>(pairs.size(), 2), 0);
         if (hipMalloc((void**)&m->d_circ_pair, sizeof(int32_t) * pairs.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_model_create: hipMalloc failed");
         if (hipMemcpy(m->d_circ_pair, pairs.data(), sizeof(int32_t) * pairs.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(OCTO_EHIP, "octo_model_create: upload failed");
-        // constants of each prior (prior_apply): −log(Φ(hi) − Φ(lo)), the truncated Normal's normalisation (Distributions.jl: truncated),
+        // constants of each prior (prior_density_lanes): −log(Φ(hi) − Φ(lo)), the truncated Normal's normalisation (Distributions.jl: truncated),
         // 1/(b − a), −log(b − a) | log(b/a) | −log σ, 1/σ
         std::vector<double> logz((size_t)D * PRIOR_NC, std::nan(""));
         for (int k = 0; k < D; ++k) {
@@ -1338,8 +1338,10 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
         double *m_in = nullptr, *m_out = nullptr;
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_in, ctx->h_in, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&m_out, ctx->h_out, 0));
-        hipLaunchKernelGGL(k_copy_in, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, m_in, m->d_th, n_in);
-        rc = octo_model_logpost_device(ctx, m, m->d_th, ldd, W, m_out, grad_out ? m_out + ldd : nullptr, st);
+        // θ_t's only reader on this route is k_model_fwd, which reads every θ_t[k][w] exactly once (coalesced rows): it takes the mapped
+        // buffer itself — a PCIe read under its first phase instead of a copy kernel in front of the launch (rounds 2-4: k_copy_in, one more
+        // launch boundary per callback)
+        rc = octo_model_logpost_device(ctx, m, m_in, ldd, W, m_out, grad_out ? m_out + ldd : nullptr, st);
         if (rc) return rc;
         HIPCHK(ctx, hipStreamSynchronize(st));
         std::memcpy(lp_out, ctx->h_out, sizeof(double) * W);

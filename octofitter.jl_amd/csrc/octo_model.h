@@ -1,9 +1,10 @@
 // octo_model.h — standard parameterisation on the device: θ_t -> natural θ (Bijectors invlink,
 // src/variables.jl:1449-1493), log-prior with Jacobian in declaration order (:1205-1369), UniformCircular angles and
 // their UnitLengthPrior terms (:279-323), tp = θ_at_epoch_to_tperi (src/parameterizations.jl:6-69) -> the kernel's
-// inputs, their Jacobian w.r.t. θ_t by forward-mode duals (exactly what ForwardDiff does on the host in the reference,
-// src/logdensitymodel.jl:169-177 — this part has no epoch loop, it is O(W·D²)), then after the likelihood kernels
-// ∇θ_t = Jᵀ ḡ + ∇(prior). One thread per walker; cost is negligible next to k_main.
+// inputs and their Jacobian w.r.t. θ_t (what ForwardDiff does on the host in the reference, src/logdensitymodel.jl:169-177; this part
+// has no epoch loop), then after the likelihood kernels ∇θ_t = Jᵀ ḡ + ∇(prior).
+//   k_small<MODEL> (octo_small.h): one-partial fast-math duals, lane = ∂/∂θ_t[d] — the Dual type and its operations below.
+//   k_model_fwd (throughput path): the Jacobian in its sparse form — two entries per input + tp's closed-form gradient (tperi_campbell).
 #pragma once
 #include "octo_kernels.h"
 
@@ -55,7 +56,7 @@ constexpr int MODEL_MAXCIRC = 12;   // UniformCircular pairs whose atan2 / UnitL
 
 struct ModelArgs {
     const octo_prior* priors;       // [D]
-    const double* prior_logz;       // [D][PRIOR_NC] constants of each prior (prior_apply)
+    const double* prior_logz;       // [D][PRIOR_NC] constants of each prior (prior_density_lanes)
     const octo_source* esrc;        // [n_el]
     const octo_source* nsrc;        // [n_nu] or null
     const DevObs* obs;
@@ -73,58 +74,14 @@ struct ModelArgs {
     double k_yr, yd;
 };
 
-// Bijectors.invlink + logpdf_with_trans (TruncatedBijector; Distributions densities) — mirrors oracle/octo_oracle_core.inc
-// pc: four constants of the prior precomputed at model creation (octo_model_create: prior_consts) — {−log(Φ(hi) − Φ(lo)) of a truncated
+// Bijectors.invlink + logpdf_with_trans (TruncatedBijector; Distributions densities) — mirrors oracle/octo_oracle_core.inc.
+// pc: four constants of the prior precomputed at model creation (octo_model_create) — {−log(Φ(hi) − Φ(lo)) of a truncated
 // Normal, 1/(b − a), −log(b − a) | log(b/a) | −log σ, 1/σ} — so that the serial chain of a call holds no logarithm or division of constants.
 constexpr int PRIOR_NC = 4;
-DT void prior_apply(const octo_prior& pr, const DU& y, DU& x, DU& lp, const double* __restrict__ pc = nullptr) {
-    double a = -INFINITY, b = INFINITY;
-    if (pr.kind == OCTO_PRIOR_UNIFORM || pr.kind == OCTO_PRIOR_LOGUNIFORM) { a = pr.p0; b = pr.p1; }
-    else if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) { a = pr.lo; b = pr.hi; }
-    else if (pr.kind == OCTO_PRIOR_SINE) { a = 0.0 + 2.220446049250313e-16; b = PI - 2.220446049250313e-16; }
-    DU ladj;
-    if (isfinite(a) && isfinite(b)) {
-        const double sg = m_div<FAST>(1.0, 1.0 + exp(-y.v));
-        x = chain(y, (b - a) * sg + a, (b - a) * sg * (1.0 - sg));
-        ladj = dlog(((x + (-a)) * (dconst<N, FAST>(b) - x)) * (pc ? pc[1] : 1.0 / (b - a)));
-    } else if (isfinite(a)) {
-        const double ey = exp(y.v);
-        x = chain(y, ey + a, ey);
-        ladj = dlog(x + (-a));
-    } else if (isfinite(b)) {
-        const double ey = exp(y.v);
-        x = chain(y, b - ey, -ey);
-        ladj = dlog(dconst<N, FAST>(b) - x);
-    } else {
-        x = y; ladj = dconst<N, FAST>(0.0);
-    }
-    switch (pr.kind) {
-        case OCTO_PRIOR_UNIFORM: lp = dconst<N, FAST>((x.v >= a && x.v <= b) ? (pc ? pc[2] : -log(b - a)) : -INFINITY); break;
-        case OCTO_PRIOR_LOGUNIFORM: lp = (x.v >= a && x.v <= b) ? dlog(dconst<N, FAST>(1.0) / (x * (pc ? pc[2] : log(b / a)))) : dconst<N, FAST>(-INFINITY); break;
-        case OCTO_PRIOR_NORMAL: case OCTO_PRIOR_TRUNCNORMAL: {
-            const DU z = (x + (-pr.p0)) * (pc ? pc[3] : 1.0 / pr.p1);
-            lp = (-(z * z + LOG2PI)) * 0.5 + (pc ? pc[2] : -log(pr.p1));
-            if (pr.kind == OCTO_PRIOR_TRUNCNORMAL) {
-                double nlz = pc ? pc[0] : NAN;
-                if (isnan(nlz)) {
-                    const double lo = isfinite(pr.lo) ? 0.5 * erfc(-((pr.lo - pr.p0) / pr.p1) * 0.70710678118654752440) : 0.0;
-                    const double hi = isfinite(pr.hi) ? 0.5 * erfc(-((pr.hi - pr.p0) / pr.p1) * 0.70710678118654752440) : 1.0;
-                    nlz = -log(hi - lo);
-                }
-                lp = lp + nlz;
-                if (!(x.v >= pr.lo && x.v <= pr.hi)) lp = dconst<N, FAST>(-INFINITY);
-            }
-            break;
-        }
-        case OCTO_PRIOR_SINE: lp = (x.v > 0.0 && x.v < PI) ? dlog(dsin(x) * 0.5) : dconst<N, FAST>(-INFINITY); break;
-        default: lp = dconst<N, FAST>(NAN);
-    }
-    lp = lp + ladj;
-}
 
-// The same for the lane = parameter mapping of k_small<MODEL>: every lane applies ITS OWN prior, so the kinds differ across the wave and the
-// branches above run one after the other (five kinds: ~700 serial instructions, most of them the transcendentals of kinds a lane does
-// not have). Branch-free instead — ONE exp, TWO logs and (only if some lane holds a Sine prior: a wave-uniform test) one sincos for all
+// Written for the lane = parameter mapping of k_small<MODEL>: every lane applies ITS OWN prior, so the kinds differ across the wave and
+// branches on the kind would run one after the other (five kinds: ~700 serial instructions, most of them the transcendentals of kinds a lane
+// does not have). Branch-free instead — ONE exp, TWO logs and (only if some lane holds a Sine prior: a wave-uniform test) one sincos for all
 // kinds, everything else selects on per-lane flags. Same formulas, same constants (`pc`, octo_model_create), one-partial fast-math duals:
 //   link       both bounds: x = a + (b − a)·σ(y), dx = (b − a)σ(1 − σ);  lower only: x = a + e^y;  upper only: x = b − e^y;  none: x = y
 //   log|J|     log((x − a)(b − x)/(b − a)) | log(x − a) | log(b − x) | 0                                  — the first log
@@ -198,10 +155,9 @@ DT DU unit_length(const DU& x, const DU& y) {
 
 // θ_at_epoch_to_tperi   src/parameterizations.jl:34-67
 // Thiele-Innes planets (ti): the arguments a, inc, w, O carry A, B, F, G [mas] and a = α/plx (:14-19).
-// pre (k_small<MODEL>, wave-uniform arguments): {sin, cos} of Ω, ω, i and θ computed in one lane-batched pass (sincos_lanes) by the caller.
+// (The reference-order route through dual numbers: Thiele-Innes planets, and the oracle's twin. Campbell planets: tperi_campbell below.)
 DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU& a_in,
-            const DU& inc, const DU& w, const DU& O, double k_yr, double yd, bool ti = false, const DU* plx = nullptr,
-            const double (*pre)[2] = nullptr) {
+            const DU& inc, const DU& w, const DU& O, double k_yr, double yd, bool ti = false, const DU* plx = nullptr) {
     DU A, B, F, G, a = a_in;
     if (ti) {
         A = a_in; B = inc; F = w; G = O;
@@ -209,21 +165,14 @@ DT DU tperi(const DU& th, double theta_epoch, const DU& M, const DU& e, const DU
         const DU pp = ((A + G) * (A + G) + (B - F) * (B - F)) * 0.5, mm = ((A - G) * (A - G) + (B + F) * (B + F)) * 0.5;
         a = ((dsqrt(pp) + dsqrt(mm)) * 0.70710678118654752440) / *plx;
     } else {
-        DU cO, sO, cw, sw, ci;
-        if (pre) {
-            sO = chain(O, pre[0][0], pre[0][1]); cO = chain(O, pre[0][1], -pre[0][0]);
-            sw = chain(w, pre[1][0], pre[1][1]); cw = chain(w, pre[1][1], -pre[1][0]);
-            ci = chain(inc, pre[2][1], -pre[2][0]);
-        } else {
-            dsincos(O, sO, cO); dsincos(w, sw, cw);
-            ci = dcos(inc);
-        }
+        DU cO, sO, cw, sw;
+        dsincos(O, sO, cO); dsincos(w, sw, cw);
+        const DU ci = dcos(inc);
         A = cO * cw - sO * sw * ci; B = sO * cw + cO * sw * ci;
         F = -(cO * sw) - sO * cw * ci; G = -(sO * sw) + cO * cw * ci;
     }
     DU ct, st;
-    if (pre) { st = chain(th, pre[3][0], pre[3][1]); ct = chain(th, pre[3][1], -pre[3][0]); }
-    else dsincos(th, st, ct);
+    dsincos(th, st, ct);
     const DU det = A * G - F * B;
     const DU xr = (G * ct - F * st) / det, yr = (A * st - B * ct) / det;
     const DU s1 = dsqrt(dconst<N, FAST>(1.0) - e * e);
@@ -322,10 +271,19 @@ static __global__ __launch_bounds__(TI ? 512 : 1024) void k_model_fwd(ModelArgs 
     const int D = a.D, P = a.n_planets;
     double* Lx = lds; double* Ldx = lds + (int64_t)D * WAVE; double* Lp = lds + 2 * (int64_t)D * WAVE; double* Ldp = lds + 3 * (int64_t)D * WAVE;
     double* Lc = lds + 4 * (int64_t)D * WAVE;
-    for (int k = wy; k < D; k += NW) {
-        double xv, xd;
-        prior_link_lanes(a.priors[k], a.theta_t[(int64_t)k * a.ld + wl], xv, xd);
-        Lx[k * WAVE + lane] = xv; Ldx[k * WAVE + lane] = xd;
+    // θ_t is read exactly ONCE per (walker, parameter): a mid-size host-buffer call hands this kernel the mapped pinned staging buffer itself
+    // (a PCIe read under the first phase instead of a copy kernel in front of the launch)
+    __shared__ unsigned char sfin[16][WAVE];      // wave wy: every θ_t[k] it linked is finite (logdensitymodel.jl:120-124)
+    {
+        bool fin = true;
+        for (int k = wy; k < D; k += NW) {
+            const double y = a.theta_t[(int64_t)k * a.ld + wl];
+            fin = fin && isfinite(y);
+            double xv, xd;
+            prior_link_lanes(a.priors[k], y, xv, xd);
+            Lx[k * WAVE + lane] = xv; Ldx[k * WAVE + lane] = xd;
+        }
+        sfin[wy][lane] = fin ? 1 : 0;
     }
     __syncthreads();
     // the six numbers of a UniformCircular pair: angle, ∂angle/∂x, ∂angle/∂y, UnitLength term, its two partials (variables.jl:279-323)
@@ -457,8 +415,8 @@ static __global__ __launch_bounds__(TI ? 512 : 1024) void k_model_fwd(ModelArgs 
             }
             bool finite_in = true, healed = false;
             double lp = 0.0;
+            for (int q = 0; q < NW; ++q) finite_in = finite_in && sfin[q][lane] != 0;
             for (int k = 0; k < D; ++k) {
-                finite_in = finite_in && isfinite(a.theta_t[(int64_t)k * a.ld + wl]);
                 const double pv = Lp[k * WAVE + lane];
                 healed = healed || !isfinite(pv);
                 lp += pv;

@@ -192,7 +192,7 @@ def test_gpu_model_tail_inside_k_finish(pkg, oracle, model_golden):
     """Round 4: for batches on the throughput kernels the tail of the callback — lp = prior + ll with the callback's rules, ∇θ_t = Jᵀḡ +
     ∇prior (src/logdensitymodel.jl:110-146, 169-177) — runs inside k_finish (model_tail), for one planet (finish_tile) and for several
     (finish_tile_multi, with nuisance variables). Same θ_t through the fused small-batch launch and through the throughput route must
-    agree to rounding and with the oracle; the forward-only callback (k_model_fwd<0>) returns the value the gradient callback returns;
+    agree to rounding and with the oracle; the forward-only callback (k_model_fwd<false, ·>) returns the value the gradient callback returns;
     a non-finite θ_t gives -Inf and a zero gradient on both routes."""
     rng = np.random.default_rng(44)
     for case, build in ((model_golden[0], lambda: _reference_test_model(pkg)), (model_golden[1], lambda: _two_planet_model(pkg, model_golden[1]))):

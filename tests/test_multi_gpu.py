@@ -251,3 +251,46 @@ def test_host_threads_with_their_own_contexts_share_one_dataset():
         for c in ctxs:
             lib.octo_ctx_destroy(c)
         assert not errors, errors[:5]
+
+
+def test_lifecycle_returns_every_byte_of_device_memory(pkg):
+    """Library-owned device memory (SURVEY §8b "Ownership": device buffers are freed by *_destroy, nothing is handed to the caller): contexts,
+    datasets and models created, used on both kernel families with growing batches — so that scratch is outgrown and retired mid-stream — through
+    host-buffer, registered-array and device entry points, and destroyed again, 40 times over: the device's free memory ends where it started."""
+    import torch
+    capi = pkg.capi
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(77)
+
+    def one_cycle(k):
+        cfg = synth.config_astrom(n_epochs=60 + 7 * (k % 5), n_walkers=700 + 300 * (k % 4), seed=100 + k)
+        obs, planet = synth.to_mirror(pkg, cfg)
+        fn = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
+        el = np.ascontiguousarray(cfg["elems"])
+        for W in (1, 40, el.shape[1]):                       # fused small-batch launch, mapped staging, throughput kernels; scratch grows
+            ll, g, _ = fn.ln_like_arrays(el[:, :W], None, grad=True)
+            assert np.isfinite(ll).any()
+        ll_h = np.empty(el.shape[1]); g_h = np.empty_like(el)
+        fn.host_register(el, ll_h, g_h)
+        a_ = (fn._ctx, fn._ds, capi._dptr(el), None, el.shape[1], el.shape[1], capi._dptr(ll_h), capi._dptr(g_h), None)
+        assert fn.lib.octo_eval(*a_) == 0 and np.array_equal(ll_h, ll, equal_nan=True)
+        fn.host_unregister(el, ll_h, g_h)
+        fn.close()
+        if k % 4 == 0:                                        # the standard parameterisation on top: model buffers, both routes
+            import test_model as tm
+            model = pkg.LogDensityModel(tm._reference_test_model(pkg))
+            th = model.link(model.sample_priors(rng, 600))
+            lp, gr = model.logdensity_and_gradient(th)
+            lp1, _ = model.logdensity_and_gradient(th[:, :3])
+            assert np.isfinite(lp).any() and np.allclose(lp1[np.isfinite(lp1)], lp[:3][np.isfinite(lp1)], rtol=1e-12, atol=0)
+            model.close()
+
+    for k in range(4):                                        # warm-up: the runtime's own pools (code objects, streams, events) settle
+        one_cycle(k)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(40):
+        one_cycle(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 <= 8 << 20, f"device memory not returned: {(free0 - free1) / 2**20:.1f} MiB after 40 create/use/destroy cycles"

@@ -772,7 +772,16 @@ constexpr size_t fused_lds_bytes() {
 // allocation granule too many; held to 72 the compiler parks 12 bytes outside the row loop and the loop itself is unchanged
 // (same-box A/B: −1 % step time). Every other variant keeps the register count it wants (forcing them spills in the loop).
 template <int P, bool GRAD, bool NUIS, int KM>
-constexpr unsigned main_min_waves() { return (P == 1 && GRAD && !NUIS && (KM & ~KM_COR) == KM_RADEC) ? 7u : 1u; }
+constexpr unsigned main_min_waves() {
+    // Four planets with a gradient: left alone the kernel takes 312 registers (56 of them AGPRs, 8-62 moves per row) = ONE wave per SIMD, which
+    // cannot cover the latency of its own dependent FP64 chains (0.21 of the FP64 peak against 0.41 for two planets). Held to 256 it parks
+    // 2-4 doubles per astrometry row and ~17 per RV row in scratch memory and runs two waves: 906 -> 765 µs per step of the 4-planet probe
+    // (same box, profiles/r4_p4_waves_ab.txt). Measured and NOT kept: the projection constants and K, cos ω, sin ω of every planet read from
+    // an LDS copy inside the row bodies instead (72 registers fewer on paper): the volatile loads it needs cost the register allocator more
+    // than they free — 11-21 scratch accesses per row instead of 4-17.
+    if (P >= 4 && GRAD) return 2u;
+    return (P == 1 && GRAD && !NUIS && (KM & ~KM_COR) == KM_RADEC) ? 7u : 1u;
+}
 
 // FUSED: the orbit constructors inside the launch — wave 0 of every block derives its tile's constants (what k_setup stores in `wc`) and
 // hands them to the other waves through LDS while those fetch the sin/cos table. No k_setup launch, no `wc` round trip: one stream

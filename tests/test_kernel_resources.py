@@ -49,6 +49,12 @@ def test_latency_kernels_have_no_scratch_and_no_vgpr_spills(rows):
 SEVEN_WAVES = re.compile(r"k_main<1, true, false, (1|33), (true|false)>")
 
 
+# The four-planet gradient kernels are held to 256 VGPRs = two waves per SIMD (main_min_waves): left alone they take 312-339 registers, ONE wave
+# per SIMD, and run at 0.21 of the FP64 peak. Held, they park 2-23 doubles per row in scratch memory and are 18 % faster (same-box A/B,
+# profiles/r4_p4_waves_ab.txt). Deliberate; the budget below keeps the parking from growing unnoticed.
+FOUR_PLANETS_TWO_WAVES = re.compile(r"k_main<4, true, (true|false), \d+, (true|false)>")
+
+
 def test_throughput_kernels_do_not_spill(rows):
     bad = []
     for r in rows:
@@ -57,6 +63,9 @@ def test_throughput_kernels_do_not_spill(rows):
             if SEVEN_WAVES.fullmatch(n):
                 if r["vgpr_spill_count"] > 2 or r["private_segment_fixed_size"] > 12 or r["scratch_instructions"] > 2:
                     bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"], r["scratch_instructions"]))
+            elif FOUR_PLANETS_TWO_WAVES.fullmatch(n):
+                if r["vgpr_count"] > 256 or r["vgpr_spill_count"] > 140 or r["private_segment_fixed_size"] > 400:
+                    bad.append((n, r["vgpr_count"], r["vgpr_spill_count"], r["private_segment_fixed_size"]))
             elif r["vgpr_spill_count"] or r["private_segment_fixed_size"]:
                 bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
         if n.startswith("k_finish<"):
@@ -67,10 +76,11 @@ def test_throughput_kernels_do_not_spill(rows):
 
 
 def test_private_segments_are_dead_spill_slots_or_listed(rows):
-    """Whatever still declares a private segment either never touches it (dead slot) or is one of the 4-planet finish variants."""
+    """Whatever still declares a private segment either never touches it (dead slot) or is one of the listed, deliberate cases."""
     for r in rows:
         if r["private_segment_fixed_size"] and r["scratch_instructions"]:
-            assert r["name"].startswith("k_finish<4") or SEVEN_WAVES.fullmatch(r["name"]), (r["name"], r["private_segment_fixed_size"], r["scratch_instructions"])
+            assert r["name"].startswith("k_finish<4") or SEVEN_WAVES.fullmatch(r["name"]) or FOUR_PLANETS_TWO_WAVES.fullmatch(r["name"]), \
+                (r["name"], r["private_segment_fixed_size"], r["scratch_instructions"])
 
 
 def test_code_size_budget(rows):

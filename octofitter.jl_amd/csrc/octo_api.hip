@@ -159,11 +159,11 @@ double row_cost(const octo_ctx* ctx, int kind, int n_planets, bool nuis) {
 // straddle tables and tables keep their order, so k_finish can sum each observation's partials contiguously and in a
 // fixed order. key <= −SMALL_KEY: k_small's partition, −key − SMALL_KEY rows per wave; key > 0: about `key` tasks in total, shared between the tables in proportion to rows × row cost, each
 // table cut into EQUAL tasks (no ragged last task); key < 0: −key rows per wave everywhere (OCTO_CHUNK experiments).
-int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis) {
+int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis, int wpb) {
     // The cache belongs to the CONTEXT (one owner thread), not to the dataset, which stays immutable and can therefore be
     // shared between contexts and host threads.
     for (auto& t : ctx->tables)
-        if (t.ds_serial == ds->serial && t.key == key && t.nuis == nuis) { *out = &t; return OCTO_OK; }
+        if (t.ds_serial == ds->serial && t.key == key && t.nuis == nuis && t.wpb == wpb) { *out = &t; return OCTO_OK; }
     if (ctx->tables.size() >= 48) {                           // many datasets / batch sizes: drop the oldest half. hipFree waits
         for (size_t k = 0; k < 24; ++k) free_table(ctx->tables[k]);      // for the device, so no launched kernel still reads them
         ctx->tables.erase(ctx->tables.begin(), ctx->tables.begin() + 24);
@@ -172,6 +172,7 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
     tt.ds_serial = ds->serial;
     tt.key = key;
     tt.nuis = nuis;      // the row weights differ between the nuisance and the nuisance-free kernels
+    tt.wpb = wpb;
     std::vector<double> cpre, craw;
     double wsum = 0.0;
     for (int o = 0; o < ds->n_obs; ++o)
@@ -184,8 +185,8 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
     {
         int64_t n_all = 0, t32 = 0;
         for (int o = 0; o < ds->n_obs; ++o)
-            if (ds->h_obs[o].kind != OCTO_HGCA && ds->h_obs[o].n > 0) { n_all += ds->h_obs[o].n; t32 += std::max<int64_t>(1, ds->h_obs[o].n / (32 * WPB)); }
-        if (t32 < 32) rows_min = std::min<int64_t>(32, std::max<int64_t>(8, n_all / (32 * WPB)));
+            if (ds->h_obs[o].kind != OCTO_HGCA && ds->h_obs[o].n > 0) { n_all += ds->h_obs[o].n; t32 += std::max<int64_t>(1, ds->h_obs[o].n / (32 * wpb)); }
+        if (t32 < 32) rows_min = std::min<int64_t>(32, std::max<int64_t>(8, n_all / (32 * wpb)));
     }
     // key > 0: `key` tasks shared between the tables in proportion to rows x row cost — largest-remainder apportionment, so that the
     // shares add up to the target (independent rounding gave 7 or 9 tasks for a target of 8: a one-round grid then leaves CUs idle or
@@ -209,15 +210,15 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
         const int64_t n = ds->h_obs[o].n;
         if (n <= 0) continue;
         int64_t chunk;
-        if (key <= -SMALL_KEY) chunk = (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) ? (n + WPB - 1) / WPB : -(key + SMALL_KEY);   // k_small: a marginalised-RV table in ONE block (its μ̂)
+        if (key <= -SMALL_KEY) chunk = (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) ? (n + wpb - 1) / wpb : -(key + SMALL_KEY);   // k_small: a marginalised-RV table in ONE block (its μ̂)
         else if (key < 0) chunk = -key;
         else {
             int64_t t_o = t_plan[o];
-            t_o = std::min<int64_t>(std::max<int64_t>(t_o, 1), std::max<int64_t>(1, n / (rows_min * WPB)));
+            t_o = std::min<int64_t>(std::max<int64_t>(t_o, 1), std::max<int64_t>(1, n / (rows_min * wpb)));
             const int64_t rows_per_task = (n + t_o - 1) / t_o;
-            chunk = (rows_per_task + WPB - 1) / WPB;
+            chunk = (rows_per_task + wpb - 1) / wpb;
         }
-        const int64_t span = chunk * WPB;
+        const int64_t span = chunk * wpb;
         for (int64_t r0 = 0; r0 < n; r0 += span) {
             Task t;
             t.obs = o; t.row0 = (int32_t)r0; t.nrows = (int32_t)std::min<int64_t>(span, n - r0); t.chunk = (int32_t)chunk;
@@ -274,8 +275,9 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
 // (A persistent kernel pulling (task, tile) items from an atomic queue, with and without a tapered item size, was
 // measured against this grid-mapped launch in the same run and was not faster at any batch size: the hardware
 // dispatcher already backfills freed slots fast enough for an FP64-issue-bound kernel.)
-int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu) {
+int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu, bool* wide) {
     const int n_cus = ctx->n_cus;
+    if (wide) *wide = false;
     if (ctx->env_chunk > 0) return -ctx->env_chunk;      // OCTO_CHUNK, tuning knob for experiments: uniform rows per wave
     const int64_t cols = (W + WAVE - 1) / WAVE;
     const int64_t capacity = std::max<int64_t>((int64_t)blocks_per_cu * n_cus, 256);
@@ -304,6 +306,12 @@ int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_
         static const double g[8] = {1.59, 1.59, 1.13, 1.045, 1.03, 1.015, 1.005, 1.0};
         const double cost = n * g[(int)std::min(n, 7.0)] * (chunk + 2.7) + 0.34 * (double)t;
         if (cost < best_cost) { best_cost = cost; best_t = t; }
+    }
+    // The WIDE block (k_main<…, NWV = 8>, offered by the caller for the kernels it is compiled for): the same task count with eight waves per
+    // block — twice the waves per SIMD for the row loop, the per-block costs (table fill, orbit-constructor pieces, partials, k_finish) unchanged.
+    if (wide && ctx->env_wide >= 0) {
+        const double n4 = std::ceil((double)(cols * best_t) / (double)n_cus);
+        *wide = (2.0 * n4 <= (double)blocks_per_cu && n_rows >= (int64_t)best_t * 8 * 32) || (ctx->env_wide > 0 && n4 <= (double)blocks_per_cu);
     }
     return best_t;
 }
@@ -414,6 +422,7 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     if (const char* ev = std::getenv("OCTO_FLAG_W")) ctx->flag_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     ctx->env_small_blocks = env_int("OCTO_SMALL_BLOCKS"); ctx->env_small_min_span = env_int("OCTO_SMALL_MIN_SPAN");
     ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST"); ctx->env_kind_all = env_int("OCTO_KIND_ALL");
+    if (const char* ev = std::getenv("OCTO_WIDE")) ctx->env_wide = std::atoi(ev);
     *out = ctx;
     return OCTO_OK;
 }

@@ -29,6 +29,7 @@ struct TaskTable {
     uint64_t ds_serial = 0;          // the dataset this partition belongs to (octo_dataset::serial)
     bool nuis = false;               // planned with the nuisance kernels' row weights
     int64_t key = 0;                 // > 0: target number of tasks of the plan; < 0: forced uniform rows-per-wave (OCTO_CHUNK)
+    int wpb = WPB;                   // waves per block the rows of a task are split over (8: the wide block of one-round launches)
     int n_tasks = 0;
     Task* d_tasks = nullptr;
     double* d_const_pre = nullptr;   // per-task constants for the no-nuisance path
@@ -111,6 +112,7 @@ struct octo_ctx {
     // experiment knobs, read from the environment ONCE at context creation (0 = not set): a getenv per call is a linear scan of the
     // environment on a 12 µs path
     int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0, env_rv_cost = 0, env_kind_all = 0;
+    int env_wide = 0;                           // OCTO_WIDE: experiments (1: eight-wave k_main blocks for every one-round single-planet launch, -1: never)
     int flag_w = 128;                           // ... and signal completion through per-walker flags the host spins on (OCTO_FLAG_W: experiments)
     int mapped_w = 128;                         // host-buffer calls up to this size let k_small read/write mapped pinned memory; larger
                                                 // ones cross the link as one DMA each way (OCTO_MAPPED_W: experiments)
@@ -158,8 +160,8 @@ int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
     return OCTO_OK;
 }
 
-int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis = false);
-int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu);
+int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis = false, int wpb = WPB);
+int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu, bool* wide = nullptr);
 int busy(octo_ctx* ctx, const char* what);      // OCTO_EINVAL while an octo_eval_begin of this context is outstanding
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);
 

@@ -762,10 +762,12 @@ constexpr int NPC = WC_CAE + 1;     // the per-walker constants the row loop rea
 template <int P, bool GRAD, bool NUIS, int KM>
 constexpr size_t main_lds_bytes() { return sizeof(double) * (2 * SCT_N + Layout<P, GRAD, NUIS, KM>::NACC * WAVE); }
 // the fused-setup launch also stages the block's per-walker constants (P × NPC × 64 doubles, before the table is written) in the same allocation
-template <int P, bool GRAD, bool NUIS, int KM>
+// (NWV > 4, the wide block of one-round launches: room for all the other waves' sums at once — one combine round, two barriers)
+template <int P, bool GRAD, bool NUIS, int KM, int NWV = WPB>
 constexpr size_t fused_lds_bytes() {
     const size_t b = main_lds_bytes<P, GRAD, NUIS, KM>(), c = sizeof(double) * (size_t)P * NPC * WAVE;
-    return b > c ? b : c;
+    const size_t d = NWV > WPB ? sizeof(double) * (size_t)(NWV - 1) * Layout<P, GRAD, NUIS, KM>::NACC * WAVE : 0;
+    return b > c ? (b > d ? b : d) : (c > d ? c : d);
 }
 
 // Seven waves per SIMD (72 VGPRs) for the nuisance-free single-planet RA/Dec gradient kernels: they need 76 left alone, one
@@ -789,10 +791,16 @@ constexpr unsigned main_min_waves() {
 // k_finish<FROM_WC = false> derives the handful of constants the finish needs again. Measured and NOT kept (profiles/r3_fused_ab.txt):
 // the finish inside the same launch (last block of a tile, counter + write-through partials) — its tail, one block gathering 87 tasks'
 // partials with the loop's register budget, is longer than the launch gap it saves, at every batch size.
-template <int P, bool GRAD, bool NUIS, int KM, bool FUSED = false>
+// NWV: waves per block. 4 everywhere except the WIDE block of one-round launches (few walker tiles: a strong-scaled shard, a mid-size batch):
+// there every block of the grid starts at the same moment and the number of waves a SIMD holds decides how well the row loop issues. Eight
+// waves per block buy six waves per SIMD with the SAME number of blocks — table fills, orbit-constructor pieces, partials and k_finish work
+// unchanged — where twice as many 4-wave blocks paid all of those twice (profiles/r4_chunk_sweep_1250.txt: no gain). 1 250 walkers x 1e4
+// epochs: 53.25 -> 51.8 µs per step (same box, profiles/r4_wide_ab.txt); the planner (plan_key) offers it only while a wave keeps >= 32 rows.
+template <int P, bool GRAD, bool NUIS, int KM, bool FUSED = false, int NWV = WPB>
 __attribute__((amdgpu_waves_per_eu(main_min_waves<P, GRAD, NUIS, KM>())))
-static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
+static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
+    static_assert(NWV == WPB || (FUSED && NWV == 2 * WPB), "k_main: four waves per block, or eight in the fused launch");
     // The hand-scheduled row prefetch (row_issue / row_wait_issue below) is used where the ISA check passes: the multi-planet variants of
     // the k_setup route (a marginalised-RV gradient and its forward pre-pass) run out of SGPRs, and the compiler spilled the prefetched
     // tuple to VGPR lanes WHILE the load was in flight (tools/kernel_resources.py: scalar_load_hazards found it) — they read their rows
@@ -820,7 +828,7 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         {
             const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
             double2* t = reinterpret_cast<double2*>(lds);
-            for (int i = threadIdx.x; i < SCT_N; i += WAVE * WPB) t[i] = g[i];
+            for (int i = threadIdx.x; i < SCT_N; i += WAVE * NWV) t[i] = g[i];
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) load_pc(pc[p], a.wc, a.ldw, p, wl);
@@ -830,8 +838,8 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         // chain it left three of the four SIMDs idle for its duration (rounds 3: ~8.5 µs of fixed cost per launch, most of it here).
         // The pieces meet in LDS, and every wave assembles the constants it keeps in registers from them. The sin/cos table travels
         // global -> registers (issued first: one memory round trip under the pieces) -> LDS once the pieces have been read.
-        static_assert(WPB == 4, "k_main<FUSED>: one setup piece per wave");
-        constexpr int TPT = (SCT_N + WAVE * WPB - 1) / (WAVE * WPB);
+        static_assert(WPB == 4, "k_main<FUSED>: one setup piece per wave (waves 4-7 of a wide block have none)");
+        constexpr int TPT = (SCT_N + WAVE * NWV - 1) / (WAVE * NWV);
         constexpr int NRAW = 15;      // si ci | sw cw | sO cO | sma T invP beta eob K0 mu f32a f32b
         static_assert(NRAW <= NPC, "the pieces fit in the LDS the fused launch allocates");
         double trs[TPT], trc[TPT];      // (scalars, not double2[]: the aggregate copies kept the array in scratch memory)
@@ -839,7 +847,7 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
             const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
 #pragma unroll
             for (int k = 0; k < TPT; ++k) {
-                const int i = (int)threadIdx.x + k * WAVE * WPB;
+                const int i = (int)threadIdx.x + k * WAVE * NWV;
                 const double2 v = g[i < SCT_N ? i : SCT_N - 1];
                 trs[k] = v.x; trc[k] = v.y;
             }
@@ -857,7 +865,7 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
             if (wv == 0) { double sn, cs; setup_angle<0, true>(elv[p], a.orbit_kind[p], sn, cs); raw[0 * WAVE] = sn; raw[1 * WAVE] = cs; }
             else if (wv == 1) { double sn, cs; setup_angle<1, true>(elv[p], a.orbit_kind[p], sn, cs); raw[2 * WAVE] = sn; raw[3 * WAVE] = cs; }
             else if (wv == 2) { double sn, cs; setup_angle<2, true>(elv[p], a.orbit_kind[p], sn, cs); raw[4 * WAVE] = sn; raw[5 * WAVE] = cs; }
-            else {
+            else if (wv == 3) {
                 const SetupScalars q = setup_scalars<true>(elv[p], a.c, a.orbit_kind[p], a.has_mass[p]);
                 raw[6 * WAVE] = q.sma; raw[7 * WAVE] = q.T; raw[8 * WAVE] = q.invP; raw[9 * WAVE] = q.beta; raw[10 * WAVE] = q.eob;
                 raw[11 * WAVE] = q.K0; raw[12 * WAVE] = q.mu; raw[13 * WAVE] = q.f32a; raw[14 * WAVE] = q.f32b;
@@ -884,7 +892,7 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         {
             double2* t = reinterpret_cast<double2*>(lds);
 #pragma unroll
-            for (int k = 0; k < TPT; ++k) { const int i = (int)threadIdx.x + k * WAVE * WPB; if (i < SCT_N) t[i] = make_double2(trs[k], trc[k]); }
+            for (int k = 0; k < TPT; ++k) { const int i = (int)threadIdx.x + k * WAVE * NWV; if (i < SCT_N) t[i] = make_double2(trs[k], trc[k]); }
         }
     }
 
@@ -959,12 +967,12 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
     // the NACC×64 buffer behind it), as many waves per round as fit: all three at once for the narrow layouts (config 3: one round, two
     // barriers, where rounds 1-3 took turns through the buffer alone: three rounds, six barriers at the tail of every block). Wave 0
     // adds them in wave order, as before: bit-identical sums.
-    constexpr int LDS_DOUBLES = (int)((FUSED ? fused_lds_bytes<P, GRAD, NUIS, KM>() : main_lds_bytes<P, GRAD, NUIS, KM>()) / sizeof(double));
-    constexpr int WPR = (LDS_DOUBLES / (L::NACC * WAVE)) < (WPB - 1) ? (LDS_DOUBLES / (L::NACC * WAVE)) : (WPB - 1);      // waves per round
+    constexpr int LDS_DOUBLES = (int)((FUSED ? fused_lds_bytes<P, GRAD, NUIS, KM, NWV>() : main_lds_bytes<P, GRAD, NUIS, KM>()) / sizeof(double));
+    constexpr int WPR = (LDS_DOUBLES / (L::NACC * WAVE)) < (NWV - 1) ? (LDS_DOUBLES / (L::NACC * WAVE)) : (NWV - 1);      // waves per round
     static_assert(WPR >= 1, "k_main: the combine buffer holds one wave's sums");
     (void)comb;
 #pragma unroll 1
-    for (int q0 = 1; q0 < WPB; q0 += WPR) {
+    for (int q0 = 1; q0 < NWV; q0 += WPR) {
         __syncthreads();                                // table (first round) / previous round's sums no longer needed
         if (wv >= q0 && wv < q0 + WPR) {
 #pragma unroll
@@ -973,7 +981,7 @@ static __global__ __launch_bounds__(64 * WPB) void k_main(EvalArgs a) {
         __syncthreads();
         if (wv == 0) {
 #pragma unroll 1
-            for (int q = q0; q < (q0 + WPR < WPB ? q0 + WPR : WPB); ++q) {
+            for (int q = q0; q < (q0 + WPR < NWV ? q0 + WPR : NWV); ++q) {
 #pragma unroll
                 for (int k = 0; k < L::NACC; ++k) acc[k] += lds[((q - q0) * L::NACC + k) * WAVE + lane];
             }

@@ -123,7 +123,11 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         blocks_per_cu = nb;
     }
     TaskTable* tt = nullptr;
-    int rc0 = get_tasks(ctx, ds, plan_key(ctx, a.W, ds->n_rows, blocks_per_cu), &tt, NUIS);
+    // one planet, fused launch: a one-round grid may take eight-wave blocks (octo_kernels.h: k_main<…, NWV>; plan_key decides)
+    constexpr bool WIDE_OK = P == 1;
+    bool wide = false;
+    const int64_t pkey = plan_key(ctx, a.W, ds->n_rows, blocks_per_cu, (WIDE_OK && !marg_ds) ? &wide : nullptr);
+    int rc0 = get_tasks(ctx, ds, pkey, &tt, NUIS, wide ? 2 * WPB : WPB);
     if (rc0) return rc0;
     a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;
     a.obs_range = tt->d_obs_range; a.obs_const = NUIS ? tt->d_obs_const_raw : tt->d_obs_const_pre;
@@ -164,8 +168,17 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         if (a.n_tasks > 0) {      // (a dataset without rows — an HGCA table alone, empty tables — is k_finish's closed forms only)
             rc = timing_begin();
             if (rc) return rc;
-            hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
-                               (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+            bool launched = false;
+            if constexpr (WIDE_OK) {
+                if (wide) {
+                    hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true, 2 * WPB>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * 2 * WPB),
+                                       (fused_lds_bytes<P, GRAD, NUIS, KM, 2 * WPB>()), st, a);
+                    launched = true;
+                }
+            }
+            if (!launched)
+                hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                                   (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
             if (e1) HIPCHK(ctx, hipEventRecord(e1, st));
         }
         hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * fin_waves<P, GRAD, NUIS, KM>()), (fin_lds_bytes<P, GRAD, NUIS, KM>()), st, a);

@@ -156,6 +156,53 @@ def test_config5_per_gpu_shape(pkg, oracle):
     fn.close()
 
 
+def test_strong_scaled_shard_wide_blocks(pkg, oracle, monkeypatch):
+    """SURVEY §8(d) "Scaling runs": the per-GPU share of config 3 at 8 GPUs — 1 250 walkers x 1e4 epochs, a ONE-ROUND launch, which the planner
+    gives eight-wave k_main blocks (octo_kernels.h: k_main<…, NWV = 8>; 2 000 walkers likewise, with and without per-walker nuisances). Against the
+    oracle on a seeded sample of walkers at the full epoch count, the forward-only value bit-identical to the value returned with the gradient
+    (same partition), and against the same shard evaluated with four-wave blocks (OCTO_WIDE=-1, read at context creation): a different row
+    partition, so equal to rounding, not bitwise."""
+    E = 10_000
+    for W, with_nuis in ((1250, False), (2000, True)):
+        cfg = synth.config_astrom(n_epochs=E, n_walkers=W, cfg=3, seed=20260929 + 8 + W)
+        obs_m, planet = synth.to_mirror(pkg, cfg)
+        el = np.ascontiguousarray(cfg["elems"])
+        nuis = None
+        if with_nuis:
+            rng = np.random.default_rng(W)
+            nuis = np.ascontiguousarray(np.stack([rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W)]))
+        res = {}
+        for tag in ("wide", "narrow"):
+            if tag == "narrow":
+                monkeypatch.setenv("OCTO_WIDE", "-1")
+            fn = pkg.make_ln_like(pkg.System(name="shard", companions=[planet]), cfg["theta_example"])
+            monkeypatch.delenv("OCTO_WIDE", raising=False)
+            out = fn.ln_like_arrays(el, nuis, grad=True)
+            ll_f = fn.ln_like_arrays(el, nuis, grad=False)
+            assert np.array_equal(out[0], ll_f, equal_nan=True), f"{tag}: forward-only value != value returned with the gradient"
+            res[tag] = out
+            fn.close()
+        ll, g_el, g_nu = res["wide"]
+        ok = np.isfinite(ll)
+        assert ok.sum() > 0.9 * W and np.array_equal(ok, np.isfinite(res["narrow"][0]))
+        assert np.max(np.abs(ll[ok] - res["narrow"][0][ok]) / np.maximum(1.0, np.abs(ll[ok]))) < 1e-12
+        sc = np.maximum(np.abs(res["narrow"][1][:8, ok]).max(axis=1, keepdims=True), 1e-300)
+        assert np.max(np.abs(g_el[:8, ok] - res["narrow"][1][:8, ok]) / sc) < 1e-11
+        idx = np.random.default_rng(11).choice(W, 24, replace=False)
+        t = cfg["table"]
+        obs = [dict(kind=0, planet=0, epoch=t["epoch"], y1=t["ra"], y2=t["dec"], s1=t["σ_ra"], s2=t["σ_dec"], cor=None)]
+        ll_o, g_o, gn_o = oracle.oracle_eval(obs, [dict(orbit_kind=0, has_mass=False)], el[:, idx], None if nuis is None else nuis[:, idx], grad=True,
+                                             active=synth.active_mask(1, 1 if with_nuis else 0, mass=False), n_threads=0)
+        oko = np.isfinite(ll_o)
+        assert np.array_equal(oko, ok[idx])
+        assert np.all(rel_err(ll[idx][oko], ll_o[oko], 1.0) < 1e-11)
+        sco = np.maximum(np.abs(g_o[:8, oko]).max(axis=1, keepdims=True), 1e-300)
+        assert np.max(np.abs(g_el[:8, idx][:, oko] - g_o[:8, oko]) / sco) < 1e-9
+        if with_nuis:
+            scn = np.maximum(np.abs(gn_o[:, oko]).max(axis=1, keepdims=True), 1e-300)
+            assert np.max(np.abs(g_nu[:, idx][:, oko] - gn_o[:, oko]) / scn) < 1e-9
+
+
 def test_torch_stream_ordering(pkg, oracle):
     """torch op -> device entry point -> torch op on torch's current stream with NO device-wide synchronisation: the results
     are right only if the kernels really run on that stream (default stream, then a side stream)."""

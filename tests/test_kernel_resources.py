@@ -46,13 +46,13 @@ def test_latency_kernels_have_no_scratch_and_no_vgpr_spills(rows):
 
 # The nuisance-free single-planet RA/Dec gradient kernels are held to 72 VGPRs (seven waves per SIMD, octo_kernels.h: main_min_waves): the
 # compiler parks 12-16 bytes OUTSIDE the row loop (two to four scratch instructions per wave, measured -1 % step time in round 2). Deliberate.
-SEVEN_WAVES = re.compile(r"k_main<1, true, false, (1|33), (true|false)>")
+SEVEN_WAVES = re.compile(r"k_main<1, true, false, (1|33), (true|false), (4|8)>")
 
 
 # The four-planet gradient kernels are held to 256 VGPRs = two waves per SIMD (main_min_waves): left alone they take 312-339 registers, ONE wave
 # per SIMD, and run at 0.21 of the FP64 peak. Held, they park 2-23 doubles per row in scratch memory and are 18 % faster (same-box A/B,
 # profiles/r4_p4_waves_ab.txt). Deliberate; the budget below keeps the parking from growing unnoticed.
-FOUR_PLANETS_TWO_WAVES = re.compile(r"k_main<4, true, (true|false), \d+, (true|false)>")
+FOUR_PLANETS_TWO_WAVES = re.compile(r"k_main<4, true, (true|false), \d+, (true|false), 4>")
 
 
 def test_throughput_kernels_do_not_spill(rows):

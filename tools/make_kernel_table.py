@@ -10,16 +10,16 @@ PEAK_TF = 78.6
 # workload -> (kernels of interest: substring -> (evaluations per launch, row-waves per launch, solves per evaluation))
 E4 = 10_000
 WORK = {
-    "two_planet": {"k_main<2, true, true, 5, true>": (5000 * 4096, 5000 * 64, 2), "k_finish<2, true, true, 5, false>": (5000 * 4096, None, 2)},
-    "nuis": {"k_main<1, true, true, 1, true>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, true, 1, false>": (E4 * E4, None, 1)},
-    "fwd": {"k_main<1, false, false, 1, true>": (E4 * E4, E4 * 157, 1), "k_finish<1, false, false, 1, false>": (E4 * E4, None, 1)},
+    "two_planet": {"k_main<2, true, true, 5, true, 4>": (5000 * 4096, 5000 * 64, 2), "k_finish<2, true, true, 5, false>": (5000 * 4096, None, 2)},
+    "nuis": {"k_main<1, true, true, 1, true, 4>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, true, 1, false>": (E4 * E4, None, 1)},
+    "fwd": {"k_main<1, false, false, 1, true, 4>": (E4 * E4, E4 * 157, 1), "k_finish<1, false, false, 1, false>": (E4 * E4, None, 1)},
     "ofti": {"k_ofti_main": (E4 * E4, E4 * 157, 1), "k_ofti_finish": (E4 * E4, None, 1)},
     "logpost": {"k_model_fwd<true, false>": (E4 * E4, None, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
-    "three_planet": {"k_main<3, true, true, 5, true>": (6250 * 4096, 6250 * 64, 3), "k_finish<3, true, true, 5, false>": (6250 * 4096, None, 3)},
-    "four_planet": {"k_main<4, true, true, 5, true>": (7500 * 4096, 7500 * 64, 4), "k_finish<4, true, true, 5, false>": (7500 * 4096, None, 4)},
+    "three_planet": {"k_main<3, true, true, 5, true, 4>": (6250 * 4096, 6250 * 64, 3), "k_finish<3, true, true, 5, false>": (6250 * 4096, None, 3)},
+    "four_planet": {"k_main<4, true, true, 5, true, 4>": (7500 * 4096, 7500 * 64, 4), "k_finish<4, true, true, 5, false>": (7500 * 4096, None, 4)},
     "small_w1": {"k_small<1, true, false, 1, false>": (E4 * 1, E4 * 1 / 64.0, 1)},
     "small_w512": {"k_small<1, true, false, 1, false>": (E4 * 512, E4 * 512 / 64.0, 1)},
-    "config3": {"k_main<1, true, false, 1, true>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
+    "config3": {"k_main<1, true, false, 1, true, 4>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
 }
 
 

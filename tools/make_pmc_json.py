@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from __graft_entry__ import kernel_source_hash
 
-KERNEL = "k_main<1, true, false, 1, true>"
+KERNEL = "k_main<1, true, false, 1, true, 4>"      # (P, GRAD, NUIS, KM, FUSED, waves per block)
 W, E = 10_000, 10_000
 
 

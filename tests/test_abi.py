@@ -19,6 +19,15 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 HEADER = ROOT / "include" / "octofitter_hip.h"
 JULIA = ROOT / "octofitter.jl_amd" / "julia" / "OctofitterHIP.jl"
+JULIA_CAPI = ROOT / "octofitter.jl_amd" / "julia" / "OctofitterHIP_capi.jl"      # the thin layer: constants, structs, one ccall per symbol
+
+
+def _julia_text():
+    """The shim as Julia sees it: OctofitterHIP.jl with its include of the ccall layer expanded."""
+    main = JULIA.read_text()
+    inc = 'include("OctofitterHIP_capi.jl")'
+    assert main.count(inc) == 1, "OctofitterHIP.jl includes the ccall layer exactly once"
+    return main.replace(inc, JULIA_CAPI.read_text())
 
 
 @pytest.fixture(scope="module")
@@ -72,7 +81,7 @@ _JL_SIZES = {"Int32": 4, "Int64": 8, "Float64": 8, "UInt64": 8}
 
 
 def _julia_structs():
-    txt = JULIA.read_text()
+    txt = _julia_text()
     out = {}
     for m in re.finditer(r"^struct (Octo\w+)[ \t]*(?:#[^\n]*)?\n(.*?)^end", txt, flags=re.S | re.M):
         fields = []
@@ -106,7 +115,7 @@ def test_julia_structs_match_the_header(layout):
 
 def test_julia_shim_binds_every_symbol_with_the_right_arity():
     funcs = _header_functions()
-    txt = JULIA.read_text()
+    txt = _julia_text()
     seen = {}
     for m in re.finditer(r"ccall\(\(:(octo_\w+), LIB\),\s*\w+,\s*\(", txt):
         # argument-type tuple: balanced parentheses after the return type
@@ -138,7 +147,7 @@ def test_julia_shim_binds_every_symbol_with_the_right_arity():
 def test_julia_constants_match_the_header():
     hdr = HEADER.read_text()
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(OCTO_\w+)\s+(-?\d+)\b", hdr)}
-    txt = JULIA.read_text()
+    txt = _julia_text()
     groups = {
         "ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL": ["OCTO_ASTROM_RADEC", "OCTO_ASTROM_SEPPA", "OCTO_RV_ABS", "OCTO_RV_ABS_MARG", "OCTO_RV_REL"],
         "ONEIL_RADEC, ONEIL_SEPPA, HGCA": ["OCTO_ONEIL_RADEC", "OCTO_ONEIL_SEPPA", "OCTO_HGCA"],
@@ -167,7 +176,7 @@ def test_julia_shim_names_exist_in_the_reference():
     spec = importlib.util.spec_from_file_location("julia_api_manifest", ROOT / "tools" / "julia_api_manifest.py")
     jm = importlib.util.module_from_spec(spec); spec.loader.exec_module(jm)
     man = json.loads((ROOT / "tests" / "golden" / "julia_api_names.json").read_text())
-    qualified, imported, own_fields, fields = jm.shim_names(JULIA.read_text())
+    qualified, imported, own_fields, fields = jm.shim_names(_julia_text())
     assert {"ln_like", "likelihoodname", "_isprior", "likeobj_from_epoch_subset", "orbittype", "make_arr2nt", "make_prior_sampler"} <= qualified
     missing = sorted(n for n in qualified | imported if n not in man["names"])
     assert not missing, f"OctofitterHIP.jl uses Octofitter names the manifest does not know: {missing} (run tools/julia_api_manifest.py)"
@@ -191,7 +200,7 @@ def test_julia_shim_classifies_the_trend_closure():
     """The boundary defect of VERDICT r2: `_table` took every RV observation without a GP, although `trend_function` is always a closure
     (rv-absolute.jl:69). Structural check of the fix: the RV branch goes through `_trend_basis`, an unclassifiable closure makes the
     observation ineligible (`return nothing`), the basis column is uploaded as `extra`, and the coefficient reaches the third nuisance row."""
-    txt = JULIA.read_text()
+    txt = _julia_text()
     rv = txt[txt.index("kind = T === :StarAbsoluteRVObs"):txt.index("_has_epochs(obs) =")]
     assert "_trend_basis(obs, θobs_draws)" in rv and "tb === nothing && return nothing" in rv and "gaussian_process" in rv
     assert rv.index("gaussian_process") < rv.index("_trend_basis")
@@ -207,3 +216,16 @@ def test_plain_c_consumer_evaluates(pkg, abi_exe):
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     out = json.loads(r.stdout)
     assert out["ok"] == 1 and out["ll1_is_minus_inf"] == 1
+
+
+def test_julia_ccall_layer_is_thin_and_self_contained():
+    """SURVEY.md §7 asks for a thin, pure-`ccall` shim: the layer a maintainer needs to reach the C ABI from Julia is ONE file of about 200 lines
+    that names nothing of Octofitter (no `Octofitter.`, no `using`), holds every `ccall` of the binding, and nothing but constants, structs
+    and call wrappers; everything that touches the reference's types lives in OctofitterHIP.jl on top of it."""
+    capi = JULIA_CAPI.read_text()
+    code = [l for l in capi.splitlines() if l.strip() and not l.lstrip().startswith("#")]
+    assert len(code) <= 200, len(code)
+    assert "Octofitter." not in capi.replace("OctofitterHIP", "") and not re.search(r"^\s*using\s", capi, re.M)
+    main = JULIA.read_text()
+    assert "ccall(" not in main, "every ccall belongs to the thin layer"
+    assert not re.search(r"^\s*(mutable\s+)?struct\s+Octo[A-Z]\w*", main, re.M), "the header's structs are mirrored in the thin layer"

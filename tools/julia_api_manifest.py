@@ -99,7 +99,7 @@ def scan_reference():
 
 
 def build():
-    qualified, imported, own_fields, fields = shim_names(JULIA.read_text())
+    qualified, imported, own_fields, fields = shim_names(JULIA.read_text().replace('include("OctofitterHIP_capi.jl")', (JULIA.parent / 'OctofitterHIP_capi.jl').read_text()))
     defs, struct_fields = scan_reference()
     names = {}
     missing = []

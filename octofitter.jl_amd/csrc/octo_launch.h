@@ -126,7 +126,8 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     // one planet, fused launch: a one-round grid may take eight-wave blocks (octo_kernels.h: k_main<…, NWV>; plan_key decides)
     // (… and three of its blocks — plan_key offers it up to that many per CU — must fit in a CU's 160 KB of LDS next to each other: their combine
     // buffer holds seven waves' sums. The gradient layout decides for the forward-only launch too: both take the same partition.)
-    constexpr bool WIDE_OK = P == 1 && 3 * fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>() <= 160 * 1024;
+    constexpr bool WIDE_OK = P == 1 && 3 * fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>() <= 160 * 1024 &&
+                             fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>() <= 48 * 1024;      // (… and stays under the default dynamic-LDS limit of a launch)
     bool wide = false;
     const int64_t pkey = plan_key(ctx, a.W, ds->n_rows, blocks_per_cu, (WIDE_OK && !marg_ds) ? &wide : nullptr);
     int rc0 = get_tasks(ctx, ds, pkey, &tt, NUIS, wide ? 2 * WPB : WPB);

@@ -203,6 +203,47 @@ def test_strong_scaled_shard_wide_blocks(pkg, oracle, monkeypatch):
             assert np.max(np.abs(g_nu[:, idx][:, oko] - gn_o[:, oko]) / scn) < 1e-9
 
 
+def test_one_round_launches_of_the_other_kind_sets(pkg, oracle, monkeypatch):
+    """One-round launches (1 250 walkers, long tables) of kind sets other than RA/Dec alone: a sep/PA table with `cor` (same sums as RA/Dec: the planner
+    gives it eight-wave blocks) and an O'Neil-wrapped RA/Dec table with per-walker nuisances (four more sums per wave: its combine buffer would pass the
+    dynamic-LDS limit of a launch, so it keeps four-wave blocks — octo_launch.h: WIDE_OK). Both against the oracle on a seeded sample and against the same
+    shard with OCTO_WIDE=-1."""
+    gb = _gpu()
+    W, E = 1250, 6000
+    cfg = synth.config_astrom(n_epochs=E, n_walkers=W, cfg=3, seed=20260929 + 77)
+    t = cfg["table"]
+    rng = np.random.default_rng(77)
+    ra, dec = np.asarray(t["ra"]), np.asarray(t["dec"])
+    cases = {
+        "seppa+cor": ([dict(kind=1, planet=0, epoch=t["epoch"], y1=np.arctan2(ra, dec), y2=np.hypot(ra, dec), s1=np.full(E, 0.02), s2=np.asarray(t["σ_ra"]),
+                            cor=rng.uniform(-0.5, 0.5, E))], None),
+        "oneil+nuis": ([dict(kind=0, planet=0, epoch=t["epoch"], y1=ra, y2=dec, s1=t["σ_ra"], s2=t["σ_dec"], cor=None),
+                        dict(kind=5, planet=0, epoch=t["epoch"], y1=ra, y2=dec, s1=t["σ_ra"], s2=t["σ_dec"], cor=None)],
+                       np.ascontiguousarray(np.stack([rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W)] * 2))),
+    }
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    el = np.ascontiguousarray(cfg["elems"])
+    idx = np.random.default_rng(12).choice(W, 16, replace=False)
+    for name, (obs, nuis) in cases.items():
+        res = {}
+        for tag in ("default", "narrow"):
+            if tag == "narrow":
+                monkeypatch.setenv("OCTO_WIDE", "-1")
+            res[tag] = gb.gpu_eval(obs, planets, el, nuis, grad=True, small_batch=0)
+            monkeypatch.delenv("OCTO_WIDE", raising=False)
+        ll, g_el = res["default"][0], res["default"][1]
+        ok = np.isfinite(ll)
+        assert ok.sum() > 0.9 * W and np.array_equal(ok, np.isfinite(res["narrow"][0])), name
+        assert np.max(np.abs(ll[ok] - res["narrow"][0][ok]) / np.maximum(1.0, np.abs(ll[ok]))) < 1e-12, name
+        ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el[:, idx], None if nuis is None else nuis[:, idx], grad=True,
+                                          active=synth.active_mask(1, len(obs) if nuis is not None else 0, mass=False), n_threads=0)
+        oko = np.isfinite(ll_o)
+        assert np.array_equal(oko, ok[idx]), name
+        assert np.all(rel_err(ll[idx][oko], ll_o[oko], 1.0) < 1e-10), name
+        sco = np.maximum(np.abs(g_o[:8, oko]).max(axis=1, keepdims=True), 1e-300)
+        assert np.max(np.abs(g_el[:8, idx][:, oko] - g_o[:8, oko]) / sco) < 1e-8, name
+
+
 def test_torch_stream_ordering(pkg, oracle):
     """torch op -> device entry point -> torch op on torch's current stream with NO device-wide synchronisation: the results
     are right only if the kernels really run on that stream (default stream, then a side stream)."""

@@ -16,11 +16,14 @@ the same line as `value_pcie_inclusive` (octo_eval on host arrays the caller reg
 next to `value_pcie_inclusive_blocking_call` (the same calls by the host's clock) and the breakdown in `pcie_inclusive`.
 Multi-GPU: walkers are independent, the dataset is replicated, and there is NO collective on the data path (the only collective of the
 path is the parallel-tempering swap step, exercised with --workload pt).
-  --scaling weak    (default, the bench contract's mode for a path that shards by independent units): every rank owns its own 1e4 walkers;
-  --scaling strong  SURVEY §8(d) "Scaling runs": the SAME 1e4 walkers split evenly over the ranks (1 250 per GPU at 8).
+  --scaling strong  (default for the contracted workloads grad / fwd / nuis) SURVEY §8(d) "Scaling runs": the SAME 1e4 walkers split evenly
+                    over the ranks (1 250 per GPU at 8), so that the metric's "1e4 epochs x 1e4 walkers" is literally what ran at every N;
+  --scaling weak    every rank owns its own --walkers (the default of the per-GPU-shaped workloads pt / two_planet / ofti / logpost).
 At N = 1 the line also carries `strong_scaling_projection`: the per-GPU shares of a strong-scaled run (W/2, W/4, W/8 walkers) measured
 on this one GPU — shards are independent, so N x rate(W/N) / rate(W) is what N GPUs deliver short of launch jitter. At N > 1 the default
-(weak) run also MEASURES that strong-scaling point (`strong_scaling_measured`: one rank's W walkers split over the N ranks, max over ranks).
+(strong) run also MEASURES the weak-scaling point (`weak_scaling_measured`: every rank its own 1e4 walkers, max over ranks), and a
+`--scaling weak` run the strong one (`strong_scaling_measured`). Every N > 1 line carries `cpu_baseline` (rank 0, the full 1e4-walker
+workload) and a `roofline` for the per-GPU launch shape (profiles/pmc_traffic.json holds counter passes per shard size).
 
 Timed region: W warm-up steps, then an untimed spin-up until the device has been busy for >= 0.3 s (clocks ramped, so that a
 20-step run measures the same thing as a 200-step run), barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over
@@ -77,8 +80,9 @@ def parse():
     ap.add_argument("--epochs", type=int, default=10_000)
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default 10000; 8192 = 8 temperatures x 1024 for --workload pt)")
     ap.add_argument("--workload", choices=["grad", "fwd", "nuis", "two_planet", "pt", "ofti", "logpost"], default="grad")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --walkers per GPU (default); strong: --walkers in total, split evenly over the ranks (SURVEY 8d)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong (default for grad / fwd / nuis): --walkers in total, split evenly over the ranks (SURVEY 8d 'Scaling runs'); "
+                         "weak (default for the other workloads): --walkers per GPU")
     ap.add_argument("--pt-comm", choices=["c_abi", "torch"], default="c_abi",
                     help="--workload pt: all-gather inside the library (octo_pt_step_device, RCCL bound by the C ABI) or through torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,6 +93,10 @@ def parse():
     args = ap.parse_args()
     if args.walkers is None:      # BASELINE config 5: 64 temperatures x 1024 walkers over 8 GPUs = 8 x 1024 per GPU
         args.walkers = 8192 if args.workload == "pt" else 10_000
+    if args.scaling is None:
+        args.scaling = "strong" if args.workload in ("grad", "fwd", "nuis") else "weak"
+    if args.scaling == "strong" and args.workload not in ("grad", "fwd", "nuis"):
+        raise SystemExit(f"--scaling strong is defined for the walker-sharded workloads grad / fwd / nuis, not for {args.workload}")
     return args
 
 
@@ -124,6 +132,7 @@ def cpu_baseline(cfg, obs_tables, planets, seconds):
 
     def timed(n_threads, grad, budget):
         width = cores if n_threads == 0 else 1
+        n_threads = width      # explicit team size: torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks, which "all cores" (0) would obey
         probe = min(cfg["n_walkers"], 4 * width)
         ob.oracle_eval(obs_tables, planets, cfg["elems"][:, :probe], None, grad=grad, active=mask, n_threads=n_threads)   # warm
         t0 = time.perf_counter()
@@ -344,17 +353,19 @@ def main():
         n_rows, W = c4["n_rows"], c4["n_walkers"]
         workload = "config4: 2 planets, 2500 RA/Dec + 2500 abs-RV epochs x 4096 walkers, fwd+grad"
         bytes_per_launch = W * (2500 * 40.0 + 2500 * 24.0) + W * 8.0 * (18 + 6 + 1 + 18 + 6)
-        cfg = None
+        cfg = cfg_full = None
     else:
+        # the whole batch of the metric (one seed): what a strong-scaled run splits, what the CPU baseline samples, and (N > 1, strong) what
+        # the weak-scaling point gives every rank
+        cfg_full = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2)
         if args.scaling == "strong":
             # SURVEY §8(d) "Scaling runs": the SAME --walkers split evenly over the ranks (contiguous shards, host/sharding.py:shard_range —
             # what octo_eval_multi does inside one process); every rank draws the whole batch with the one seed and keeps its slice
-            cfg = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2)
             lo, hi = pkg.shard_range(args.walkers, rank, world)
-            cfg = dict(cfg, elems=np.ascontiguousarray(cfg["elems"][:, lo:hi]), n_walkers=hi - lo)
+            cfg = dict(cfg_full, elems=np.ascontiguousarray(cfg_full["elems"][:, lo:hi]), n_walkers=hi - lo)
         else:
-            cfg = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2,
-                                      seed=None if world == 1 else 20260929 + 3 + 1000 * rank)
+            cfg = cfg_full if world == 1 else synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2,
+                                                                  seed=20260929 + 3 + 1000 * rank)
         obs, planet = synth.to_mirror(pkg, cfg)
         system = pkg.System(name="bench", companions=[planet], observations=[])
         fn = pkg.make_ln_like(system, cfg["theta_example"], device=dev_index)
@@ -363,8 +374,9 @@ def main():
         if args.workload == "nuis":      # config 3 with per-walker jitter, platescale and northangle: the raw-σ branch of relative-astrometry.jl:234-252
             rng = np.random.default_rng(1)
             nuis_h = np.stack([rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W)])
-        workload = (f"config{'3' if grad else '2'}: 1 planet, {n_rows} RA/Dec epochs x {W} walkers/GPU"
-                    + (f" ({args.walkers} walkers split over {world} GPUs)" if args.scaling == "strong" else "")
+        workload = (f"config{'3' if grad else '2'}: 1 planet, {n_rows} RA/Dec epochs x "
+                    + (f"{args.walkers} walkers in total ({args.walkers} walkers split over {world} GPUs: {W} walkers/GPU)" if args.scaling == "strong"
+                       else f"{W} walkers/GPU")
                     + (", per-walker jitter/platescale/northangle" if args.workload == "nuis" else "")
                     + f", {'fwd+reverse-grad' if grad else 'fwd only'}, inputs and outputs resident in HBM (PCIe-inclusive rate: value_pcie_inclusive)")
         bytes_per_launch = W * n_rows * BYTES_PER_ROW + W * (BYTES_PER_WALKER if grad else 72.0)
@@ -464,6 +476,28 @@ def main():
                         "region / this",
                 "n_gpus": world, "walkers_total": W, "walkers_per_gpu": hi - lo, "us_per_step": best * 1e6, "value": W * n_rows / best, "unit": "evals/s"}
 
+    def weak_measured():
+        """N > 1, default (strong) run: the weak-scaling point of this job measured in the same launch — EVERY rank evaluates its own batch of
+        --walkers walkers (the whole batch of the metric; the ranks' batches differ only by a rotation of the walker order), barrier +
+        synchronize around 100 back-to-back steps, MAX over ranks, best of 3."""
+        Wf = cfg_full["n_walkers"]
+        el_f = torch.tensor(np.roll(cfg_full["elems"], 64 * rank, axis=1), device=dev)
+        out_f = (torch.empty(Wf, dtype=torch.float64, device=dev), torch.empty_like(el_f) if grad else None, None)
+        for _ in range(10):
+            fn.ln_like_device(el_f, None, grad=grad, out=out_f)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); dist.barrier(); t1 = time.perf_counter()
+            for _ in range(50):
+                fn.ln_like_device(el_f, None, grad=grad, out=out_f)
+            torch.cuda.synchronize(); dist.barrier()
+            tt = torch.tensor([(time.perf_counter() - t1) / 50], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            best = min(best, float(tt.item()))
+        return {"what": "weak scaling measured in this run: every rank its own full batch (walkers per GPU = the metric's walkers in total), dataset "
+                        "replicated, no collective, 50 back-to-back steps between barriers, max over ranks, best of 3",
+                "n_gpus": world, "walkers_per_gpu": Wf, "us_per_step": best * 1e6, "value": world * Wf * n_rows / best, "unit": "evals/s"}
+
     fn.timing_enable(TIMED_EVERY)      # HIP events around k_main of every TIMED_EVERY-th evaluation, on its launch stream
     dt, per_step, n_spin = timed_loop(run_step, on_timed_start=lambda: fn.timing_read(reset=True))
     kern_med, kern_min, kern_max, kern_n = fn.timing_stats()
@@ -479,7 +513,13 @@ def main():
         evals = float(W) * n_rows * args.steps * world
     value = evals / dt
     metric = "epoch-likelihood evals/sec (fwd+grad), 1e4 epochs x 1e4 walkers" if args.workload == "grad" else f"epoch-likelihood evals/sec ({args.workload})"
-    res = base_line(metric, value, dt, per_step, n_spin, workload, {"walkers_per_gpu": W, "rows": n_rows, "parallelism": parallelism})
+    res = base_line(metric, value, dt, per_step, n_spin, workload,
+                    {"walkers_per_gpu": W, "walkers_total": (args.walkers if args.scaling == "strong" else W * world), "rows": n_rows, "parallelism": parallelism})
+    if world > 1 and args.scaling == "strong" and cfg is not None and args.workload in ("grad", "fwd") and not args.no_extras:
+        try:      # every rank takes part (barriers + a MAX all-reduce); rank 0 reports
+            res["weak_scaling_measured"] = weak_measured()
+        except Exception as ex:
+            res["weak_scaling_measured"] = {"error": str(ex)}
     if world > 1 and args.scaling == "weak" and cfg is not None and args.workload in ("grad", "fwd") and not args.no_extras:
         try:      # every rank takes part (barriers + a MAX all-reduce); rank 0 reports
             sm_ = strong_measured()
@@ -494,13 +534,21 @@ def main():
         res["swap_step_what"] = ("median over 200 steps, max over ranks: " + ("ncclAllGather of the local replicas' log-likelihoods + " if world > 1 else "")
                                  + "deterministic neighbour-swap kernel, host-synchronised per step")
     if rank == 0:
-        is_cfg3 = args.workload == "grad" and (n_rows, W) == (10_000, 10_000)
-        pmc, pmc_ok, pmc_note = None, False, None
+        is_cfg3 = args.workload == "grad" and n_rows == 10_000 and cfg is not None
+        pmc, pmc_ok, pmc_note, pmc_exact = None, False, None, True
         pmc_path = ROOT / "profiles" / "pmc_traffic.json"
         if is_cfg3 and pmc_path.exists():
-            try:      # PMC figures are per launch of exactly this kernel and workload; measured off-line (separate --pmc passes)
-                pmc = json.loads(pmc_path.read_text())
-                pmc_ok = pmc.get("kernel_source_sha256") == kernel_source_hash()
+            try:      # PMC figures are per launch of exactly this kernel and LAUNCH SHAPE (walkers per GPU); measured off-line (separate --pmc passes)
+                allp = json.loads(pmc_path.read_text())
+                pmc_ok = allp.get("kernel_source_sha256") == kernel_source_hash()
+                shapes = {10_000: allp}
+                shapes.update({int(k): v for k, v in allp.get("shapes", {}).items()})
+                if W in shapes:
+                    pmc = shapes[W]
+                else:      # a shard size without its own counter pass (an uneven split): the nearest profiled shape's per-evaluation counts, said so
+                    near = min(shapes, key=lambda k: abs(np.log(k / W)))
+                    pmc, pmc_exact = shapes[near], False
+                    pmc_note = f"no counter pass for {W} walkers per GPU: per-evaluation instruction counts of the nearest profiled launch shape ({near} walkers)"
                 if not pmc_ok:
                     pmc_note = ("profiles/pmc_traffic.json was collected for a DIFFERENT kernel source (sha256 mismatch): counter-derived "
                                 "fields withheld; re-run tools/profile_round.sh + tools/make_pmc_json.py")
@@ -518,10 +566,13 @@ def main():
         if pmc is not None and pmc_ok and kernel_s:
             flops_per_eval = pmc["fp64_flops_per_eval"]
             tf = flops_per_eval * float(W) * n_rows / kernel_s / 1e12
-            traffic = pmc["hbm_bytes_per_launch"]
+            traffic = pmc["hbm_bytes_per_launch"] * (1.0 if pmc_exact else float(W) / pmc["walkers_per_launch"])
             roof.update({"achieved": tf, "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "fp64_flops_per_eval": flops_per_eval,
+                         "kernel": pmc.get("kernel", "k_main"), "launch_shape": {"walkers": W, "rows": n_rows, "pmc_walkers": pmc.get("walkers_per_launch", 10_000)},
                          "valu_instructions_per_row_per_wave": pmc.get("valu_instructions_per_row_per_wave"),
-                         "pmc_source": pmc.get("source"), "pmc_kernel_source_sha256": pmc.get("kernel_source_sha256")})
+                         "pmc_source": pmc.get("source"), "pmc_kernel_source_sha256": allp.get("kernel_source_sha256")})
+            if pmc_note:
+                roof["pmc_note"] = pmc_note
             issue = pmc.get("issue_model")
             if issue:
                 # time the chip needs just to ISSUE this kernel's VALU instructions (measured mix x measured cost per class)
@@ -534,6 +585,9 @@ def main():
                            "what": "real HBM bytes per launch (PMC FETCH_SIZE x2 on gfx950 + WRITE_SIZE) / live kernel duration"}
         elif pmc_note:
             roof["note"] = pmc_note + " | " + roof["note"]
+        if world > 1:
+            roof["per_gpu"] = ("rank 0's GPU: its shard's k_main launches timed live on its launch stream; every rank runs the same launch shape "
+                               "(walkers split evenly, dataset replicated)")
         roof["north_star_algorithmic_hbm"] = {
             "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_stream_GBps": alg_gbps,
             "frac_of_hbm_peak": (alg_gbps / HBM_PEAK_GBPS) if alg_gbps else None,
@@ -541,13 +595,14 @@ def main():
                     "north_star words the claim; NOT a bandwidth measurement — it exceeds the 8 TB/s peak because the rows are reused "
                     "by 64 lanes from the scalar cache"}
         res["roofline"] = roof
-        if not args.no_extras and cfg is not None and world == 1 and args.workload == "grad":
-            # ---- parity of the batch just timed
+        if not args.no_extras and cfg is not None and args.workload == "grad":
+            # ---- parity of the batch just timed (N > 1: of rank 0's shard)
             try:
                 res["parity"] = parity_sample(fn, cfg, out[0].cpu().numpy(), out[1].cpu().numpy())
                 res["max_rel_err"] = max(res["parity"]["max_rel_err_ll"], res["parity"]["max_rel_err_grad"])
             except Exception as ex:
                 res["parity"] = {"ok": None, "error": str(ex)}
+        if not args.no_extras and cfg is not None and world == 1 and args.workload == "grad":
             # ---- the same batch through octo_eval, host buffers, H2D + D2H inside the timed call
             el_h = np.ascontiguousarray(elems_h); ll_h = np.empty(W); g_h = np.empty_like(el_h)
             a_ = (fn._ctx, fn._ds, capi._dptr(el_h), None, W, W, capi._dptr(ll_h), capi._dptr(g_h), None)
@@ -581,10 +636,14 @@ def main():
                 fn.timing_read(reset=True)
                 fn.timing_enable(0)
                 fn.host_unregister(el_h, ll_h, g_h)
-                res["value_pcie_inclusive"] = W * n_rows / (dev_med * 1e-3)
-                res["value_pcie_inclusive_what"] = ("SURVEY.md 8(d)'s definition of the metric: device time (HIP events on the call's stream) of octo_eval on host arrays "
-                                                    "registered once by the caller, H2D of the elements and D2H of ll + gradient inside; median of 25 calls. "
-                                                    "value_pcie_inclusive_blocking_call: the same calls by the host's clock (adds one launch + synchronisation per call)")
+                # key meanings: `value_pcie_inclusive` = the BLOCKING call by the host's clock, as in BENCH_r01..r03 (r04 carried the
+                # device-clock figure under this key); the device-clock figure of SURVEY 8(d)'s wording travels as `value_pcie_inclusive_device_clock`
+                res["value_pcie_inclusive"] = W * n_rows / medr
+                res["value_pcie_inclusive_device_clock"] = W * n_rows / (dev_med * 1e-3)
+                res["value_pcie_inclusive_what"] = ("octo_eval on host arrays registered once by the caller, H2D of the elements and D2H of ll + gradient inside the call; "
+                                                    "median of 25 calls. value_pcie_inclusive: wall time of the blocking call by the host's clock (launch + "
+                                                    "synchronisation included; the meaning of this key in BENCH_r01..r03). value_pcie_inclusive_device_clock: SURVEY.md "
+                                                    "8(d)'s clock, device time by HIP events on the call's stream (BENCH_r04 carried this one as value_pcie_inclusive)")
                 res["value_pcie_inclusive_blocking_call"] = W * n_rows / medr
                 res["pcie_inclusive"]["registered"] = {
                     "value": W * n_rows / (dev_med * 1e-3), "unit": "evals/s", "device_ms_per_call_median": dev_med, "device_ms_min": dev_min, "device_ms_max": dev_max,
@@ -635,9 +694,9 @@ def main():
                 res["config1"] = config1_latency(pkg, dev_index)
             except Exception as ex:
                 res["config1"] = {"error": str(ex)}
-        if not args.no_cpu_baseline and cfg is not None and world == 1 and args.workload == "grad":
+        if not args.no_cpu_baseline and cfg_full is not None and args.workload == "grad":      # rank 0, at every N: the whole workload of the metric
             try:
-                res["cpu_baseline"] = cpu_baseline(cfg, fn.obs_tables, fn.planet_desc, args.cpu_seconds)
+                res["cpu_baseline"] = cpu_baseline(cfg_full, fn.obs_tables, fn.planet_desc, args.cpu_seconds)
             except Exception as ex:  # the checker is optional for the measurement itself
                 res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex}"}
         emit(res)

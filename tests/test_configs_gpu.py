@@ -13,6 +13,7 @@ BASELINE.json's configurations that round 1 measured only in bench.py, now under
 """
 import ctypes as C
 import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -285,7 +286,7 @@ def test_bench_line_contract():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["dtype"] == "f64" and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["workload"].startswith("config3")
     assert d["value"] > 1e9 and abs(d["value"] - 1e8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     roof = d["roofline"]
@@ -308,8 +309,11 @@ def test_bench_line_contract():
     # single-thread pair is ordered strictly)
     assert cb["forward_only"]["value"] > 0.5 * cb["value"] and cb["single_thread_forward_only"]["value"] > cb["single_thread"]["value"]
     # the metric as SURVEY §8(d) defines it (H2D + D2H inside the timed call) travels on the same line, below the HBM-resident `value`
-    assert 0.5 * d["value"] < d["value_pcie_inclusive"] < d["value"] and d["value_pcie_inclusive"] == d["pcie_inclusive"]["registered"]["value"]
-    assert "HBM" in d["config"]["workload"]
+    # (key meanings, ADVICE r4: value_pcie_inclusive = the blocking call by the host's clock as in BENCH_r01..r03; the device-clock figure has its own key)
+    assert 0.5 * d["value"] < d["value_pcie_inclusive"] < d["value"] and d["value_pcie_inclusive"] == d["pcie_inclusive"]["registered"]["blocking_call_value"]
+    assert d["value_pcie_inclusive"] <= d["value_pcie_inclusive_device_clock"] < d["value"]
+    assert d["value_pcie_inclusive_device_clock"] == d["pcie_inclusive"]["registered"]["value"]
+    assert "HBM" in d["config"]["workload"] and "10000 walkers in total" in d["config"]["workload"] and d["config"]["walkers_total"] == 10000
     # strong-scaling shares measured on the one GPU: 1e4 / N walkers, projected speed-up N x rate(W/N) / rate(W)
     sp = d["strong_scaling_projection"]["by_n_gpus"]
     assert [sp[k]["walkers_per_gpu"] for k in ("1", "2", "4", "8")] == [10000, 5000, 2500, 1250]
@@ -317,13 +321,53 @@ def test_bench_line_contract():
 
 
 def test_bench_strong_scaling_mode():
-    """`--scaling strong` (SURVEY §8d "Scaling runs": the same walkers split evenly over the ranks) at N = 1 is the same job as weak scaling;
-    the line says which mode it ran and the workload names the split."""
+    """`--scaling strong` (SURVEY §8d "Scaling runs": the same walkers split evenly over the ranks) is the DEFAULT of the contracted workload; at
+    N = 1 it is the same job as weak scaling, and `--scaling weak` still exists; the line says which mode it ran and the workload names the split."""
     import subprocess, sys
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "10", "--warmup", "3", "--scaling", "strong", "--no-extras", "--no-cpu-baseline"],
+    for flags, mode in (([], "strong"), (["--scaling", "weak"], "weak")):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "10", "--warmup", "3", *flags, "--no-extras", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+        assert d["scaling"] == mode and d["n_gpus"] == 1 and d["config"]["walkers_per_gpu"] == 10000 and d["config"]["walkers_total"] == 10000
+        assert ("10000 walkers split over 1 GPUs" in d["config"]["workload"]) == (mode == "strong")
+        assert abs(d["value"] - 1e8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_shard_shape_has_its_own_roofline():
+    """The per-GPU launch shape of an 8-GPU strong-scaled run (1 250 walkers x 1e4 epochs) through the same command on one GPU: the line carries
+    a non-null roofline from the counter passes of THAT shape (profiles/pmc_traffic.json "shapes"), whose kernel is the eight-wave block."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "40", "--warmup", "5", "--walkers", "1250", "--no-extras", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
-    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["walkers_per_gpu"] == 10000
-    assert "10000 walkers split over 1 GPUs" in d["config"]["workload"]
-    assert abs(d["value"] - 1e8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert roof["frac"] is not None and 0.1 < roof["frac"] <= 1.0, roof.get("note")
+    assert roof["launch_shape"] == {"walkers": 1250, "rows": 10000, "pmc_walkers": 1250} and roof["kernel"].endswith(", 8>") and "pmc_note" not in roof
+    assert 0.02 < roof["kernel_avg_ms"] < 0.09 and roof["traffic"] > 1e5
+
+
+def test_bench_two_rank_line_is_the_contracted_measurement():
+    """The N > 1 line BEFORE an 8-GPU box ever sees it: two ranks on the one GPU of this box (gloo for the barrier and the
+    MAX all-reduce; RCCL refuses two ranks on one device). Default scaling is strong — the SAME 1e4 walkers split evenly — so the metric's
+    "1e4 epochs x 1e4 walkers" stays literally true; the line carries a non-null roofline for the per-GPU launch shape (5 000 walkers),
+    cpu_baseline from rank 0 and the weak-scaling point beside it. Plumbing evidence, not a scaling number: both ranks share one GPU."""
+    import subprocess, sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--backend", "gloo", "--device", "0",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["metric"].endswith("1e4 epochs x 1e4 walkers")
+    assert d["config"]["walkers_total"] == 10000 and d["config"]["walkers_per_gpu"] == 5000 and "10000 walkers in total" in d["config"]["workload"]
+    assert abs(d["value"] - 1e8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]                 # the whole job = 1e4 x 1e4 evaluations per step
+    roof = d["roofline"]
+    assert roof["frac"] is not None and 0.05 < roof["frac"] <= 1.0 and roof["launch_shape"]["walkers"] == 5000 and roof["launch_shape"]["pmc_walkers"] == 5000
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 1e5 and "10000 epochs" in cb["sample"]
+    wk = d["weak_scaling_measured"]
+    assert wk["walkers_per_gpu"] == 10000 and wk["n_gpus"] == 2 and wk["value"] > 1e9
+    assert d["parity"]["ok"] is True

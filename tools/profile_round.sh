@@ -15,6 +15,14 @@ rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $out/pmc_fetch -o k -- $B >
 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $out/pmc_write -o k -- $B > $out/b_write.log 2>&1
 rocprofv3 --kernel-trace --stats --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 -d $out/pmc_mix -o k -- $B > $out/b_mix.log 2>&1
 rocprofv3 --kernel-trace --stats --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d $out/pmc_sq -o k -- $B > $out/b_sq.log 2>&1
+# the per-GPU launch shapes of a strong-scaled run (1e4 walkers over 2 / 4 / 8 GPUs): counter passes of the same command at --walkers W
+MIX="GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32"
+for Wn in 5000 2500 1250; do
+  Bn="$B --steps 100 --walkers $Wn"
+  rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $out/w$Wn/pmc_fetch -o k -- $Bn > $out/b_w${Wn}_fetch.log 2>&1
+  rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $out/w$Wn/pmc_write -o k -- $Bn > $out/b_w${Wn}_write.log 2>&1
+  rocprofv3 --kernel-trace --stats --pmc $MIX -d $out/w$Wn/pmc_mix -o k -- $Bn > $out/b_w${Wn}_mix.log 2>&1
+done
 cd $ROOT
 python profiles/summarize_rocpd.py gpurun_out/$tag gpurun_out/$tag > /dev/null
 python tools/make_pmc_json.py gpurun_out/$tag gpurun_out/${tag}_pmc_traffic.json > /dev/null

@@ -423,6 +423,7 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     ctx->env_small_blocks = env_int("OCTO_SMALL_BLOCKS"); ctx->env_small_min_span = env_int("OCTO_SMALL_MIN_SPAN");
     ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST"); ctx->env_kind_all = env_int("OCTO_KIND_ALL");
     if (const char* ev = std::getenv("OCTO_WIDE")) ctx->env_wide = std::atoi(ev);
+    if (const char* ev = std::getenv("OCTO_WARM")) ctx->env_warm = std::atoi(ev);
     *out = ctx;
     return OCTO_OK;
 }
@@ -530,7 +531,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
                 raw[(size_t)r * ROW_STRIDE] = d.epoch[r]; raw[(size_t)r * ROW_STRIDE + 1] = ax; raw[(size_t)r * ROW_STRIDE + 2] = ms;
             }
             DevObs& h = ds->h_obs[o];
-            h.kind = d.kind; h.planet = -1; h.has_cor = 0; h.pad = 0; h.n = n;
+            h.kind = d.kind; h.planet = -1; h.has_cor = 0; h.dm_max = 0.0f; h.n = n;
             double *dr = nullptr, *dx = nullptr;
             if (hipMalloc((void**)&dr, sizeof(double) * raw.size()) != hipSuccess) return bail(OCTO_ENOMEM, "octo_dataset_create: hipMalloc failed");
             ds->d_bufs.push_back(dr);
@@ -610,8 +611,16 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
                 }
             }
         }
+        // slot 6 of every record: 2π·(t − t of the previous row), 0 in row 0 — the mean-anomaly step per unit mean motion that k_main's
+        // warm-started row loop multiplies by 1/P (octo_device.h: KWarm); the table's largest one bounds the predictor's error a priori
+        double dm_max = 0.0;
+        for (int64_t r = 1; r < n; ++r) {
+            const double dm = TWO_PI * (d.epoch[r] - d.epoch[r - 1]);
+            raw[(size_t)r * ROW_STRIDE + 6] = pre[(size_t)r * ROW_STRIDE + 6] = dm;
+            dm_max = std::max(dm_max, std::fabs(dm));
+        }
         DevObs& h = ds->h_obs[o];
-        h.kind = d.kind; h.planet = planet_obs ? d.planet : -1; h.has_cor = d.cor ? 1 : 0; h.pad = 0; h.n = n;
+        h.kind = d.kind; h.planet = planet_obs ? d.planet : -1; h.has_cor = d.cor ? 1 : 0; h.dm_max = ctx->env_warm ? (float)(dm_max * 1.000001) : 0.0f; h.n = n;
         h.raw = h.pre = nullptr;
         if (n > 0) {
             double *dr = nullptr, *dp = nullptr;
@@ -981,6 +990,33 @@ static int32_t kepler_solve_host(octo_ctx* ctx, const double* MA, const double* 
     HIPCHK(ctx, hipMemcpyAsync(E_out, ctx->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     if (sinE_out) HIPCHK(ctx, hipMemcpyAsync(sinE_out, ctx->d_out + n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     if (cosE_out) HIPCHK(ctx, hipMemcpyAsync(cosE_out, ctx->d_out + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    free_retired(ctx);
+    return OCTO_OK;
+}
+
+// Test hook (not part of the C ABI, like octo_debug_poison_lds): k_main's warm-started Kepler step on its own — octo_kernels.h: k_kepler_warm.
+int32_t octo_debug_kepler_warm(octo_ctx* ctx, const double* MA, const double* dM, const double* e, int64_t n, double* sinE_out, double* cosE_out,
+                               double* used_warm_out) {
+    if (!ctx || !MA || !dM || !e || !sinE_out || !cosE_out || !used_warm_out || n < 0) return fail(ctx, OCTO_EINVAL, "octo_debug_kepler_warm: null argument");
+    { int rcb = busy(ctx, "octo_debug_kepler_warm"); if (rcb) return rcb; }
+    if (n == 0) return OCTO_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = grow(ctx, ctx->d_in, ctx->cap_in, 3 * n);
+    if (rc) return rc;
+    rc = grow(ctx, ctx->d_out, ctx->cap_out, 3 * n);
+    if (rc) return rc;
+    hipStream_t st;
+    { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, MA, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_in + n, dM, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_in + 2 * n, e, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_kepler_warm, dim3((unsigned)((n + 255) / 256)), dim3(256), sizeof(double) * 2 * SCT_N, st, ctx->d_in, ctx->d_in + n, ctx->d_in + 2 * n, n,
+                       ctx->d_out, ctx->d_out + n, ctx->d_out + 2 * n, ctx->d_sctab);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(sinE_out, ctx->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(cosE_out, ctx->d_out + n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(used_warm_out, ctx->d_out + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     free_retired(ctx);
     return OCTO_OK;

@@ -86,6 +86,25 @@ __device__ __forceinline__ void set_starter(PC& pc, float ef, float omef, float 
 
 struct KSol { double sE, cE, invD, dt, E; };
 
+// WARM START from the previous row (k_main, round 5). Rows of a table are epoch-sorted (relative-astrometry.jl:46-47, rv-absolute.jl:98-99) and a
+// wave walks a contiguous slice of them for the same 64 walkers, so the previous row's (sin E, cos E, 1/(1 − e cos E)) IS a starter: with
+// ΔM = 2π Δt / P and x = ΔM / D,   dE = x − ½ (e sin E / D) x²   (second-order Taylor of E(M)),   (sin, cos)(E + dE) by a rotation through dE,
+// f0 = E1 − e sin E1 − M = dE − ΔM − e (sin E1 − sin E)   — no E, no M as numbers, no FP32 Markley starter, no table lookup — and then the SAME
+// fifth-order correction. The predictor's error is <= x³/D² (third derivative of E(M): (3e² sin²E − e cos E · D)/D⁵), and the correction is as
+// good from there as from Markley's starter while that stays below ~5e-4 (tools/kepler_warm_proto.py; a sample of 4e6 (e, E, ΔM) incl.
+// e -> 1 − 1e-9: D-weighted error of (sin E, cos E) 3.9e-16 below 1e-3, 2.2e-16 below 1e-4). Where it does not (a fast orbit near the periastron
+// of a high-e walker) the wave falls back to the Markley starter for that row — WAVE-UNIFORMLY (one ballot, one scalar branch: the loop stays
+// divergence-free), and the root is unique, so the result is the same E to rounding either way.
+// The test is a priori and one compare: x³/D² < tol  <=>  1/D < thr with thr = (tol / ΔM³)^(1/5) per lane, from the TABLE's largest
+// 2π Δt (DevObs::dm_max; exact for a uniform cadence, conservative otherwise). 1/D >= 1/2, so a pass also bounds |x| < (4 tol)^(1/3) = 0.117:
+// the rotation's polynomials (sin to dE⁹, cos to dE⁸) are exact to 1e-16 there.
+// What the chain gives up: E and M never appear, so the solve of row j starts from the SOLUTION of row j−1 and its rounding (~1e-16 in M per
+// row) accumulates until the next cold row — at most a wave's chunk of rows (tens to a few hundred: < 1e-13 in M, the size of the
+// rounding of (t − tp)/P itself for a walker a few orbits from tp; the prototype measures 8e-15 after 72 rows).
+struct KWarm { double sE, cE, invD; };
+constexpr double WARM_TOL = 4.0e-4;
+constexpr double WARM_MIN_THR = 2.0;      // a wave takes the warm loop only if every lane passes at least wherever D >= 1/2
+
 __device__ __forceinline__ void load_pc(PC& pc, const double* __restrict__ wc, int64_t ldw, int p, int64_t w) {
     const double* b = wc + (int64_t)p * NWC * ldw + w;
     pc.invP = b[WC_INVP * ldw]; pc.tp = b[WC_TP * ldw]; pc.e = b[WC_E * ldw]; pc.beta = b[WC_BETA * ldw];
@@ -116,7 +135,8 @@ __constant__ double OCTO_KT[24] = {
     -2.7557319207812853e-07, 2.480158730147785e-05, -0.0013888888888888464, 0.04166666666666666, -0.5,
     // Taylor: sin δ = δ(1 + δ²(−1/6 + δ²/120)), cos δ − 1 = δ²(−1/2 + δ²(1/24 − δ²/720))
     1.0 / 120.0, -1.0 / 6.0, -1.0 / 720.0, 1.0 / 24.0,
-    0.0, 0.0, 0.0};
+    // warm-start rotation (|dE| <= 0.117): sin dE/dE − 1 = u(−1/6 + u(1/120 + u(−1/5040 + u/362880))), cos dE − 1 = u(−1/2 + u(1/24 + u(−1/720 + u/40320)))
+    1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 40320.0};
 
 // sin and cos of x for |x| <= 3.18 via the half angle: h = x/2, polynomials in u = h², then
 // sin x = 2 s c, cos x = 1 − 2 s². 24 FP64 instructions, branch-free, no range reduction.
@@ -279,17 +299,8 @@ struct LogProd {
     __device__ __forceinline__ double log_value() const { return fma((double)e, 0.69314718055994530942, log(m)); }
 };
 
-// Eccentric anomaly and the quantities every projection needs. INV_NR: Newton steps on 1/(1 − e cos E)
-// (1 when it only feeds adjoints, 2 when it feeds a model value, -1 when nobody needs it).
-// tab: the block's LDS copy of the sin/cos table, or null for the polynomial sincos (kernels without the table).
-template <int INV_NR, bool TAB = false>
-__device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCosTab& tab = SinCosTab{nullptr, 0.0, 0.0f, 0u}) {
-    KSol s;
-    // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
-    s.dt = t - pc.tp;
-    const double u = s.dt * pc.invP;
-    const double frac = u - rint(u);                  // M = 2π·frac enters f0 through an FMA below
-    // ---- Markley (1995) starter, eqs (20),(5),(9),(10),(14),(15), in FP32
+// Markley (1995) starter, eqs (20),(5),(9),(10),(14),(15), in FP32; frac = M/2π in [−1/2, 1/2]
+__device__ __forceinline__ float markley_starter_f32(double frac, const PC& pc) {
     const float ff = (float)frac;
     const float Mf = ff * (float)TWO_PI;              // scale in FP32: one FP64 multiply less per row
     const float alpha = fmaf(pc.A1, fabsf(ff), pc.A0);
@@ -303,18 +314,19 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     const float x = fabsf(r) + __builtin_amdgcn_sqrtf(disc);
     const float w = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (2.0f / 3.0f));   // cbrt(x²)
     const float den = fmaf(w, w + q, q2);
-    const float E1f = fmaf(Mf, den, 2.0f * r * w) * __builtin_amdgcn_rcpf(den * d);     // (2rw/den + M)/d, one reciprocal
-    const double E1 = (double)E1f;
-    // ---- one fifth-order correction, eqs (21)-(29), FP64
-    double s1, c1;
-    if constexpr (TAB) sincos_table(E1f, tab, s1, c1);
-    else sincos_halfangle(E1, s1, c1);
+    return fmaf(Mf, den, 2.0f * r * w) * __builtin_amdgcn_rcpf(den * d);     // (2rw/den + M)/d, one reciprocal
+}
+
+// The part both starters share: Markley's fifth-order correction, eqs (21)-(29), from (sin E1, cos E1, f0 = E1 − e sin E1 − M) in FP64, then
+// sin/cos(E1 + δ5) by rotation. E1 itself only feeds s.E (dead code unless a caller reads it).
+// INV_NR: Newton steps on 1/(1 − e cos E) (1 when it only feeds adjoints, 2 when it feeds a model value, -1 when nobody needs it).
+template <int INV_NR>
+__device__ __forceinline__ void kepler_correct(KSol& s, const PC& pc, double E1, double s1, double c1, double f0) {
     const double e = pc.e;
     // f2/2, f2/24, f3/6 of Markley's (21)-(27) from the loop-invariant e/2 and e/6 (f2 = e sin E1 itself is not needed)
     const double hf2 = pc.he * s1, q24 = hf2 * (1.0 / 12.0);
     const double sf3 = (e * (1.0 / 6.0)) * c1;
     const double f1 = fma(-e, c1, 1.0);
-    const double f0 = fma(-e, s1, fma(-frac, TWO_PI, E1));           // E1 − e sin E1 − M
     // One hardware reciprocal for the three divisions: the denominators are f1·(den4 + O(δ²)), den4, den4 + O(δ³), so
     // each reciprocal is a Newton step away from the previous one (prototype: tools/kepler_proto.py, same error).
     const double r3 = __builtin_amdgcn_rcp(fma(f1, f1, -(f0 * hf2)));                // ≈2^-23
@@ -336,9 +348,60 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
     const double cm1 = dd * fma(dd, OCTO_KT[20], -0.5);
     s.sE = fma(s1, cm1, fma(c1, sd, s1));
     s.cE = fma(c1, cm1, fma(-s1, sd, c1));
+    if constexpr (INV_NR >= 0) s.invD = rcp_nr<(INV_NR >= 0 ? INV_NR : 0)>(fma(-e, s.cE, 1.0));
+}
+
+// Eccentric anomaly and the quantities every projection needs.
+// tab: the block's LDS copy of the sin/cos table, or null for the polynomial sincos (kernels without the table).
+template <int INV_NR, bool TAB = false>
+__device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCosTab& tab = SinCosTab{nullptr, 0.0, 0.0f, 0u}) {
+    KSol s;
+    // mean anomaly reduced to [-π, π]: work in orbits, subtract the nearest integer (exact), scale.
+    s.dt = t - pc.tp;
+    const double u = s.dt * pc.invP;
+    const double frac = u - rint(u);                  // M = 2π·frac enters f0 through an FMA below
+    const float E1f = markley_starter_f32(frac, pc);
+    const double E1 = (double)E1f;
+    double s1, c1;
+    if constexpr (TAB) sincos_table(E1f, tab, s1, c1);
+    else sincos_halfangle(E1, s1, c1);
+    const double f0 = fma(-pc.e, s1, fma(-frac, TWO_PI, E1));           // E1 − e sin E1 − M
     // M == 0: E1f = 0 exactly and f0 = 0, so E = 0 like the reference's early return; e == 0: f2 = f3 = 0,
     // d5 = −(E1 − M) exactly, E = M to rounding, like the reference's early return.
-    if constexpr (INV_NR >= 0) s.invD = rcp_nr<(INV_NR >= 0 ? INV_NR : 0)>(fma(-e, s.cE, 1.0));
+    kepler_correct<INV_NR>(s, pc, E1, s1, c1, f0);
+    return s;
+}
+
+// The warm-started solve (KWarm above). st: the previous row's solution of this (walker, planet), updated; thr: the lane's bound on 1/D;
+// dm = 2π (t − t of the previous row), wave-uniform (row record slot 6). A wave's first row enters with st.invD = +Inf: cold.
+template <int INV_NR>
+__device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const SinCosTab& tab, KWarm& st, double thr, double dm) {
+    static_assert(INV_NR >= 0, "the warm start needs 1/(1 − e cos E) of every row");
+    KSol s;
+    s.dt = t - pc.tp;
+    double E1 = 0.0, s1, c1, f0;
+    if (__builtin_amdgcn_ballot_w64(st.invD >= thr) == 0) {      // every lane of the wave passes (a NaN bound — an invalid walker — passes: its sums are discarded)
+        const double dM = dm * pc.invP;
+        const double x = dM * st.invD;
+        const double z = x * st.invD;
+        const double dE = fma(-((pc.he * st.sE) * z), x, x);
+        const double u = dE * dE;
+        const double sr = dE * fma(u, fma(u, fma(u, fma(u, OCTO_KT[21], OCTO_KT[22]), OCTO_KT[17]), OCTO_KT[18]), 1.0);
+        const double cm1 = u * fma(u, fma(u, fma(u, OCTO_KT[23], OCTO_KT[19]), OCTO_KT[20]), -0.5);
+        const double ds = fma(st.sE, cm1, st.cE * sr);               // sin E1 − sin E, without cancellation
+        s1 = st.sE + ds;
+        c1 = fma(st.cE, cm1, fma(-st.sE, sr, st.cE));
+        f0 = fma(-pc.e, ds, dE - dM);
+    } else {
+        const double uo = s.dt * pc.invP;
+        const double frac = uo - rint(uo);
+        const float E1f = markley_starter_f32(frac, pc);
+        E1 = (double)E1f;
+        sincos_table(E1f, tab, s1, c1);
+        f0 = fma(-pc.e, s1, fma(-frac, TWO_PI, E1));
+    }
+    kepler_correct<INV_NR>(s, pc, E1, s1, c1, f0);
+    st.sE = s.sE; st.cE = s.cE; st.invD = s.invD;
     return s;
 }
 

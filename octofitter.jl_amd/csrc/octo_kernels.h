@@ -50,10 +50,11 @@ constexpr int KM_ALL = 127;      // every ROW kind (the epoch-loop kernels' kind
 constexpr int KM_HGCA = 128;
 
 struct DevObs {
-    int32_t kind, planet, has_cor, pad;
+    int32_t kind, planet, has_cor;
+    float dm_max;        // largest 2π·(t_j − t_{j−1}) of the table's rows [rad·day]: the warm start's a-priori bound (octo_device.h: KWarm); 0 for a table of one row
     int64_t n;
-    const double* raw;   // [n][8]: astrom {t,y1,y2,s1,s2,cor,0,0}; rv {t,rv,σ,trend basis,0...}
-    const double* pre;   // [n][8]: astrom {t,y1,y2,p11,p22,p12,0,0} (Σ⁻¹ entries); rv {t,rv,1/σ²,0...}
+    const double* raw;   // [n][8]: astrom {t,y1,y2,s1,s2,cor,dm,0}; rv {t,rv,σ,trend basis,0,0,dm,0}; dm = 2π·(t − t of the previous row), 0 in row 0
+    const double* pre;   // [n][8]: astrom {t,y1,y2,p11,p22,p12,dm,0} (Σ⁻¹ entries); rv {t,rv,1/σ²,0,0,0,dm,0}
 };
 
 struct Task {
@@ -379,6 +380,35 @@ static __global__ __launch_bounds__(256) void k_kepler(const double* __restrict_
     if (cE) cE[i] = ok ? s.cE : NAN;
 }
 
+// The warm-started solve on its own (a test hook, octo_debug_kepler_warm): element i is solved cold at MA[i] — that solution is the
+// "previous row" — and then advanced by dM[i] with kepler_solve_warm, the lane's bound computed from dM[i] as k_main computes it from the
+// table's largest step. used[i] = 1 where the wave took the warm path (the ballot is the wave's: the caller groups its inputs).
+static __global__ __launch_bounds__(256) void k_kepler_warm(const double* __restrict__ MA, const double* __restrict__ dMa, const double* __restrict__ ecc,
+                                                            int64_t n, double* sE, double* cE, double* used, const double* __restrict__ sctab) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const SinCosTab tab = make_sincos_tab(reinterpret_cast<const double2*>(lds));
+    {
+        const double2* __restrict__ g = reinterpret_cast<const double2*>(sctab);
+        double2* t = reinterpret_cast<double2*>(lds);
+        for (int i = threadIdx.x; i < SCT_N; i += blockDim.x) t[i] = g[i];
+        __syncthreads();
+    }
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = i0 < n ? i0 : n - 1;
+    PC pc = {};
+    const double e = ecc[i];
+    pc.invP = 1.0 / TWO_PI; pc.tp = 0.0; pc.e = e; pc.beta = sqrt(1.0 - e * e); pc.eob = e / pc.beta;
+    set_starter(pc, (float)e, (float)(1.0 - e), (float)(MK_K1N / (1.0 + e)));
+    const KSol s0 = kepler_solve<2, true>(MA[i], pc, tab);
+    KWarm st{s0.sE, s0.cE, s0.invD};
+    const float dmx = fabsf((float)dMa[i]);
+    const double thr = (double)__builtin_amdgcn_exp2f(0.2f * (__builtin_amdgcn_logf((float)WARM_TOL) - 3.0f * __builtin_amdgcn_logf(dmx)));
+    const bool warm = __builtin_amdgcn_ballot_w64(st.invD >= thr) == 0;
+    // dm = 2π·Δt with 1/P = 1/2π: ΔM = dMa[i]; t = MA + dM so that the cold fallback solves the same row
+    const KSol s = kepler_solve_warm<2>(MA[i] + dMa[i], pc, tab, st, thr, dMa[i] * TWO_PI);
+    if (i0 < n) { sE[i] = s.sE; cE[i] = s.cE; used[i] = warm ? 1.0 : 0.0; }
+}
+
 #endif      // OCTO_API_TU
 
 // ------------------------------------------------------------------------------------ row bodies
@@ -432,10 +462,14 @@ __device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ 
     return astrom_coef_vals<P, GRAD, NUIS, KM>(jit, ps, na, ob_kind, ob_planet, ob_has_cor, pc);
 }
 
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB>
+// The warm start's per-wave state (octo_device.h: KWarm): the previous row's solution and the lane's bound on 1/D, per planet.
+template <int P>
+struct WarmState { KWarm st[P]; double thr[P]; };
+
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false>
 __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                            const AstromCoef<P>& co, double t, double y1, double y2, double c3, double c4, double c5,
-                                           const SinCosTab& tab) {
+                                           const SinCosTab& tab, WarmState<P>* ws = nullptr, double dm = 0.0) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const double (&f)[P] = co.f;
     const double jit = co.jit, j2 = co.j2, ps = co.ps, na = co.na, sn = co.sn, cn = co.cn;
@@ -445,7 +479,8 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
     double ra_m, dec_m;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        s[p] = kepler_solve<1, TAB>(t, pc[p], tab);
+        if constexpr (WARM) s[p] = kepler_solve_warm<1>(t, pc[p], tab, ws->st[p], ws->thr[p], dm);
+        else s[p] = kepler_solve<1, TAB>(t, pc[p], tab);
         rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
         dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
     }
@@ -641,9 +676,10 @@ __device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, in
     return rv_coef_vals<P, GRAD, NUIS, KM>(off, jit, trend, margp, ldw, ob_kind, ob_planet, obs_index, pc, wl);
 }
 
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB>
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false>
 __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
-                                       const RvCoef<P>& co, double t, double rv, double c2, double basis, const SinCosTab& tab) {
+                                       const RvCoef<P>& co, double t, double rv, double c2, double basis, const SinCosTab& tab,
+                                       WarmState<P>* ws = nullptr, double dm = 0.0) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const double (&gc)[P] = co.gc;
     const bool rel = co.rel, marg = co.marg;
@@ -655,7 +691,8 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
     double model = NUIS ? fma(co.trend, basis, co.off) : co.off;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
+        if constexpr (WARM) s[p] = kepler_solve_warm<2>(t, pc[p], tab, ws->st[p], ws->thr[p], dm);
+        else s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
         cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
         snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
         V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
@@ -756,6 +793,23 @@ __device__ __forceinline__ RowRegs row_wait_issue(RowRegs& cur, crow_t p) {
 __device__ __forceinline__ double row_get(const RowRegs& r, int k) {      // k: compile-time constant after inlining
     return k < 4 ? __hiloint2double(r.lo[2 * k + 1], r.lo[2 * k]) : __hiloint2double(r.hi[2 * (k - 4) + 1], r.hi[2 * (k - 4)]);
 }
+// The same with the whole 64-byte record (doubles 0-7): the warm-start loops also read slot 6, 2π·(t − t of the previous row).
+struct RowRegs8 { sgpr8_t lo; sgpr8_t hi; };
+__device__ __forceinline__ RowRegs8 row_issue8(crow_t p) {
+    RowRegs8 r;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x20" : "=&s"(r.lo), "=&s"(r.hi) : "s"(p));
+    return r;
+}
+__device__ __forceinline__ void row_drain(const RowRegs8& r) { asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(r.lo), "s"(r.hi)); }
+__device__ __forceinline__ RowRegs8 row_wait_issue(RowRegs8& cur, crow_t p) {
+    RowRegs8 r;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20"
+                 : "=&s"(r.lo), "=&s"(r.hi), "+s"(cur.lo), "+s"(cur.hi) : "s"(p));
+    return r;
+}
+__device__ __forceinline__ double row_get(const RowRegs8& r, int k) {
+    return k < 4 ? __hiloint2double(r.lo[2 * k + 1], r.lo[2 * k]) : __hiloint2double(r.hi[2 * (k - 4) + 1], r.hi[2 * (k - 4)]);
+}
 
 constexpr int NPC = WC_CAE + 1;     // the per-walker constants the row loop reads (PC): WC_INVP … WC_CAE; the rest of `wc` is the finish's
 
@@ -783,6 +837,36 @@ constexpr unsigned main_min_waves() {
     // than they free — 11-21 scratch accesses per row instead of 4-17.
     if (P >= 4 && GRAD) return 2u;
     return (P == 1 && GRAD && !NUIS && (KM & ~KM_COR) == KM_RADEC) ? 7u : 1u;
+}
+
+// Which k_main variants carry the warm-started row loop (octo_device.h: KWarm) next to the cold one: the single-planet fused launches
+// (the O'Neil term reads E as a number; the multi-planet kernels have no registers to carry a second solution per planet).
+// A wave chooses between the two loops once, from its lanes' bounds (WARM_MIN_THR): a table whose cadence is too coarse for its walkers'
+// periods — any real astrometry table — runs the cold loop at no cost but the code's size.
+#ifndef OCTO_WARM
+#define OCTO_WARM 1
+#endif
+template <int P, bool GRAD, bool NUIS, int KM, bool FUSED>
+constexpr bool main_warm() {
+    // (… and not the nuisance kernels of the kind sets with sep/PA or RV rows: with the 16-dword row buffers of a second pair of loops they run
+    // out of SGPRs, and the compiler then parks an in-flight prefetch tuple in VGPR lanes — tools/kernel_resources.py: scalar_load_hazards finds it)
+    return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL) && !(NUIS && (KM & (KM_SEPPA | KM_RV)));
+}
+
+// thr = (tol / ΔM_max³)^(1/5) per lane, ΔM_max = the table's largest 2π Δt / P (v_log_f32 / v_exp_f32 are base 2); the wave takes the warm
+// loop when every lane's bound leaves it something to pass (a NaN — an invalid walker — does not veto). The first row of a wave is cold.
+template <int P>
+__device__ __forceinline__ bool warm_init(WarmState<P>& ws, const PC (&pc)[P], float dm_max) {
+    bool veto = false;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const float dmx = fabsf(dm_max * (float)pc[p].invP);
+        const float th = __builtin_amdgcn_exp2f(0.2f * (__builtin_amdgcn_logf((float)WARM_TOL) - 3.0f * __builtin_amdgcn_logf(dmx)));
+        ws.thr[p] = (double)th;
+        ws.st[p].sE = 0.0; ws.st[p].cE = 1.0; ws.st[p].invD = __builtin_huge_val();
+        veto = veto || (th < (float)WARM_MIN_THR);
+    }
+    return __builtin_amdgcn_ballot_w64(veto) == 0 && dm_max > 0.0f;
 }
 
 // FUSED: the orbit constructors inside the launch — wave 0 of every block derives its tile's constants (what k_setup stores in `wc`) and
@@ -912,10 +996,31 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         auto body = [&](const RowRegs& r) {
             astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4), row_get(r, 5), tab);
         };
+        bool warm_loop = false;
+        WarmState<P> ws;
+        if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) warm_loop = warm_init<P>(ws, pc, ob.dm_max);
         if constexpr (!ROW_PREFETCH) {
             for (int j = 0; j < n_rows; ++j) {
                 const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
                 astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab);
+            }
+        } else if (main_warm<P, GRAD, NUIS, KM, FUSED>() && warm_loop) {
+            if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
+                auto wbody = [&](const RowRegs8& r) {
+                    astrom_row<P, GRAD, NUIS, KM, true, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4),
+                                                              row_get(r, 5), tab, &ws, row_get(r, 6));
+                };
+                if (n_rows > 0) {
+                    RowRegs8 A = row_issue8(rows);
+                    for (int j = 0; j < n_rows; j += 2) {
+                        RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
+                        wbody(A);
+                        if (j + 1 >= n_rows) { row_drain(B); break; }
+                        A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
+                        wbody(B);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)");
+                }
             }
         } else if (n_rows > 0) {
             // Two rows per trip through two SGPR buffers that swap roles (no copies): B is fetched while A is computed and vice versa. Either
@@ -939,10 +1044,30 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         auto body = [&](const RowRegs& r) {
             rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab);
         };
+        bool warm_loop = false;
+        WarmState<P> ws;
+        if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) warm_loop = warm_init<P>(ws, pc, ob.dm_max);
         if constexpr (!ROW_PREFETCH) {
             for (int j = 0; j < n_rows; ++j) {
                 const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
                 rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, tab);
+            }
+        } else if (main_warm<P, GRAD, NUIS, KM, FUSED>() && warm_loop) {
+            if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
+                auto wbody = [&](const RowRegs8& r) {
+                    rv_row<P, GRAD, NUIS, KM, true, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab, &ws, row_get(r, 6));
+                };
+                if (n_rows > 0) {
+                    RowRegs8 A = row_issue8(rows);
+                    for (int j = 0; j < n_rows; j += 2) {
+                        RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
+                        wbody(A);
+                        if (j + 1 >= n_rows) { row_drain(B); break; }
+                        A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
+                        wbody(B);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)");
+                }
             }
         } else if (n_rows > 0) {
             RowRegs A = row_issue(rows);

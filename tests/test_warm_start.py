@@ -1,0 +1,240 @@
+"""
+k_main's warm-started row loop (octo_device.h: KWarm): on tables whose cadence is dense against the walkers' periods
+the previous row's (sin E, cos E, 1/(1 − e cos E)) replaces the Markley starter + table lookup, with a WAVE-UNIFORM fallback to the cold
+starter. The root of Kepler's equation is unique (src/likelihoods/system.jl:250-269 solve every epoch independently), so the loop must
+agree with the cold loop to rounding and with the oracle to the usual bars, on every single-planet kind set it is compiled for.
+
+OCTO_WARM=0 in the environment of octo_ctx_create gives datasets that never take the warm loop: the same library, the cold loop.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import rel_err
+from test_gpu_parity import _cmp_oracle, _gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _eval(gb, obs, planets, elems, nuis, grad, warm, env=None):
+    old = {k: os.environ.get(k) for k in ("OCTO_WARM", *(env or {}))}
+    os.environ["OCTO_WARM"] = "1" if warm else "0"
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    try:
+        return gb.gpu_eval(obs, planets, elems, nuis, grad=grad, small_batch=0)      # the throughput kernels whatever the batch size
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _close(name, a, b, ll_tol=1e-12, g_tol=1e-10):
+    ok = np.isfinite(b[0])
+    assert np.array_equal(np.isfinite(a[0]), ok), name
+    e = rel_err(a[0][ok], b[0][ok], 1.0)
+    assert np.all(e < ll_tol), (name, "ll warm vs cold", e.max())
+    for ga, gc in ((a[1], b[1]), (a[2], b[2])):
+        if ga is None:
+            continue
+        sc = np.maximum(np.abs(gc[:, ok]).max(axis=1, keepdims=True), 1e-300)
+        eg = np.abs(ga[:, ok] - gc[:, ok]) / sc
+        assert np.all(eg < g_tol), (name, "gradient warm vs cold", eg.max())
+
+
+def _dense_walkers(rng, W, a_lo, a_hi, e_hi=0.97):
+    el = synth.draw_walkers(rng, W, a_lo, a_hi)
+    el[1] = rng.uniform(0.0, e_hi, W)
+    # a few walkers that pass periastron inside the table, some of them nearly parabolic
+    k = min(W // 4, 40)
+    el[5, :k] = 50000.0 + rng.uniform(5.0, 200.0, k)
+    el[1, :k // 2] = 1.0 - 10.0 ** rng.uniform(-4, -1.3, k // 2)      # (conditioning cases for ANY solver: the oracle comparisons below use 1e-10 / 1e-8)
+    return el
+
+
+def test_warm_loop_matches_cold_loop_and_oracle_radec(oracle):
+    """Config 3's shape in small: RA/Dec rows at half-day cadence, walkers whose fastest period still passes the wave's entry test, high
+    eccentricities and periastron passages inside the table. Warm vs cold vs oracle; forward value == value with the gradient, bitwise."""
+    gb = _gpu()
+    rng = np.random.default_rng(51)
+    n, W = 700, 333
+    t = 50000.0 + 0.5 * np.arange(n)
+    ra, dec = synth.truth_radec(t)
+    obs = [dict(kind=0, planet=0, epoch=t, y1=ra + rng.normal(0, 5, n), y2=dec + rng.normal(0, 5, n), s1=np.full(n, 5.0), s2=np.full(n, 7.0), cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    el = _dense_walkers(rng, W, 0.7, 60.0)
+    warm = _eval(gb, obs, planets, el, None, True, True)
+    cold = _eval(gb, obs, planets, el, None, True, False)
+    assert not np.array_equal(warm[0], cold[0]), "the warm loop did not run: the two launches are bit-identical"
+    _close("radec", warm, cold)
+    warm_f = _eval(gb, obs, planets, el, None, False, True)
+    assert np.array_equal(warm_f[0], warm[0]), "forward-only and gradient launches of the warm loop disagree"
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el, None, grad=True, active=synth.active_mask(1, 1, mass=False, nuis=False))
+    _cmp_oracle("radec warm", warm[0], warm[1], None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
+    _cmp_oracle("radec cold", cold[0], cold[1], None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
+    assert np.array_equal(_eval(gb, obs, planets, el, None, True, True)[0], warm[0]), "run-to-run determinism"
+
+
+def test_warm_loop_every_single_planet_kind(oracle):
+    """sep/PA + cor + per-walker nuisances, absolute / relative / marginalised RV with offsets, jitter and a trend: the warm loops of the
+    astrometry AND the RV row bodies (kepler_solve_warm<1> / <2>), dense cadence."""
+    gb = _gpu()
+    rng = np.random.default_rng(52)
+    n, W = 420, 200
+    t = 50000.0 + 1.0 * np.arange(n)
+    ra, dec = synth.truth_radec(t)
+    pa = np.arctan2(ra, dec); sep = np.hypot(ra, dec)
+    el0 = dict(synth.TRUTH)
+    rv = synth.truth_rv_star(t, el0, 8.0)
+    obs = [
+        dict(kind=0, planet=0, epoch=t, y1=ra + rng.normal(0, 5, n), y2=dec + rng.normal(0, 5, n), s1=np.full(n, 5.0), s2=np.full(n, 6.0), cor=rng.uniform(-0.6, 0.6, n)),
+        dict(kind=1, planet=0, epoch=t + 0.25, y1=pa + rng.normal(0, 0.01, n), y2=sep + rng.normal(0, 4, n), s1=np.full(n, 0.01), s2=np.full(n, 4.0), cor=None),
+        dict(kind=2, planet=-1, epoch=t, y1=rv + rng.normal(0, 3, n), y2=None, s1=np.full(n, 3.0), s2=None, cor=None, extra=(t - 50200.0) / 100.0),
+        dict(kind=4, planet=0, epoch=t[::2], y1=-rv[::2] * 100 + rng.normal(0, 30, n // 2), y2=None, s1=np.full(n // 2, 30.0), s2=None, cor=None),
+    ]
+    planets = [dict(orbit_kind=0, has_mass=True)]
+    el = _dense_walkers(rng, W, 1.2, 40.0, e_hi=0.9)
+    el[8] = rng.uniform(1.0, 15.0, W)
+    nuis = np.zeros((len(obs) * 3, W))
+    for o in range(2):
+        nuis[o * 3 + 0] = rng.uniform(0, 3, W); nuis[o * 3 + 1] = rng.normal(1, 0.01, W); nuis[o * 3 + 2] = rng.normal(0, 0.01, W)
+    for o in range(2, 4):
+        nuis[o * 3 + 0] = rng.normal(0, 5, W); nuis[o * 3 + 1] = rng.uniform(0.1, 4, W)
+    nuis[2 * 3 + 2] = rng.normal(0, 2, W)      # trend coefficient of the absolute-RV table
+    for nz in (nuis, None):
+        warm = _eval(gb, obs, planets, el, nz, True, True)
+        cold = _eval(gb, obs, planets, el, nz, True, False)
+        # (the NUISANCE kernels of kind sets with sep/PA or RV rows carry no warm loop — octo_kernels.h: main_warm, they run out of SGPRs — so with
+        # `nuis` this dataset runs cold either way; the nuisance kernel that has one is exercised below)
+        assert np.array_equal(warm[0], cold[0]) == (nz is not None)
+        _close("kinds", warm, cold, g_tol=1e-9)
+        assert np.array_equal(_eval(gb, obs, planets, el, nz, False, True)[0], warm[0])
+        ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, el, nz, grad=True)
+        _cmp_oracle("kinds warm", warm[0], warm[1], warm[2], ll_o, g_o, gn_o, ll_rtol=1e-9, g_rtol=2e-8)
+        _cmp_oracle("kinds cold", cold[0], cold[1], cold[2], ll_o, g_o, gn_o, ll_rtol=1e-9, g_rtol=2e-8)
+    # RA/Dec + cor with per-walker jitter / platescale / northangle: k_main<1, ·, true, RADEC|COR>, the nuisance kernel with a warm loop
+    obs1, nuis1 = obs[:1], nuis[:3]
+    planets1 = [dict(orbit_kind=0, has_mass=False)]
+    warm = _eval(gb, obs1, planets1, el, nuis1, True, True)
+    cold = _eval(gb, obs1, planets1, el, nuis1, True, False)
+    assert not np.array_equal(warm[0], cold[0])
+    _close("radec+cor nuis", warm, cold, g_tol=1e-9)
+    assert np.array_equal(_eval(gb, obs1, planets1, el, nuis1, False, True)[0], warm[0])
+    ll_o, g_o, gn_o = oracle.oracle_eval(obs1, planets1, el, nuis1, grad=True, active=synth.active_mask(1, 1, mass=False))
+    _cmp_oracle("radec+cor nuis warm", warm[0], warm[1], warm[2], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)
+
+
+def test_warm_entry_test_and_odd_tables(oracle):
+    """What keeps a wave in the cold loop, and tables the predictor must survive: (a) one walker of the tile too fast for the cadence —
+    its whole wave stays cold, bit-identical to OCTO_WARM=0; (b) a table with one long gap (dm_max is the table's largest step): cold;
+    (c) duplicate epochs (Δt = 0) and an UNSORTED table (negative steps) on the warm loop; (d) an invalid walker (e >= 1, NaN) among valid
+    ones: −Inf for it, its neighbours against the oracle."""
+    gb = _gpu()
+    rng = np.random.default_rng(53)
+    n, W = 300, 128
+    t = 50000.0 + 0.5 * np.arange(n)
+    mk = lambda tt: [dict(kind=0, planet=0, epoch=tt, y1=rng.normal(0, 300, tt.size), y2=rng.normal(0, 300, tt.size), s1=np.full(tt.size, 5.0), s2=np.full(tt.size, 7.0), cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    act = synth.active_mask(1, 1, mass=False, nuis=False)
+    el = _dense_walkers(rng, W, 1.0, 30.0)
+    # (a) walker 70 (second tile) at a = 0.05 AU: ΔM per half day ~ 0.8 rad
+    el_a = el.copy(); el_a[0, 70] = 0.05
+    obs = mk(t)
+    warm = _eval(gb, obs, planets, el_a, None, True, True); cold = _eval(gb, obs, planets, el_a, None, True, False)
+    assert np.array_equal(warm[0][64:], cold[0][64:]) and np.array_equal(warm[1][:, 64:], cold[1][:, 64:]), "a vetoed wave must run the cold loop"
+    assert not np.array_equal(warm[0][:64], cold[0][:64])
+    _close("veto", warm, cold)
+    # (b) one long gap
+    tg = t.copy(); tg[n // 2:] += 900.0
+    obs = mk(tg)
+    warm = _eval(gb, obs, planets, el, None, True, True); cold = _eval(gb, obs, planets, el, None, True, False)
+    assert np.array_equal(warm[0], cold[0]) and np.array_equal(warm[1], cold[1])
+    # (c) duplicates and an unsorted table
+    td = t.copy(); td[10:13] = td[10]; td[100:140:2], td[101:141:2] = t[101:141:2], t[100:140:2]      # steps of 0, +1.0, -0.5 days
+    obs = mk(td)
+    el_c = el.copy(); el_c[0] = np.maximum(el_c[0], 1.6)      # (the largest step is 1.5 days now: periods the entry test still admits)
+    warm = _eval(gb, obs, planets, el_c, None, True, True); cold = _eval(gb, obs, planets, el_c, None, True, False)
+    assert not np.array_equal(warm[0], cold[0])
+    _close("unsorted", warm, cold)
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el_c, None, grad=True, active=act)
+    _cmp_oracle("unsorted warm", warm[0], warm[1], None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
+    # (d) invalid walkers inside a tile
+    el_d = el.copy(); el_d[1, 5] = 1.2; el_d[0, 17] = np.nan; el_d[6, 90] = -1.0
+    obs = mk(t)
+    warm = _eval(gb, obs, planets, el_d, None, True, True)
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el_d, None, grad=True, active=act)
+    assert np.isneginf(warm[0][[5, 17, 90]]).all() and np.isfinite(warm[0]).sum() == W - 3
+    _cmp_oracle("invalid among valid", warm[0], warm[1], None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
+
+
+def test_warm_chain_does_not_drift_over_a_long_chunk(oracle):
+    """The warm chain never sees E or M as numbers, so its rounding accumulates until the next cold row. OCTO_CHUNK forces 2 500 rows per
+    wave (the planner's own chunks are tens to a few hundred rows): slow, low-e walkers that never fall back — the longest chains there are —
+    against the oracle at the usual bar and against the cold loop at 1e-11."""
+    gb = _gpu()
+    rng = np.random.default_rng(54)
+    n, W = 10_000, 64
+    t = 50000.0 + 1.0 * np.arange(n)
+    ra, dec = synth.truth_radec(t)
+    obs = [dict(kind=0, planet=0, epoch=t, y1=ra + rng.normal(0, 10, n), y2=dec + rng.normal(0, 10, n), s1=np.full(n, 10.0), s2=np.full(n, 10.0), cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    el = synth.draw_walkers(rng, W, 3.0, 100.0)
+    el[1] = rng.uniform(0.0, 0.4, W)
+    warm = _eval(gb, obs, planets, el, None, True, True, env={"OCTO_CHUNK": "2500"})
+    cold = _eval(gb, obs, planets, el, None, True, False, env={"OCTO_CHUNK": "2500"})
+    assert not np.array_equal(warm[0], cold[0])
+    _close("long chain", warm, cold, ll_tol=1e-11, g_tol=1e-9)
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el, None, grad=True, active=synth.active_mask(1, 1, mass=False, nuis=False))
+    _cmp_oracle("long chain warm", warm[0], warm[1], None, ll_o, g_o, None)
+
+
+def test_warm_step_device_routine_over_the_elliptic_domain(pkg):
+    """kepler_solve_warm on its own (octo_debug_kepler_warm, a test hook): a cold solve at M, then ONE warm step by ΔM, over e up to
+    1 − 1e-9, every phase of the orbit and ΔM from 1e-7 to 0.3 rad — against an 80-bit Newton solve at M + ΔM, error weighted by 1 − e cos E
+    like test_kepler_device_solver. The inputs are grouped so that whole waves pass or fail the bound: where the wave took the warm path
+    (`used`) the result must be as good as the cold routine's; and the bound must admit a useful share of the sample."""
+    import ctypes as C
+    capi = pkg.capi
+    lib = capi.load_library()
+    lib.octo_debug_kepler_warm.restype = C.c_int32
+    lib.octo_debug_kepler_warm.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 3
+    rng = np.random.default_rng(77)
+    n = 64 * 6000
+    e = np.concatenate([rng.uniform(0, 1, n // 2), 1 - 10 ** rng.uniform(-9, -1, n // 2)])
+    Ep = np.concatenate([rng.uniform(-np.pi, np.pi, n // 2), 10 ** rng.uniform(-6, 0.49, n // 2) * rng.choice([-1, 1], n // 2)])
+    rng.shuffle(Ep)
+    dM = 10 ** rng.uniform(-7, -0.5, n) * rng.choice([-1, 1], n)
+    el = e.astype(np.longdouble); Epl = Ep.astype(np.longdouble)
+    M = (Epl - el * np.sin(Epl)).astype(np.float64)
+    M = np.clip(M, -np.pi, np.pi)
+    # group by pass / fail of the a-priori bound so that a wave is (mostly) homogeneous
+    D = 1 - e * np.cos(Ep)
+    thr = (4e-4 / np.abs(dM) ** 3) ** 0.2
+    order = np.argsort(~((1 / D) < 0.98 * thr), kind="stable")
+    M, dM, e = (np.ascontiguousarray(x[order]) for x in (M, dM, e))
+    sE = np.empty(n); cE = np.empty(n); used = np.empty(n)
+    ctx = C.c_void_p()
+    assert lib.octo_ctx_create(C.byref(ctx), 0) == 0
+    try:
+        assert lib.octo_debug_kepler_warm(ctx, capi._dptr(M), capi._dptr(dM), capi._dptr(e), n, capi._dptr(sE), capi._dptr(cE), capi._dptr(used)) == 0
+    finally:
+        lib.octo_ctx_destroy(ctx)
+    Mn = M.astype(np.longdouble) + dM.astype(np.longdouble)
+    el = e.astype(np.longdouble)
+    Et = np.arctan2(sE, cE).astype(np.longdouble)
+    Et = Et + np.longdouble(2 * np.pi) * np.rint((Mn - Et) / np.longdouble(2 * np.pi))      # the branch of E that goes with M + ΔM
+    for _ in range(60):
+        Et = Et - (Et - el * np.sin(Et) - Mn) / (1 - el * np.cos(Et))
+    conv = np.abs(Et - el * np.sin(Et) - Mn) < 1e-17
+    cond = (1 - el * np.cos(Et)).astype(np.float64)
+    err = np.maximum(np.abs(sE - np.sin(Et).astype(np.float64)), np.abs(cE - np.cos(Et).astype(np.float64))) * cond
+    w = (used > 0) & conv
+    assert w.mean() > 0.3, w.mean()
+    assert err[w].max() < 2e-15, (err[w].max(), e[w][np.argmax(err[w])], dM[w][np.argmax(err[w])])
+    c = (used == 0) & conv
+    assert err[c].max() < 2e-15, err[c].max()                                                  # the fallback rows: the cold routine
+    assert np.all(np.abs(sE[w] ** 2 + cE[w] ** 2 - 1) < 1e-14)

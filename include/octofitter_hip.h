@@ -101,6 +101,9 @@ extern "C" {
 #define OCTO_EL_PLX   7   /* parallax [mas]                       */
 #define OCTO_EL_MASS  8   /* companion mass [M_jup]               */
 #define OCTO_N_EL     9
+/* planets per dataset: the epoch-loop kernels are compiled for 1 … OCTO_MAX_PLANETS (octo_dataset_create refuses more with OCTO_EINVAL;
+ * the reference unrolls over any number, src/likelihoods/system.jl:116-118 — a host-side binding keeps such a system on its own path) */
+#define OCTO_MAX_PLANETS 4
 /* the same rows for an OCTO_ORBIT_THIELE_INNES planet: A, B, F, G replace a, i, ω, Ω */
 #define OCTO_EL_TI_A  0
 #define OCTO_EL_TI_B  2

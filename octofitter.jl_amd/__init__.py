@@ -13,7 +13,7 @@ from .host.observations import (  # noqa: F401
     MarginalizedStarAbsoluteRVObs, PlanetRelativeRVObs, PlanetRelativeRVLikelihood, ObsPriorAstromONeil2019,
     HGCAInstantaneousObs, HGCAInstantaneousLikelihood,
 )
-from .host.system import Planet, System, make_ln_like, BatchedLnLike  # noqa: F401
+from .host.system import Planet, System, make_ln_like, BatchedLnLike, accelerate, not_on_device  # noqa: F401
 from .host.sharding import shard_range, ShardedLnLike  # noqa: F401,E402
 from .host.tempering import TemperedSwap  # noqa: F401,E402
 from .host.ofti import OftiLinearSolver, ofti_linear_solve  # noqa: F401,E402

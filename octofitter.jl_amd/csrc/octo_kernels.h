@@ -17,7 +17,7 @@
 
 namespace octo {
 
-constexpr int MAXP = 4;
+constexpr int MAXP = OCTO_MAX_PLANETS;
 constexpr int ROW_STRIDE = 8;   // doubles per observation row record (64 B = one s_load_dwordx16)
 constexpr int WPB = 4;          // waves per k_main block (row split + LDS combine)
 #ifndef OCTO_FIN_G

@@ -48,6 +48,14 @@ class LogDensityModel:
         θex = dict(planets={pl.name: {k: 0.0 for k in (pl.variables or {})} for pl in system.planets})
         self.ln_like = BatchedLnLike(system, θex, device=device, consts=consts)
         fn = self.ln_like
+        try:
+            self._build(system, fn, verbosity)
+        except Exception:
+            fn.close()      # a model the library (or this classifier) refuses must not leak the context and dataset created for it
+            raise
+
+    def _build(self, system, fn, verbosity):
+        lib = fn.lib
         # ---- kernel-input sources
         used_circ = set()
         esrc = []

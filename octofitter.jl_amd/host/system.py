@@ -132,15 +132,19 @@ class BatchedLnLike:
         self.obs_tables = [e[0]._c_table(e[1]) for e in self.obs_entries]
         # ---- C side ------------------------------------------------------------------------------
         self._ctx = C.c_void_p()
-        self._check(self.lib.octo_ctx_create(C.byref(self._ctx), int(device)), "octo_ctx_create")
-        if consts is not None:
-            self._check(self.lib.octo_consts_set(self._ctx, C.byref(consts)), "octo_consts_set")
-        obs_arr, keep = capi.pack_obs(self.obs_tables)
-        pl_arr = capi.pack_planets(self.planet_desc)
         self._ds = C.c_void_p()
-        self._check(self.lib.octo_dataset_create(self._ctx, obs_arr, len(self.obs_tables), pl_arr, self.n_planets,
-                                                 C.byref(self._ds)), "octo_dataset_create")
-        del keep
+        try:
+            self._check(self.lib.octo_ctx_create(C.byref(self._ctx), int(device)), "octo_ctx_create")
+            if consts is not None:
+                self._check(self.lib.octo_consts_set(self._ctx, C.byref(consts)), "octo_consts_set")
+            obs_arr, keep = capi.pack_obs(self.obs_tables)
+            pl_arr = capi.pack_planets(self.planet_desc)
+            self._check(self.lib.octo_dataset_create(self._ctx, obs_arr, len(self.obs_tables), pl_arr, self.n_planets,
+                                                     C.byref(self._ds)), "octo_dataset_create")
+            del keep
+        except Exception:
+            self.close()      # a refused dataset must not leak the context it was offered to
+            raise
         self.n_obs = len(self.obs_tables)
         self.n_rows = int(self.lib.octo_dataset_n_rows(self._ds))
 
@@ -344,6 +348,38 @@ class BatchedLnLike:
         n = C.c_int64()
         self._check(self.lib.octo_timing_read(self._ctx, C.byref(ms), C.byref(n), int(reset)), "octo_timing_read")
         return ms.value, n.value
+
+
+def not_on_device(system: System):
+    """Why a system cannot go to the device at all, or None (julia/OctofitterHIP.jl: _not_on_device): the library compiles its epoch-loop
+    kernels for 1 … OCTO_MAX_PLANETS planets; the reference unrolls over any number (src/likelihoods/system.jl:116-118,156-170)."""
+    n = len(system.planets)
+    if n < 1:
+        return "the system has no planet"
+    if n > capi.MAX_PLANETS:
+        return f"{n} planets: the device kernels are compiled for at most {capi.MAX_PLANETS}"
+    return None
+
+
+def accelerate(system: System, θ_example: dict, device: int = 0, consts=None, verbosity: int = 1):
+    """Mirror of `OctofitterHIP.accelerate(system)` ("falls back to the reference closure" instead of throwing): the batched
+    device evaluator of `system` — or, when the system cannot go to the device (more planets than the kernels are compiled for, no usable
+    HIP device, a dataset the library refuses), the SAME `system` object back, untouched, with the reason in `system.hip_fallback_reason`
+    and one log line. What evaluates an un-accelerated system is the caller's business — in Julia, the reference itself; this package has no
+    CPU evaluator and never pretends to (a missing library is still an error: load_library raises). Nothing is leaked on the fallback paths."""
+    import logging
+    why = not_on_device(system)
+    if why is None:
+        try:
+            fn = BatchedLnLike(system, θ_example, device=device, consts=consts)
+            system.hip_fallback_reason = None
+            return fn
+        except capi.OctoError as ex:      # OCTO_ENODEV, OCTO_EINVAL from octo_dataset_create, OCTO_EHIP / OCTO_ENOMEM at creation
+            why = str(ex)
+    system.hip_fallback_reason = why
+    if verbosity >= 1:
+        logging.getLogger("octofitter_hip").info("OctofitterHIP: %s — the system stays on the host path", why)
+    return system
 
 
 def make_ln_like(system: System, θ_system: dict, device: int = 0, consts=None) -> BatchedLnLike:

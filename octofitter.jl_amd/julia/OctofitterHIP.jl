@@ -150,9 +150,25 @@ function _upload(system, eligible, θs; device::Integer=0)
         push!(planets, OctoPlanetDesc(_orbit_kind(pl), hasproperty(θ0.planets[ip], :mass)))                 # relative-astrometry.jl:122
     end
     ctx = octo_ctx_create(device)
-    octo_consts_set(ctx, _consts())
-    ds = GC.@preserve columns octo_dataset_create(ctx, descs, planets)
-    return ctx, ds, entries, columns
+    try
+        octo_consts_set(ctx, _consts())
+        ds = GC.@preserve columns octo_dataset_create(ctx, descs, planets)
+        return ctx, ds, entries, columns
+    catch
+        octo_ctx_destroy(ctx)                                              # a refused dataset must not leak the context it was offered to
+        rethrow()
+    end
+end
+
+"""
+Why a system cannot go to the device at all, or `nothing`: SURVEY.md §8(b) — the shim FALLS BACK to the reference closure, it does not throw.
+The library compiles its epoch-loop kernels for 1 … OCTO_MAX_PLANETS planets (the reference unrolls over any number, system.jl:116-118,156-170).
+"""
+function _not_on_device(system)
+    np = length(system.planets)
+    np < 1 && return "the system has no planet"
+    np > OCTO_MAX_PLANETS && return "$np planets: the device kernels are compiled for at most $OCTO_MAX_PLANETS"
+    return nothing
 end
 
 "Resolved orbital elements and nuisances of ONE parameter set, in C-ABI order; generic in the number type (Float64 or Dual)."
@@ -252,12 +268,33 @@ function accelerate(system::System; device::Integer=0, n_contexts::Integer=Threa
         _eligible(obs, 0, θs) && push!(eligible, (obs, 0))
     end
     isempty(eligible) && (verbosity >= 1 && @info "OctofitterHIP: no observation of this system is on the HIP path"; return system)
-    ctx, ds, entries, columns = _upload(system, eligible, θs; device)
+    # ---- fall back to the un-accelerated system (the reference's own closure) instead of throwing: more planets than the kernels are
+    # compiled for, no usable device, or a dataset the library refuses (SURVEY.md §8(b)); nothing is leaked on any of these paths
+    why = _not_on_device(system)
+    if why !== nothing
+        verbosity >= 1 && @info "OctofitterHIP: $why — the system stays on the reference's CPU path"
+        return system
+    end
+    local ctx, ds, entries, columns
+    try
+        ctx, ds, entries, columns = _upload(system, eligible, θs; device)
+    catch e
+        e isa OctoError || rethrow()
+        verbosity >= 1 && @info "OctofitterHIP: $(sprint(showerror, e)) — the system stays on the reference's CPU path"
+        return system
+    end
     n_in = length(system.planets) * N_EL + length(entries) * N_NUIS
     slot(c) = HIPSlot(c, Matrix{Float64}(undef, 1, n_in), Matrix{Float64}(undef, 1, n_in), Vector{Float64}(undef, 1))
     slots = [slot(ctx)]
     for _ in 2:max(1, n_contexts)                                       # more contexts on the same device share the dataset
-        c = octo_ctx_create(device); octo_consts_set(c, _consts()); push!(slots, slot(c))
+        try
+            c = octo_ctx_create(device)
+            try octo_consts_set(c, _consts()) catch; octo_ctx_destroy(c); rethrow() end
+            push!(slots, slot(c))
+        catch e
+            e isa OctoError || rethrow()
+            break                                                        # fewer slots than threads: callers queue on `free`, nothing else changes
+        end
     end
     free = Channel{Int}(length(slots)); foreach(i -> put!(free, i), eachindex(slots))
     nuis_default = Float64[]
@@ -522,7 +559,25 @@ mutable struct HIPLogDensityModel{TModel,Tℓπ,T∇ℓπ}
     const lock::ReentrantLock
 end
 
-function HIPLogDensityModel(model; device::Integer=0)
+function HIPLogDensityModel(model; device::Integer=0, fallback::Bool=true, verbosity::Integer=1)
+    # SURVEY.md §8(b): fall back to the reference's model instead of throwing — more planets than the kernels are compiled for, no usable
+    # device, a dataset or model the library refuses, a prior / Derived expression / observation outside the standard blocks. `fallback = false`
+    # (tests, debugging) lets the exception through.
+    fallback || return _hip_log_density_model(model; device)
+    why = _not_on_device(model.system)
+    if why === nothing
+        try
+            return _hip_log_density_model(model; device)
+        catch e
+            (e isa OctoError || e isa ErrorException) || rethrow()
+            why = sprint(showerror, e)
+        end
+    end
+    verbosity >= 1 && @info "OctofitterHIP: $why — returning the reference's LogDensityModel unchanged"
+    return model
+end
+
+function _hip_log_density_model(model; device::Integer=0)
     g = GPUBatchedLikelihood(model; device)
     # the UnitLengthPrior terms of UniformCircular variables are part of the device model; any other host term is not
     for (obs, _, _) in g.host_terms

@@ -18,6 +18,7 @@ const SRC_CONST, SRC_THETA, SRC_CIRCULAR, SRC_TPERI = Int32(0), Int32(1), Int32(
 const SRC_FLAG_UNITLEN, SRC_FLAG_TI = Int32(1), Int32(2)
 const STREAM_CTX = Ptr{Cvoid}(typemax(UInt))       # OCTO_STREAM_CTX = (void*)-1: the context's own stream
 const N_EL, N_NUIS = 9, 3
+const OCTO_MAX_PLANETS = 4
 const EL_KEYS = (:a, :e, :i, :ω, :Ω, :tp, :M, :plx, :mass)
 const EL_KEYS_TI = (:A, :e, :B, :F, :G, :tp, :M, :plx, :mass)     # ThieleInnesOrbit: constants [mas] in the rows of a, i, ω, Ω
 
@@ -65,15 +66,22 @@ struct OctoSource            # mirrors `octo_source`
 end
 
 # ---------------------------------------------------------------------------------------------------- one ccall per exported symbol
+"A non-zero status of the library (include/octofitter_hip.h: OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV) as a Julia exception the shim can catch by kind."
+struct OctoError <: Exception
+    status::Int32
+    what::String
+    msg::String
+end
+Base.showerror(io::IO, e::OctoError) = print(io, "$(e.what) failed with status $(e.status): $(e.msg)")
 check(ctx, st, what) = st == OCTO_OK ? nothing :
-    error("$what failed with status $st: " * unsafe_string(ccall((:octo_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
+    throw(OctoError(st, what, ctx == C_NULL ? "" : unsafe_string(ccall((:octo_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))))
 
 octo_version() = (a = Ref{Int32}(0); b = Ref{Int32}(0); ccall((:octo_version, LIB), Int32, (Ref{Int32}, Ref{Int32}), a, b); (a[], b[]))
 octo_consts_default() = (c = Ref{OctoConsts}(); ccall((:octo_consts_default, LIB), Int32, (Ref{OctoConsts},), c); c[])
 function octo_ctx_create(device::Integer)
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     st = ccall((:octo_ctx_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32), ctx, device)
-    st == OCTO_OK || error("octo_ctx_create failed with status $st (no usable MI355X?)")
+    st == OCTO_OK || throw(OctoError(st, "octo_ctx_create", st == OCTO_ENODEV ? "no usable HIP device $device" : ""))
     return ctx[]
 end
 octo_ctx_destroy(ctx) = ccall((:octo_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), ctx)
@@ -188,7 +196,7 @@ end
 
 # parallel tempering (BASELINE config 5): one process per GPU, one all-gather per swap step inside the library
 "Rank 0: the 128-byte RCCL rendezvous id; hand it to the other ranks (MPI.Bcast!, a file, …)."
-octo_comm_unique_id() = (id = zeros(UInt8, 128); st = ccall((:octo_comm_unique_id, LIB), Int32, (Ptr{UInt8},), id); st == OCTO_OK || error("octo_comm_unique_id: status $st"); id)
+octo_comm_unique_id() = (id = zeros(UInt8, 128); st = ccall((:octo_comm_unique_id, LIB), Int32, (Ptr{UInt8},), id); st == OCTO_OK || throw(OctoError(st, "octo_comm_unique_id", "")); id)
 octo_comm_create(ctx, id::Union{Nothing,Vector{UInt8}}, rank::Integer, world::Integer) = check(ctx, ccall((:octo_comm_create, LIB), Int32,
     (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), ctx, id === nothing ? Ptr{UInt8}(C_NULL) : pointer(id), rank, world), "octo_comm_create")
 octo_comm_destroy(ctx) = ccall((:octo_comm_destroy, LIB), Int32, (Ptr{Cvoid},), ctx)

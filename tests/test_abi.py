@@ -229,3 +229,39 @@ def test_julia_ccall_layer_is_thin_and_self_contained():
     main = JULIA.read_text()
     assert "ccall(" not in main, "every ccall belongs to the thin layer"
     assert not re.search(r"^\s*(mutable\s+)?struct\s+Octo[A-Z]\w*", main, re.M), "the header's structs are mirrored in the thin layer"
+
+
+def test_julia_shim_falls_back_instead_of_throwing():
+    """the shim "falls back to the reference closure when any observation is ineligible" — VERDICT r4: `accelerate(system)` on a
+    5-planet system, or on a host without a usable GPU, used to reach octo_dataset_create / octo_ctx_create -> check -> error(), leaking the
+    context. Structural check (Julia is not in the image) of the three branches and of the failure paths' clean-up:
+      * more planets than OCTO_MAX_PLANETS (the reference unrolls over any number, src/likelihoods/system.jl:116-118): decided on the host
+        BEFORE anything is created;
+      * no usable device / a refused dataset: the library's status arrives as a typed `OctoError` (not a bare `error`), `accelerate` and
+        `HIPLogDensityModel` catch exactly that, log one `@info` and return the object they were given;
+      * `_upload` destroys the context it created when the dataset is refused; a failed extra slot destroys its context too."""
+    capi = JULIA_CAPI.read_text()
+    main = JULIA.read_text()
+    hdr = HEADER.read_text()
+    n_max = int(re.search(r"#define\s+OCTO_MAX_PLANETS\s+(\d+)", hdr).group(1))
+    assert re.search(rf"const OCTO_MAX_PLANETS = {n_max}\b", capi)
+    # typed exception, thrown by every status check and by octo_ctx_create
+    assert re.search(r"struct OctoError <: Exception\s+status::Int32", capi)
+    assert "throw(OctoError(st, what" in capi and 'throw(OctoError(st, "octo_ctx_create"' in capi
+    assert not re.search(r"(?<![A-Za-z_.])error\(", capi), "the ccall layer reports library failures as OctoError only"
+    # the host-side planet-count rule
+    m = re.search(r"function _not_on_device\(system\)(.*?)\nend\n", main, re.S)
+    assert m and "length(system.planets)" in m.group(1) and "np > OCTO_MAX_PLANETS" in m.group(1)
+    # _upload: context destroyed on the failure path
+    up = re.search(r"function _upload\(.*?\n(.*?)\nend\n", main, re.S).group(1)
+    assert re.search(r"ctx = octo_ctx_create\(device\)\s+try\b.*octo_dataset_create\(ctx.*catch\s+octo_ctx_destroy\(ctx\).*rethrow\(\)", up, re.S)
+    # accelerate: the three branches, each returning `system`
+    acc = re.search(r"function accelerate\(system::System;.*?\n(.*?)\n    n_in = ", main, re.S).group(1)
+    assert re.search(r"why = _not_on_device\(system\)\s+if why !== nothing.*?@info.*?return system\s+end", acc, re.S)
+    assert re.search(r"try\s+ctx, ds, entries, columns = _upload\(.*?catch e\s+e isa OctoError \|\| rethrow\(\).*?@info.*?return system\s+end", acc, re.S)
+    slots = re.search(r"for _ in 2:max\(1, n_contexts\)(.*?)\n    end\n", main, re.S).group(1)
+    assert "octo_ctx_destroy(c)" in slots and "e isa OctoError || rethrow()" in slots and "break" in slots
+    # HIPLogDensityModel: returns the reference's model
+    h = re.search(r"function HIPLogDensityModel\(model;.*?\n(.*?)\nend\n", main, re.S).group(1)
+    assert "_not_on_device(model.system)" in h and "e isa OctoError || e isa ErrorException" in h and "@info" in h and h.rstrip().endswith("return model")
+    assert "fallback || return _hip_log_density_model(model; device)" in h

@@ -218,3 +218,47 @@ def test_bench_self_launches_n_ranks():
     cmd = json.loads(r.stdout.strip().splitlines()[-1])
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
     assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+
+
+def _five_planet_system(pkg, n=5):
+    rng = np.random.default_rng(2)
+    t = 50000.0 + 30.0 * np.arange(12)
+    planets = []
+    for k in range(n):
+        tab = dict(epoch=t, ra=rng.normal(0, 100, t.size), dec=rng.normal(0, 100, t.size), σ_ra=np.full(t.size, 5.0), σ_dec=np.full(t.size, 5.0))
+        planets.append(pkg.Planet(name=f"p{k}", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromObs(tab, name=f"astrom{k}")]))
+    return pkg.System(name="five", companions=planets, observations=[])
+
+
+def test_mirror_falls_back_instead_of_throwing(pkg, monkeypatch, caplog):
+    """SURVEY.md §8(b) / VERDICT r4 item 2, the Python mirror of `OctofitterHIP.accelerate`: a system the device path cannot take comes back
+    UNCHANGED (the caller keeps evaluating it however it did before: in Julia, the reference itself) with the reason attached and one log line —
+    (a) more planets than OCTO_MAX_PLANETS: decided on the host before any library call; (b) no usable HIP device (this container has none;
+    HIP_VISIBLE_DEVICES="" makes sure): octo_ctx_create's OCTO_ENODEV is caught. The constructors that are ASKED for a device evaluator
+    (make_ln_like, LogDensityModel) still raise: the product has no CPU evaluator to fall back to."""
+    import logging
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    sys5 = _five_planet_system(pkg, 5)
+    θ5 = dict(M=1.2, plx=50.0, planets={f"p{k}": dict(a=3.0 + k, e=0.1, i=1.0, ω=1.0, Ω=2.0, tp=5e4) for k in range(5)})
+    assert pkg.not_on_device(sys5) is not None and str(pkg.capi.MAX_PLANETS) in pkg.not_on_device(sys5)
+    with caplog.at_level(logging.INFO, logger="octofitter_hip"):
+        out = pkg.accelerate(sys5, θ5)
+    assert out is sys5 and "5 planets" in sys5.hip_fallback_reason
+    assert sum("stays on the host path" in r.getMessage() for r in caplog.records) == 1
+    with pytest.raises(pkg.capi.OctoError):      # asked for the device evaluator explicitly: the library's refusal (or the missing device) is an error
+        pkg.make_ln_like(sys5, θ5)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible to this process: the no-device branch is exercised in the CPU container")
+    sys1 = _five_planet_system(pkg, 1)
+    θ1 = dict(M=1.2, plx=50.0, planets=dict(p0=dict(a=3.0, e=0.1, i=1.0, ω=1.0, Ω=2.0, tp=5e4)))
+    assert pkg.not_on_device(sys1) is None
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="octofitter_hip"):
+        out = pkg.accelerate(sys1, θ1)
+    assert out is sys1 and "OCTO_ENODEV" in sys1.hip_fallback_reason
+    assert sum("stays on the host path" in r.getMessage() for r in caplog.records) == 1
+    with pytest.raises(pkg.capi.OctoError) as ei:
+        pkg.make_ln_like(sys1, θ1)
+    assert ei.value.status == pkg.capi.OCTO_ENODEV

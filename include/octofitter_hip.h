@@ -101,9 +101,12 @@ extern "C" {
 #define OCTO_EL_PLX   7   /* parallax [mas]                       */
 #define OCTO_EL_MASS  8   /* companion mass [M_jup]               */
 #define OCTO_N_EL     9
-/* planets per dataset: the epoch-loop kernels are compiled for 1 … OCTO_MAX_PLANETS (octo_dataset_create refuses more with OCTO_EINVAL;
- * the reference unrolls over any number, src/likelihoods/system.jl:116-118 — a host-side binding keeps such a system on its own path) */
-#define OCTO_MAX_PLANETS 4
+/* planets per dataset. 1 … OCTO_MAX_PLANETS_ALL_KINDS: every observation kind, both kernel families. Up to OCTO_MAX_PLANETS: the
+ * planet-per-wave throughput kernels (one planet per wave of a block, any batch size) for relative astrometry and absolute / relative RV —
+ * octo_dataset_create refuses marginalised RV, the O'Neil prior and HGCA tables there, and more planets than that, with OCTO_EINVAL. (The
+ * reference unrolls over any number, src/likelihoods/system.jl:116-118: a host-side binding keeps a refused system on its own path.) */
+#define OCTO_MAX_PLANETS 8
+#define OCTO_MAX_PLANETS_ALL_KINDS 4
 /* the same rows for an OCTO_ORBIT_THIELE_INNES planet: A, B, F, G replace a, i, ω, Ω */
 #define OCTO_EL_TI_A  0
 #define OCTO_EL_TI_B  2

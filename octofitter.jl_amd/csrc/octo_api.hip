@@ -321,6 +321,7 @@ int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_
 // crossover at W·P ≈ 400-1000 (tools/latency_vs_w.py, tools/latency_multi.py). An HGCA table adds blocks to the same launch
 // (one input direction per wave) for W <= 16, the k_hgca launch ahead of it otherwise.
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
+    if (ds->n_planets > MAXP_T) return false;      // k_small<P> is compiled for 1 … 4 planets
     if (!(W * ds->n_planets <= ctx->small_w && W <= SMALL_W)) return false;
     if (ds->kind_mask & KM_MARG)      // a marginalised-RV table is ONE block's work there (two passes): not for a very long table
         for (int o = 0; o < ds->n_obs; ++o)
@@ -494,7 +495,12 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
                             const octo_planet_desc* planets, int32_t n_planets, octo_dataset** out) {
     if (!ctx || !out || n_obs < 0 || (n_obs > 0 && !obs) || !planets) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: null argument");
     *out = nullptr;
-    if (n_planets < 1 || n_planets > MAXP) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: 1..4 planets supported");
+    if (n_planets < 1 || n_planets > MAXP) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: 1.." + std::to_string(MAXP) + " planets supported");
+    if (n_planets > MAXP_T)      // beyond the templated kernels: the planet-per-wave kernels' kind sets only (octo_mainp.h)
+        for (int o = 0; o < n_obs; ++o)
+            if (obs[o].kind == OCTO_RV_ABS_MARG || obs[o].kind == OCTO_ONEIL_RADEC || obs[o].kind == OCTO_ONEIL_SEPPA || obs[o].kind == OCTO_HGCA)
+                return fail(ctx, OCTO_EINVAL, "octo_dataset_create: with more than " + std::to_string(MAXP_T) + " planets only relative astrometry and absolute / relative RV tables "
+                                              "are supported (no marginalised RV, O'Neil prior or HGCA)");
     for (int p = 0; p < n_planets; ++p)
         if (planets[p].orbit_kind != OCTO_ORBIT_VISUAL_KEP && planets[p].orbit_kind != OCTO_ORBIT_RADVEL &&
             planets[p].orbit_kind != OCTO_ORBIT_THIELE_INNES && planets[p].orbit_kind != OCTO_ORBIT_KEP)
@@ -691,7 +697,8 @@ static int eval_impl(octo_ctx* ctx, const octo_dataset* ds, const double* d_elem
         case 1: return dispatch1<1>(ctx, ds, a, grad, nuis, sm, st);
         case 2: return dispatch1<2>(ctx, ds, a, grad, nuis, sm, st);
         case 3: return dispatch1<3>(ctx, ds, a, grad, nuis, sm, st);
-        default: return dispatch1<4>(ctx, ds, a, grad, nuis, sm, st);
+        case 4: return dispatch1<4>(ctx, ds, a, grad, nuis, sm, st);
+        default: return dispatch_many(ctx, ds, a, grad, nuis, sm, st);
     }
 }
 

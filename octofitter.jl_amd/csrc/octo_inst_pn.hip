@@ -1,0 +1,116 @@
+// The planet-per-wave kernels (octo_mainp.h): their only instantiations, the launchers the per-planet-count translation units call for
+// four planets, and the whole dispatch for datasets of more planets than the templated kernels are compiled for (see octo_host.h).
+#include "octo_host.h"
+#include "octo_mainp.h"
+
+namespace octo {
+
+// The grain: a block is P waves that ALL walk the task's rows, so a task is what ONE wave of k_main walks — two rounds of the resident
+// capacity while that leaves a block >= 64 rows, one otherwise (get_tasks keeps >= 32 rows per task).
+int64_t plan_key_mainp(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu) {
+    if (ctx->env_chunk > 0) return -ctx->env_chunk;
+    const int64_t cols = (W + WAVE - 1) / WAVE;
+    const int64_t capacity = std::max<int64_t>((int64_t)blocks_per_cu * ctx->n_cus, 64);
+    int64_t rounds = 2;
+    while (rounds > 1 && n_rows * cols < 64 * rounds * capacity) --rounds;
+    if (ctx->env_rounds > 0) rounds = ctx->env_rounds;
+    return std::max<int64_t>(1, rounds * capacity / cols);
+}
+
+namespace {
+constexpr int KA = KM_RADEC | KM_SEPPA | KM_COR, KB = KM_ALL & ~KM_MARG & ~KM_ONEIL;
+
+template <bool GRAD, bool NUIS, int KM>
+int launch_mainp_t(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t st) {
+    const int P = a.n_planets;
+    (void)ctx;
+    static_assert(mainp_lds_bytes<true, true, KM, mp_rows(8)>(8) <= 48 * 1024 && mainp_lds_bytes<true, true, KM, mp_rows(6)>(6) <= 48 * 1024,
+                  "k_mainp stays under the default dynamic-LDS limit of a launch");
+    if (P > 6)
+        hipLaunchKernelGGL((k_mainp<GRAD, NUIS, KM, mp_rows(8), mp_wpe(8)>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3((unsigned)(WAVE * P)),
+                           (mainp_lds_bytes<GRAD, NUIS, KM, mp_rows(8)>(P)), st, a);
+    else
+        hipLaunchKernelGGL((k_mainp<GRAD, NUIS, KM, mp_rows(4), mp_wpe(4)>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3((unsigned)(WAVE * P)),
+                           (mainp_lds_bytes<GRAD, NUIS, KM, mp_rows(4)>(P)), st, a);
+    return OCTO_OK;
+}
+template <bool GRAD, bool NUIS, int KM>
+int launch_finishp_t(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t st) {
+    const int waves = GRAD ? 1 + a.n_planets : 1;
+    hipLaunchKernelGGL((k_finishp<GRAD, NUIS, KM>), dim3((unsigned)cols), dim3((unsigned)(WAVE * waves)), sizeof(double) * WAVE * (size_t)(1 + a.n_planets), st, a);
+    (void)ctx;
+    return OCTO_OK;
+}
+template <bool NUIS, int KM>
+int occupancy_t(int P) {
+    int nb = 0;
+    // (the API counts registers and LDS; what the hardware really places is bounded by its fixed wave -> SIMD order as well: see octo_mainp.h)
+    hipError_t e = P > 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mainp<true, NUIS, KM, mp_rows(8), mp_wpe(8)>, WAVE * P, (mainp_lds_bytes<true, NUIS, KM, mp_rows(8)>(P)))
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mainp<true, NUIS, KM, mp_rows(4), mp_wpe(4)>, WAVE * P, (mainp_lds_bytes<true, NUIS, KM, mp_rows(4)>(P)));
+    if (e != hipSuccess || nb < 1) nb = 2;
+    if (P > 4) nb = std::min(nb, P > 6 ? 2 : 1 + (P < 6));      // what the fixed wave -> SIMD order really places (5 planets: two blocks, 6: one, 7-8 at 128 VGPRs: two)
+    return nb;
+}
+}  // namespace
+
+#define OCTO_PN_DISPATCH(FN, ...)                                                                                   \
+    (km_p == KA ? (grad ? (nuis ? FN<true, true, KA>(__VA_ARGS__) : FN<true, false, KA>(__VA_ARGS__))              \
+                        : (nuis ? FN<false, true, KA>(__VA_ARGS__) : FN<false, false, KA>(__VA_ARGS__)))           \
+                : (grad ? (nuis ? FN<true, true, KB>(__VA_ARGS__) : FN<true, false, KB>(__VA_ARGS__))              \
+                        : (nuis ? FN<false, true, KB>(__VA_ARGS__) : FN<false, false, KB>(__VA_ARGS__))))
+
+int mainp_occupancy(octo_ctx* ctx, bool nuis, int km_p, int P) {
+    (void)ctx;
+    return km_p == KA ? (nuis ? occupancy_t<true, KA>(P) : occupancy_t<false, KA>(P)) : (nuis ? occupancy_t<true, KB>(P) : occupancy_t<false, KB>(P));
+}
+int launch_mainp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st) {
+    return OCTO_PN_DISPATCH(launch_mainp_t, ctx, cols, a, st);
+}
+int launch_finishp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st) {
+    return OCTO_PN_DISPATCH(launch_finishp_t, ctx, cols, a, st);
+}
+
+// A dataset of MAXP_T < P <= MAXP planets: always the throughput kernels (no k_small<P> there), k_mainp -> k_finishp on one stream.
+int dispatch_many(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st) {
+    if (sm) return fail(ctx, OCTO_EINVAL, "internal: fused model launch requested for a dataset of more than four planets");
+    if (ds->kind_mask & (KM_MARG | KM_ONEIL | KM_HGCA)) return fail(ctx, OCTO_EINVAL, "internal: kind set outside the planet-per-wave kernels");
+    const int P = ds->n_planets;
+    const int km_p = mainp_kind_set(ds->kind_mask);
+    const int64_t cols = (a.W + WAVE - 1) / WAVE;
+    int& blocks_per_cu = ctx->occupancy[(uint32_t)((P << 16) | ((nuis ? 1 : 0) << 15) | km_p)];
+    if (blocks_per_cu == 0) blocks_per_cu = mainp_occupancy(ctx, nuis, km_p, P);
+    TaskTable* tt = nullptr;
+    int rc = get_tasks(ctx, ds, plan_key_mainp(ctx, a.W, ds->n_rows, blocks_per_cu), &tt, nuis, 1);
+    if (rc) return rc;
+    a.tasks = tt->d_tasks; a.task_const = nuis ? tt->d_const_raw : tt->d_const_pre;
+    a.obs_range = tt->d_obs_range; a.obs_const = nuis ? tt->d_obs_const_raw : tt->d_obs_const_pre;
+    a.n_tasks = tt->n_tasks;
+    // partials: OFF_PL + P·PL_N rows per task — bounded by the widest layout (11 observation sums + 12 per planet)
+    const int64_t nacc_max = NOBS_ACC + (int64_t)P * 12;
+    rc = grow(ctx, ctx->d_partials, ctx->cap_part, (int64_t)std::max(a.n_tasks, 1) * nacc_max * a.ldw);
+    if (rc) return rc;
+    a.partials = ctx->d_partials;
+    a.extra = nullptr; a.marg = nullptr; a.marg_out = nullptr;
+    if (a.n_tasks > 0) {
+        hipEvent_t e1 = nullptr;
+        if (ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0) {      // HIP events around the epoch-loop kernel, as in launch_all
+            if (ctx->ev_used == ctx->ev_pool.size()) {
+                hipEvent_t x, y;
+                HIPCHK(ctx, hipEventCreate(&x)); HIPCHK(ctx, hipEventCreate(&y));
+                ctx->ev_pool.emplace_back(x, y);
+            }
+            hipEvent_t e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
+            HIPCHK(ctx, hipEventRecord(e0, st));
+        }
+        rc = launch_mainp(ctx, grad, nuis, km_p, cols, a, st);
+        if (rc) return rc;
+        if (e1) HIPCHK(ctx, hipEventRecord(e1, st));
+    }
+    rc = launch_finishp(ctx, grad, nuis, km_p, cols, a, st);
+    if (rc) return rc;
+    HIPCHK(ctx, hipGetLastError());
+    ctx->mt_applied = a.mt_lpp != nullptr;
+    return OCTO_OK;
+}
+
+}  // namespace octo

@@ -17,7 +17,8 @@
 
 namespace octo {
 
-constexpr int MAXP = OCTO_MAX_PLANETS;
+constexpr int MAXP = OCTO_MAX_PLANETS;                 // planets per dataset (array sizes)
+constexpr int MAXP_T = OCTO_MAX_PLANETS_ALL_KINDS;      // … that the templated kernels (k_main<P>, k_small<P>, k_finish<P>, k_hgca<P>) are compiled for
 constexpr int ROW_STRIDE = 8;   // doubles per observation row record (64 B = one s_load_dwordx16)
 constexpr int WPB = 4;          // waves per k_main block (row split + LDS combine)
 #ifndef OCTO_FIN_G
@@ -1325,8 +1326,7 @@ __device__ __forceinline__ double model_grad_row(int d, int64_t w, int n_planets
 
 // Called by every thread of a k_finish block once the tile's ll, ḡ_elems and ḡ_nuis are in memory (written by other waves of the SAME
 // block: a block-scope fence + barrier make them visible). Wave g forms the gradient rows d = g, g + NG, … for its lane's walker.
-template <int P>
-__device__ __forceinline__ void model_tail(const EvalArgs& a, int64_t w, int grp, int n_waves) {
+__device__ __forceinline__ void model_tail_n(const EvalArgs& a, int64_t w, int grp, int n_waves, int P) {
     __threadfence_block();
     __syncthreads();
     if (w >= a.W) return;
@@ -1343,6 +1343,8 @@ __device__ __forceinline__ void model_tail(const EvalArgs& a, int64_t w, int grp
         a.mt_grad[(int64_t)d * a.mt_ldo + w] = ok ? g : 0.0;
     }
 }
+template <int P>
+__device__ __forceinline__ void model_tail(const EvalArgs& a, int64_t w, int grp, int n_waves) { model_tail_n(a, w, grp, n_waves, P); }
 
 // ------------------------------------------------------------------------------------ finish_tile / k_finish
 // The per-walker tail for one tile of 64 walkers, run by NG waves. It is a latency chain (a tile's partials were written by other CUs;

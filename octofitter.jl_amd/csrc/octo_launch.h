@@ -2,6 +2,9 @@
 // k_small for small ones, and the choice of the compiled kind set. Included only by octo_inst_p{1..4}.hip.
 #pragma once
 #include "octo_host.h"
+#ifndef OCTO_MAINP
+#define OCTO_MAINP 1      // 0: experiments — four planets on k_main<4> as before round 5
+#endif
 
 namespace octo {
 
@@ -108,6 +111,10 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     // keeps the round-2 shape (k_setup -> forward pre-pass -> k_marg -> k_main -> k_finish: the pre-pass and k_marg read `wc`); that path,
     // its non-fused k_main and the k_finish that reads `wc` are compiled for the kind sets with marginalised RV only.
     const bool marg_ds = L::HAS_MARG && (ds->kind_mask & KM_MARG);
+    // Three and more planets, kind sets without marginalised RV / O'Neil: one planet per wave (octo_mainp.h), the partials in k_main's layout
+    // (measured, same box: 4 planets 774 -> 573 µs per step of the probe; 3 planets 345 -> 427: k_main<3> stays)
+    constexpr bool MAINP = OCTO_MAINP && P >= 4 && !(KM & (KM_MARG | KM_ONEIL));
+    constexpr int KMP = mainp_kind_set(KM);      // same partial layout as KM: the sets differ in sep/PA and cor only, or in which RV kinds
     // Occupancy of the GRADIENT variant that is launched (FUSED: more registers, and for several planets more LDS), also for forward-only
     // launches: both then use the same row partition, so the forward value and the value returned with a gradient are the same sum in
     // the same order — bit-identical, like the primal of a ForwardDiff dual. Cached per context (= per device) and variant.
@@ -118,7 +125,8 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         if constexpr (L::HAS_MARG) {
             if (marg_ds) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM, false>, WAVE * WPB, (main_lds_bytes<P, true, NUIS, KM>()));
         }
-        if (!marg_ds) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM, true>, WAVE * WPB, (fused_lds_bytes<P, true, NUIS, KM>()));
+        if constexpr (MAINP) { nb = mainp_occupancy(ctx, NUIS, KMP, P); qe = hipSuccess; }
+        else if (!marg_ds) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM, true>, WAVE * WPB, (fused_lds_bytes<P, true, NUIS, KM>()));
         if (qe != hipSuccess || nb < 1) nb = 2;
         blocks_per_cu = nb;
     }
@@ -129,8 +137,9 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     constexpr bool WIDE_OK = P == 1 && 3 * fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>() <= 160 * 1024 &&
                              fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>() <= 48 * 1024;      // (… and stays under the default dynamic-LDS limit of a launch)
     bool wide = false;
-    const int64_t pkey = plan_key(ctx, a.W, ds->n_rows, blocks_per_cu, (WIDE_OK && !marg_ds) ? &wide : nullptr);
-    int rc0 = get_tasks(ctx, ds, pkey, &tt, NUIS, wide ? 2 * WPB : WPB);
+    const int64_t pkey = MAINP ? plan_key_mainp(ctx, a.W, ds->n_rows, blocks_per_cu)
+                               : plan_key(ctx, a.W, ds->n_rows, blocks_per_cu, (WIDE_OK && !marg_ds) ? &wide : nullptr);
+    int rc0 = get_tasks(ctx, ds, pkey, &tt, NUIS, MAINP ? 1 : (wide ? 2 * WPB : WPB));
     if (rc0) return rc0;
     a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;
     a.obs_range = tt->d_obs_range; a.obs_const = NUIS ? tt->d_obs_const_raw : tt->d_obs_const_pre;
@@ -179,9 +188,17 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
                     launched = true;
                 }
             }
-            if (!launched)
-                hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
-                                   (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+            if constexpr (MAINP) {
+                static_assert(Layout<2, GRAD, NUIS, KMP>::OFF_PL == L::OFF_PL && Layout<2, GRAD, NUIS, KMP>::PL_N == L::PL_N, "k_mainp writes k_finish<P>'s partial layout");
+                rc = launch_mainp(ctx, GRAD, NUIS, KMP, cols, a, st);
+                if (rc) return rc;
+                launched = true;
+            }
+            if constexpr (!MAINP) {
+                if (!launched)
+                    hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                                       (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+            }
             if (e1) HIPCHK(ctx, hipEventRecord(e1, st));
         }
         hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * fin_waves<P, GRAD, NUIS, KM>()), (fin_lds_bytes<P, GRAD, NUIS, KM>()), st, a);

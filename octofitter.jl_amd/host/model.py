@@ -49,13 +49,12 @@ class LogDensityModel:
         self.ln_like = BatchedLnLike(system, θex, device=device, consts=consts)
         fn = self.ln_like
         try:
-            self._build(system, fn, verbosity)
+            self._build(system, fn, sysvars)
         except Exception:
             fn.close()      # a model the library (or this classifier) refuses must not leak the context and dataset created for it
             raise
 
-    def _build(self, system, fn, verbosity):
-        lib = fn.lib
+    def _build(self, system, fn, sysvars):
         # ---- kernel-input sources
         used_circ = set()
         esrc = []

@@ -74,6 +74,25 @@ def oracle_eval(obs_tables, planets, elems, nuis=None, grad=True, active=None, c
     mask = None
     if active is not None:
         mask = np.ascontiguousarray(active, dtype=np.uint8)
+    # The restatement carries at most 64 forward-mode partials per pass (a ForwardDiff chunk): systems of more than ~5 planets have more
+    # inputs than that, so their gradient is gathered in several passes over disjoint sets of active inputs.
+    n_in = elems.shape[0] + (0 if nu is None else nu.shape[0])
+    act = np.ones(n_in, dtype=np.uint8) if mask is None else mask.copy()
+    if nu is None:
+        act[elems.shape[0]:] = 0
+    if grad and int(act.sum()) > 64:
+        idx = np.nonzero(act)[0]
+        for c0 in range(0, idx.size, 64):
+            m = np.zeros(n_in, dtype=np.uint8); m[idx[c0:c0 + 64]] = 1
+            ll_c, ge_c, gn_c = oracle_eval(obs_tables, planets, elems, nuis, grad=True, active=m, consts=consts, n_threads=n_threads)
+            ll = ll_c
+            sel = m[:elems.shape[0]].astype(bool)
+            g_el[sel] = ge_c[sel]
+            if g_nu is not None:
+                seln = m[elems.shape[0]:].astype(bool)
+                g_nu[seln] = gn_c[seln]
+        del keep
+        return ll, g_el, g_nu
     st = lib.octo_oracle_eval(C.byref(consts), obs_arr, len(obs_tables), pl_arr, len(planets),
                               capi._dptr(elems), capi._dptr(nu), W, W, capi._dptr(ll), capi._dptr(g_el), capi._dptr(g_nu),
                               mask.ctypes.data_as(C.POINTER(C.c_uint8)) if mask is not None else None, n_threads)

@@ -233,7 +233,7 @@ def test_julia_ccall_layer_is_thin_and_self_contained():
 
 def test_julia_shim_falls_back_instead_of_throwing():
     """the shim "falls back to the reference closure when any observation is ineligible" — VERDICT r4: `accelerate(system)` on a
-    5-planet system, or on a host without a usable GPU, used to reach octo_dataset_create / octo_ctx_create -> check -> error(), leaking the
+    system of more planets than the kernels take, or on a host without a usable GPU, used to reach octo_dataset_create / octo_ctx_create -> check -> error(), leaking the
     context. Structural check (Julia is not in the image) of the three branches and of the failure paths' clean-up:
       * more planets than OCTO_MAX_PLANETS (the reference unrolls over any number, src/likelihoods/system.jl:116-118): decided on the host
         BEFORE anything is created;

@@ -527,7 +527,8 @@ def test_c_abi_argument_checking_and_strides(pkg, oracle):
         assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
         assert b"octo_dataset_create" in lib.octo_last_error(ctx)
     arr, keep = capi.pack_obs([tab])
-    assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)] * 5), 5, C.byref(ds)) == capi.OCTO_EINVAL
+    n_many = capi.MAX_PLANETS + 1      # (round 5: up to OCTO_MAX_PLANETS = 8 planets on the planet-per-wave kernels)
+    assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)] * n_many), n_many, C.byref(ds)) == capi.OCTO_EINVAL
     rv = dict(kind=2, planet=-1, epoch=t["epoch"], y1=t["ra"], y2=None, s1=t["σ_ra"], s2=None, cor=None)
     arr2, keep2 = capi.pack_obs([rv])
     assert lib.octo_dataset_create(ctx, arr2, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
@@ -737,3 +738,74 @@ def test_thiele_innes_near_face_on_vs_60_digits(oracle):
     ref = np.asarray(case["g_elems"]); sc = np.abs(ref).max(axis=1, keepdims=True)
     e_dev = np.max(np.abs(g_el - ref) / np.maximum(sc, 1e-300)); e_ora = np.max(np.abs(g_o - ref) / np.maximum(sc, 1e-300))
     assert e_dev < 1e-9 and 100 * e_dev < e_ora < 1e-3, (e_dev, e_ora)
+
+
+@pytest.mark.parametrize("P", [4, 5, 6, 8])
+def test_planet_per_wave_kernels_vs_oracle(oracle, P):
+    """k_mainp / k_finishp (octo_mainp.h): ONE planet per wave, the number of planets a run-time block shape — four planets (k_mainp ->
+    k_finish<4>) and five to OCTO_MAX_PLANETS = 8 (k_mainp -> k_finishp; the reference unrolls over any number, src/likelihoods/system.jl:116-118,
+    156-170). A RA/Dec (+ cor) or sep/PA table on every planet, absolute and relative RV, with and without per-walker nuisances, a batch
+    of 200 walkers (ragged last tile, short last chunk of rows) and one of 3 (no small-batch kernel beyond four planets): against the
+    oracle, forward value == value with the gradient, some walkers with the planets' order swapped (the strictly-inner rule) and invalid ones."""
+    gb = _gpu()
+    rng = np.random.default_rng(100 + P)
+    import stress_parity as sp
+    for W in (200, 3):
+        planets = [dict(orbit_kind=0, has_mass=True) for _ in range(P)]
+        elems = np.concatenate([sp.planet_elems(rng, W, 0, 1.5 + 4 * i, 4.5 + 4 * i) for i in range(P)])
+        for p in range(1, P):
+            elems[p * 9 + 6] = elems[6]; elems[p * 9 + 7] = elems[7]      # shared system M, plx
+        if W > 20:
+            elems[0, :15] = elems[9 + 0, :15] * 1.7                       # planet 0 outside planet 1 for some walkers
+            elems[1, 20] = 1.3; elems[9 * (P - 1) + 0, 21] = -2.0; elems[9 * 2 + 5, 22] = np.nan      # invalid walkers
+        obs = []
+        for ip in range(P):
+            n = int(rng.integers(30, 90)) + (1 if ip == 0 else 0)
+            ep = np.sort(50000 + rng.uniform(0, 4000, n))
+            if ip % 3 == 1:
+                obs.append(dict(kind=1, planet=ip, epoch=ep, y1=rng.uniform(-3, 3, n), y2=rng.uniform(100, 900, n), s1=rng.uniform(0.005, 0.03, n), s2=rng.uniform(3, 12, n), cor=None))
+            else:
+                obs.append(dict(kind=0, planet=ip, epoch=ep, y1=rng.normal(0, 300, n), y2=rng.normal(0, 300, n), s1=rng.uniform(3, 12, n), s2=rng.uniform(3, 12, n),
+                                cor=rng.uniform(-0.6, 0.6, n) if ip % 3 == 2 else None))
+        n = 77; ep = np.sort(50000 + rng.uniform(0, 4000, n))
+        obs.append(dict(kind=4, planet=P - 2, epoch=ep, y1=rng.normal(0, 900, n), y2=None, s1=rng.uniform(20, 60, n), s2=None, cor=None))
+        n = 101; ep = np.sort(50000 + rng.uniform(0, 4000, n))
+        obs.append(dict(kind=2, planet=-1, epoch=ep, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None, extra=(ep - 52000.0) / 1000.0))
+        nuis = np.zeros((len(obs) * 3, W))
+        for io in range(P):
+            nuis[io * 3] = rng.uniform(0, 4, W); nuis[io * 3 + 1] = rng.normal(1, 0.01, W); nuis[io * 3 + 2] = rng.normal(0, 0.01, W)
+        nuis[0, : W // 4] = 0.0
+        for io in (P, P + 1):
+            nuis[io * 3] = rng.normal(0, 5, W); nuis[io * 3 + 1] = rng.uniform(0.1, 5, W)
+        nuis[(P + 1) * 3 + 2] = rng.normal(0, 3, W)
+        for nz in (nuis, None):
+            ll, g_el, g_nu = gb.gpu_eval(obs, planets, elems, nz, grad=True)
+            ll_f, _, _ = gb.gpu_eval(obs, planets, elems, nz, grad=False)
+            assert np.array_equal(ll, ll_f), (P, W, "forward-only and gradient launches disagree")
+            ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, elems, nz, grad=True)
+            if W > 20:
+                assert np.isneginf(ll[[20, 21, 22]]).all()
+            _cmp_oracle(f"{P} planets, W = {W}", ll, g_el, g_nu, ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)
+        # only the astrometry tables: the kind set without RV (k_mainp<·, ·, RA/Dec | sep/PA | cor>)
+        ll, g_el, _ = gb.gpu_eval(obs[:P], planets, elems, None, grad=True)
+        ll_o, g_o, _ = oracle.oracle_eval(obs[:P], planets, elems, None, grad=True, active=synth.active_mask(P, P, nuis=False))
+        _cmp_oracle(f"{P} planets astrometry only, W = {W}", ll, g_el, None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
+
+
+def test_more_than_four_planets_refuses_the_other_kinds(pkg):
+    """Beyond OCTO_MAX_PLANETS_ALL_KINDS the library takes relative astrometry and absolute / relative RV only: marginalised RV, the O'Neil
+    prior and HGCA are refused at octo_dataset_create (OCTO_EINVAL — the shim then keeps the system on the reference's path), and so are
+    more than OCTO_MAX_PLANETS planets."""
+    gb = _gpu()
+    capi = pkg.capi
+    ep = np.linspace(50000.0, 50400.0, 12)
+    rv = dict(kind=3, planet=-1, epoch=ep, y1=np.zeros(12), y2=None, s1=np.ones(12), s2=None, cor=None)
+    on = dict(kind=5, planet=0, epoch=ep, y1=np.zeros(12), y2=np.zeros(12), s1=np.ones(12), s2=np.ones(12), cor=None)
+    ok = dict(kind=0, planet=4, epoch=ep, y1=np.zeros(12), y2=np.zeros(12), s1=np.ones(12), s2=np.ones(12), cor=None)
+    pl = lambda n: [dict(orbit_kind=0, has_mass=True) for _ in range(n)]
+    for obs, n in (([rv], 5), ([on], 5), ([ok], capi.MAX_PLANETS + 1)):
+        with pytest.raises(capi.OctoError) as ei:
+            gb.GpuPath(obs, pl(n))
+        assert ei.value.status == capi.OCTO_EINVAL
+    gb.GpuPath([ok], pl(5)).close()
+    gb.GpuPath([rv, on], pl(4)).close()

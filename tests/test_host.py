@@ -233,18 +233,19 @@ def _five_planet_system(pkg, n=5):
 def test_mirror_falls_back_instead_of_throwing(pkg, monkeypatch, caplog):
     """SURVEY.md §8(b) / VERDICT r4 item 2, the Python mirror of `OctofitterHIP.accelerate`: a system the device path cannot take comes back
     UNCHANGED (the caller keeps evaluating it however it did before: in Julia, the reference itself) with the reason attached and one log line —
-    (a) more planets than OCTO_MAX_PLANETS: decided on the host before any library call; (b) no usable HIP device (this container has none;
+    (a) more planets than OCTO_MAX_PLANETS (8): decided on the host before any library call; (b) no usable HIP device (this container has none;
     HIP_VISIBLE_DEVICES="" makes sure): octo_ctx_create's OCTO_ENODEV is caught. The constructors that are ASKED for a device evaluator
     (make_ln_like, LogDensityModel) still raise: the product has no CPU evaluator to fall back to."""
     import logging
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
-    sys5 = _five_planet_system(pkg, 5)
-    θ5 = dict(M=1.2, plx=50.0, planets={f"p{k}": dict(a=3.0 + k, e=0.1, i=1.0, ω=1.0, Ω=2.0, tp=5e4) for k in range(5)})
+    n_too_many = pkg.capi.MAX_PLANETS + 1      # (round 5: the planet-per-wave kernels take up to OCTO_MAX_PLANETS = 8)
+    sys5 = _five_planet_system(pkg, n_too_many)
+    θ5 = dict(M=1.2, plx=50.0, planets={f"p{k}": dict(a=3.0 + k, e=0.1, i=1.0, ω=1.0, Ω=2.0, tp=5e4) for k in range(n_too_many)})
     assert pkg.not_on_device(sys5) is not None and str(pkg.capi.MAX_PLANETS) in pkg.not_on_device(sys5)
     with caplog.at_level(logging.INFO, logger="octofitter_hip"):
         out = pkg.accelerate(sys5, θ5)
-    assert out is sys5 and "5 planets" in sys5.hip_fallback_reason
+    assert out is sys5 and f"{n_too_many} planets" in sys5.hip_fallback_reason
     assert sum("stays on the host path" in r.getMessage() for r in caplog.records) == 1
     with pytest.raises(pkg.capi.OctoError):      # asked for the device evaluator explicitly: the library's refusal (or the missing device) is an error
         pkg.make_ln_like(sys5, θ5)

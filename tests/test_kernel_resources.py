@@ -55,6 +55,12 @@ SEVEN_WAVES = re.compile(r"k_main<1, true, false, (1|33), (true|false), (4|8)>")
 FOUR_PLANETS_TWO_WAVES = re.compile(r"k_main<4, true, (true|false), \d+, (true|false), 4>")
 
 
+# The planet-per-wave kernels (octo_mainp.h, round 5) are held to three (4-6 planets) or four (7-8) waves per SIMD: the nuisance gradient variants
+# then park 13-40 VGPRs around the density phase (the per-table θ_obs and its sin/cos, reloaded once per owned row), the rest nothing. Deliberate:
+# at the next lower occupancy they do not spill and are slower (profiles/r5_mainp_ab.txt); the budget keeps the parking from growing unnoticed.
+PLANET_PER_WAVE = re.compile(r"k_mainp<(true|false), (true|false), \d+, \d+, \d+>")
+
+
 def test_throughput_kernels_do_not_spill(rows):
     bad = []
     for r in rows:
@@ -69,6 +75,12 @@ def test_throughput_kernels_do_not_spill(rows):
                     bad.append((n, r["vgpr_count"], r["vgpr_spill_count"], r["private_segment_fixed_size"]))
             elif r["vgpr_spill_count"] or r["private_segment_fixed_size"]:
                 bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
+        if PLANET_PER_WAVE.fullmatch(n):
+            limit = 48 if ", true, true, " in n[:24] or n.startswith("k_mainp<true, true") else 2
+            if r["vgpr_spill_count"] > limit or r["private_segment_fixed_size"] > 128:
+                bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
+        if n.startswith("k_finishp<") and (r["vgpr_spill_count"] or r["private_segment_fixed_size"]):
+            bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
         if n.startswith("k_finish<"):
             limit = 0 if _planets(n) <= 3 else 16
             if r["vgpr_spill_count"] > limit:
@@ -80,7 +92,8 @@ def test_private_segments_are_dead_spill_slots_or_listed(rows):
     """Whatever still declares a private segment either never touches it (dead slot) or is one of the listed, deliberate cases."""
     for r in rows:
         if r["private_segment_fixed_size"] and r["scratch_instructions"]:
-            assert r["name"].startswith("k_finish<4") or SEVEN_WAVES.fullmatch(r["name"]) or FOUR_PLANETS_TWO_WAVES.fullmatch(r["name"]), \
+            assert r["name"].startswith("k_finish<4") or SEVEN_WAVES.fullmatch(r["name"]) or FOUR_PLANETS_TWO_WAVES.fullmatch(r["name"]) or \
+                PLANET_PER_WAVE.fullmatch(r["name"]), \
                 (r["name"], r["private_segment_fixed_size"], r["scratch_instructions"])
 
 

@@ -597,3 +597,40 @@ def test_gpu_model_many_observation_tables(pkg):
         assert np.all(np.isfinite(lp1)) and np.allclose(lp17, lp1, rtol=1e-12, atol=0)
         assert np.allclose(g17, g1, rtol=1e-9, atol=1e-9 * np.abs(g1).max())
     m1.close(); m17.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_five_planets(pkg, oracle):
+    """The whole callback for a system of FIVE planets (more than the templated kernels are compiled for): θ_t -> elements (k_model_fwd) ->
+    planet-per-wave epoch loop (k_mainp) -> finish with the model's tail (k_finishp: model_tail_n) — log-posterior and ∇θ_t of a batch of 70
+    and of ONE θ_t (no fused small-batch launch beyond four planets) against the oracle's callback; the reference builds such a system with the
+    same unrolled code as any other (src/likelihoods/system.jl:116-118, 156-170)."""
+    import synth
+    rng = np.random.default_rng(23)
+    planets = []
+    for k in range(5):
+        t = np.sort(50000.0 + rng.uniform(0, 3000, 9))
+        tab = dict(epoch=t, ra=rng.normal(0, 200, 9), dec=rng.normal(0, 200, 9), σ_ra=np.full(9, 30.0), σ_dec=np.full(9, 30.0))
+        obs = [pkg.PlanetRelAstromObs(tab, name=f"astrom{k}", variables=pkg.variables(jitter=pkg.LogUniform(0.1, 30.0)) if k == 2 else None)]
+        planets.append(pkg.Planet(name=f"p{k}", basis="Visual{KepOrbit}", observations=obs,
+                                  variables=pkg.variables(a=pkg.LogUniform(1.0 + 3 * k, 3.0 + 3 * k), e=pkg.Uniform(0.0, 0.6), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                                          Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000),
+                                                          mass=pkg.LogUniform(0.5, 30.0))))
+    t = np.sort(50000.0 + rng.uniform(0, 3000, 14))
+    rv = pkg.StarAbsoluteRVObs(dict(epoch=t, rv=rng.normal(0, 40, 14), σ_rv=np.full(14, 6.0)), name="rv",
+                               variables=pkg.variables(offset=pkg.Normal(0, 20), jitter=pkg.LogUniform(0.1, 20.0)))
+    sys_ = pkg.System(name="five", companions=planets, observations=[rv],
+                      variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.05), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.1), lower=0.1)))
+    model = pkg.LogDensityModel(sys_)
+    fn = model.ln_like
+    assert fn.n_planets == 5 and model.D == 2 + 2 + 1 + 5 * 10
+    th = model.link(model.sample_priors(rng, 70))
+    for sub in (th, th[:, :1]):
+        lp, g = model.logdensity_and_gradient(sub)
+        lp_o, g_o = oracle.oracle_model_logpost(fn.obs_tables, fn.planet_desc, model._c_priors, model._c_esrc, model._c_nsrc, sub, grad=True)
+        ok = np.isfinite(lp_o)
+        assert ok.all() and np.all(np.abs(lp - lp_o) <= 1e-11 * np.abs(lp_o))
+        sc = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-300)
+        assert np.all(np.abs(g - g_o) / sc < 1e-9), (np.abs(g - g_o) / sc).max()
+        assert np.array_equal(model(sub), lp)                          # the forward-only callback returns the gradient callback's value
+    model.close()

@@ -275,7 +275,7 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
 // (A persistent kernel pulling (task, tile) items from an atomic queue, with and without a tapered item size, was
 // measured against this grid-mapped launch in the same run and was not faster at any batch size: the hardware
 // dispatcher already backfills freed slots fast enough for an FP64-issue-bound kernel.)
-int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu, bool* wide) {
+int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu, bool* wide, int blocks8_per_cu) {
     const int n_cus = ctx->n_cus;
     if (wide) *wide = false;
     if (ctx->env_chunk > 0) return -ctx->env_chunk;      // OCTO_CHUNK, tuning knob for experiments: uniform rows per wave
@@ -311,7 +311,10 @@ int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_
     // block — twice the waves per SIMD for the row loop, the per-block costs (table fill, orbit-constructor pieces, partials, k_finish) unchanged.
     if (wide && ctx->env_wide >= 0) {
         const double n4 = std::ceil((double)(cols * best_t) / (double)n_cus);
-        *wide = (2.0 * n4 <= (double)blocks_per_cu && n_rows >= (int64_t)best_t * 8 * 32) || (ctx->env_wide > 0 && n4 <= (double)blocks_per_cu);
+        // (n4 blocks per CU in the chosen partition: as eight-wave blocks they need n4 <= the eight-wave kernel's own occupancy, and twice the
+        // waves must still be worth it — the four-wave kernel could hold 2·n4 — while a wave keeps >= 32 rows)
+        *wide = (n4 <= (double)blocks8_per_cu && 2.0 * n4 <= (double)blocks_per_cu && n_rows >= (int64_t)best_t * 8 * 32) ||
+                (ctx->env_wide > 0 && n4 <= (double)blocks8_per_cu);
     }
     return best_t;
 }
@@ -664,8 +667,15 @@ int64_t octo_dataset_n_rows(const octo_dataset* ds) { return ds ? ds->n_rows : -
 
 // The evaluation behind octo_eval_device and octo_model_logpost_device. `sm` non-null: the fused small-batch launch with the
 // standard parameterisation inside (θ_t in, log-posterior out; d_elems / outputs unused), `grad` / `nuis` given by the caller.
+// `mt` non-null: the model's tail for k_finish (octo_model_logpost_device on the throughput kernels); *tail_applied then says whether a k_finish /
+// k_finishp launch carried it (a batch that k_small took has no k_finish: the caller launches k_model_bwd). Both are explicit arguments — rounds
+// 3-4 passed them through mutable context state (mt_req / a flag the caller had to reset), which a new early-return path could have left stale
+// (ADVICE r4). ctx->mt_applied remains only as the launch code's way to report back, reset here on every call.
 static int eval_impl(octo_ctx* ctx, const octo_dataset* ds, const double* d_elems, const double* d_nuis, int64_t ld, int64_t W,
-                     double* d_ll, double* d_g_elems, double* d_g_nuis, hipStream_t st, const SmallModel* sm, bool grad, bool nuis) {
+                     double* d_ll, double* d_g_elems, double* d_g_nuis, hipStream_t st, const SmallModel* sm, bool grad, bool nuis,
+                     const octo_ctx::ModelTail* mt = nullptr, bool* tail_applied = nullptr) {
+    ctx->mt_applied = false;
+    if (tail_applied) *tail_applied = false;
     if (ctx->timing_every > 0 && ctx->ev_used >= 4096) { int rc = drain_timing(ctx); if (rc) return rc; }
     const int64_t ldw = (W + WAVE - 1) / WAVE * WAVE;
     if (ldw > ctx->cap_w) {
@@ -688,18 +698,21 @@ static int eval_impl(octo_ctx* ctx, const octo_dataset* ds, const double* d_elem
     if (ctx->stage_ws_in > 0) { a.ws_in = ctx->stage_ws_in; a.ws_out = ctx->stage_ws_out; }      // octo_eval's walker-major staging (k_small only)
     a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w; a.sctab = ctx->d_sctab;
     a.ll_out = d_ll; a.g_elems = d_g_elems; a.g_nuis = d_g_nuis;
-    if (ctx->mt_req) {
-        a.mt_Jc = ctx->mt.Jc; a.mt_gtp = ctx->mt.gtp; a.mt_esrc = ctx->mt.esrc; a.mt_nsrc = ctx->mt.nsrc; a.mt_glp = ctx->mt.glp; a.mt_lpp = ctx->mt.lpp; a.mt_lp = ctx->mt.lp; a.mt_grad = ctx->mt.grad;
-        a.mt_ld = ctx->mt.ld; a.mt_ldo = ctx->mt.ldo; a.mt_D = ctx->mt.D; a.mt_n_nu = ctx->mt.n_nu;
+    if (mt) {
+        a.mt_Jc = mt->Jc; a.mt_gtp = mt->gtp; a.mt_esrc = mt->esrc; a.mt_nsrc = mt->nsrc; a.mt_glp = mt->glp; a.mt_lpp = mt->lpp; a.mt_lp = mt->lp; a.mt_grad = mt->grad;
+        a.mt_ld = mt->ld; a.mt_ldo = mt->ldo; a.mt_D = mt->D; a.mt_n_nu = mt->n_nu;
     }
     a.c = dev_consts(ctx->consts);
+    int rc;
     switch (ds->n_planets) {
-        case 1: return dispatch1<1>(ctx, ds, a, grad, nuis, sm, st);
-        case 2: return dispatch1<2>(ctx, ds, a, grad, nuis, sm, st);
-        case 3: return dispatch1<3>(ctx, ds, a, grad, nuis, sm, st);
-        case 4: return dispatch1<4>(ctx, ds, a, grad, nuis, sm, st);
-        default: return dispatch_many(ctx, ds, a, grad, nuis, sm, st);
+        case 1: rc = dispatch1<1>(ctx, ds, a, grad, nuis, sm, st); break;
+        case 2: rc = dispatch1<2>(ctx, ds, a, grad, nuis, sm, st); break;
+        case 3: rc = dispatch1<3>(ctx, ds, a, grad, nuis, sm, st); break;
+        case 4: rc = dispatch1<4>(ctx, ds, a, grad, nuis, sm, st); break;
+        default: rc = dispatch_many(ctx, ds, a, grad, nuis, sm, st); break;
     }
+    if (tail_applied) *tail_applied = rc == OCTO_OK && mt != nullptr && ctx->mt_applied;
+    return rc;
 }
 
 int32_t octo_eval_device(octo_ctx* ctx, const octo_dataset* cds, const double* d_elems, const double* d_nuis,
@@ -1211,15 +1224,17 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
     }
     // k_model_fwd shares x, dx, p, dp of every prior and 6 numbers per UniformCircular pair through LDS: 512 B each.
     m->lds_bytes = (int64_t)sizeof(double) * (4 * D + 6 * m->n_circ) * WAVE;
-    if (m->lds_bytes > ctx->max_lds)
+    // (the kernel also declares 1 KB of STATIC LDS — sfin, octo_model.h — which counts against the same per-block limits: ADVICE r4)
+    const int64_t lds_static = 16 * WAVE;
+    if (m->lds_bytes + lds_static > ctx->max_lds)
         return bail(OCTO_EINVAL, "octo_model_create: the model needs more LDS per block than this device has ((4·D + 6·n_circular)·512 B)");
-    if (m->lds_bytes > 48 * 1024 &&
+    if (m->lds_bytes + lds_static > 48 * 1024 &&
         (hipFuncSetAttribute((const void*)k_model_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
          hipFuncSetAttribute((const void*)k_model_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
          hipFuncSetAttribute((const void*)k_model_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
          hipFuncSetAttribute((const void*)k_model_fwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess)) {
         (void)hipGetLastError();
-        if (m->lds_bytes > 64 * 1024) return bail(OCTO_EINVAL, "octo_model_create: cannot raise k_model_fwd's dynamic LDS limit for this model");
+        if (m->lds_bytes + lds_static > 64 * 1024) return bail(OCTO_EINVAL, "octo_model_create: cannot raise k_model_fwd's dynamic LDS limit for this model");
     }
     *out = m;
     return OCTO_OK;
@@ -1301,14 +1316,14 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     }
     HIPCHK(ctx, hipGetLastError());
     // lp = prior + ll and ∇θ_t = Jᵀḡ + ∇prior: inside k_finish (model_tail), tile by tile as the adjoints become known
-    ctx->mt.Jc = a.Jc; ctx->mt.gtp = a.gtp; ctx->mt.esrc = m->d_esrc; ctx->mt.nsrc = m->d_nsrc; ctx->mt.glp = a.glp; ctx->mt.lpp = a.lpp; ctx->mt.lp = d_lp; ctx->mt.grad = d_grad;
-    ctx->mt.ld = L; ctx->mt.ldo = ld; ctx->mt.D = m->D; ctx->mt.n_nu = m->has_nuis ? m->n_nu : 0;
-    ctx->mt_req = true; ctx->mt_applied = false;
+    octo_ctx::ModelTail mt;
+    mt.Jc = a.Jc; mt.gtp = a.gtp; mt.esrc = m->d_esrc; mt.nsrc = m->d_nsrc; mt.glp = a.glp; mt.lpp = a.lpp; mt.lp = d_lp; mt.grad = d_grad;
+    mt.ld = L; mt.ldo = ld; mt.D = m->D; mt.n_nu = m->has_nuis ? m->n_nu : 0;
+    bool tail_applied = false;
     int rc = eval_impl(ctx, m->ds, a.elems, m->has_nuis ? a.nuis : nullptr, L, W, d_ll, grad ? d_gel : nullptr,
-                       (grad && m->has_nuis) ? d_gnu : nullptr, st, nullptr, grad, m->has_nuis);
-    ctx->mt_req = false;
+                       (grad && m->has_nuis) ? d_gnu : nullptr, st, nullptr, grad, m->has_nuis, &mt, &tail_applied);
     if (rc) return rc;
-    if (ctx->mt_applied) return OCTO_OK;
+    if (tail_applied) return OCTO_OK;
     hipLaunchKernelGGL(k_model_bwd, dim3((unsigned)((W + 255) / 256), (unsigned)(d_grad ? m->D : 1)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return OCTO_OK;

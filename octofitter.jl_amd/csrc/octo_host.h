@@ -94,10 +94,10 @@ struct octo_ctx {
     bool flag_request = false, flag_armed = false;
     SmallInline inl = {};                       // n > 0 while a one-θ host-buffer call hands k_small its inputs inside the kernel arguments
     int64_t stage_ws_in = 0, stage_ws_out = 0;  // > 0 while octo_eval hands k_small its walker-major staging buffers
-    // octo_model_logpost_device (big batches): the model's tail for k_finish (EvalArgs::mt_*), valid while mt_req; launch_all sets mt_applied
-    // when a k_finish launch carried it (a batch that k_small took has no k_finish: the caller then launches k_model_bwd)
-    struct ModelTail { const double *Jc = nullptr, *gtp = nullptr, *glp = nullptr, *lpp = nullptr; const octo_source *esrc = nullptr, *nsrc = nullptr; double *lp = nullptr, *grad = nullptr; int64_t ld = 0, ldo = 0; int32_t D = 0, n_nu = 0; } mt;
-    bool mt_req = false, mt_applied = false;
+    // octo_model_logpost_device (big batches): the model's tail for k_finish (EvalArgs::mt_*) travels as an explicit argument of eval_impl;
+    // mt_applied is how the launch code reports that a k_finish launch carried it (reset by eval_impl on every call)
+    struct ModelTail { const double *Jc = nullptr, *gtp = nullptr, *glp = nullptr, *lpp = nullptr; const octo_source *esrc = nullptr, *nsrc = nullptr; double *lp = nullptr, *grad = nullptr; int64_t ld = 0, ldo = 0; int32_t D = 0, n_nu = 0; };
+    bool mt_applied = false;
     // octo_eval_begin .. octo_eval_end: what is still to be waited for and copied out
     struct Pending {
         bool active = false, staged = false, walker_major = false;
@@ -162,7 +162,7 @@ int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
 }
 
 int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis = false, int wpb = WPB);
-int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu, bool* wide = nullptr);
+int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu, bool* wide = nullptr, int blocks8_per_cu = 0);
 int busy(octo_ctx* ctx, const char* what);      // OCTO_EINVAL while an octo_eval_begin of this context is outstanding
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);
 

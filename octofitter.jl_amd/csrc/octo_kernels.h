@@ -1327,7 +1327,12 @@ __device__ __forceinline__ double model_grad_row(int d, int64_t w, int n_planets
 // Called by every thread of a k_finish block once the tile's ll, ḡ_elems and ḡ_nuis are in memory (written by other waves of the SAME
 // block: a block-scope fence + barrier make them visible). Wave g forms the gradient rows d = g, g + NG, … for its lane's walker.
 __device__ __forceinline__ void model_tail_n(const EvalArgs& a, int64_t w, int grp, int n_waves, int P) {
+    // ll_out, ḡ_elems, ḡ_nuis were written by OTHER waves of this block with plain global stores. A workgroup-scope release does not wait for
+    // vmcnt on gfx950 (the stores are only ordered, not completed), which is enough while the waves share one CU's L1 — not in tgsplit mode, where
+    // a block's waves may sit on two CUs. An explicit wait for the stores before the barrier costs nothing at the tail of a block and holds in
+    // both modes (k_small's protocol does the same).
     __threadfence_block();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (w >= a.W) return;
     const double lpp = a.mt_lpp[w], ll = a.ll_out[w];

@@ -134,11 +134,23 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     // one planet, fused launch: a one-round grid may take eight-wave blocks (octo_kernels.h: k_main<…, NWV>; plan_key decides)
     // (… and three of its blocks — plan_key offers it up to that many per CU — must fit in a CU's 160 KB of LDS next to each other: their combine
     // buffer holds seven waves' sums. The gradient layout decides for the forward-only launch too: both take the same partition.)
-    constexpr bool WIDE_OK = P == 1 && 3 * fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>() <= 160 * 1024 &&
-                             fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>() <= 48 * 1024;      // (… and stays under the default dynamic-LDS limit of a launch)
+    constexpr bool WIDE_OK = P == 1 && fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>() <= 48 * 1024;      // (stays under the default dynamic-LDS limit of a launch)
+    // … and the blocks of the one-round grid must be resident at once in their EIGHT-wave form: the occupancy of that instantiation on this
+    // device (512 threads, a combine buffer of seven waves' sums), queried once and cached like the four-wave kernel's (rounds 4's
+    // rule hard-coded three blocks per CU and 160 KB of LDS)
+    int blocks8_per_cu = 0;
+    if constexpr (WIDE_OK) {
+        int& nb8 = ctx->occupancy[(uint32_t)((P << 16) | ((NUIS ? 1 : 0) << 15) | (1 << 13) | KM)];
+        if (nb8 == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_main<P, true, NUIS, KM, true, 2 * WPB>, WAVE * 2 * WPB, (fused_lds_bytes<P, true, NUIS, KM, 2 * WPB>())) != hipSuccess || nb < 1) nb = -1;
+            nb8 = nb;
+        }
+        blocks8_per_cu = nb8 > 0 ? nb8 : 0;
+    }
     bool wide = false;
     const int64_t pkey = MAINP ? plan_key_mainp(ctx, a.W, ds->n_rows, blocks_per_cu)
-                               : plan_key(ctx, a.W, ds->n_rows, blocks_per_cu, (WIDE_OK && !marg_ds) ? &wide : nullptr);
+                               : plan_key(ctx, a.W, ds->n_rows, blocks_per_cu, (WIDE_OK && !marg_ds && blocks8_per_cu > 0) ? &wide : nullptr, blocks8_per_cu);
     int rc0 = get_tasks(ctx, ds, pkey, &tt, NUIS, MAINP ? 1 : (wide ? 2 * WPB : WPB));
     if (rc0) return rc0;
     a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;

@@ -634,3 +634,37 @@ def test_gpu_model_five_planets(pkg, oracle):
         assert np.all(np.abs(g - g_o) / sc < 1e-9), (np.abs(g - g_o) / sc).max()
         assert np.array_equal(model(sub), lp)                          # the forward-only callback returns the gradient callback's value
     model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_small_batch_without_the_fused_launch(pkg, oracle):
+    """A model whose observations outgrow the fused small-batch launch (70 tables, five of them with a jitter variable: 210 nuisance inputs against
+    the 192 the one-θ launch shares through LDS — fused_ok is false) still takes SMALL batches through the small-batch likelihood kernel, with the
+    model transform ahead of it (k_model_fwd) and its tail behind it (k_model_bwd): the route on which no k_finish launch carries the model's
+    tail, i.e. the `tail applied == false` branch of octo_model_logpost_device (ADVICE r4 asked for a test of it). One θ_t, three, and a batch
+    of 70 on the throughput kernels (tail inside k_finish) against the oracle's callback."""
+    rng = np.random.default_rng(29)
+    n_tab, per = 70, 2
+    ep = np.sort(50000 + rng.uniform(0, 3000, n_tab * per))
+    likes = []
+    for k in range(n_tab):
+        sl = slice(k * per, (k + 1) * per)
+        tab = dict(epoch=ep[sl], ra=rng.normal(-480, 30, per), dec=rng.normal(40, 60, per), σ_ra=np.full(per, 10.0), σ_dec=np.full(per, 12.0))
+        likes.append(pkg.PlanetRelAstromObs(tab, name=f"t{k}", variables=pkg.variables(jitter=pkg.LogUniform(0.1, 30.0)) if k % 14 == 3 else None))
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=likes,
+                   variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                           Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+    model = pkg.LogDensityModel(pkg.System(name="many", companions=[b], observations=[],
+                                variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))))
+    fn = model.ln_like
+    assert model.D == 11 + 5
+    th = model.link(model.sample_priors(np.random.default_rng(3), 70))
+    lp_o, g_o = oracle.oracle_model_logpost(fn.obs_tables, fn.planet_desc, model._c_priors, model._c_esrc, model._c_nsrc, th, grad=True)
+    sc = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-300)
+    for W in (1, 3, 70):
+        sub = th[:, :W]
+        lp, g = model.logdensity_and_gradient(sub)
+        assert np.all(np.isfinite(lp)) and np.all(np.abs(lp - lp_o[:W]) <= 1e-11 * np.abs(lp_o[:W])), W
+        assert np.all(np.abs(g - g_o[:, :W]) / sc < 1e-9), (W, (np.abs(g - g_o[:, :W]) / sc).max())
+        assert np.array_equal(model(sub), lp)
+    model.close()

@@ -27,6 +27,10 @@ run ofti $B --workload ofti
 run logpost $B --workload logpost
 run three_planet python $ROOT/tools/multi_planet_steps.py 3 60
 run four_planet python $ROOT/tools/multi_planet_steps.py 4 60
+run five_planet python $ROOT/tools/multi_planet_steps.py 5 40
+run eight_planet python $ROOT/tools/multi_planet_steps.py 8 30
+run shard_1250 $B --steps 100 --walkers 1250
+run shard_2500 $B --steps 100 --walkers 2500
 run small_w1 python $ROOT/tools/small_batch_one.py 10000 1 600
 run small_w512 python $ROOT/tools/small_batch_one.py 10000 512 300
 cd $ROOT

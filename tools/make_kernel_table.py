@@ -49,8 +49,11 @@ def counters(con, sub, grid):
 
 
 def collect(wdir, subs):
+    import re
     res = {s: {} for s in subs}
     for db in sorted(glob.glob(f"{wdir}/**/*.db", recursive=True)):
+        if re.search(r"/w\d+/", db[len(str(wdir)):]):      # the round directory also holds the shard shapes' passes (w5000, w2500, w1250): not config 3
+            continue
         con = sqlite3.connect(db)
         for s in subs:
             try:

@@ -279,7 +279,9 @@ function accelerate(system::System; device::Integer=0, n_contexts::Integer=Threa
     try
         ctx, ds, entries, columns = _upload(system, eligible, θs; device)
     catch e
-        e isa OctoError || rethrow()
+        # OctoError: the library's refusal (no device, a kind set it does not take for this many planets, …); ErrorException: this shim's own
+        # (an orbit type that is not on the HIP path, `_orbit_kind`)
+        (e isa OctoError || e isa ErrorException) || rethrow()
         verbosity >= 1 && @info "OctofitterHIP: $(sprint(showerror, e)) — the system stays on the reference's CPU path"
         return system
     end

@@ -258,7 +258,7 @@ def test_julia_shim_falls_back_instead_of_throwing():
     # accelerate: the three branches, each returning `system`
     acc = re.search(r"function accelerate\(system::System;.*?\n(.*?)\n    n_in = ", main, re.S).group(1)
     assert re.search(r"why = _not_on_device\(system\)\s+if why !== nothing.*?@info.*?return system\s+end", acc, re.S)
-    assert re.search(r"try\s+ctx, ds, entries, columns = _upload\(.*?catch e\s+e isa OctoError \|\| rethrow\(\).*?@info.*?return system\s+end", acc, re.S)
+    assert re.search(r"try\s+ctx, ds, entries, columns = _upload\(.*?catch e\s.*?\(e isa OctoError \|\| e isa ErrorException\) \|\| rethrow\(\).*?@info.*?return system\s+end", acc, re.S)
     slots = re.search(r"for _ in 2:max\(1, n_contexts\)(.*?)\n    end\n", main, re.S).group(1)
     assert "octo_ctx_destroy(c)" in slots and "e isa OctoError || rethrow()" in slots and "break" in slots
     # HIPLogDensityModel: returns the reference's model

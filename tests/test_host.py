@@ -263,3 +263,25 @@ def test_mirror_falls_back_instead_of_throwing(pkg, monkeypatch, caplog):
     with pytest.raises(pkg.capi.OctoError) as ei:
         pkg.make_ln_like(sys1, θ1)
     assert ei.value.status == pkg.capi.OCTO_ENODEV
+
+
+def test_bench_defaults_to_strong_scaling_for_the_contracted_workload(monkeypatch):
+    """VERDICT r4 item 1, the part a CPU can check: `bench.py --gpus N` splits the SAME --walkers over the ranks by default for the walker-sharded
+    workloads (SURVEY §8d "Scaling runs"), the per-GPU-shaped workloads keep weak scaling, and asking for a strong split of those is an error."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    def parsed(*argv):
+        monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+        return bench.parse()
+    for wl in ("grad", "fwd", "nuis"):
+        a = parsed("--gpus", "8", "--workload", wl)
+        assert a.scaling == "strong" and a.walkers == 10_000 and a.gpus == 8
+    assert parsed().scaling == "strong"
+    assert parsed("--scaling", "weak").scaling == "weak"
+    for wl, w in (("pt", 8192), ("two_planet", 10_000), ("ofti", 10_000), ("logpost", 10_000)):
+        a = parsed("--workload", wl)
+        assert a.scaling == "weak" and a.walkers == w
+    with pytest.raises(SystemExit):
+        parsed("--workload", "pt", "--scaling", "strong")

@@ -268,7 +268,7 @@ def test_mirror_falls_back_instead_of_throwing(pkg, monkeypatch, caplog):
 def test_bench_defaults_to_strong_scaling_for_the_contracted_workload(monkeypatch):
     """VERDICT r4 item 1, the part a CPU can check: `bench.py --gpus N` splits the SAME --walkers over the ranks by default for the walker-sharded
     workloads (SURVEY §8d "Scaling runs"), the per-GPU-shaped workloads keep weak scaling, and asking for a strong split of those is an error."""
-    import importlib.util
+    import importlib.util, sys
     spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)

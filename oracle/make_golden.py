@@ -554,9 +554,88 @@ def trend_cases():
     print("wrote", p, p.stat().st_size, "bytes")
 
 
+def dense_cases():
+    """tests/golden/dense.json — round 5's two new code paths against 60 digits.
+    F14: DENSE tables (half-day and one-day cadence: rows sorted by epoch at construction, src/likelihoods/relative-astrometry.jl:46-47,
+    rv-relative.jl:85-86) — what k_main's warm-started row loop runs on: each Kepler solve starts from the previous row's solution, with a
+    wave-uniform fallback to the Markley starter. Walkers whose periods still pass the wave's entry test, eccentricities to 0.93, periastron
+    passages inside the table (where the fallback fires). The root is unique, so the 60-digit values are those of ANY correct solver.
+    F15: a SIX-planet system (the reference unrolls over any number of planets, src/likelihoods/system.jl:116-118, 156-170): RA/Dec, sep/PA and cor
+    tables on four of the planets, relative RV on one, absolute RV, per-walker nuisances — the planet-per-wave kernels (k_mainp, k_finishp)."""
+    rng = np.random.default_rng(20260929 + 71)
+    out = []
+    # ---- F14a: RA/Dec, half-day cadence
+    W = 6
+    n = 120
+    t = 50000.0 + 0.5 * np.arange(n)
+    def walkers(a_lo, a_hi, mass=False):
+        a = np.exp(rng.uniform(np.log(a_lo), np.log(a_hi), W)); e = rng.uniform(0.0, 0.93, W)
+        el = np.stack([a, e, np.arccos(rng.uniform(-1, 1, W)), rng.uniform(0, 6.28, W), rng.uniform(0, 6.28, W),
+                       50000.0 + rng.uniform(5.0, 55.0, W), rng.normal(1.2, 0.05, W), rng.normal(50.0, 0.5, W), rng.uniform(1, 20, W) if mass else np.zeros(W)])
+        el[1, 0] = 0.9; el[0, 0] = a_lo * 1.05      # the fastest orbit, eccentric, periastron inside the table
+        el[1, 1] = 0.0
+        return el
+    el = walkers(0.75, 20.0)
+    ra, dec = rng.normal(0, 200, n), rng.normal(0, 200, n)
+    out.append(run_case("F14_dense_radec_half_day", [VIS], [astrom(0, t, ra, dec, [5.0] * n, [7.0] * n)], el, None,
+                        "RA/Dec table at half-day cadence, no nuisances: k_main<1, ·, false, RADEC> warm loop"))
+    # ---- F14b: RA/Dec + cor with per-walker jitter / platescale / northangle, one-day cadence
+    n = 90
+    t = 50000.0 + 1.0 * np.arange(n)
+    el = walkers(1.2, 25.0)
+    nu = col(rng.uniform(0.5, 4, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W))
+    nu[0, 2] = 0.0
+    out.append(run_case("F14_dense_radec_cor_nuisances", [VIS], [astrom(0, t, rng.normal(0, 200, n), rng.normal(0, 200, n), rng.uniform(3, 9, n), rng.uniform(3, 9, n),
+                                                                          cor=rng.uniform(-0.6, 0.6, n))], el, nu,
+                        "RA/Dec + cor at one-day cadence with jitter / platescale / northangle: k_main<1, ·, true, RADEC|COR> warm loop"))
+    # ---- F14c: sep/PA + relative RV + absolute RV, no nuisances (the widest kind set with a warm loop), one-day cadence
+    n = 70
+    t = 50000.0 + 1.0 * np.arange(n)
+    el = walkers(1.2, 25.0, mass=True)
+    ra, dec = rng.normal(0, 300, n), rng.normal(0, 300, n)
+    obs = [astrom(0, t, np.arctan2(ra, dec), np.hypot(ra, dec), [0.02] * n, [6.0] * n, seppa=True),
+           rvtab("RV_REL", 0, t[::2], rng.normal(0, 800, n // 2), [50.0] * (n // 2)),
+           rvtab("RV_ABS", -1, t, rng.normal(0, 30, n), [3.0] * n)]
+    out.append(run_case("F14_dense_seppa_rv", [VISM], obs, el, None, "sep/PA + relative RV + absolute RV at one-day cadence, no nuisances: warm loops of both row bodies"))
+    # ---- F15: six planets
+    P = 6
+    W = 4
+    planets = [VISM] * P
+    els = []
+    for p in range(P):
+        a = rng.uniform(1.5 + 4 * p, 4.5 + 4 * p, W)
+        els.append(np.stack([a, rng.uniform(0, 0.7, W), np.arccos(rng.uniform(-1, 1, W)), rng.uniform(-7, 7, W), rng.uniform(-7, 7, W),
+                             50000 + rng.uniform(-3000, 3000, W), np.zeros(W), np.zeros(W), rng.uniform(1, 30, W)]))
+    el6 = np.concatenate(els)
+    Mt, plx = rng.uniform(0.9, 1.5, W), rng.uniform(20, 60, W)
+    for p in range(P):
+        el6[p * 9 + 6] = Mt; el6[p * 9 + 7] = plx
+    el6[0, 0] = el6[9, 0] * 1.5      # planet 0 outside planet 1 for one walker (the strictly-inner rule)
+    obs = []
+    for p, kind in ((0, "radec"), (1, "seppa"), (3, "cor"), (5, "radec")):
+        m = 9
+        ep = np.sort(50000 + rng.uniform(0, 4000, m))
+        ra, dec = rng.normal(0, 300, m), rng.normal(0, 300, m)
+        if kind == "seppa": obs.append(astrom(p, ep, np.arctan2(ra, dec), np.hypot(ra, dec), [0.03] * m, rng.uniform(3, 12, m), seppa=True))
+        else: obs.append(astrom(p, ep, ra, dec, rng.uniform(3, 12, m), rng.uniform(3, 12, m), cor=rng.uniform(-0.7, 0.7, m) if kind == "cor" else None))
+    ep = np.sort(50000 + rng.uniform(0, 4000, 11))
+    obs.append(rvtab("RV_REL", 4, ep, rng.normal(0, 500, 11), rng.uniform(20, 80, 11)))
+    ep = np.sort(50000 + rng.uniform(0, 4000, 13))
+    obs.append(rvtab("RV_ABS", -1, ep, rng.normal(0, 30, 13), rng.uniform(1, 8, 13)))
+    nu = np.zeros((len(obs) * 3, W))
+    for io in range(4):
+        nu[io * 3] = rng.uniform(0, 4, W); nu[io * 3 + 1] = rng.normal(1, 0.01, W); nu[io * 3 + 2] = rng.normal(0, 0.02, W)
+    for io in (4, 5):
+        nu[io * 3] = rng.normal(0, 10, W); nu[io * 3 + 1] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+    out.append(run_case("F15_six_planets", planets, obs, el6, nu, "six planets: RA/Dec, sep/PA, cor tables, relative and absolute RV, per-walker nuisances (k_mainp, k_finishp)"))
+    p = ROOT / "tests" / "golden" / "dense.json"
+    p.write_text(json.dumps(dict(consts=C, cases=out, generator="oracle/make_golden.py dense_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(ROOT / "oracle"))
-    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only", "--kep-only", "--trend-only") if f in sys.argv]
+    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only", "--kep-only", "--trend-only", "--dense-only") if f in sys.argv]
     if not only:
         main()
     if not only or "--ofti-only" in only:
@@ -573,3 +652,5 @@ if __name__ == "__main__":
         kep_cases()
     if not only or "--trend-only" in only:
         trend_cases()
+    if not only or "--dense-only" in only:
+        dense_cases()

@@ -54,6 +54,8 @@ def golden():
         g["cases"] = g["cases"] + json.load(f)["cases"]
     with open(ROOT / "tests" / "golden" / "trend.json") as f:     # F13: RV tables with a trend_function (oracle/make_golden.py --trend-only)
         g["cases"] = g["cases"] + json.load(f)["cases"]
+    with open(ROOT / "tests" / "golden" / "dense.json") as f:     # F14: dense tables (k_main's warm-started row loop); F15: six planets (k_mainp) (--dense-only)
+        g["cases"] = g["cases"] + json.load(f)["cases"]
     return g
 
 

@@ -114,7 +114,7 @@ def main():
         ref = ob.oracle_eval(obs, planets, el, nz, grad=True, n_threads=0)
         same, e_ll, e_g = errs(warm, ref)
         _, c_ll, c_g = errs(warm, tuple(x if x is not None else None for x in cold)) if np.isfinite(cold[0]).any() else (True, 0.0, 0.0)
-        n_warm_ran += int(not np.array_equal(warm[0], cold[0]))
+        n_warm_ran += int(not (np.array_equal(warm[0], cold[0]) and np.array_equal(warm[1], cold[1], equal_nan=True)))
         bad = (not same) or (not np.array_equal(warm[0], warm_f[0])) or e_ll > 1e-9 or e_g > 2e-8 or c_ll > 1e-11 or c_g > 1e-9
         fails += int(bad)
         if bad: print(f"FAIL warm system {i}: same={same} fwd==grad {np.array_equal(warm[0], warm_f[0])} vs oracle {e_ll:.2e} {e_g:.2e} vs cold {c_ll:.2e} {c_g:.2e}", flush=True)

@@ -323,9 +323,13 @@ int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_
 // (one per walker, each deriving P orbits and running the finish), the throughput kernels' with three launches: measured
 // crossover at W·P ≈ 400-1000 (tools/latency_vs_w.py, tools/latency_multi.py). An HGCA table adds blocks to the same launch
 // (one input direction per wave) for W <= 16, the k_hgca launch ahead of it otherwise.
-bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W) {
+// model: the whole callback (octo_model_logpost*). There the alternative is THREE launches (k_model_fwd, k_main, k_finish), so the fused launch pays for
+// longer: single-planet D = 11 callback at 768 θ_t 40-41 µs fused against 43 on the three-launch route, 46-48 against 45 at 1 024
+// (tools/r5_midsize_small.py) — the limit there is ctx->small_w_model (768 unless the caller set a limit of its own).
+bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W, bool model) {
     if (ds->n_planets > MAXP_T) return false;      // k_small<P> is compiled for 1 … 4 planets
-    if (!(W * ds->n_planets <= ctx->small_w && W <= SMALL_W)) return false;
+    const int limit = (model && ds->n_planets == 1) ? std::max(ctx->small_w, ctx->small_w_model) : ctx->small_w;
+    if (!(W * ds->n_planets <= limit && W <= SMALL_W)) return false;
     if (ds->kind_mask & KM_MARG)      // a marginalised-RV table is ONE block's work there (two passes): not for a very long table
         for (int o = 0; o < ds->n_obs; ++o)
             if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG && ds->h_obs[o].n > SMALL_MARG_ROWS) return false;
@@ -489,6 +493,7 @@ const uint64_t* octo_debug_small_trace(octo_ctx* ctx) { return ctx ? ctx->h_flag
 int32_t octo_ctx_set_small_batch(octo_ctx* ctx, int32_t max_walkers) {
     if (!ctx || max_walkers < 0) return OCTO_EINVAL;
     ctx->small_w = std::min<int>(max_walkers, SMALL_W);
+    ctx->small_w_model = 0;      // an explicit limit holds for the model callback too
     return OCTO_OK;
 }
 
@@ -1258,7 +1263,7 @@ int32_t octo_model_logpost_device(octo_ctx* ctx, octo_model* m, const double* d_
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st;
     { int rcs = use_stream(ctx, hip_stream, &st); if (rcs) return rcs; }
-    if (small_eligible(ctx, m->ds, W) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
+    if (small_eligible(ctx, m->ds, W, true) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
         // one launch: θ_t -> priors, elements, likelihood, ∇θ_t inside k_small<MODEL> (octo_small.h)
         SmallModel sm;
         std::memset(&sm, 0, sizeof(sm));
@@ -1339,7 +1344,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     hipStream_t st;
     { int rcs = use_stream(ctx, OCTO_STREAM_CTX, &st); if (rcs) return rcs; }
     const int64_t n_in = (int64_t)m->D * ldd, n_out = (int64_t)(grad_out ? m->D + 1 : 1) * ldd;
-    if (small_eligible(ctx, m->ds, W) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W)) && W <= ctx->mapped_w) {
+    if (small_eligible(ctx, m->ds, W, true) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W)) && W <= ctx->mapped_w) {
         // one θ_t per call (NUTS): the fused launch on mapped pinned buffers, no copy engine (see octo_eval) — θ_t of one walker
         // contiguous on the way in, [lp | ∇θ_t] on the way out, completion by flag
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))
@@ -1373,7 +1378,7 @@ int32_t octo_model_logpost(octo_ctx* ctx, octo_model* m, const double* theta_t, 
     if (rc) return rc;
     rc = grow(ctx, m->d_res, m->cap_res, (int64_t)(m->D + 1) * ldd);
     if (rc) return rc;
-    if (small_eligible(ctx, m->ds, W) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
+    if (small_eligible(ctx, m->ds, W, true) && m->fused_ok && (m->ds->n_hgca == 0 || hgca_in_small(W))) {
         // the fused launch beyond the mapped-input range: k_stage_in brings θ_t walker-major into device memory, [lp | ∇θ_t] come
         // back through the mapped buffer + flags (see octo_eval)
         if (!grow_pinned(ctx->h_in, ctx->cap_hin, n_in) || !grow_pinned(ctx->h_out, ctx->cap_hout, n_out))

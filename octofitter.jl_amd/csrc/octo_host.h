@@ -108,6 +108,7 @@ struct octo_ctx {
     // parallel tempering over RCCL (octo_comm.hip)
     void* comm = nullptr;                       // ncclComm_t
     int comm_rank = 0, comm_world = 1;
+    int small_w_model = 768;                    // … and single-planet whole-callback batches (octo_model_logpost*) up to this size: three launches is what they would pay otherwise
     int small_w = OCTO_SMALL_BATCH_DEFAULT;     // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
     // experiment knobs, read from the environment ONCE at context creation (0 = not set): a getenv per call is a linear scan of the
     // environment on a 12 µs path
@@ -164,7 +165,7 @@ int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
 int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis = false, int wpb = WPB);
 int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu, bool* wide = nullptr, int blocks8_per_cu = 0);
 int busy(octo_ctx* ctx, const char* what);      // OCTO_EINVAL while an octo_eval_begin of this context is outstanding
-bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W);
+bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W, bool model = false);
 
 // Launch of one evaluation for a dataset with P planets (octo_launch.h; instantiated in octo_inst_p<P>.hip).
 template <int P>

@@ -668,3 +668,27 @@ def test_gpu_model_small_batch_without_the_fused_launch(pkg, oracle):
         assert np.all(np.abs(g - g_o[:, :W]) / sc < 1e-9), (W, (np.abs(g - g_o[:, :W]) / sc).max())
         assert np.array_equal(model(sub), lp)
     model.close()
+
+
+@pytest.mark.gpu
+def test_gpu_model_fused_launch_up_to_768_single_planet_callbacks(pkg, oracle, model_golden):
+    """Round 5: single-planet whole-callback batches take the fused launch (k_small<MODEL>) up to 768 θ_t — three launches is what they would pay
+    otherwise (tools/r5_midsize_small.py: 40 µs against 43 at 768, 46-48 against 45 at 1 024); likelihood-only batches keep the 512 limit. 700 θ_t
+    through the library's default route and forced onto the throughput kernels: the same log-posterior and gradient to rounding, and the oracle's."""
+    case = model_golden[0]
+    model = pkg.LogDensityModel(_reference_test_model(pkg))
+    fn = model.ln_like
+    th = model.link(model.sample_priors(np.random.default_rng(41), 700))
+    lp, g = model.logdensity_and_gradient(th)
+    fn._check(fn.lib.octo_ctx_set_small_batch(fn._ctx, 0), "set")      # throughput kernels
+    lp_t, g_t = model.logdensity_and_gradient(th)
+    obs, planets = _tables(case)
+    lp_o, g_o = oracle.oracle_model_logpost(obs, planets, model._c_priors, model._c_esrc, None, th, n_threads=0)
+    ok = np.isfinite(lp_o)
+    assert ok.sum() > 600 and np.array_equal(np.isfinite(lp), ok) and np.array_equal(np.isfinite(lp_t), ok)
+    for a, ga in ((lp, g), (lp_t, g_t)):
+        assert np.all(np.abs(a[ok] - lp_o[ok]) <= 1e-11 * np.abs(lp_o[ok]))
+        sc = np.maximum(np.abs(g_o[:, ok]).max(axis=1, keepdims=True), 1e-300)
+        assert np.all(np.abs(ga[:, ok] - g_o[:, ok]) / sc < 1e-9)
+    assert not np.array_equal(lp, lp_t) or not np.array_equal(g, g_t), "both calls took the same route"
+    model.close()

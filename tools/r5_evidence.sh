@@ -14,7 +14,7 @@ python -m pytest tests -q -m gpu > gpurun_out/${tag}_gputests.txt 2>&1
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 python bench.py --gpus 2 --backend gloo --device 0 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_2rank_gloo_dryrun.json 2> gpurun_out/${tag}_2rank.err
 for w in fwd nuis two_planet logpost ofti pt; do python bench.py --workload $w --steps 100 --no-extras --no-cpu-baseline 2>/dev/null | cut -c1-420; done > gpurun_out/${tag}_workloads.txt
-{
+[ -n "${OCTO_SKIP_SWEEPS:-}" ] || {
   python tests/stress_round5.py 400 601 2>&1 | tail -4
   OCTO_TEST_POISON_LDS=nan python tests/stress_round5.py 200 602 2>&1 | tail -4
   export OCTO_TEST_MAX_P=4
@@ -27,4 +27,4 @@ for w in fwd nuis two_planet logpost ofti pt; do python bench.py --workload $w -
   done
 } > gpurun_out/${tag}_stress_sweeps.txt 2>&1
 tail -3 gpurun_out/${tag}_gputests.txt | cut -c1-200
-cat gpurun_out/${tag}_stress_sweeps.txt | cut -c1-300
+[ -n "${OCTO_SKIP_SWEEPS:-}" ] || cat gpurun_out/${tag}_stress_sweeps.txt | cut -c1-300

@@ -1,0 +1,166 @@
+"""Pins of the oracle against THIRD-PARTY implementations that are in the image (scipy): not the reference — Julia cannot run here, DESIGN.md §1 —
+but code and constants written by someone else, so that a slip in a recalled constant, in a density's normalisation or in the bivariate normal's
+form cannot hide behind two in-house derivations that share the recollection. What these tests can NOT pin is a convention of the reference
+itself (which bijector a bounded prior gets, the sign of an offset): that stays with tools/julia_crosscheck.jl.
+
+  constants      scipy.constants (CODATA / IAU): au, the Julian year; the parsec only enters through rad2as / pc2au
+  priors         scipy.stats logpdf of Uniform, LogUniform (reciprocal), Normal, truncated Normal and the sine law, + the log-Jacobian of the
+                 bijector written out here (Bijectors' logit-type map of a two-sided support, the log map of a lower-bounded one: src/variables.jl:1449-1493)
+  MvNormal       scipy.stats.multivariate_normal.logpdf of the row covariance [[σ1², ρσ1σ2], [ρσ1σ2, σ2²]] (src/likelihoods/relative-astrometry.jl:241-252)
+  Kepler         scipy.optimize.brentq on M = E − e sin E against octo_oracle_orbitsolve's position (the solver row a4 of SURVEY.md §8)
+"""
+import numpy as np
+import pytest
+
+scipy = pytest.importorskip("scipy")
+import scipy.constants as sc
+import scipy.optimize
+import scipy.stats as ss
+
+
+def test_constants_vs_scipy(oracle):
+    c = oracle.oracle_consts()
+    assert c.au2m == sc.au                                                   # IAU 2012 B2: exact
+    assert abs(c.sec2year_julian * sc.Julian_year - 1.0) < 1e-15             # 1 / (365.25 · 86400)
+    assert c.year2day_julian == sc.Julian_year / sc.day
+    # Gaussian year from the IAU nominal GM☉ = 1.3271244e20 m³ s⁻² (Resolution B3 2015) and scipy's au: 2π√(au³/GM☉)
+    gm_sun = 1.3271244e20
+    assert abs(c.kepler_year_to_julian_day - 2 * np.pi * np.sqrt(sc.au ** 3 / gm_sun) / sc.day) < 1e-10
+    # the parsec and the radian-to-arcsecond factor are both rounded to 206265 in PlanetOrbits; only their ratio reaches an observable (mas per AU per mas of parallax)
+    assert c.rad2as / c.pc2au == 1.0
+    assert abs(c.pc2au / (sc.parsec / sc.au) - 1.0) < 1e-6 and abs(c.rad2as / np.degrees(1.0) / 3600.0 - 1.0) < 1e-6
+    # Jupiter mass in solar masses: ratio of the IAU 2015 nominal mass parameters
+    assert abs(c.mjup2msol - 1.2668653e17 / gm_sun) < 1e-18
+
+
+def _prior_only_lp(oracle, prior, theta_t):
+    """lp of a model whose only term is ONE prior: a planet without observation tables, every element a constant but tp."""
+    PR = dict(kind=prior[0], p0=prior[1], p1=prior[2], lo=prior[3], hi=prior[4])
+    esrc = [dict(kind=0, i0=0, i1=0, flags=0, value=v) for v in (10.0, 0.1, 0.5, 0.3, 0.2, 50000.0, 1.0, 50.0, 0.0)]
+    esrc[5] = dict(kind=1, i0=0, i1=0, flags=0, value=0.0)      # tp = θ[0]: any real number is a valid epoch of periastron
+    th = np.asarray(theta_t, dtype=np.float64)[None, :]
+    return oracle.oracle_model_logpost([], [dict(orbit_kind=0, has_mass=False)], oracle.make_priors([PR]), oracle.make_sources(esrc), None, th)
+
+
+def _logistic(y):
+    return 1.0 / (1.0 + np.exp(-y))
+
+
+def test_prior_densities_vs_scipy(oracle):
+    """logpdf_with_trans(prior, invlink(y), true) = logpdf(x) + log|dx/dy| (src/variables.jl:1205-1236, 1449-1493) for every prior kind of the C ABI,
+    the density from scipy.stats, the Jacobian of the bijector spelled out, its derivative by central differences of the scipy value."""
+    y = np.linspace(-6.0, 6.0, 25)
+    two_sided = lambda lo, hi, y: (lo + (hi - lo) * _logistic(y), np.log(hi - lo) + np.log(_logistic(y)) + np.log1p(-_logistic(y)))
+
+    def on(lo, hi, logpdf):      # y -> logpdf(x(y)) + log|dx/dy| under the bijector of the support (lo, hi)
+        def f(y):
+            if lo is not None and hi is not None: x, lj = two_sided(lo, hi, y)
+            elif lo is not None: x, lj = lo + np.exp(y), y                  # lower bound only: log link
+            elif hi is not None: x, lj = hi - np.exp(y), y                  # upper bound only
+            else: x, lj = y, 0.0                                            # identity
+            return logpdf(x) + lj
+        return f
+    cases = [((0, 2.0, 7.5, None, None), on(2.0, 7.5, ss.uniform(2.0, 5.5).logpdf)),
+             ((1, 0.1, 300.0, None, None), on(0.1, 300.0, ss.loguniform(0.1, 300.0).logpdf)),
+             ((2, 1.3, 0.4, None, None), on(None, None, ss.norm(1.3, 0.4).logpdf)),
+             ((3, 1.2, 0.4, 0.1, None), on(0.1, None, ss.truncnorm((0.1 - 1.2) / 0.4, np.inf, 1.2, 0.4).logpdf)),
+             ((3, 1.2, 0.4, 0.5, 2.0), on(0.5, 2.0, ss.truncnorm((0.5 - 1.2) / 0.4, (2.0 - 1.2) / 0.4, 1.2, 0.4).logpdf)),
+             ((3, 1.2, 0.4, None, 3.0), on(None, 3.0, ss.truncnorm(-np.inf, (3.0 - 1.2) / 0.4, 1.2, 0.4).logpdf)),
+             ((4, 0.0, 0.0, None, None), on(0.0, np.pi, lambda x: np.log(np.sin(x) / 2.0)))]      # Sine(): pdf sin(x)/2 on (0, π), src/distributions.jl:14-39
+    for prior, f in cases:
+        ref = f(y)
+        lp, g = _prior_only_lp(oracle, prior, y)
+        assert np.all(np.abs(lp - ref) <= 1e-12 * np.maximum(1.0, np.abs(ref))), (prior, np.max(np.abs(lp - ref)))
+        h = 1e-5
+        gnum = (f(y + h) - f(y - h)) / (2 * h)                              # central differences of the scipy value
+        assert np.all(np.abs(g[0] - gnum) <= 1e-7 * np.maximum(1.0, np.abs(gnum))), (prior, np.max(np.abs(g[0] - gnum) / np.maximum(1.0, np.abs(gnum))))
+    # the sine law integrates to one (the normalisation 1/2 is the only number in it)
+    xs = np.linspace(0.0, np.pi, 20001)
+    assert abs(np.trapezoid(np.sin(xs) / 2.0, xs) - 1.0) < 1e-8
+
+
+def _mvnormal_case(oracle):
+    """Three RA/Dec rows with correlations, and the scipy values of their log-likelihood without and with per-walker nuisances."""
+    rng = np.random.default_rng(8)
+    el = np.array([12.0, 0.3, 1.0, 0.5, 2.0, 50100.0, 1.2, 50.0, 0.0])
+    t = np.array([50000.0, 50400.0, 51000.0])
+    sol = [oracle.oracle_orbitsolve(el, tj) for tj in t]
+    ra_m, dec_m = np.array([q["raoff"] for q in sol]), np.array([q["decoff"] for q in sol])      # [mas]
+    s1, s2, cor = np.array([3.0, 5.0, 2.0]), np.array([4.0, 2.5, 6.0]), np.array([0.6, -0.35, 0.0])
+    ra, dec = ra_m + rng.normal(0, 3, 3), dec_m + rng.normal(0, 3, 3)
+    obs = [dict(kind=0, planet=0, epoch=t, y1=ra, y2=dec, s1=s1, s2=s2, cor=cor, extra=None)]
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    ref = sum(ss.multivariate_normal([0, 0], [[a * a, r * a * b], [r * a * b, b * b]]).logpdf([y1 - m1, y2 - m2])
+              for a, b, r, y1, m1, y2, m2 in zip(s1, s2, cor, ra, ra_m, dec, dec_m))
+    jit, ps, na = 1.7, 1.002, 0.01                                                # jitter, platescale, northangle (rad)
+    nuis = np.array([[jit], [ps], [na]])
+    ref_n = 0.0
+    for a, b, r, y1, m1, y2, m2 in zip(s1, s2, cor, ra, ra_m, dec, dec_m):
+        a2, b2 = np.hypot(a, jit), np.hypot(b, jit)
+        u1 = ps * (y1 * np.cos(na) + y2 * np.sin(na)); u2 = ps * (y2 * np.cos(na) - y1 * np.sin(na))      # the data rotated / scaled, :210-215
+        ref_n += ss.multivariate_normal([0, 0], [[a2 * a2, r * a2 * b2], [r * a2 * b2, b2 * b2]]).logpdf([u1 - m1, u2 - m2])
+    return obs, planets, el[:, None], nuis, ref, ref_n
+
+
+def test_row_density_vs_scipy_multivariate_normal(oracle):
+    """One RA/Dec row with a correlation and a per-walker jitter: ll = logpdf(MvNormal([σ1² + j², ρσ1σ2; ρσ1σ2, σ2² + j²]), resid) with
+    σ_k ← √(σ_k² + j²) BEFORE the off-diagonal is formed (relative-astrometry.jl:234-252); without nuisances and with cor = 0 the same call
+    is two independent normals. scipy's multivariate_normal does the linear algebra; the model offset comes from octo_oracle_orbitsolve."""
+    obs, planets, el, nuis, ref, ref_n = _mvnormal_case(oracle)
+    ll, _, _ = oracle.oracle_eval(obs, planets, el, None, grad=False)
+    assert abs(ll[0] - ref) < 1e-11 * abs(ref)
+    ll_n, _, _ = oracle.oracle_eval(obs, planets, el, nuis, grad=False)
+    assert abs(ll_n[0] - ref_n) < 1e-11 * abs(ref_n)
+
+
+@pytest.mark.gpu
+def test_gpu_row_density_vs_scipy_multivariate_normal(oracle):
+    """The same rows through the HIP path (both kernel families): the product against scipy directly, not only against the oracle."""
+    import gpu_binding
+    obs, planets, el, nuis, ref, ref_n = _mvnormal_case(oracle)
+    for small in (None, 0):
+        W = 1 if small is None else 70
+        ll, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), None, grad=True, small_batch=small)
+        assert np.all(np.abs(ll - ref) < 1e-11 * abs(ref))
+        ll_n, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), np.repeat(nuis, W, axis=1), grad=True, small_batch=small)
+        assert np.all(np.abs(ll_n - ref_n) < 1e-11 * abs(ref_n))
+
+
+def test_kepler_root_vs_scipy_brentq(oracle):
+    """Position of a face-on, ω = Ω = 0 orbit from the oracle against E from scipy's bracketing root finder: x = a(cos E − e), y = a√(1−e²) sin E
+    scaled by plx (mas per AU); eccentricities up to 0.999, mean anomalies over several revolutions and both signs."""
+    c = oracle.oracle_consts()
+    rng = np.random.default_rng(9)
+    for e in (0.0, 0.1, 0.5, 0.9, 0.99, 0.999):
+        for _ in range(12):
+            a, M_tot, plx, tp = 3.0, 1.1, 40.0, 50000.0
+            period_d = np.sqrt(a ** 3 / M_tot) * c.kepler_year_to_julian_day
+            t = tp + period_d * rng.uniform(-2.5, 2.5)
+            MA = 2 * np.pi * (t - tp) / period_d
+            Mw = np.remainder(MA + np.pi, 2 * np.pi) - np.pi
+            E = scipy.optimize.brentq(lambda E: E - e * np.sin(E) - Mw, -np.pi - 1e-9, np.pi + 1e-9, xtol=1e-15, rtol=1e-15)
+            el = np.array([a, e, 0.0, 0.0, 0.0, tp, M_tot, plx, 0.0])
+            out = oracle.oracle_orbitsolve(el, t)
+            # i = 0, ω = Ω = 0: north (dec) carries cos ν, east (ra) sin ν  (PlanetOrbits: ra ∝ sin(ν+ω) at Ω = 0)
+            x_mas = a * (np.cos(E) - e) * plx * (c.rad2as / c.pc2au); y_mas = a * np.sqrt(1 - e * e) * np.sin(E) * plx * (c.rad2as / c.pc2au)
+            scale = a * plx * (1 + e)
+            # near periastron of a very eccentric orbit the root itself is conditioned like 1/(1−e): the bracketing solver's 1e-15 on E is the bar
+            tol = 1e-11 * scale / max(1.0 - e, 1e-3) ** 0.5
+            assert abs(out["decoff"] - x_mas) < tol and abs(out["raoff"] - y_mas) < tol, (e, t, out["raoff"], out["decoff"], x_mas, y_mas)
+
+
+def test_radial_velocity_is_the_time_derivative_of_the_line_of_sight_position(oracle):
+    """K and the RV law K(cos(ν+ω) + e cos ω) [m/s] (the [PO] formulas the oracle restates from memory) against the central difference of
+    z(t) = r sin(ν+ω) sin i [AU] in scipy's units (au, day): a slip in K's formula, in au2m or in the Julian-year factor would show here."""
+    rng = np.random.default_rng(10)
+    for _ in range(40):
+        a, e, inc, w, O = rng.uniform(0.5, 20), rng.uniform(0, 0.9), rng.uniform(0.1, 3.0), rng.uniform(0, 6.28), rng.uniform(0, 6.28)
+        el = np.array([a, e, inc, w, O, 50000.0 + rng.uniform(0, 3000), rng.uniform(0.5, 2.0), 25.0, 0.0])
+        t = 50000.0 + rng.uniform(0, 5000)
+        z = lambda tt: (lambda q: q["r"] * np.sin(q["nu"] + w) * np.sin(inc))(oracle.oracle_orbitsolve(el, tt))
+        h = 1e-4 * np.sqrt(a ** 3 / el[6]) * 365.25 * (1 - e) ** 1.5      # a small fraction of the periastron passage time [d]
+        vz = (z(t + h) - z(t - h)) / (2 * h) * sc.au / sc.day              # m/s
+        rv = oracle.oracle_orbitsolve(el, t)["radvel"]
+        K = oracle.oracle_orbitsolve(el, t)["K"]
+        assert abs(rv - vz) < 2e-7 * abs(K), (rv, vz, K)
+

@@ -164,3 +164,36 @@ def test_radial_velocity_is_the_time_derivative_of_the_line_of_sight_position(or
         K = oracle.oracle_orbitsolve(el, t)["K"]
         assert abs(rv - vz) < 2e-7 * abs(K), (rv, vz, K)
 
+
+def test_ofti_marginal_likelihood_vs_scipy(oracle):
+    """ofti_linear_solve (src/parameterizations.jl:318-405) marginalises (A, B, F, G) ~ N(0, σ²I) out of a linear-Gaussian model, so its
+    log-marginal is logpdf(MvNormal(0, σ² D Dᵀ + Σ_data), d) on the 2N-vector of data, and its (A, B, F, G) the ridge-regression mean. scipy does both
+    from the design matrix built here with brentq's E: the completed-square form the oracle (and the kernels) restate must reproduce them."""
+    import scipy.linalg
+    c = oracle.oracle_consts()
+    rng = np.random.default_rng(12)
+    N = 9
+    t = np.sort(50000.0 + rng.uniform(0, 2500, N))
+    ra, dec = rng.normal(0, 300, N), rng.normal(0, 300, N)
+    s_ra, s_dec, cor = rng.uniform(2, 9, N), rng.uniform(2, 9, N), rng.uniform(-0.6, 0.6, N)
+    sigma = 1500.0
+    nl = np.array([[0.0, 0.35, 0.8], [6.0, 9.0, 14.0], [50100.0, 49800.0, 51234.5], [1.0, 1.3, 0.9], [40.0, 25.0, 60.0]])      # e, a, tp, M, plx
+    abfg, logml = oracle.oracle_ofti(t, ra, dec, s_ra, s_dec, cor, sigma, nl)
+    for w in range(nl.shape[1]):
+        e, a, tp, M, _ = nl[:, w]
+        period_d = np.sqrt(a ** 3 / M) * c.kepler_year_to_julian_day
+        D = np.zeros((2 * N, 4)); d = np.zeros(2 * N); S = np.zeros((2 * N, 2 * N))
+        for j in range(N):
+            Mw = np.remainder(2 * np.pi * (t[j] - tp) / period_d + np.pi, 2 * np.pi) - np.pi
+            E = scipy.optimize.brentq(lambda E: E - e * np.sin(E) - Mw, -np.pi - 1e-9, np.pi + 1e-9, xtol=1e-15, rtol=1e-15)
+            x, y = np.cos(E) - e, np.sin(E) * np.sqrt(1 - e * e)
+            D[2 * j, 1] = x; D[2 * j, 3] = y; D[2 * j + 1, 0] = x; D[2 * j + 1, 2] = y      # ra = xB + yG, dec = xA + yF  (:347-351)
+            d[2 * j], d[2 * j + 1] = ra[j], dec[j]
+            S[2 * j, 2 * j] = s_ra[j] ** 2; S[2 * j + 1, 2 * j + 1] = s_dec[j] ** 2
+            S[2 * j, 2 * j + 1] = S[2 * j + 1, 2 * j] = cor[j] * s_ra[j] * s_dec[j]
+        ref = ss.multivariate_normal(np.zeros(2 * N), sigma ** 2 * D @ D.T + S).logpdf(d)
+        assert abs(logml[w] - ref) < 1e-10 * abs(ref), (w, logml[w], ref)
+        Wt = np.linalg.inv(S)
+        mean = scipy.linalg.solve(D.T @ Wt @ D + np.eye(4) / sigma ** 2, D.T @ Wt @ d, assume_a="pos")
+        assert np.all(np.abs(abfg[:, w] - mean) < 1e-9 * np.abs(mean).max()), (w, abfg[:, w], mean)
+

@@ -429,7 +429,7 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     if (const char* ev = std::getenv("OCTO_MAPPED_W")) ctx->mapped_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     if (const char* ev = std::getenv("OCTO_FLAG_W")) ctx->flag_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     ctx->env_small_blocks = env_int("OCTO_SMALL_BLOCKS"); ctx->env_small_min_span = env_int("OCTO_SMALL_MIN_SPAN");
-    ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST"); ctx->env_kind_all = env_int("OCTO_KIND_ALL");
+    ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST"); ctx->env_kind_all = env_int("OCTO_KIND_ALL"); ctx->env_mainp_tpb = env_int("OCTO_MAINP_TPB");
     if (const char* ev = std::getenv("OCTO_WIDE")) ctx->env_wide = std::atoi(ev);
     if (const char* ev = std::getenv("OCTO_WARM")) ctx->env_warm = std::atoi(ev);
     *out = ctx;

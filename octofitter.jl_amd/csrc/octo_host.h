@@ -112,7 +112,7 @@ struct octo_ctx {
     int small_w = OCTO_SMALL_BATCH_DEFAULT;     // batches up to this size take the fused small-batch launch (OCTO_SMALL_W: experiments)
     // experiment knobs, read from the environment ONCE at context creation (0 = not set): a getenv per call is a linear scan of the
     // environment on a 12 µs path
-    int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0, env_rv_cost = 0, env_kind_all = 0;
+    int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0, env_rv_cost = 0, env_kind_all = 0, env_mainp_tpb = 0;
     int env_warm = 1;                           // OCTO_WARM=0: experiments and tests — datasets created by this context never take k_main's warm-started row loop (DevObs::dm_max = 0)
     int env_wide = 0;                           // OCTO_WIDE: experiments (1: eight-wave k_main blocks for every one-round single-planet launch, -1: never)
     int flag_w = 128;                           // ... and signal completion through per-walker flags the host spins on (OCTO_FLAG_W: experiments)

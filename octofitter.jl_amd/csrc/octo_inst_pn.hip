@@ -20,19 +20,37 @@ int64_t plan_key_mainp(const octo_ctx* ctx, int64_t W, int64_t n_rows, int block
 namespace {
 constexpr int KA = KM_RADEC | KM_SEPPA | KM_COR, KB = KM_ALL & ~KM_MARG & ~KM_ONEIL;
 
+// Tiles per block (octo_mainp.h), from the probes of tools/r5_tpb_ab.sh (profiles/r5_tpb_ab.txt): two for 5 and 6 planets — ten waves (3, 3, 2, 2 per SIMD)
+// and twelve (3 each): 1.70 -> 1.15 ms and 1.80 -> 1.16 ms per step of the probe; one for 4 and 8 planets (whole multiples of four waves already) and for
+// 7 (fourteen waves at four per SIMD: 2.40 -> 2.80 ms). Three planets (experiment builds with -DOCTO_MAINP_MINP=3 only): four tiles, still behind k_main<3>.
+// OCTO_MAINP_TPB: experiments.
+int mainp_tpb(const octo_ctx* ctx, int P) {
+    int tpb = (P == 3) ? 4 : ((P == 5 || P == 6) ? 2 : 1);
+    if (ctx->env_mainp_tpb > 0) tpb = (int)ctx->env_mainp_tpb;
+    const int max_waves = 4 * mp_wpe(P);
+    while (tpb > 1 && (tpb > 4 || tpb * P > max_waves)) --tpb;
+    return tpb;
+}
+
+template <bool GRAD, bool NUIS, int KM, int MP_R, int WPE>
+int launch_mainp_shape(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t st) {
+    const int P = a.n_planets, tpb = mainp_tpb(ctx, P);
+    const size_t lds = mainp_lds_bytes<GRAD, NUIS, KM, MP_R>(P, tpb);
+    static size_t raised = 48 * 1024;      // (per instantiation; contexts of one process share the code object)
+    if (lds > raised) {
+        if (lds > (size_t)ctx->max_lds) return fail(ctx, OCTO_EINVAL, "k_mainp: the block shape needs more LDS than this device has");
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_mainp<GRAD, NUIS, KM, MP_R, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = lds;
+    }
+    EvalArgs b = a;
+    b.n_rblocks = tpb;
+    hipLaunchKernelGGL((k_mainp<GRAD, NUIS, KM, MP_R, WPE>), dim3((unsigned)((cols + tpb - 1) / tpb), (unsigned)a.n_tasks), dim3((unsigned)(WAVE * P * tpb)), lds, st, b);
+    return OCTO_OK;
+}
 template <bool GRAD, bool NUIS, int KM>
 int launch_mainp_t(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t st) {
-    const int P = a.n_planets;
-    (void)ctx;
-    static_assert(mainp_lds_bytes<true, true, KM, mp_rows(8)>(8) <= 48 * 1024 && mainp_lds_bytes<true, true, KM, mp_rows(6)>(6) <= 48 * 1024,
-                  "k_mainp stays under the default dynamic-LDS limit of a launch");
-    if (P > 6)
-        hipLaunchKernelGGL((k_mainp<GRAD, NUIS, KM, mp_rows(8), mp_wpe(8)>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3((unsigned)(WAVE * P)),
-                           (mainp_lds_bytes<GRAD, NUIS, KM, mp_rows(8)>(P)), st, a);
-    else
-        hipLaunchKernelGGL((k_mainp<GRAD, NUIS, KM, mp_rows(4), mp_wpe(4)>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3((unsigned)(WAVE * P)),
-                           (mainp_lds_bytes<GRAD, NUIS, KM, mp_rows(4)>(P)), st, a);
-    return OCTO_OK;
+    if (a.n_planets > 6) return launch_mainp_shape<GRAD, NUIS, KM, mp_rows(8), mp_wpe(8)>(ctx, cols, a, st);
+    return launch_mainp_shape<GRAD, NUIS, KM, mp_rows(4), mp_wpe(4)>(ctx, cols, a, st);
 }
 template <bool GRAD, bool NUIS, int KM>
 int launch_finishp_t(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t st) {
@@ -42,14 +60,16 @@ int launch_finishp_t(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t
     return OCTO_OK;
 }
 template <bool NUIS, int KM>
-int occupancy_t(int P) {
+int occupancy_t(const octo_ctx* ctx, int P) {
+    // in TILES per CU. (The API counts registers and LDS; what the hardware really places is bounded by its fixed wave -> SIMD order as well: octo_mainp.h)
+    const int tpb = mainp_tpb(ctx, P);
     int nb = 0;
-    // (the API counts registers and LDS; what the hardware really places is bounded by its fixed wave -> SIMD order as well: see octo_mainp.h)
-    hipError_t e = P > 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mainp<true, NUIS, KM, mp_rows(8), mp_wpe(8)>, WAVE * P, (mainp_lds_bytes<true, NUIS, KM, mp_rows(8)>(P)))
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mainp<true, NUIS, KM, mp_rows(4), mp_wpe(4)>, WAVE * P, (mainp_lds_bytes<true, NUIS, KM, mp_rows(4)>(P)));
-    if (e != hipSuccess || nb < 1) nb = 2;
-    if (P > 4) nb = std::min(nb, P > 6 ? 2 : 1 + (P < 6));      // what the fixed wave -> SIMD order really places (5 planets: two blocks, 6: one, 7-8 at 128 VGPRs: two)
-    return nb;
+    hipError_t e = P > 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mainp<true, NUIS, KM, mp_rows(8), mp_wpe(8)>, WAVE * P * tpb, (mainp_lds_bytes<true, NUIS, KM, mp_rows(8)>(P, tpb)))
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mainp<true, NUIS, KM, mp_rows(4), mp_wpe(4)>, WAVE * P * tpb, (mainp_lds_bytes<true, NUIS, KM, mp_rows(4)>(P, tpb)));
+    if (e != hipSuccess || nb < 1) nb = 1;
+    const int waves = P * tpb, per_simd = (waves + 3) / 4;               // the most loaded SIMD's share of one block
+    nb = std::max(1, std::min(nb, mp_wpe(P) / per_simd));
+    return nb * tpb;
 }
 }  // namespace
 
@@ -60,8 +80,7 @@ int occupancy_t(int P) {
                         : (nuis ? FN<false, true, KB>(__VA_ARGS__) : FN<false, false, KB>(__VA_ARGS__))))
 
 int mainp_occupancy(octo_ctx* ctx, bool nuis, int km_p, int P) {
-    (void)ctx;
-    return km_p == KA ? (nuis ? occupancy_t<true, KA>(P) : occupancy_t<false, KA>(P)) : (nuis ? occupancy_t<true, KB>(P) : occupancy_t<false, KB>(P));
+    return km_p == KA ? (nuis ? occupancy_t<true, KA>(ctx, P) : occupancy_t<false, KA>(ctx, P)) : (nuis ? occupancy_t<true, KB>(ctx, P) : occupancy_t<false, KB>(ctx, P));
 }
 int launch_mainp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st) {
     return OCTO_PN_DISPATCH(launch_mainp_t, ctx, cols, a, st);

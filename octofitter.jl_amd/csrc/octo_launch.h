@@ -5,6 +5,9 @@
 #ifndef OCTO_MAINP
 #define OCTO_MAINP 1      // 0: experiments — four planets on k_main<4> as before round 5
 #endif
+#ifndef OCTO_MAINP_MINP
+#define OCTO_MAINP_MINP 4 // fewest planets that take the planet-per-wave kernel (3: experiments)
+#endif
 
 namespace octo {
 
@@ -113,7 +116,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     const bool marg_ds = L::HAS_MARG && (ds->kind_mask & KM_MARG);
     // Three and more planets, kind sets without marginalised RV / O'Neil: one planet per wave (octo_mainp.h), the partials in k_main's layout
     // (measured, same box: 4 planets 774 -> 573 µs per step of the probe; 3 planets 345 -> 427: k_main<3> stays)
-    constexpr bool MAINP = OCTO_MAINP && P >= 4 && !(KM & (KM_MARG | KM_ONEIL));
+    constexpr bool MAINP = OCTO_MAINP && P >= OCTO_MAINP_MINP && !(KM & (KM_MARG | KM_ONEIL));
     constexpr int KMP = mainp_kind_set(KM);      // same partial layout as KM: the sets differ in sep/PA and cor only, or in which RV kinds
     // Occupancy of the GRADIENT variant that is launched (FUSED: more registers, and for several planets more LDS), also for forward-only
     // launches: both then use the same row partition, so the forward value and the value returned with a gradient are the same sum in

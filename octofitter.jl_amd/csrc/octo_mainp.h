@@ -32,9 +32,10 @@ namespace octo {
 //   7-8 planets   MP_R = 2, 128 VGPRs (four waves per SIMD): an 8-wave block puts two waves on every SIMD, so at three per SIMD a CU holds ONE
 //                 block; at four it holds two (8 planets: 3.81 -> 2.56 ms per step of the probe). (MP_R = 4 would also pass the 48 KB default
 //                 limit of a launch's dynamic LDS from seven planets on.)
-// What the planet counts in between pay: the hardware deals a block's waves to the SIMDs in order, so 5 (6, 7) waves load SIMD 0 (0-1, 0-2) twice as
-// much as the rest, and the lock-stepped phases run at the pace of the doubly loaded SIMD — 1.06e11 (5 planets) and 1.32e11 (6) Kepler solves per
-// second against 2.1e11 for four planets and 1.6e11 for eight. The reference has no such systems in its tests or docs; recorded, not pursued.
+// The planet counts in between: the hardware deals a block's waves to the SIMDs in order, so a block of 5 (6, 7) waves loads SIMD 0 (0-1, 0-2) twice as
+// much as the rest and the lock-stepped phases run at the pace of the doubly loaded SIMD — 1.05e11 (5 planets) and 1.36e11 (6) Kepler solves per second
+// against 2.1e11 for four planets and 1.6e11 for eight. Blocks of TWO tiles (TPB, a run-time block shape like P: launch_mainp_shape) spread ten or twelve
+// waves over the four SIMDs: 1.55e11 and 2.11e11 (profiles/r5_tpb_ab.txt). Seven planets stay at one tile (fourteen waves were slower: 1.34e11 -> 1.15e11).
 constexpr int mp_rows(int P) { return P > 6 ? 2 : 4; }
 constexpr int mp_wpe(int P) { return P > 6 ? 4 : 3; }
 
@@ -48,22 +49,31 @@ __host__ __device__ constexpr size_t mainp_contrib_doubles(int P) {
     const size_t contrib = (size_t)MP_R * P * WAVE * 2, comb = (size_t)P * LayoutP<GRAD, NUIS, KM>::OFF_PL * WAVE;
     return contrib > comb ? contrib : comb;
 }
+// (TPB tiles per block: the table once, the exchange areas once per tile)
 template <bool GRAD, bool NUIS, int KM, int MP_R>
-__host__ __device__ constexpr size_t mainp_lds_bytes(int P) { return sizeof(double) * (2 * SCT_N + mainp_contrib_doubles<GRAD, NUIS, KM, MP_R>(P) + (size_t)MP_R * WAVE * 2); }
+__host__ __device__ constexpr size_t mainp_tile_doubles(int P) { return mainp_contrib_doubles<GRAD, NUIS, KM, MP_R>(P) + (size_t)MP_R * WAVE * 2; }
+template <bool GRAD, bool NUIS, int KM, int MP_R>
+__host__ __device__ constexpr size_t mainp_lds_bytes(int P, int TPB = 1) { return sizeof(double) * (2 * SCT_N + (size_t)TPB * mainp_tile_doubles<GRAD, NUIS, KM, MP_R>(P)); }
 
 // one planet's share of a row, kept from phase 1 to phase 2b
 struct MpKept { double sE, cE, invD; };      // (t − tp is re-derived in phase 2b from the row's epoch, which stays in SGPRs: one v_add instead of two registers per row)
 
 template <bool GRAD, bool NUIS, int KM, int MP_R, int WPE>
 __attribute__((amdgpu_waves_per_eu(WPE)))
-static __global__ __launch_bounds__(64 * OCTO_MAX_PLANETS) void k_mainp(EvalArgs a) {
+static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
     using L = LayoutP<GRAD, NUIS, KM>;
     static_assert(!(KM & (KM_MARG | KM_ONEIL)), "k_mainp: marginalised RV and the O'Neil prior stay on k_main<P>");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // = the planet this wave owns
-    const int P = a.n_planets;                                             // = waves per block
-    const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
+    const int P = a.n_planets;                                             // = waves per tile
+    // TPB tiles per block (blockDim.x = 64·P·TPB): the hardware deals a block's waves to the four SIMDs in order, so a block of 3, 5, 6 or 7
+    // waves leaves SIMDs idle or doubly loaded in every lock-stepped phase; several tiles in one block (3 planets x 4, 5-7 planets x 2) fill
+    // them evenly. The tiles share the sin/cos table and the barriers, nothing else.
+    const int wvb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tib = (wvb >= P ? 1 : 0) + (wvb >= 2 * P ? 1 : 0) + (wvb >= 3 * P ? 1 : 0);      // tile in block (TPB <= 4)
+    const int wv = wvb - tib * P;                                          // = the planet this wave owns
+    const int TPB = a.n_rblocks;                                           // (k_small's field, free here: tiles per block, set by launch_mainp_shape)
+    const int64_t w = ((int64_t)blockIdx.x * TPB + tib) * WAVE + lane;     // (a tile past the batch recomputes the last walker and stores nothing)
     const int64_t wl = w < a.W ? w : a.W - 1;
     const int task = a.task0 + (int)blockIdx.y;
     const Task tk = a.tasks[task];
@@ -71,14 +81,14 @@ static __global__ __launch_bounds__(64 * OCTO_MAX_PLANETS) void k_mainp(EvalArgs
     const int n_rows = tk.nrows;
 
     const SinCosTab tab = make_sincos_tab(reinterpret_cast<const double2*>(lds));
-    double* const contrib = lds + 2 * SCT_N;
+    double* const contrib = lds + 2 * SCT_N + (size_t)tib * mainp_tile_doubles<GRAD, NUIS, KM, MP_R>(P);
     double* const adj = contrib + mainp_contrib_doubles<GRAD, NUIS, KM, MP_R>(P);
 
     // ---- prologue: the table, this wave's planet, and what the coefficients need of the others (a_p, m_p/M)
     {
         const double2* __restrict__ g = reinterpret_cast<const double2*>(a.sctab);
         double2* t = reinterpret_cast<double2*>(lds);
-        for (int i = threadIdx.x; i < SCT_N; i += WAVE * P) t[i] = g[i];
+        for (int i = threadIdx.x; i < SCT_N; i += (int)blockDim.x) t[i] = g[i];
     }
     PC pc;
     {

@@ -740,7 +740,7 @@ def test_thiele_innes_near_face_on_vs_60_digits(oracle):
     assert e_dev < 1e-9 and 100 * e_dev < e_ora < 1e-3, (e_dev, e_ora)
 
 
-@pytest.mark.parametrize("P", [4, 5, 6, 8])
+@pytest.mark.parametrize("P", [4, 5, 6, 7, 8])
 def test_planet_per_wave_kernels_vs_oracle(oracle, P):
     """k_mainp / k_finishp (octo_mainp.h): ONE planet per wave, the number of planets a run-time block shape — four planets (k_mainp ->
     k_finish<4>) and five to OCTO_MAX_PLANETS = 8 (k_mainp -> k_finishp; the reference unrolls over any number, src/likelihoods/system.jl:116-118,

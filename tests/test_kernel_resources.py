@@ -76,7 +76,8 @@ def test_throughput_kernels_do_not_spill(rows):
             elif r["vgpr_spill_count"] or r["private_segment_fixed_size"]:
                 bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
         if PLANET_PER_WAVE.fullmatch(n):
-            limit = 48 if ", true, true, " in n[:24] or n.startswith("k_mainp<true, true") else 2
+            # (the others: up to four dwords parked outside the row loops — the tile-in-block index and its LDS offsets joined the 128-VGPR shape's prologue)
+            limit = 48 if ", true, true, " in n[:24] or n.startswith("k_mainp<true, true") else 4
             if r["vgpr_spill_count"] > limit or r["private_segment_fixed_size"] > 128:
                 bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
         if n.startswith("k_finishp<") and (r["vgpr_spill_count"] or r["private_segment_fixed_size"]):

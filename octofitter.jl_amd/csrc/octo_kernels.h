@@ -825,9 +825,11 @@ constexpr size_t fused_lds_bytes() {
     return b > c ? (b > d ? b : d) : (c > d ? c : d);
 }
 
-// Seven waves per SIMD (72 VGPRs) for the nuisance-free single-planet RA/Dec gradient kernels: they need 76 left alone, one
-// allocation granule too many; held to 72 the compiler parks 12 bytes outside the row loop and the loop itself is unchanged
-// (same-box A/B: −1 % step time). Every other variant keeps the register count it wants (forcing them spills in the loop).
+// Every variant but the four-planet gradient kernels keeps the register count it wants. (Rounds 3-4 held the nuisance-free single-planet RA/Dec
+// gradient kernels to 72 VGPRs = seven waves per SIMD: −1 % then. With the warm-started loop next to the cold one the cap costs three moves per row —
+// two polynomial coefficients re-fetched from SGPRs, one loop-carried copy — and e·cA recomputed; at the 79 registers the kernel takes left alone it
+// runs six waves per SIMD and 2-3 % faster at every batch shape: 305.6 -> 299.2 µs (1e4 walkers), 88.7 -> 85.9 (2 500), 51.0 -> 49.7 (1 250);
+// profiles/r5_waves_ab.txt.)
 template <int P, bool GRAD, bool NUIS, int KM>
 constexpr unsigned main_min_waves() {
     // Four planets with a gradient: left alone the kernel takes 312 registers (56 of them AGPRs, 8-62 moves per row) = ONE wave per SIMD, which
@@ -837,7 +839,7 @@ constexpr unsigned main_min_waves() {
     // an LDS copy inside the row bodies instead (72 registers fewer on paper): the volatile loads it needs cost the register allocator more
     // than they free — 11-21 scratch accesses per row instead of 4-17.
     if (P >= 4 && GRAD) return 2u;
-    return (P == 1 && GRAD && !NUIS && (KM & ~KM_COR) == KM_RADEC) ? 7u : 1u;
+    return 1u;
 }
 
 // Which k_main variants carry the warm-started row loop (octo_device.h: KWarm) next to the cold one: the single-planet fused launches

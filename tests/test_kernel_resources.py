@@ -44,8 +44,9 @@ def test_latency_kernels_have_no_scratch_and_no_vgpr_spills(rows):
     assert not bad, bad
 
 
-# The nuisance-free single-planet RA/Dec gradient kernels are held to 72 VGPRs (seven waves per SIMD, octo_kernels.h: main_min_waves): the
-# compiler parks 12-16 bytes OUTSIDE the row loop (two to four scratch instructions per wave, measured -1 % step time in round 2). Deliberate.
+# The nuisance-free single-planet RA/Dec gradient kernels: rounds 2-4 held them to 72 VGPRs (seven waves per SIMD) with 12-16 bytes parked outside
+# the row loop; since round 5's warm-started loop they keep the 79 registers they want (six waves, 2-3 % faster: octo_kernels.h: main_min_waves) and the
+# budget below — nothing in the loop, at most a few dwords outside it — now simply holds them to no spills worth the name.
 SEVEN_WAVES = re.compile(r"k_main<1, true, false, (1|33), (true|false), (4|8)>")
 
 

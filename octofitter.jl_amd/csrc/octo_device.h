@@ -320,7 +320,9 @@ __device__ __forceinline__ float markley_starter_f32(double frac, const PC& pc) 
 // The part both starters share: Markley's fifth-order correction, eqs (21)-(29), from (sin E1, cos E1, f0 = E1 − e sin E1 − M) in FP64, then
 // sin/cos(E1 + δ5) by rotation. E1 itself only feeds s.E (dead code unless a caller reads it).
 // INV_NR: Newton steps on 1/(1 − e cos E) (1 when it only feeds adjoints, 2 when it feeds a model value, -1 when nobody needs it).
-template <int INV_NR>
+// FOURTH_ORDER: stop at δ4 — for a start within WARM_TOL of the root (the warm rows of k_main) δ4's error is already below the rounding
+// of the rotation that follows (tools/kepler_warm_proto.py: the same 1.1e-15 D-weighted maximum as δ5 over config 3's walkers; 1.4e-14 at ten times the tolerance).
+template <int INV_NR, bool FOURTH_ORDER = false>
 __device__ __forceinline__ void kepler_correct(KSol& s, const PC& pc, double E1, double s1, double c1, double f0) {
     const double e = pc.e;
     // f2/2, f2/24, f3/6 of Markley's (21)-(27) from the loop-invariant e/2 and e/6 (f2 = e sin E1 itself is not needed)
@@ -339,8 +341,11 @@ __device__ __forceinline__ void kepler_correct(KSol& s, const PC& pc, double E1,
     // samples: identical 5.13e-16 weighted maximum over 2e6 (M, e) pairs, e -> 1 − 1e-9).
     const double den4 = fma(d3, fma(d3, sf3, hf2), f1);
     const double d4 = fma(-r4, fma(den4, d3, f0), d3);
-    const double den5 = fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1);
-    const double d5 = fma(-r4, fma(den5, d4, f0), d4);
+    double d5 = d4;
+    if constexpr (!FOURTH_ORDER) {
+        const double den5 = fma(d4, fma(d4, fma(-d4, q24, sf3), hf2), f1);
+        d5 = fma(-r4, fma(den5, d4, f0), d4);
+    }
     s.E = E1 + d5;                                                   // eq. (29); dead code unless a caller reads it
     // ---- sin/cos(E1 + δ5) by rotation; |δ5| < 5e-4: sin δ = δ(1 − δ²/6) (+1e-19), cos δ − 1 = δ²(−1/2 + δ²/24) (+1e-23)
     const double dd = d5 * d5;
@@ -380,7 +385,8 @@ __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const 
     KSol s;
     s.dt = t - pc.tp;
     double E1 = 0.0, s1, c1, f0;
-    if (__builtin_amdgcn_ballot_w64(st.invD >= thr) == 0) {      // every lane of the wave passes (a NaN bound — an invalid walker — passes: its sums are discarded)
+    const bool warm_row = __builtin_amdgcn_ballot_w64(st.invD >= thr) == 0;      // every lane of the wave passes (a NaN bound — an invalid walker — passes: its sums are discarded)
+    if (warm_row) {
         const double dM = dm * pc.invP;
         const double x = dM * st.invD;
         const double z = x * st.invD;
@@ -392,6 +398,7 @@ __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const 
         s1 = st.sE + ds;
         c1 = fma(st.cE, cm1, fma(-st.sE, sr, st.cE));
         f0 = fma(-pc.e, ds, dE - dM);
+        kepler_correct<INV_NR, true>(s, pc, E1, s1, c1, f0);      // (each branch carries its own copy of the correction: a flag would become a select)
     } else {
         const double uo = s.dt * pc.invP;
         const double frac = uo - rint(uo);
@@ -399,8 +406,8 @@ __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const 
         E1 = (double)E1f;
         sincos_table(E1f, tab, s1, c1);
         f0 = fma(-pc.e, s1, fma(-frac, TWO_PI, E1));
+        kepler_correct<INV_NR>(s, pc, E1, s1, c1, f0);
     }
-    kepler_correct<INV_NR>(s, pc, E1, s1, c1, f0);
     st.sE = s.sE; st.cE = s.cE; st.invD = s.invD;
     return s;
 }

@@ -825,12 +825,12 @@ constexpr size_t fused_lds_bytes() {
     return b > c ? (b > d ? b : d) : (c > d ? c : d);
 }
 
-// Every variant but the four-planet gradient kernels keeps the register count it wants. (Rounds 3-4 held the nuisance-free single-planet RA/Dec
-// gradient kernels to 72 VGPRs = seven waves per SIMD: −1 % then. With the warm-started loop next to the cold one the cap costs three moves per row —
-// two polynomial coefficients re-fetched from SGPRs, one loop-carried copy — and e·cA recomputed; at the 79 registers the kernel takes left alone it
-// runs six waves per SIMD and 2-3 % faster at every batch shape: 305.6 -> 299.2 µs (1e4 walkers), 88.7 -> 85.9 (2 500), 51.0 -> 49.7 (1 250);
-// profiles/r5_waves_ab.txt.)
-template <int P, bool GRAD, bool NUIS, int KM>
+// Every variant but the four-planet gradient kernels (and config 3's eight-wave block, below) keeps the register count it wants. (Rounds 3-4 held the
+// nuisance-free single-planet RA/Dec gradient kernels to 72 VGPRs = seven waves per SIMD: −1 % then. With the warm-started loop next to the cold one the
+// cap costs three moves per row — two polynomial coefficients re-fetched from SGPRs, one loop-carried copy — and e·cA recomputed; left alone the kernel
+// took 79 registers, six waves per SIMD, and ran 2-3 % faster at every batch shape: 305.6 -> 299.2 µs (1e4 walkers), 88.7 -> 85.9 (2 500), 51.0 -> 49.7
+// (1 250); profiles/r5_waves_ab.txt.)
+template <int P, bool GRAD, bool NUIS, int KM, int NWV = WPB>
 constexpr unsigned main_min_waves() {
     // Four planets with a gradient: left alone the kernel takes 312 registers (56 of them AGPRs, 8-62 moves per row) = ONE wave per SIMD, which
     // cannot cover the latency of its own dependent FP64 chains (0.21 of the FP64 peak against 0.41 for two planets). Held to 256 it parks
@@ -839,6 +839,10 @@ constexpr unsigned main_min_waves() {
     // an LDS copy inside the row bodies instead (72 registers fewer on paper): the volatile loads it needs cost the register allocator more
     // than they free — 11-21 scratch accesses per row instead of 4-17.
     if (P >= 4 && GRAD) return 2u;
+    // The eight-wave block of a one-round launch puts two waves of every block on each SIMD: at the 84 registers config 3's kernel takes since its warm
+    // rows carry their own (fourth-order) copy of the correction a CU holds two such blocks, at 80 (two dwords parked outside the loop) three —
+    // 1 250 walkers x 1e4 epochs: 49.9 -> 48.9 µs per step (profiles/r5_d4_ab.txt). The four-wave kernel keeps its 84 (five waves: 280 µs against 285).
+    if (NWV == 2 * WPB && P == 1 && GRAD && !NUIS && (KM & ~KM_COR) == KM_RADEC) return 6u;
     return 1u;
 }
 
@@ -884,7 +888,7 @@ __device__ __forceinline__ bool warm_init(WarmState<P>& ws, const PC (&pc)[P], f
 // unchanged — where twice as many 4-wave blocks paid all of those twice (profiles/r4_chunk_sweep_1250.txt: no gain). 1 250 walkers x 1e4
 // epochs: 53.25 -> 51.8 µs per step (same box, profiles/r4_wide_ab.txt); the planner (plan_key) offers it only while a wave keeps >= 32 rows.
 template <int P, bool GRAD, bool NUIS, int KM, bool FUSED = false, int NWV = WPB>
-__attribute__((amdgpu_waves_per_eu(main_min_waves<P, GRAD, NUIS, KM>())))
+__attribute__((amdgpu_waves_per_eu(main_min_waves<P, GRAD, NUIS, KM, NWV>())))
 static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
     static_assert(NWV == WPB || (FUSED && NWV == 2 * WPB), "k_main: four waves per block, or eight in the fused launch");

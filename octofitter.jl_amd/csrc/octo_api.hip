@@ -311,10 +311,9 @@ int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_
     // block — twice the waves per SIMD for the row loop, the per-block costs (table fill, orbit-constructor pieces, partials, k_finish) unchanged.
     if (wide && ctx->env_wide >= 0) {
         const double n4 = std::ceil((double)(cols * best_t) / (double)n_cus);
-        // (n4 blocks per CU in the chosen partition: as eight-wave blocks they need n4 <= the eight-wave kernel's own occupancy, and twice the
-        // waves must still be worth it — the four-wave kernel could hold 2·n4 — while a wave keeps >= 32 rows)
-        *wide = (n4 <= (double)blocks8_per_cu && 2.0 * n4 <= (double)blocks_per_cu && n_rows >= (int64_t)best_t * 8 * 32) ||
-                (ctx->env_wide > 0 && n4 <= (double)blocks8_per_cu);
+        // (n4 blocks per CU in the chosen partition: as eight-wave blocks they need n4 <= the eight-wave kernel's own occupancy — it is held to a
+        // register count of its own, octo_kernels.h: main_min_waves — while a wave keeps >= 32 rows)
+        *wide = (n4 <= (double)blocks8_per_cu && n_rows >= (int64_t)best_t * 8 * 32) || (ctx->env_wide > 0 && n4 <= (double)blocks8_per_cu);
     }
     return best_t;
 }

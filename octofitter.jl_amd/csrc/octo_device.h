@@ -392,7 +392,7 @@ __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const 
         const double z = x * st.invD;
         const double dE = fma(-((pc.he * st.sE) * z), x, x);
         const double u = dE * dE;
-        const double sr = dE * fma(u, fma(u, fma(u, fma(u, OCTO_KT[21], OCTO_KT[22]), OCTO_KT[17]), OCTO_KT[18]), 1.0);
+        const double sr = dE * fma(u, fma(u, fma(u, OCTO_KT[22], OCTO_KT[17]), OCTO_KT[18]), 1.0);      // |dE| < 0.05 here (thr >= WARM_MIN_THR): dE⁹/9! < 6e-18
         const double cm1 = u * fma(u, fma(u, fma(u, OCTO_KT[23], OCTO_KT[19]), OCTO_KT[20]), -0.5);
         const double ds = fma(st.sE, cm1, st.cE * sr);               // sin E1 − sin E, without cancellation
         s1 = st.sE + ds;

@@ -96,13 +96,16 @@ struct KSol { double sE, cE, invD, dt, E; };
 // of a high-e walker) the wave falls back to the Markley starter for that row — WAVE-UNIFORMLY (one ballot, one scalar branch: the loop stays
 // divergence-free), and the root is unique, so the result is the same E to rounding either way.
 // The test is a priori and one compare: x³/D² < tol  <=>  1/D < thr with thr = (tol / ΔM³)^(1/5) per lane, from the TABLE's largest
-// 2π Δt (DevObs::dm_max; exact for a uniform cadence, conservative otherwise). 1/D >= 1/2, so a pass also bounds |x| < (4 tol)^(1/3) = 0.117:
-// the rotation's polynomials (sin to dE⁹, cos to dE⁸) are exact to 1e-16 there.
+// 2π Δt (DevObs::dm_max; exact for a uniform cadence, conservative otherwise). A wave starts warm only where every lane's thr >= WARM_MIN_THR, i.e.
+// ΔM_max <= (tol/32)^(1/3) = 0.0315, so a pass bounds |x| = ΔM/D < ΔM_max · thr = tol^(1/5) ΔM_max^(2/5) <= 0.063 and |dE| < 0.066:
+// the rotation's polynomials (sin to dE⁷, cos to dE⁸) are exact to 1e-16 there. tol = 1e-3 with the FOURTH-order correction of the warm rows
+// (kepler_correct): its truncation is ~2e-16 there (tools/kepler_warm_proto.py: D-weighted maximum 1.1e-15 at 4e-4 and at 1e-3 — the rounding
+// level of the cold solve — 3.4e-15 at 2e-3); config 3 falls back on 8 % of its wave-rows at 1e-3, on 12.5 % at 4e-4.
 // What the chain gives up: E and M never appear, so the solve of row j starts from the SOLUTION of row j−1 and its rounding (~1e-16 in M per
 // row) accumulates until the next cold row — at most a wave's chunk of rows (tens to a few hundred: < 1e-13 in M, the size of the
 // rounding of (t − tp)/P itself for a walker a few orbits from tp; the prototype measures 8e-15 after 72 rows).
 struct KWarm { double sE, cE, invD; };
-constexpr double WARM_TOL = 4.0e-4;
+constexpr double WARM_TOL = 1.0e-3;
 constexpr double WARM_MIN_THR = 2.0;      // a wave takes the warm loop only if every lane passes at least wherever D >= 1/2
 
 __device__ __forceinline__ void load_pc(PC& pc, const double* __restrict__ wc, int64_t ldw, int p, int64_t w) {
@@ -321,7 +324,7 @@ __device__ __forceinline__ float markley_starter_f32(double frac, const PC& pc) 
 // sin/cos(E1 + δ5) by rotation. E1 itself only feeds s.E (dead code unless a caller reads it).
 // INV_NR: Newton steps on 1/(1 − e cos E) (1 when it only feeds adjoints, 2 when it feeds a model value, -1 when nobody needs it).
 // FOURTH_ORDER: stop at δ4 — for a start within WARM_TOL of the root (the warm rows of k_main) δ4's error is already below the rounding
-// of the rotation that follows (tools/kepler_warm_proto.py: the same 1.1e-15 D-weighted maximum as δ5 over config 3's walkers; 1.4e-14 at ten times the tolerance).
+// of the rotation that follows (tools/kepler_warm_proto.py: the same 1.1e-15 D-weighted maximum as δ5 over config 3's walkers; 1.4e-14 at four times the tolerance).
 template <int INV_NR, bool FOURTH_ORDER = false>
 __device__ __forceinline__ void kepler_correct(KSol& s, const PC& pc, double E1, double s1, double c1, double f0) {
     const double e = pc.e;
@@ -392,7 +395,7 @@ __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const 
         const double z = x * st.invD;
         const double dE = fma(-((pc.he * st.sE) * z), x, x);
         const double u = dE * dE;
-        const double sr = dE * fma(u, fma(u, fma(u, OCTO_KT[22], OCTO_KT[17]), OCTO_KT[18]), 1.0);      // |dE| < 0.05 here (thr >= WARM_MIN_THR): dE⁹/9! < 6e-18
+        const double sr = dE * fma(u, fma(u, fma(u, OCTO_KT[22], OCTO_KT[17]), OCTO_KT[18]), 1.0);      // |dE| < 0.066 here (thr >= WARM_MIN_THR): dE⁹/9! < 7e-17
         const double cm1 = u * fma(u, fma(u, fma(u, OCTO_KT[23], OCTO_KT[19]), OCTO_KT[20]), -0.5);
         const double ds = fma(st.sE, cm1, st.cE * sr);               // sin E1 − sin E, without cancellation
         s1 = st.sE + ds;

@@ -404,7 +404,7 @@ static __global__ __launch_bounds__(256) void k_kepler_warm(const double* __rest
     KWarm st{s0.sE, s0.cE, s0.invD};
     const float dmx = fabsf((float)dMa[i]);
     double thr = (double)__builtin_amdgcn_exp2f(0.2f * (__builtin_amdgcn_logf((float)WARM_TOL) - 3.0f * __builtin_amdgcn_logf(dmx)));
-    if (thr < WARM_MIN_THR) thr = 0.0;      // k_main's veto (warm_init): a bound below WARM_MIN_THR never starts warm — the routine's polynomials count on |dE| < 0.05
+    if (thr < WARM_MIN_THR) thr = 0.0;      // k_main's veto (warm_init): a bound below WARM_MIN_THR never starts warm — the routine's polynomials count on |dE| < 0.066
     const bool warm = __builtin_amdgcn_ballot_w64(st.invD >= thr) == 0;
     // dm = 2π·Δt with 1/P = 1/2π: ΔM = dMa[i]; t = MA + dM so that the cold fallback solves the same row
     const KSol s = kepler_solve_warm<2>(MA[i] + dMa[i], pc, tab, st, thr, dMa[i] * TWO_PI);

@@ -220,8 +220,8 @@ def test_warm_step_device_routine_over_the_elliptic_domain(pkg):
     M = np.clip(M, -np.pi, np.pi)
     # group by pass / fail of the a-priori bound so that a wave is (mostly) homogeneous
     D = 1 - e * np.cos(Ep)
-    thr = (4e-4 / np.abs(dM) ** 3) ** 0.2
-    # (a bound below WARM_MIN_THR = 2 never starts warm, as in k_main: ΔM above 0.023 rad is the cold routine's)
+    thr = (1e-3 / np.abs(dM) ** 3) ** 0.2      # WARM_TOL
+    # (a bound below WARM_MIN_THR = 2 never starts warm, as in k_main: ΔM above 0.031 rad is the cold routine's)
     order = np.argsort(~(((1 / D) < 0.98 * thr) & (thr > 2.05)), kind="stable")
     M, dM, e = (np.ascontiguousarray(x[order]) for x in (M, dM, e))
     sE = np.empty(n); cE = np.empty(n); used = np.empty(n)

@@ -197,3 +197,50 @@ def test_ofti_marginal_likelihood_vs_scipy(oracle):
         mean = scipy.linalg.solve(D.T @ Wt @ D + np.eye(4) / sigma ** 2, D.T @ Wt @ d, assume_a="pos")
         assert np.all(np.abs(abfg[:, w] - mean) < 1e-9 * np.abs(mean).max()), (w, abfg[:, w], mean)
 
+
+
+@pytest.mark.gpu
+def test_gpu_model_priors_vs_scipy(pkg):
+    """The standard parameterisation ON THE DEVICE (k_model_fwd / k_small<MODEL>: invlink, logpdf_with_trans, healing rule) for a model whose likelihood
+    is a constant: one RA/Dec row far inside its error bar, every planet variable a prior of a different kind — the log-posterior's variation with θ_t is
+    the priors' alone, held to scipy.stats + the bijectors' Jacobians (as test_prior_densities_vs_scipy holds the oracle), both kernel families."""
+    table = dict(epoch=[50000.0], ra=[0.0], dec=[0.0], σ_ra=[1e9], σ_dec=[1e9])
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromObs(table, name="one_row")],
+                   variables=pkg.variables(a=pkg.LogUniform(0.1, 300.0), e=pkg.Uniform(0.0, 0.5), i=pkg.Sine(), ω=pkg.Normal(1.3, 0.4), Ω=pkg.Uniform(2.0, 7.5),
+                                           tp=pkg.Normal(50100.0, 30.0)))
+    system = pkg.System(name="PriorsOnly", companions=[b], observations=[],
+                        variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.4), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 4.0), lower=40.0, upper=60.0)))
+    model = pkg.LogDensityModel(system)
+    assert model.names == ["M", "plx", "b_a", "b_e", "b_i", "b_ω", "b_Ω", "b_tp"]
+    rng = np.random.default_rng(21)
+
+    def logistic(y): return 1.0 / (1.0 + np.exp(-y))
+
+    def two_sided(lo, hi, y): return lo + (hi - lo) * logistic(y), np.log(hi - lo) + np.log(logistic(y)) + np.log1p(-logistic(y))
+
+    def ref(th):
+        out = np.zeros(th.shape[1])
+        x, lj = 0.1 + np.exp(th[0]), th[0];          out += ss.truncnorm((0.1 - 1.2) / 0.4, np.inf, 1.2, 0.4).logpdf(x) + lj
+        x, lj = two_sided(40.0, 60.0, th[1]);        out += ss.truncnorm(-2.5, 2.5, 50.0, 4.0).logpdf(x) + lj
+        x, lj = two_sided(0.1, 300.0, th[2]);        out += ss.loguniform(0.1, 300.0).logpdf(x) + lj
+        x, lj = two_sided(0.0, 0.5, th[3]);          out += ss.uniform(0.0, 0.5).logpdf(x) + lj
+        x, lj = two_sided(0.0, np.pi, th[4]);        out += np.log(np.sin(x) / 2.0) + lj
+        out += ss.norm(1.3, 0.4).logpdf(th[5])
+        x, lj = two_sided(2.0, 7.5, th[6]);          out += ss.uniform(2.0, 5.5).logpdf(x) + lj
+        out += ss.norm(50100.0, 30.0).logpdf(th[7])
+        return out
+    for W, small in ((5, None), (700, 0)):
+        if small is not None:
+            model.ln_like._check(model.ln_like.lib.octo_ctx_set_small_batch(model.ln_like._ctx, small), "set")
+        th = rng.normal(0.0, 1.5, (model.D, W)); th[7] = rng.normal(50100.0, 30.0, W)
+        lp, g = model.logdensity_and_gradient(th)
+        r = ref(th)
+        const = lp - r                                   # the likelihood of the one row: −log(2π σ²) up to 1e-18 of curvature
+        assert np.all(np.abs(const - const[0]) < 1e-9), np.abs(const - const[0]).max()
+        assert abs(const[0] + np.log(2 * np.pi * 1e18)) < 1e-9
+        h = 1e-5
+        for k in range(model.D):
+            tp_, tm_ = th.copy(), th.copy(); tp_[k] += h; tm_[k] -= h
+            gnum = (ref(tp_) - ref(tm_)) / (2 * h)
+            assert np.all(np.abs(g[k] - gnum) <= 1e-6 * np.maximum(1.0, np.abs(gnum))), (k, np.abs(g[k] - gnum).max())
+    model.close()

@@ -165,12 +165,9 @@ def test_radial_velocity_is_the_time_derivative_of_the_line_of_sight_position(or
         assert abs(rv - vz) < 2e-7 * abs(K), (rv, vz, K)
 
 
-def test_ofti_marginal_likelihood_vs_scipy(oracle):
-    """ofti_linear_solve (src/parameterizations.jl:318-405) marginalises (A, B, F, G) ~ N(0, σ²I) out of a linear-Gaussian model, so its
-    log-marginal is logpdf(MvNormal(0, σ² D Dᵀ + Σ_data), d) on the 2N-vector of data, and its (A, B, F, G) the ridge-regression mean. scipy does both
-    from the design matrix built here with brentq's E: the completed-square form the oracle (and the kernels) restate must reproduce them."""
+def _ofti_case(c):
+    """A nine-epoch table with correlations, three (e, a, tp, M, plx) sets, and scipy's log-marginal / ridge mean for each."""
     import scipy.linalg
-    c = oracle.oracle_consts()
     rng = np.random.default_rng(12)
     N = 9
     t = np.sort(50000.0 + rng.uniform(0, 2500, N))
@@ -178,7 +175,7 @@ def test_ofti_marginal_likelihood_vs_scipy(oracle):
     s_ra, s_dec, cor = rng.uniform(2, 9, N), rng.uniform(2, 9, N), rng.uniform(-0.6, 0.6, N)
     sigma = 1500.0
     nl = np.array([[0.0, 0.35, 0.8], [6.0, 9.0, 14.0], [50100.0, 49800.0, 51234.5], [1.0, 1.3, 0.9], [40.0, 25.0, 60.0]])      # e, a, tp, M, plx
-    abfg, logml = oracle.oracle_ofti(t, ra, dec, s_ra, s_dec, cor, sigma, nl)
+    refs, means = [], []
     for w in range(nl.shape[1]):
         e, a, tp, M, _ = nl[:, w]
         period_d = np.sqrt(a ** 3 / M) * c.kepler_year_to_julian_day
@@ -191,12 +188,49 @@ def test_ofti_marginal_likelihood_vs_scipy(oracle):
             d[2 * j], d[2 * j + 1] = ra[j], dec[j]
             S[2 * j, 2 * j] = s_ra[j] ** 2; S[2 * j + 1, 2 * j + 1] = s_dec[j] ** 2
             S[2 * j, 2 * j + 1] = S[2 * j + 1, 2 * j] = cor[j] * s_ra[j] * s_dec[j]
-        ref = ss.multivariate_normal(np.zeros(2 * N), sigma ** 2 * D @ D.T + S).logpdf(d)
-        assert abs(logml[w] - ref) < 1e-10 * abs(ref), (w, logml[w], ref)
+        refs.append(ss.multivariate_normal(np.zeros(2 * N), sigma ** 2 * D @ D.T + S).logpdf(d))
         Wt = np.linalg.inv(S)
-        mean = scipy.linalg.solve(D.T @ Wt @ D + np.eye(4) / sigma ** 2, D.T @ Wt @ d, assume_a="pos")
-        assert np.all(np.abs(abfg[:, w] - mean) < 1e-9 * np.abs(mean).max()), (w, abfg[:, w], mean)
+        means.append(scipy.linalg.solve(D.T @ Wt @ D + np.eye(4) / sigma ** 2, D.T @ Wt @ d, assume_a="pos"))
+    return (t, ra, dec, s_ra, s_dec, cor, sigma, nl), np.array(refs), np.array(means).T
 
+
+def test_ofti_marginal_likelihood_vs_scipy(oracle):
+    """ofti_linear_solve (src/parameterizations.jl:318-405) marginalises (A, B, F, G) ~ N(0, σ²I) out of a linear-Gaussian model, so its
+    log-marginal is logpdf(MvNormal(0, σ² D Dᵀ + Σ_data), d) on the 2N-vector of data, and its (A, B, F, G) the ridge-regression mean. scipy does both
+    from the design matrix built here with brentq's E: the completed-square form the oracle (and the kernels) restate must reproduce them."""
+    (t, ra, dec, s_ra, s_dec, cor, sigma, nl), ref, mean = _ofti_case(oracle.oracle_consts())
+    abfg, logml = oracle.oracle_ofti(t, ra, dec, s_ra, s_dec, cor, sigma, nl)
+    assert np.all(np.abs(logml - ref) < 1e-10 * np.abs(ref)), (logml, ref)
+    assert np.all(np.abs(abfg - mean) < 1e-9 * np.abs(mean).max(axis=0)), (abfg, mean)
+
+
+@pytest.mark.gpu
+def test_gpu_ofti_and_kepler_vs_scipy(pkg, oracle):
+    """The device OFTI kernels (k_ofti_main / k_ofti_finish through the mirror's ofti_linear_solve) against scipy's multivariate normal and ridge
+    solve, and the device Kepler routine (octo_kepler_solve, octo_kepler_solve_table) against scipy.optimize.brentq — directly, not via the oracle."""
+    import ctypes as C
+    (t, ra, dec, s_ra, s_dec, cor, sigma, nl), ref, mean = _ofti_case(oracle.oracle_consts())
+    out = pkg.ofti_linear_solve(t, ra, dec, s_ra, s_dec, cor, sigma, *nl)
+    assert np.all(np.abs(out["log_marginal_likelihood"] - ref) < 1e-10 * np.abs(ref))
+    got = np.stack([out["A"], out["B"], out["F"], out["G"]])
+    assert np.all(np.abs(got - mean) < 1e-9 * np.abs(mean).max(axis=0))
+    rng = np.random.default_rng(14)
+    n = 400
+    e = np.concatenate([rng.uniform(0, 0.9, n // 2), 1 - 10 ** rng.uniform(-6, -1, n // 2)])
+    M = rng.uniform(-np.pi, np.pi, n)
+    Eb = np.array([scipy.optimize.brentq(lambda E: E - ei * np.sin(E) - Mi, -np.pi - 1e-9, np.pi + 1e-9, xtol=1e-16, rtol=1e-15) for Mi, ei in zip(M, e)])
+    lib = pkg.capi.load_library()
+    ctx = C.c_void_p()
+    assert lib.octo_ctx_create(C.byref(ctx), 0) == 0
+    try:
+        for fn in (lib.octo_kepler_solve, lib.octo_kepler_solve_table):
+            E = np.empty(n); sE = np.empty(n); cE = np.empty(n)
+            dp = pkg.capi._dptr
+            assert fn(ctx, dp(M), dp(e), n, dp(E), dp(sE), dp(cE)) == 0
+            cond = 1 - e * np.cos(Eb)                                    # the root's conditioning: brentq's own 1e-15 on E is the bar
+            assert np.all(np.abs(sE - np.sin(Eb)) * cond < 5e-15) and np.all(np.abs(cE - np.cos(Eb)) * cond < 5e-15)
+    finally:
+        lib.octo_ctx_destroy(ctx)
 
 
 @pytest.mark.gpu

@@ -278,3 +278,40 @@ def test_gpu_model_priors_vs_scipy(pkg):
             gnum = (ref(tp_) - ref(tm_)) / (2 * h)
             assert np.all(np.abs(g[k] - gnum) <= 1e-6 * np.maximum(1.0, np.abs(gnum))), (k, np.abs(g[k] - gnum).max())
     model.close()
+
+
+def _rv_case():
+    """Absolute RVs of a star whose planet has no mass: the model is the offset (+ trend·basis) alone, the density scipy's normal with σ² + jitter²."""
+    rng = np.random.default_rng(15)
+    n = 40
+    t = np.sort(50000.0 + rng.uniform(0, 900, n))
+    rv, s = rng.normal(12.0, 6.0, n), rng.uniform(1.0, 5.0, n)
+    basis = (t - 50450.0) / 365.25
+    obs = [dict(kind=2, planet=-1, epoch=t, y1=rv, y2=None, s1=s, s2=None, cor=None, extra=basis)]
+    planets = [dict(orbit_kind=0, has_mass=True)]
+    el = np.array([5.0, 0.2, 1.0, 0.5, 2.0, 50100.0, 1.1, 30.0, 0.0])[:, None]       # mass = 0
+    off, jit, trend = 11.0, 2.5, -0.7
+    nuis = np.array([[off], [jit], [trend]])
+    ref = ss.norm(off + trend * basis, np.hypot(s, jit)).logpdf(rv).sum()
+    # exact derivatives of the normal: offset Σ r/v, trend Σ r·basis/v, jitter Σ j (r²/v² − 1/v)
+    r = rv - off - trend * basis; v = s * s + jit * jit
+    g = np.array([np.sum(r / v), np.sum(jit * (r * r / (v * v) - 1 / v)), np.sum(r * basis / v)])
+    return obs, planets, el, nuis, ref, g
+
+
+def test_rv_density_vs_scipy_normal(oracle):
+    """rv-absolute.jl:172-204: logpdf(Normal(0, √(σ² + jitter²)), rv − offset − trend) summed over the rows — scipy's normal, its derivatives in closed form."""
+    obs, planets, el, nuis, ref, g = _rv_case()
+    ll, _, g_nu = oracle.oracle_eval(obs, planets, el, nuis, grad=True)
+    assert abs(ll[0] - ref) < 1e-12 * abs(ref)
+    assert np.all(np.abs(g_nu[:, 0] - g) < 1e-10 * np.abs(g).max())
+
+
+@pytest.mark.gpu
+def test_gpu_rv_density_vs_scipy_normal(oracle):
+    import gpu_binding
+    obs, planets, el, nuis, ref, g = _rv_case()
+    for small, W in ((None, 1), (0, 70)):
+        ll, _, g_nu = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), np.repeat(nuis, W, axis=1), grad=True, small_batch=small)
+        assert np.all(np.abs(ll - ref) < 1e-12 * abs(ref))
+        assert np.all(np.abs(g_nu - g[:, None]) < 1e-10 * np.abs(g).max())

@@ -8,6 +8,10 @@ itself (which bijector a bounded prior gets, the sign of an offset): that stays 
                  bijector written out here (Bijectors' logit-type map of a two-sided support, the log map of a lower-bounded one: src/variables.jl:1449-1493)
   MvNormal       scipy.stats.multivariate_normal.logpdf of the row covariance [[σ1², ρσ1σ2], [ρσ1σ2, σ2²]] (src/likelihoods/relative-astrometry.jl:241-252)
   Kepler         scipy.optimize.brentq on M = E − e sin E against octo_oracle_orbitsolve's position (the solver row a4 of SURVEY.md §8)
+  RV, sep/PA     scipy.stats.norm with offset / jitter / trend (rv-absolute.jl:172-204), PA = atan(ra, dec) with the wrapped residual (:192-202)
+  barycentre     the reflex term of a planet strictly inside the observed one from per-planet solves (relative-astrometry.jl:104-142)
+  OFTI           multivariate_normal(0, σ²DDᵀ + Σ) and a ridge solve (src/parameterizations.jl:318-405)
+  Each also runs against the HIP path itself under -m gpu (both kernel families), so the product is held to third-party numbers directly.
 """
 import numpy as np
 import pytest
@@ -315,3 +319,71 @@ def test_gpu_rv_density_vs_scipy_normal(oracle):
         ll, _, g_nu = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), np.repeat(nuis, W, axis=1), grad=True, small_batch=small)
         assert np.all(np.abs(ll - ref) < 1e-12 * abs(ref))
         assert np.all(np.abs(g_nu - g[:, None]) < 1e-10 * np.abs(g).max())
+
+
+def _seppa_case(oracle):
+    """Separation / position-angle rows (relative-astrometry.jl:192-202): PA = atan(ra, dec) east of north, its residual wrapped into (−π, π]."""
+    rng = np.random.default_rng(16)
+    el = np.array([9.0, 0.4, 0.9, 0.7, 2.5, 50050.0, 1.3, 45.0, 0.0])
+    t = np.array([50000.0, 50300.0, 50800.0, 51500.0, 52400.0])
+    sol = [oracle.oracle_orbitsolve(el, tj) for tj in t]
+    ra_m, dec_m = np.array([q["raoff"] for q in sol]), np.array([q["decoff"] for q in sol])
+    sep_m, pa_m = np.hypot(ra_m, dec_m), np.arctan2(ra_m, dec_m)
+    s_pa, s_sep = rng.uniform(0.005, 0.03, 5), rng.uniform(2.0, 8.0, 5)
+    pa = pa_m + rng.normal(0, 0.01, 5) + 2 * np.pi * np.array([0, 1, -1, 2, 0])      # data on other branches of the angle
+    sep = sep_m + rng.normal(0, 4.0, 5)
+    obs = [dict(kind=1, planet=0, epoch=t, y1=pa, y2=sep, s1=s_pa, s2=s_sep, cor=None, extra=None)]
+    dpa = np.angle(np.exp(1j * (pa - pa_m)))
+    ref = ss.norm(0, s_pa).logpdf(dpa).sum() + ss.norm(0, s_sep).logpdf(sep - sep_m).sum()
+    return obs, [dict(orbit_kind=0, has_mass=False)], el[:, None], ref
+
+
+def test_seppa_density_vs_scipy(oracle):
+    obs, planets, el, ref = _seppa_case(oracle)
+    ll, _, _ = oracle.oracle_eval(obs, planets, el, None, grad=False)
+    assert abs(ll[0] - ref) < 1e-11 * abs(ref), (ll[0], ref)
+
+
+@pytest.mark.gpu
+def test_gpu_seppa_density_vs_scipy(oracle):
+    import gpu_binding
+    obs, planets, el, ref = _seppa_case(oracle)
+    for small, W in ((None, 1), (0, 70)):
+        ll, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), None, grad=True, small_batch=small)
+        assert np.all(np.abs(ll - ref) < 1e-11 * abs(ref))
+
+
+def _barycentre_case(oracle):
+    """RA/Dec of the OUTER of two planets: the model adds the reflex of the star about the inner planet, (m_in · mjup2msol / M) · (ra, dec)_inner, for
+    planets strictly inside the observed one (relative-astrometry.jl:104-142); rows of the INNER planet get nothing from the outer one."""
+    c = oracle.oracle_consts()
+    rng = np.random.default_rng(17)
+    inner = np.array([2.0, 0.1, 0.8, 1.0, 2.0, 50100.0, 1.2, 50.0, 8.0])
+    outer = np.array([11.0, 0.3, 0.9, 0.4, 2.2, 50500.0, 1.2, 50.0, 3.0])
+    t = np.array([50000.0, 50200.0, 50700.0, 51900.0])
+    so = [oracle.oracle_orbitsolve(outer, tj) for tj in t]; si = [oracle.oracle_orbitsolve(inner, tj) for tj in t]
+    f = inner[8] * c.mjup2msol / inner[6]
+    ra_o = np.array([q["raoff"] for q in so]) + f * np.array([q["raoff"] for q in si])
+    dec_o = np.array([q["decoff"] for q in so]) + f * np.array([q["decoff"] for q in si])
+    ra_i, dec_i = np.array([q["raoff"] for q in si]), np.array([q["decoff"] for q in si])
+    s = np.array([3.0, 4.0, 2.0, 5.0])
+    d_o = (ra_o + rng.normal(0, 3, 4), dec_o + rng.normal(0, 3, 4)); d_i = (ra_i + rng.normal(0, 3, 4), dec_i + rng.normal(0, 3, 4))
+    obs = [dict(kind=0, planet=1, epoch=t, y1=d_o[0], y2=d_o[1], s1=s, s2=s, cor=None, extra=None),
+           dict(kind=0, planet=0, epoch=t, y1=d_i[0], y2=d_i[1], s1=s, s2=s, cor=None, extra=None)]
+    ref = (ss.norm(ra_o, s).logpdf(d_o[0]) + ss.norm(dec_o, s).logpdf(d_o[1]) + ss.norm(ra_i, s).logpdf(d_i[0]) + ss.norm(dec_i, s).logpdf(d_i[1])).sum()
+    return obs, [dict(orbit_kind=0, has_mass=True)] * 2, np.concatenate([inner, outer])[:, None], ref
+
+
+def test_inner_barycentre_term_vs_per_planet_solves(oracle):
+    obs, planets, el, ref = _barycentre_case(oracle)
+    ll, _, _ = oracle.oracle_eval(obs, planets, el, None, grad=False)
+    assert abs(ll[0] - ref) < 1e-11 * abs(ref), (ll[0], ref)
+
+
+@pytest.mark.gpu
+def test_gpu_inner_barycentre_term_vs_per_planet_solves(oracle):
+    import gpu_binding
+    obs, planets, el, ref = _barycentre_case(oracle)
+    for small, W in ((None, 1), (0, 70)):
+        ll, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), None, grad=True, small_batch=small)
+        assert np.all(np.abs(ll - ref) < 1e-11 * abs(ref))

@@ -11,6 +11,8 @@ itself (which bijector a bounded prior gets, the sign of an offset): that stays 
   RV, sep/PA     scipy.stats.norm with offset / jitter / trend (rv-absolute.jl:172-204), PA = atan(ra, dec) with the wrapped residual (:192-202)
   barycentre     the reflex term of a planet strictly inside the observed one from per-planet solves (relative-astrometry.jl:104-142)
   OFTI           multivariate_normal(0, σ²DDᵀ + Σ) and a ridge solve (src/parameterizations.jl:318-405)
+  reflex RV      relative RV = offset + radvel(sol); the star's RV = offset − (m·mjup2msol/M)·radvel(sol): momentum conservation with M the total mass
+  tperi          θ_at_epoch_to_tperi by its meaning — the position angle at the epoch IS θ — with brentq over the orbit, not by its formula
   Each also runs against the HIP path itself under -m gpu (both kernel families), so the product is held to third-party numbers directly.
 """
 import numpy as np
@@ -387,3 +389,127 @@ def test_gpu_inner_barycentre_term_vs_per_planet_solves(oracle):
     for small, W in ((None, 1), (0, 70)):
         ll, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), None, grad=True, small_batch=small)
         assert np.all(np.abs(ll - ref) < 1e-11 * abs(ref))
+
+
+def _relrv_case(oracle):
+    """Relative RVs of a planet (OctofitterRadialVelocity/src/rv-relative.jl:128-160): offset + radvel(sol) of the planet itself, Normal(σ² + jitter²) —
+    radvel from octo_oracle_orbitsolve (itself held to d(z)/dt above)."""
+    rng = np.random.default_rng(18)
+    el = np.array([7.0, 0.25, 1.1, 0.6, 2.1, 50080.0, 1.15, 35.0, 4.0])
+    t = np.sort(50000.0 + rng.uniform(0, 3000, 12))
+    rvm = np.array([oracle.oracle_orbitsolve(el, tj)["radvel"] for tj in t])
+    s = rng.uniform(20.0, 80.0, 12)
+    off, jit = 15.0, 30.0
+    rv = rvm + off + rng.normal(0, 60.0, 12)
+    obs = [dict(kind=4, planet=0, epoch=t, y1=rv, y2=None, s1=s, s2=None, cor=None, extra=None)]
+    ref = ss.norm(rvm + off, np.hypot(s, jit)).logpdf(rv).sum()
+    return obs, [dict(orbit_kind=0, has_mass=True)], el[:, None], np.array([[off], [jit], [0.0]]), ref
+
+
+def test_relative_rv_vs_scipy(oracle):
+    obs, planets, el, nuis, ref = _relrv_case(oracle)
+    ll, _, _ = oracle.oracle_eval(obs, planets, el, nuis, grad=False)
+    assert abs(ll[0] - ref) < 1e-11 * abs(ref), (ll[0], ref)
+
+
+@pytest.mark.gpu
+def test_gpu_relative_rv_vs_scipy(oracle):
+    import gpu_binding
+    obs, planets, el, nuis, ref = _relrv_case(oracle)
+    for small, W in ((None, 1), (0, 70)):
+        ll, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), np.repeat(nuis, W, axis=1), grad=True, small_batch=small)
+        assert np.all(np.abs(ll - ref) < 1e-11 * abs(ref))
+
+
+def _absrv_planet_case(oracle):
+    """Absolute RVs of the star with a massive planet: momentum conservation in the two-body problem whose M is the TOTAL mass gives
+    v_star = −(m / M) · v_relative, i.e. offset − (m · mjup2msol / M) · radvel(sol) (OctofitterRadialVelocity/src/rv-absolute.jl:143-155)."""
+    c = oracle.oracle_consts()
+    rng = np.random.default_rng(19)
+    el = np.array([3.0, 0.3, 1.2, 0.9, 1.0, 50200.0, 1.05, 40.0, 6.0])
+    t = np.sort(50000.0 + rng.uniform(0, 2500, 15))
+    v = np.array([oracle.oracle_orbitsolve(el, tj)["radvel"] for tj in t])
+    f = el[8] * c.mjup2msol / el[6]
+    s = rng.uniform(2.0, 6.0, 15)
+    off, jit = -4.0, 1.5
+    rv = off - f * v + rng.normal(0, 4.0, 15)
+    obs = [dict(kind=2, planet=-1, epoch=t, y1=rv, y2=None, s1=s, s2=None, cor=None, extra=None)]
+    ref = ss.norm(off - f * v, np.hypot(s, jit)).logpdf(rv).sum()
+    return obs, [dict(orbit_kind=0, has_mass=True)], el[:, None], np.array([[off], [jit], [0.0]]), ref
+
+
+def test_stellar_reflex_rv_vs_scipy(oracle):
+    obs, planets, el, nuis, ref = _absrv_planet_case(oracle)
+    ll, _, _ = oracle.oracle_eval(obs, planets, el, nuis, grad=False)
+    assert abs(ll[0] - ref) < 1e-11 * abs(ref), (ll[0], ref)
+
+
+@pytest.mark.gpu
+def test_gpu_stellar_reflex_rv_vs_scipy(oracle):
+    import gpu_binding
+    obs, planets, el, nuis, ref = _absrv_planet_case(oracle)
+    for small, W in ((None, 1), (0, 70)):
+        ll, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), np.repeat(nuis, W, axis=1), grad=True, small_batch=small)
+        assert np.all(np.abs(ll - ref) < 1e-11 * abs(ref))
+
+
+def _tperi_case(oracle):
+    """θ_at_epoch_to_tperi(θ, epoch; M, e, a, i, ω, Ω) (src/parameterizations.jl:6-69) by its MEANING instead of its formula: the planet's position angle at
+    `epoch` is θ. For the D = 11 reference test model (test/integration/sampling.jl:29-64; descriptors of tests/golden/model.json) a time t* with PA(t*) = θ
+    is found on an orbit with an arbitrary tp by scipy.optimize.brentq over octo_oracle_orbitsolve; the position there is what the model must predict at the
+    epoch. One RA/Dec row holds exactly that position (σ = 0.01 mas): its residual is zero iff tp means what it should, and moving the datum by (3σ, 4σ) must
+    cost exactly 12.5 in log-posterior."""
+    import json
+    from pathlib import Path
+    case = json.loads((Path(__file__).resolve().parent / "golden" / "model.json").read_text())["cases"][0]
+    M, plx, a, e, inc, w, O, th, epoch = 1.2, 50.0, 12.0, 0.3, 0.9, 0.7, 2.0, 1.1, 50000.0
+    el = np.array([a, e, inc, w, O, 50000.0, M, plx, 0.0])
+    period = np.sqrt(a ** 3 / M) * oracle.oracle_consts().kepler_year_to_julian_day
+    pa = lambda t: (lambda q: np.arctan2(q["raoff"], q["decoff"]))(oracle.oracle_orbitsolve(el, t))
+    f = lambda t: np.angle(np.exp(1j * (pa(t) - th)))
+    grid = np.linspace(50000.0, 50000.0 + period, 2001)
+    fv = np.array([f(t) for t in grid])
+    k = next(i for i in range(2000) if fv[i] * fv[i + 1] < 0 and abs(fv[i] - fv[i + 1]) < 1.0)      # a sign change that is not the branch cut
+    ts = scipy.optimize.brentq(f, grid[k], grid[k + 1], xtol=1e-11)
+    q = oracle.oracle_orbitsolve(el, ts)
+    logit = lambda p: np.log(p / (1 - p))
+    theta_t = np.array([np.log(M - 0.1), np.log(plx - 0.1), logit(a / 100.0), logit(e / 0.99), logit(inc / np.pi),
+                        np.cos(w), np.sin(w), np.cos(O), np.sin(O), np.cos(th), np.sin(th)])[:, None]
+    sig = 0.01
+    def obs(dra, ddec):
+        return [dict(kind=0, planet=0, epoch=np.array([epoch]), y1=np.array([q["raoff"] + dra]), y2=np.array([q["decoff"] + ddec]),
+                     s1=np.array([sig]), s2=np.array([sig]), cor=None, extra=None)]
+    return case, obs, theta_t, sig
+
+
+def test_tperi_means_position_angle_at_epoch(oracle):
+    case, obs, theta_t, sig = _tperi_case(oracle)
+    pr, es = oracle.make_priors(case["priors"]), oracle.make_sources(case["esrc"])
+    lp1, _ = oracle.oracle_model_logpost(obs(0.0, 0.0), case["planets"], pr, es, None, theta_t)
+    lp2, _ = oracle.oracle_model_logpost(obs(3 * sig, 4 * sig), case["planets"], pr, es, None, theta_t)
+    assert np.isfinite(lp1[0]) and abs((lp1[0] - lp2[0]) - 12.5) < 1e-5, (lp1, lp2)
+
+
+@pytest.mark.gpu
+def test_gpu_tperi_means_position_angle_at_epoch(pkg, oracle):
+    """The same through the device-side parameterisation (the mirror's LogDensityModel of the reference test model, one θ_t: k_small<MODEL>; 70: k_model_fwd)."""
+    case, obs, theta_t, sig = _tperi_case(oracle)
+
+    def model_for(o):
+        table = dict(epoch=o[0]["epoch"], ra=o[0]["y1"], dec=o[0]["y2"], σ_ra=o[0]["s1"], σ_dec=o[0]["s2"], cor=[0.0])
+        b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromLikelihood(table, name="one_row")],
+                       variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                               Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+        return pkg.LogDensityModel(pkg.System(name="TestSys", companions=[b], observations=[],
+                                   variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))))
+    m1, m2 = model_for(obs(0.0, 0.0)), model_for(obs(3 * sig, 4 * sig))
+    try:
+        for W in (1, 70):
+            th = np.repeat(theta_t, W, axis=1)
+            if W > 1:
+                for m in (m1, m2):
+                    m.ln_like._check(m.ln_like.lib.octo_ctx_set_small_batch(m.ln_like._ctx, 0), "set")
+            d = m1.logdensity(th) - m2.logdensity(th)
+            assert np.all(np.isfinite(d)) and np.all(np.abs(d - 12.5) < 1e-5), d
+    finally:
+        m1.close(); m2.close()

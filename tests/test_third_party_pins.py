@@ -12,6 +12,7 @@ itself (which bijector a bounded prior gets, the sign of an offset): that stays 
   barycentre     the reflex term of a planet strictly inside the observed one from per-planet solves (relative-astrometry.jl:104-142)
   OFTI           multivariate_normal(0, σ²DDᵀ + Σ) and a ridge solve (src/parameterizations.jl:318-405)
   reflex RV      relative RV = offset + radvel(sol); the star's RV = offset − (m·mjup2msol/M)·radvel(sol): momentum conservation with M the total mass
+  marginal RV    scipy.integrate.quad over the zero point: the reference's ll is 2·log(integral) − log 2π (rv-absolute-margin.jl:140-185)
   tperi          θ_at_epoch_to_tperi by its meaning — the position angle at the epoch IS θ — with brentq over the orbit, not by its formula
   Each also runs against the HIP path itself under -m gpu (both kernel families), so the product is held to third-party numbers directly.
 """
@@ -513,3 +514,39 @@ def test_gpu_tperi_means_position_angle_at_epoch(pkg, oracle):
             assert np.all(np.isfinite(d)) and np.all(np.abs(d - 12.5) < 1e-5), d
     finally:
         m1.close(); m2.close()
+
+
+def _marg_case():
+    """MarginalizedStarAbsoluteRVObs (OctofitterRadialVelocity/src/rv-absolute-margin.jl:140-185, "math from the Orvara paper"): the zero point integrated out
+    under a flat prior. Its ll = −Σ log(2π var) − (C − B²/4A) − log A is TWICE the log of that integral, minus log 2π (the reference keeps Orvara's −χ² scale:
+    the 'missing ½' of DESIGN.md). scipy.integrate.quad does the integral."""
+    import scipy.integrate
+    rng = np.random.default_rng(20)
+    n = 14
+    t = np.sort(50000.0 + rng.uniform(0, 1200, n))
+    s = rng.uniform(2.0, 6.0, n); jit = 1.8
+    rv = rng.normal(7.0, 5.0, n)
+    var = s * s + jit * jit
+    mu_hat = np.sum(rv / var) / np.sum(1 / var); width = 1 / np.sqrt(np.sum(1 / var))
+    f = lambda g: np.exp(np.sum(ss.norm(g, np.sqrt(var)).logpdf(rv)) - c0)
+    c0 = np.sum(ss.norm(mu_hat, np.sqrt(var)).logpdf(rv))                   # scale out the peak so that quad sees O(1) numbers
+    integral, err = scipy.integrate.quad(f, mu_hat - 12 * width, mu_hat + 12 * width, epsabs=0, epsrel=1e-13, limit=200)
+    log_marginal = np.log(integral) + c0
+    obs = [dict(kind=3, planet=-1, epoch=t, y1=rv, y2=None, s1=s, s2=None, cor=None, extra=None)]
+    el = np.array([5.0, 0.2, 1.0, 0.5, 2.0, 50100.0, 1.1, 30.0, 0.0])[:, None]        # a massless planet: the model is the zero point alone
+    return obs, [dict(orbit_kind=0, has_mass=True)], el, np.array([[0.0], [jit], [0.0]]), 2.0 * log_marginal - np.log(2 * np.pi)
+
+
+def test_marginalised_rv_vs_scipy_quad(oracle):
+    obs, planets, el, nuis, ref = _marg_case()
+    ll, _, _ = oracle.oracle_eval(obs, planets, el, nuis, grad=False)
+    assert abs(ll[0] - ref) < 1e-10 * abs(ref), (ll[0], ref)
+
+
+@pytest.mark.gpu
+def test_gpu_marginalised_rv_vs_scipy_quad(oracle):
+    import gpu_binding
+    obs, planets, el, nuis, ref = _marg_case()
+    for small, W in ((None, 1), (0, 70)):
+        ll, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), np.repeat(nuis, W, axis=1), grad=True, small_batch=small)
+        assert np.all(np.abs(ll - ref) < 1e-10 * abs(ref))

@@ -550,3 +550,34 @@ def test_gpu_marginalised_rv_vs_scipy_quad(oracle):
     for small, W in ((None, 1), (0, 70)):
         ll, _, _ = gpu_binding.gpu_eval(obs, planets, np.repeat(el, W, axis=1), np.repeat(nuis, W, axis=1), grad=True, small_batch=small)
         assert np.all(np.abs(ll - ref) < 1e-10 * abs(ref))
+
+
+def _ti_case():
+    """A Campbell orbit and the SAME orbit through the textbook Thiele-Innes constants (A, B, F, G in mas = a·plx·(…)): dec = A·X + F·Y, ra = B·X + G·Y with
+    X = cos E − e, Y = √(1−e²) sin E. The ThieleInnesOrbit planet recovers a = α/plx from them (src/parameterizations.jl:14-19) for its period."""
+    a, e, inc, w, O, tp, M, plx = 8.0, 0.35, 1.0, 0.8, 2.3, 50040.0, 1.25, 42.0
+    ca, sa = np.cos, np.sin
+    A = a * plx * (ca(w) * ca(O) - sa(w) * sa(O) * ca(inc)); B = a * plx * (ca(w) * sa(O) + sa(w) * ca(O) * ca(inc))
+    F = a * plx * (-sa(w) * ca(O) - ca(w) * sa(O) * ca(inc)); G = a * plx * (-sa(w) * sa(O) + ca(w) * ca(O) * ca(inc))
+    camp = np.array([a, e, inc, w, O, tp, M, plx, 0.0]); ti = np.array([A, e, B, F, G, tp, M, plx, 0.0])
+    return camp, ti
+
+
+def test_thiele_innes_orbit_is_the_campbell_orbit(oracle):
+    camp, ti = _ti_case()
+    for t in (50000.0, 50500.0, 52345.6):
+        qc, qt = oracle.oracle_orbitsolve(camp, t, orbit_kind=0), oracle.oracle_orbitsolve(ti, t, orbit_kind=2)
+        assert abs(qc["raoff"] - qt["raoff"]) < 1e-10 * abs(camp[0] * camp[7]) and abs(qc["decoff"] - qt["decoff"]) < 1e-10 * abs(camp[0] * camp[7])
+
+
+@pytest.mark.gpu
+def test_gpu_thiele_innes_orbit_is_the_campbell_orbit(oracle):
+    import gpu_binding
+    camp, ti = _ti_case()
+    rng = np.random.default_rng(22)
+    t = np.sort(50000.0 + rng.uniform(0, 4000, 20))
+    obs = [dict(kind=0, planet=0, epoch=t, y1=rng.normal(0, 300, 20), y2=rng.normal(0, 300, 20), s1=np.full(20, 5.0), s2=np.full(20, 7.0), cor=rng.uniform(-0.5, 0.5, 20), extra=None)]
+    for small, W in ((None, 1), (0, 70)):
+        ll_c, _, _ = gpu_binding.gpu_eval(obs, [dict(orbit_kind=0, has_mass=False)], np.repeat(camp[:, None], W, axis=1), None, grad=True, small_batch=small)
+        ll_t, _, _ = gpu_binding.gpu_eval(obs, [dict(orbit_kind=2, has_mass=False)], np.repeat(ti[:, None], W, axis=1), None, grad=True, small_batch=small)
+        assert np.all(np.abs(ll_c - ll_t) < 1e-10 * np.abs(ll_c))

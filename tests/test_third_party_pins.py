@@ -12,6 +12,7 @@ itself (which bijector a bounded prior gets, the sign of an offset): that stays 
   barycentre     the reflex term of a planet strictly inside the observed one from per-planet solves (relative-astrometry.jl:104-142)
   OFTI           multivariate_normal(0, σ²DDᵀ + Σ) and a ridge solve (src/parameterizations.jl:318-405)
   reflex RV      relative RV = offset + radvel(sol); the star's RV = offset − (m·mjup2msol/M)·radvel(sol): momentum conservation with M the total mass
+  Thiele-Innes   the ThieleInnesOrbit planet = the Campbell orbit through the textbook constants A, B, F, G
   marginal RV    scipy.integrate.quad over the zero point: the reference's ll is 2·log(integral) − log 2π (rv-absolute-margin.jl:140-185)
   tperi          θ_at_epoch_to_tperi by its meaning — the position angle at the epoch IS θ — with brentq over the orbit, not by its formula
   Each also runs against the HIP path itself under -m gpu (both kernel families), so the product is held to third-party numbers directly.

@@ -12,6 +12,7 @@ itself (which bijector a bounded prior gets, the sign of an offset): that stays 
   barycentre     the reflex term of a planet strictly inside the observed one from per-planet solves (relative-astrometry.jl:104-142)
   OFTI           multivariate_normal(0, σ²DDᵀ + Σ) and a ridge solve (src/parameterizations.jl:318-405)
   reflex RV      relative RV = offset + radvel(sol); the star's RV = offset − (m·mjup2msol/M)·radvel(sol): momentum conservation with M the total mass
+  UnitLength     a UniformCircular pair scaled by r: two Normal(0, 1) priors + logpdf(LogNormal(0, 0.1), r) by scipy.stats.lognorm (src/variables.jl:279-323)
   Thiele-Innes   the ThieleInnesOrbit planet = the Campbell orbit through the textbook constants A, B, F, G
   marginal RV    scipy.integrate.quad over the zero point: the reference's ll is 2·log(integral) − log 2π (rv-absolute-margin.jl:140-185)
   tperi          θ_at_epoch_to_tperi by its meaning — the position angle at the epoch IS θ — with brentq over the orbit, not by its formula
@@ -492,19 +493,21 @@ def test_tperi_means_position_angle_at_epoch(oracle):
     assert np.isfinite(lp1[0]) and abs((lp1[0] - lp2[0]) - 12.5) < 1e-5, (lp1, lp2)
 
 
+def _d11_model(pkg, o):
+    """The reference test model (test/integration/sampling.jl:29-64) over a one-row table, through the mirror."""
+    table = dict(epoch=o[0]["epoch"], ra=o[0]["y1"], dec=o[0]["y2"], σ_ra=o[0]["s1"], σ_dec=o[0]["s2"], cor=[0.0])
+    b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromLikelihood(table, name="one_row")],
+                   variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                           Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+    return pkg.LogDensityModel(pkg.System(name="TestSys", companions=[b], observations=[],
+                               variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))))
+
+
 @pytest.mark.gpu
 def test_gpu_tperi_means_position_angle_at_epoch(pkg, oracle):
     """The same through the device-side parameterisation (the mirror's LogDensityModel of the reference test model, one θ_t: k_small<MODEL>; 70: k_model_fwd)."""
     case, obs, theta_t, sig = _tperi_case(oracle)
-
-    def model_for(o):
-        table = dict(epoch=o[0]["epoch"], ra=o[0]["y1"], dec=o[0]["y2"], σ_ra=o[0]["s1"], σ_dec=o[0]["s2"], cor=[0.0])
-        b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromLikelihood(table, name="one_row")],
-                       variables=pkg.variables(a=pkg.Uniform(0, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
-                                               Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
-        return pkg.LogDensityModel(pkg.System(name="TestSys", companions=[b], observations=[],
-                                   variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1), plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))))
-    m1, m2 = model_for(obs(0.0, 0.0)), model_for(obs(3 * sig, 4 * sig))
+    m1, m2 = _d11_model(pkg, obs(0.0, 0.0)), _d11_model(pkg, obs(3 * sig, 4 * sig))
     try:
         for W in (1, 70):
             th = np.repeat(theta_t, W, axis=1)
@@ -582,3 +585,39 @@ def test_gpu_thiele_innes_orbit_is_the_campbell_orbit(oracle):
         ll_c, _, _ = gpu_binding.gpu_eval(obs, [dict(orbit_kind=0, has_mass=False)], np.repeat(camp[:, None], W, axis=1), None, grad=True, small_batch=small)
         ll_t, _, _ = gpu_binding.gpu_eval(obs, [dict(orbit_kind=2, has_mass=False)], np.repeat(ti[:, None], W, axis=1), None, grad=True, small_batch=small)
         assert np.all(np.abs(ll_c - ll_t) < 1e-10 * np.abs(ll_c))
+
+
+def _unit_length_ref(r):
+    """What scaling ONE UniformCircular pair (x, y) = r·(cos, sin) changes in the log-posterior: its two Normal(0, 1) priors and its UnitLengthPrior
+    logpdf(LogNormal(log 1, 0.1), √(x² + y²)) (src/variables.jl:279-323) — the angle, hence the orbit and the likelihood, stay what they were."""
+    return (ss.lognorm(s=0.1, scale=1.0).logpdf(r) - ss.lognorm(s=0.1, scale=1.0).logpdf(1.0)) - 0.5 * (r * r - 1.0)
+
+
+def test_unit_length_prior_vs_scipy_lognorm(oracle):
+    case, obs, theta_t, sig = _tperi_case(oracle)
+    pr, es = oracle.make_priors(case["priors"]), oracle.make_sources(case["esrc"])
+    lp0, _ = oracle.oracle_model_logpost(obs(0.3, -0.2), case["planets"], pr, es, None, theta_t)
+    for pair in ((5, 6), (7, 8), (9, 10)):                       # ω, Ω, θ (the one tp is derived from)
+        for r in (0.8, 1.0, 1.17):
+            th = theta_t.copy(); th[pair[0]] *= r; th[pair[1]] *= r
+            lp, _ = oracle.oracle_model_logpost(obs(0.3, -0.2), case["planets"], pr, es, None, th)
+            assert abs((lp[0] - lp0[0]) - _unit_length_ref(r)) < 1e-9 * max(1.0, abs(lp0[0])), (pair, r, lp[0] - lp0[0], _unit_length_ref(r))
+
+
+@pytest.mark.gpu
+def test_gpu_unit_length_prior_vs_scipy_lognorm(pkg, oracle):
+    case, obs, theta_t, sig = _tperi_case(oracle)
+    m = _d11_model(pkg, obs(0.3, -0.2))
+    try:
+        for W in (1, 70):
+            if W > 1:
+                m.ln_like._check(m.ln_like.lib.octo_ctx_set_small_batch(m.ln_like._ctx, 0), "set")
+            lp0 = m.logdensity(np.repeat(theta_t, W, axis=1))
+            for pair in ((5, 6), (7, 8), (9, 10)):
+                for r in (0.8, 1.17):
+                    th = np.repeat(theta_t, W, axis=1); th[pair[0]] *= r; th[pair[1]] *= r
+                    d = m.logdensity(th) - lp0
+                    assert np.all(np.abs(d - _unit_length_ref(r)) < 1e-9 * np.maximum(1.0, np.abs(lp0))), (pair, r, d[0], _unit_length_ref(r))
+    finally:
+        m.close()
+

@@ -295,7 +295,7 @@ def test_bench_line_contract():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["traffic"] > 1e7
     assert 0 < roof["hbm"]["frac"] < 0.1 and roof["hbm"]["unit"] == "GB/s"                     # the real HBM rate: a percent or two of 8 TB/s
     assert roof["north_star_algorithmic_hbm"]["algorithmic_bytes_per_launch"] == 4001360000.0
-    assert 0.25 < roof["kernel_avg_ms"] < 0.6 and roof["kernel_launches_timed"] >= 2
+    assert 0.1 < roof["kernel_avg_ms"] < 0.6 and roof["kernel_launches_timed"] >= 2      # (0.27 ms on this round's boxes: a plausibility window, not a benchmark)
     assert d["parity"]["ok"] is True and d["max_rel_err"] < 1e-8
     assert 0.5 * d["value"] < d["pcie_inclusive"]["value"] < d["value"]
     assert d["config1"]["gpu_matches_fixture"] is True and 5 < d["config1"]["gpu_us_per_call"] < 200

@@ -79,7 +79,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--epochs", type=int, default=10_000)
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default 10000; 8192 = 8 temperatures x 1024 for --workload pt)")
-    ap.add_argument("--workload", choices=["grad", "fwd", "nuis", "two_planet", "pt", "ofti", "logpost"], default="grad")
+    ap.add_argument("--workload", choices=["grad", "fwd", "nuis", "two_planet", "pt", "ofti", "logpost", "wide_prior", "rv_gappy", "rv_gappy_nuis"], default="grad",
+                    help="grad (default): BASELINE config 3, the metric. Round 6: wide_prior = config 3's table with a ~ LogU(0.3, 100) AU; rv_gappy(_nuis) = one planet, "
+                         "1e4 absolute-RV epochs in nightly runs with seasonal gaps (with per-walker offset + jitter): tests/synth.py")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="strong (default for grad / fwd / nuis): --walkers in total, split evenly over the ranks (SURVEY 8d 'Scaling runs'); "
                          "weak (default for the other workloads): --walkers per GPU")
@@ -306,7 +308,7 @@ def main():
                 "spinup_steps_untimed": n_spin,
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfgd}
 
-    grad = args.workload in ("grad", "two_planet", "nuis")
+    grad = args.workload in ("grad", "two_planet", "nuis", "wide_prior", "rv_gappy", "rv_gappy_nuis")
     if args.workload == "ofti":
         # batched ofti_linear_solve (src/parameterizations.jl:318-405), forward marginal likelihood
         cfg0 = synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=6)
@@ -366,15 +368,25 @@ def main():
         else:
             cfg = cfg_full if world == 1 else synth.config_astrom(n_epochs=args.epochs, n_walkers=args.walkers, cfg=3 if grad else 2,
                                                                   seed=20260929 + 3 + 1000 * rank)
-        obs, planet = synth.to_mirror(pkg, cfg)
-        system = pkg.System(name="bench", companions=[planet], observations=[])
+        if args.workload in ("wide_prior", "rv_gappy", "rv_gappy_nuis"):      # round 6: non-uniform workloads (weak scaling only: every rank its own draw)
+            sd = None if world == 1 else 20260929 + 60 + 1000 * rank
+            cfg = cfg_full = (synth.config_wide_prior(n_epochs=args.epochs, n_walkers=args.walkers, seed=sd) if args.workload == "wide_prior"
+                              else synth.config_rv_gappy(n_epochs=args.epochs, n_walkers=args.walkers, nuis=args.workload == "rv_gappy_nuis", seed=sd))
+        if args.workload.startswith("rv_gappy"):
+            planet = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[])
+            system = pkg.System(name="bench", companions=[planet], observations=[pkg.StarAbsoluteRVObs(cfg["table"], name="rv")])
+        else:
+            obs, planet = synth.to_mirror(pkg, cfg)
+            system = pkg.System(name="bench", companions=[planet], observations=[])
         fn = pkg.make_ln_like(system, cfg["theta_example"], device=dev_index)
-        elems_h, nuis_h = cfg["elems"], None
+        elems_h, nuis_h = cfg["elems"], cfg.get("nuis")
         n_rows, W = cfg["n_epochs"], cfg["n_walkers"]
         if args.workload == "nuis":      # config 3 with per-walker jitter, platescale and northangle: the raw-σ branch of relative-astrometry.jl:234-252
             rng = np.random.default_rng(1)
             nuis_h = np.stack([rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W)])
-        workload = (f"config{'3' if grad else '2'}: 1 planet, {n_rows} RA/Dec epochs x "
+        wl_name = {"wide_prior": "wide_prior (config 3's table, a ~ LogU(0.3, 100) AU)", "rv_gappy": "rv_gappy (absolute RV, nightly runs with seasonal gaps, jitter == 0 path)",
+                   "rv_gappy_nuis": "rv_gappy_nuis (absolute RV, nightly runs with seasonal gaps, per-walker offset + jitter)"}.get(args.workload, f"config{'3' if grad else '2'}")
+        workload = (f"{wl_name}: 1 planet, {n_rows} {'RV' if args.workload.startswith('rv_gappy') else 'RA/Dec'} epochs x "
                     + (f"{args.walkers} walkers in total ({args.walkers} walkers split over {world} GPUs: {W} walkers/GPU)" if args.scaling == "strong"
                        else f"{W} walkers/GPU")
                     + (", per-walker jitter/platescale/northangle" if args.workload == "nuis" else "")

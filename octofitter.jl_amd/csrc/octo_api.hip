@@ -221,7 +221,16 @@ int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** ou
         const int64_t span = chunk * wpb;
         for (int64_t r0 = 0; r0 < n; r0 += span) {
             Task t;
+            std::memset(&t, 0, sizeof(t));
             t.obs = o; t.row0 = (int32_t)r0; t.nrows = (int32_t)std::min<int64_t>(span, n - r0); t.chunk = (int32_t)chunk;
+            {   // largest step among the rows that a wave may solve warm (every row but the first of each wave's slice), rounded up to a float
+                double km = 0.0;
+                for (int64_t r = r0; r < r0 + t.nrows; ++r)
+                    if ((r - r0) % chunk != 0) km = std::max(km, (double)ds->h_step[o][r]);
+                float f = (float)km;
+                if ((double)f < km) f = std::nextafterf(f, INFINITY);
+                t.key_max = std::isfinite(km) ? f : INFINITY;
+            }
             tt.h_tasks.push_back(t);
             double a = 0.0, b = 0.0;
             for (int64_t r = r0; r < r0 + t.nrows; ++r) { a += ds->h_rowconst_pre[o][r]; b += ds->h_rowconst_raw[o][r]; }
@@ -519,7 +528,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
     ds->serial = g_dataset_serial.fetch_add(1);
     for (int p = 0; p < n_planets; ++p) ds->planets[p] = planets[p];
     auto bail = [&](int code, const std::string& msg) { octo_dataset_destroy(ds); return fail(ctx, code, msg); };
-    ds->h_obs.resize(n_obs); ds->h_rowconst_pre.resize(n_obs); ds->h_rowconst_raw.resize(n_obs);
+    ds->h_obs.resize(n_obs); ds->h_rowconst_pre.resize(n_obs); ds->h_rowconst_raw.resize(n_obs); ds->h_step.resize(n_obs);
     for (int o = 0; o < n_obs; ++o) {
         const octo_obs_desc& d = obs[o];
         if (d.kind < 0 || d.kind >= OCTO_N_KINDS) return bail(OCTO_EINVAL, "octo_dataset_create: unknown observation kind");
@@ -589,7 +598,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
         if (has_basis && d.n_extra != n) return bail(OCTO_EINVAL, "octo_dataset_create: an RV table's trend basis column (extra) needs n_extra == n_epochs");
         if (astrom && d.extra != nullptr && d.n_extra > 0) return bail(OCTO_EINVAL, "octo_dataset_create: astrometry tables take no `extra`");
         std::vector<double> raw((size_t)n * ROW_STRIDE, 0.0), pre((size_t)n * ROW_STRIDE, 0.0);
-        ds->h_rowconst_pre[o].resize(n); ds->h_rowconst_raw[o].resize(n);
+        ds->h_rowconst_pre[o].resize(n); ds->h_rowconst_raw[o].resize(n); ds->h_step[o].resize(n);
         for (int64_t r = 0; r < n; ++r) {
             double* a = &raw[(size_t)r * ROW_STRIDE];
             double* b = &pre[(size_t)r * ROW_STRIDE];
@@ -625,15 +634,41 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
             }
         }
         // slot 6 of every record: 2π·(t − t of the previous row), 0 in row 0 — the mean-anomaly step per unit mean motion that k_main's
-        // warm-started row loop multiplies by 1/P (octo_device.h: KWarm); the table's largest one bounds the predictor's error a priori
+        // warm-started row loop multiplies by 1/P (octo_device.h: KWarm). Slot 7: the row's warm KEY — |that step|, or +Inf where the row must
+        // start cold whatever the wave's bound is: row 0, every WARM_RESTART-th row (the chain of warm rows never sees E or M as numbers, so its
+        // rounding accumulates until the next cold row: this bounds the chain whatever chunk the planner picks), a non-finite step.
         double dm_max = 0.0;
-        for (int64_t r = 1; r < n; ++r) {
-            const double dm = TWO_PI * (d.epoch[r] - d.epoch[r - 1]);
+        std::vector<double> steps;
+        steps.reserve((size_t)std::max<int64_t>(n, 1));
+        for (int64_t r = 0; r < n; ++r) {
+            const double dm = r > 0 ? TWO_PI * (d.epoch[r] - d.epoch[r - 1]) : 0.0;
+            double key = std::fabs(dm);
+            if (r > 0) { dm_max = std::max(dm_max, key); steps.push_back(key); }
+            ds->h_step[o][r] = std::isfinite(key) ? key : INFINITY;
+            if (r == 0 || (r % WARM_RESTART) == 0 || !std::isfinite(key)) key = INFINITY;
             raw[(size_t)r * ROW_STRIDE + 6] = pre[(size_t)r * ROW_STRIDE + 6] = dm;
-            dm_max = std::max(dm_max, std::fabs(dm));
+            raw[(size_t)r * ROW_STRIDE + 7] = pre[(size_t)r * ROW_STRIDE + 7] = key;
         }
         DevObs& h = ds->h_obs[o];
         h.kind = d.kind; h.planet = planet_obs ? d.planet : -1; h.has_cor = d.cor ? 1 : 0; h.dm_max = ctx->env_warm ? (float)(dm_max * 1.000001) : 0.0f; h.n = n;
+        // The ladder of candidate bounds (DevObs::dm_ladder), preferred first: the 97 % quantile of the steps (the largest 3 % of a table's gaps
+        // are not worth a lower bound on 1/D for every other row: a cold row costs a third more than a warm one), then smaller quantiles for
+        // waves whose periods are too short for it. Each rounded UP to a float; equal neighbours collapse; 0 = no entry.
+        for (int k = 0; k < WARM_LADDER; ++k) h.dm_ladder[k] = 0.0f;
+        if (ctx->env_warm && !steps.empty()) {
+            std::sort(steps.begin(), steps.end());
+            static const double q[WARM_LADDER] = {0.97, 0.90, 0.75, 0.50, 0.25, 0.10, 0.03, 0.01};
+            int m = 0;
+            for (int k = 0; k < WARM_LADDER; ++k) {
+                const size_t idx = (size_t)std::min<double>((double)steps.size() - 1.0, std::ceil(q[k] * (double)steps.size()) - 1.0 < 0.0 ? 0.0 : std::ceil(q[k] * (double)steps.size()) - 1.0);
+                const double v = steps[idx];
+                if (!(v > 0.0) || !std::isfinite(v)) continue;
+                float f = (float)v;
+                if ((double)f < v) f = std::nextafterf(f, INFINITY);
+                if (m > 0 && h.dm_ladder[m - 1] == f) continue;
+                h.dm_ladder[m++] = f;
+            }
+        }
         h.raw = h.pre = nullptr;
         if (n > 0) {
             double *dr = nullptr, *dp = nullptr;

@@ -104,9 +104,20 @@ struct KSol { double sE, cE, invD, dt, E; };
 // What the chain gives up: E and M never appear, so the solve of row j starts from the SOLUTION of row j−1 and its rounding (~1e-16 in M per
 // row) accumulates until the next cold row — at most a wave's chunk of rows (tens to a few hundred: < 1e-13 in M, the size of the
 // rounding of (t − tp)/P itself for a walker a few orbits from tp; the prototype measures 8e-15 after 72 rows).
+// ROUND 6 — the bound is per WAVE and the veto per ROW. Round 5 took ΔM_max from the table's single largest step: one seasonal gap in an RV table
+// (or the 120-day steps of a real astrometry table) sent every wave to the cold loop, and so did one short-period walker in a tile of 64. Now the
+// dataset carries a short LADDER of candidate step bounds per table (DevObs::dm_ladder: quantiles of |2π Δt|, preferred first), a wave takes the
+// first one none of its lanes vetoes (ΔM <= WARM_DM_VETO for every lane), thr follows from THAT bound, and a row whose own step exceeds it is
+// solved cold behind a SCALAR branch: slot 7 of the row record holds |2π Δt| (+Inf for rows that must start cold: row 0, every
+// WARM_RESTART-th row — which bounds the chain whatever the planner's chunk is, ADVICE r5 — and non-finite steps), and the test is an unsigned
+// compare of its high dword with the bound's (both SGPRs; positive doubles order like their high dwords, and thr is computed from the
+// bound stretched by 2^-18 to cover the low dword). The loop stays divergence-free; a gap costs one cold row.
 struct KWarm { double sE, cE, invD; };
 constexpr double WARM_TOL = 1.0e-3;
 constexpr double WARM_MIN_THR = 2.0;      // a wave takes the warm loop only if every lane passes at least wherever D >= 1/2
+constexpr float WARM_DM_VETO = 0.0314f;   // (WARM_TOL/32)^(1/3) = 0.03150, less the 2^-18 stretch and the float roundings: thr >= WARM_MIN_THR
+constexpr int WARM_LADDER = 8;            // candidate step bounds per table (DevObs::dm_ladder)
+constexpr int WARM_RESTART = 256;         // every WARM_RESTART-th row of a table starts cold
 
 __device__ __forceinline__ void load_pc(PC& pc, const double* __restrict__ wc, int64_t ldw, int p, int64_t w) {
     const double* b = wc + (int64_t)p * NWC * ldw + w;
@@ -381,14 +392,15 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
 }
 
 // The warm-started solve (KWarm above). st: the previous row's solution of this (walker, planet), updated; thr: the lane's bound on 1/D;
-// dm = 2π (t − t of the previous row), wave-uniform (row record slot 6). A wave's first row enters with st.invD = +Inf: cold.
+// dm = 2π (t − t of the previous row), wave-uniform (row record slot 6); row_ok: the row's own step is within the wave's bound (scalar: slot 7
+// against WarmState::key_hi). A wave's first row enters with st.invD = +Inf: cold.
 template <int INV_NR>
-__device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const SinCosTab& tab, KWarm& st, double thr, double dm) {
+__device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const SinCosTab& tab, KWarm& st, double thr, double dm, bool row_ok = true) {
     static_assert(INV_NR >= 0, "the warm start needs 1/(1 − e cos E) of every row");
     KSol s;
     s.dt = t - pc.tp;
     double E1 = 0.0, s1, c1, f0;
-    const bool warm_row = __builtin_amdgcn_ballot_w64(st.invD >= thr) == 0;      // every lane of the wave passes (a NaN bound — an invalid walker — passes: its sums are discarded)
+    const bool warm_row = row_ok && __builtin_amdgcn_ballot_w64(st.invD >= thr) == 0;      // every lane of the wave passes (a NaN bound — an invalid walker — passes: its sums are discarded)
     if (warm_row) {
         const double dM = dm * pc.invP;
         const double x = dM * st.invD;

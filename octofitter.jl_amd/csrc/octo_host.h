@@ -52,6 +52,7 @@ struct octo_dataset {
     int n_hgca = 0;                      // OCTO_HGCA tables: evaluated by k_hgca, not by the epoch-loop kernel
     std::vector<DevObs> h_obs;
     std::vector<std::vector<double>> h_rowconst_pre, h_rowconst_raw;   // per obs, per row
+    std::vector<std::vector<double>> h_step;                           // per obs, per row: |2π·(t − t of the previous row)| (0 in row 0, +Inf if not finite): Task::key_max
     DevObs* d_obs = nullptr;
     std::vector<double*> d_bufs;
     octo_planet_desc planets[MAXP];

@@ -12,6 +12,8 @@
 //   k_finish  per walker: fixed-order sum of the task partials (deterministic), closed-form terms,
 //             and the map from the running sums to ∂ll/∂(a,e,i,ω,Ω,tp,M,plx,mass) and nuisances.
 #pragma once
+#include <type_traits>
+
 #include "octo_device.h"
 #include "octofitter_hip.h"
 
@@ -52,14 +54,22 @@ constexpr int KM_HGCA = 128;
 
 struct DevObs {
     int32_t kind, planet, has_cor;
-    float dm_max;        // largest 2π·(t_j − t_{j−1}) of the table's rows [rad·day]: the warm start's a-priori bound (octo_device.h: KWarm); 0 for a table of one row
+    float dm_max;        // largest 2π·(t_j − t_{j−1}) of the table's rows [rad·day]; 0 for a table of one row (or a context created with OCTO_WARM=0)
     int64_t n;
-    const double* raw;   // [n][8]: astrom {t,y1,y2,s1,s2,cor,dm,0}; rv {t,rv,σ,trend basis,0,0,dm,0}; dm = 2π·(t − t of the previous row), 0 in row 0
-    const double* pre;   // [n][8]: astrom {t,y1,y2,p11,p22,p12,dm,0} (Σ⁻¹ entries); rv {t,rv,1/σ²,0,0,0,dm,0}
+    const double* raw;   // [n][8]: astrom {t,y1,y2,s1,s2,cor,dm,key}; rv {t,rv,σ,trend basis,0,0,dm,key}; dm = 2π·(t − t of the previous row), 0 in row 0
+    const double* pre;   // [n][8]: astrom {t,y1,y2,p11,p22,p12,dm,key} (Σ⁻¹ entries); rv {t,rv,1/σ²,0,0,0,dm,key}
+    // The warm start's candidate step bounds [rad·day], in order of preference (octo_device.h: KWarm, warm_init below): quantiles of the table's
+    // |dm| — the 97 % one first, then smaller ones — each rounded up to a float; 0 = no entry. A wave takes the FIRST entry that none of its
+    // lanes vetoes; rows whose own step exceeds it (slot 7 of the record, `key`: |dm|, or +Inf for a row that must start cold) are solved cold
+    // behind a scalar branch. One seasonal gap then costs one cold row, not the table (round 5 used dm_max for every row).
+    float dm_ladder[WARM_LADDER];
 };
 
 struct Task {
     int32_t obs, row0, nrows, chunk;   // chunk = rows per wave: the block's WPB waves split the task's nrows
+    float key_max;                     // largest |2π Δt| of the task's rows, each wave's first row aside (+Inf for a non-finite step): a wave whose bound
+                                       // covers it — and whose chunk is within WARM_RESTART — takes the warm loop WITHOUT the per-row test
+    int32_t pad[3];
 };
 
 struct DevConsts {
@@ -466,9 +476,9 @@ __device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ 
 
 // The warm start's per-wave state (octo_device.h: KWarm): the previous row's solution and the lane's bound on 1/D, per planet.
 template <int P>
-struct WarmState { KWarm st[P]; double thr[P]; };
+struct WarmState { KWarm st[P]; double thr[P]; uint32_t key_hi; bool row_ok; };
 
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false>
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true>
 __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                            const AstromCoef<P>& co, double t, double y1, double y2, double c3, double c4, double c5,
                                            const SinCosTab& tab, WarmState<P>* ws = nullptr, double dm = 0.0) {
@@ -481,7 +491,7 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
     double ra_m, dec_m;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        if constexpr (WARM) s[p] = kepler_solve_warm<1>(t, pc[p], tab, ws->st[p], ws->thr[p], dm);
+        if constexpr (WARM) s[p] = kepler_solve_warm<1>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
         else s[p] = kepler_solve<1, TAB>(t, pc[p], tab);
         rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
         dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
@@ -678,7 +688,7 @@ __device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, in
     return rv_coef_vals<P, GRAD, NUIS, KM>(off, jit, trend, margp, ldw, ob_kind, ob_planet, obs_index, pc, wl);
 }
 
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false>
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true>
 __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                        const RvCoef<P>& co, double t, double rv, double c2, double basis, const SinCosTab& tab,
                                        WarmState<P>* ws = nullptr, double dm = 0.0) {
@@ -693,7 +703,7 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
     double model = NUIS ? fma(co.trend, basis, co.off) : co.off;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        if constexpr (WARM) s[p] = kepler_solve_warm<2>(t, pc[p], tab, ws->st[p], ws->thr[p], dm);
+        if constexpr (WARM) s[p] = kepler_solve_warm<2>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
         else s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
         cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
         snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
@@ -803,6 +813,7 @@ __device__ __forceinline__ RowRegs8 row_issue8(crow_t p) {
     return r;
 }
 __device__ __forceinline__ void row_drain(const RowRegs8& r) { asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(r.lo), "s"(r.hi)); }
+
 __device__ __forceinline__ RowRegs8 row_wait_issue(RowRegs8& cur, crow_t p) {
     RowRegs8 r;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20"
@@ -861,21 +872,36 @@ constexpr bool main_warm() {
     return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL) && !(NUIS && (KM & (KM_SEPPA | KM_RV)));
 }
 
-// thr = (tol / ΔM_max³)^(1/5) per lane, ΔM_max = the table's largest 2π Δt / P (v_log_f32 / v_exp_f32 are base 2); the wave takes the warm
-// loop when every lane's bound leaves it something to pass (a NaN — an invalid walker — does not veto). The first row of a wave is cold.
+// The wave's step bound: the first entry of the table's ladder (DevObs::dm_ladder, preferred first) that no lane vetoes, a veto being
+// ΔM = bound/P > WARM_DM_VETO (thr would fall below WARM_MIN_THR; a NaN — an invalid walker — does not veto). thr = (tol / ΔM³)^(1/5) per lane from
+// that bound (v_log_f32 / v_exp_f32 are base 2). No entry passes: the wave runs the cold loop. The first row of a wave is cold.
 template <int P>
-__device__ __forceinline__ bool warm_init(WarmState<P>& ws, const PC (&pc)[P], float dm_max) {
-    bool veto = false;
+__device__ __forceinline__ float warm_init(WarmState<P>& ws, const PC (&pc)[P], const DevObs& ob) {
+    float bound = 0.0f;
+#pragma unroll
+    for (int k = WARM_LADDER - 1; k >= 0; --k) {      // (last to first: the most preferred passing entry is written last)
+        const float d = ob.dm_ladder[k];
+        bool veto = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) veto = veto || (fabsf(d * (float)pc[p].invP) > WARM_DM_VETO);
+        if (d > 0.0f && __builtin_amdgcn_ballot_w64(veto) == 0) bound = d;
+    }
+    const double bd = (double)bound;
+    ws.key_hi = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(bd));
+    const float bs = bound * (1.0f + 0x1p-18f);      // rows pass on the high dword of their step: up to 2^-20 above the bound
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const float dmx = fabsf(dm_max * (float)pc[p].invP);
+        const float dmx = fabsf(bs * (float)pc[p].invP);
         const float th = __builtin_amdgcn_exp2f(0.2f * (__builtin_amdgcn_logf((float)WARM_TOL) - 3.0f * __builtin_amdgcn_logf(dmx)));
         ws.thr[p] = (double)th;
         ws.st[p].sE = 0.0; ws.st[p].cE = 1.0; ws.st[p].invD = __builtin_huge_val();
-        veto = veto || (th < (float)WARM_MIN_THR);
     }
-    return __builtin_amdgcn_ballot_w64(veto) == 0 && dm_max > 0.0f;
+    ws.row_ok = true;
+    return bound;      // 0: the cold loop
 }
+// the row's own step against the wave's bound: slot 7 of the record (|2π Δt|, +Inf for a row that must start cold), high dwords, unsigned
+template <int P, typename Row>
+__device__ __forceinline__ bool warm_row_ok(const WarmState<P>& ws, const Row& r) { return (uint32_t)r.hi[7] <= ws.key_hi; }
 
 // FUSED: the orbit constructors inside the launch — wave 0 of every block derives its tile's constants (what k_setup stores in `wc`) and
 // hands them to the other waves through LDS while those fetch the sin/cos table. No k_setup launch, no `wc` round trip: one stream
@@ -1004,9 +1030,15 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         auto body = [&](const RowRegs& r) {
             astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4), row_get(r, 5), tab);
         };
-        bool warm_loop = false;
+        bool warm_loop = false, warm_unchecked = false;
         WarmState<P> ws;
-        if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) warm_loop = warm_init<P>(ws, pc, ob.dm_max);
+        if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
+            const float bound = warm_init<P>(ws, pc, ob);
+            warm_loop = bound > 0.0f;
+            // every row of the task within the wave's bound and no chain longer than WARM_RESTART: the loop without the per-row test (a uniform
+            // cadence — config 3 — pays nothing for the gaps other tables have: the test is seven scalar instructions and two branches per row, 1 %)
+            warm_unchecked = warm_loop && tk.key_max <= bound && tk.chunk <= WARM_RESTART;
+        }
         if constexpr (!ROW_PREFETCH) {
             for (int j = 0; j < n_rows; ++j) {
                 const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
@@ -1014,20 +1046,25 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
             }
         } else if (main_warm<P, GRAD, NUIS, KM, FUSED>() && warm_loop) {
             if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
-                auto wbody = [&](const RowRegs8& r) {
-                    astrom_row<P, GRAD, NUIS, KM, true, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4),
-                                                              row_get(r, 5), tab, &ws, row_get(r, 6));
+                auto wbody_t = [&](const RowRegs8& r, auto checked) {
+                    if constexpr (decltype(checked)::value) ws.row_ok = warm_row_ok<P>(ws, r);
+                    astrom_row<P, GRAD, NUIS, KM, true, true, decltype(checked)::value>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3),
+                                                                                         row_get(r, 4), row_get(r, 5), tab, &ws, row_get(r, 6));
                 };
-                if (n_rows > 0) {
+                auto wloop = [&](auto checked) {
                     RowRegs8 A = row_issue8(rows);
                     for (int j = 0; j < n_rows; j += 2) {
                         RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
-                        wbody(A);
+                        wbody_t(A, checked);
                         if (j + 1 >= n_rows) { row_drain(B); break; }
                         A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
-                        wbody(B);
+                        wbody_t(B, checked);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)");
+                };
+                if (n_rows > 0) {
+                    if (warm_unchecked) wloop(std::false_type{});
+                    else wloop(std::true_type{});
                 }
             }
         } else if (n_rows > 0) {
@@ -1052,9 +1089,15 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         auto body = [&](const RowRegs& r) {
             rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab);
         };
-        bool warm_loop = false;
+        bool warm_loop = false, warm_unchecked = false;
         WarmState<P> ws;
-        if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) warm_loop = warm_init<P>(ws, pc, ob.dm_max);
+        if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
+            const float bound = warm_init<P>(ws, pc, ob);
+            warm_loop = bound > 0.0f;
+            // every row of the task within the wave's bound and no chain longer than WARM_RESTART: the loop without the per-row test (a uniform
+            // cadence — config 3 — pays nothing for the gaps other tables have: the test is seven scalar instructions and two branches per row, 1 %)
+            warm_unchecked = warm_loop && tk.key_max <= bound && tk.chunk <= WARM_RESTART;
+        }
         if constexpr (!ROW_PREFETCH) {
             for (int j = 0; j < n_rows; ++j) {
                 const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
@@ -1062,19 +1105,25 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
             }
         } else if (main_warm<P, GRAD, NUIS, KM, FUSED>() && warm_loop) {
             if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
-                auto wbody = [&](const RowRegs8& r) {
-                    rv_row<P, GRAD, NUIS, KM, true, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab, &ws, row_get(r, 6));
+                auto wbody_t = [&](const RowRegs8& r, auto checked) {
+                    if constexpr (decltype(checked)::value) ws.row_ok = warm_row_ok<P>(ws, r);
+                    rv_row<P, GRAD, NUIS, KM, true, true, decltype(checked)::value>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab,
+                                                                                     &ws, row_get(r, 6));
                 };
-                if (n_rows > 0) {
+                auto wloop = [&](auto checked) {
                     RowRegs8 A = row_issue8(rows);
                     for (int j = 0; j < n_rows; j += 2) {
                         RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
-                        wbody(A);
+                        wbody_t(A, checked);
                         if (j + 1 >= n_rows) { row_drain(B); break; }
                         A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
-                        wbody(B);
+                        wbody_t(B, checked);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)");
+                };
+                if (n_rows > 0) {
+                    if (warm_unchecked) wloop(std::false_type{});
+                    else wloop(std::true_type{});
                 }
             }
         } else if (n_rows > 0) {

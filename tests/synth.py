@@ -71,6 +71,47 @@ def config_astrom(n_epochs=10_000, n_walkers=10_000, cfg=2, sigma=10.0, seed=Non
                 theta_example=dict(M=1.2, plx=50.0, planets=dict(b=dict(a=10.0, e=0.3, i=1.0, ω=0.5, Ω=2.0, tp=50000.0))))
 
 
+def config_wide_prior(n_epochs=10_000, n_walkers=10_000, a_lo=0.3, a_hi=100.0, seed=None):
+    """Round 6 workload `wide_prior`: config 3's daily table with a ~ LogUniform(0.3, 100) AU — 14 % of the walkers have periods below ~200 days,
+    too short for a warm start at a one-day cadence (ΔM > 0.0315 rad); drawn at random every tile of 64 holds some of them."""
+    cfg = config_astrom(n_epochs=n_epochs, n_walkers=n_walkers, cfg=3, seed=seed)
+    rng = np.random.default_rng(20260929 + 61 if seed is None else seed + 1)
+    cfg["elems"] = draw_walkers(rng, n_walkers, a_lo, a_hi)
+    return cfg
+
+
+def gappy_epochs(n_epochs, per_night=4, nights_per_season=125, intra_night=0.02, season=365.25, t0=50000.0, rng=None):
+    """Epochs of a ground-based RV campaign: `per_night` exposures `intra_night` days apart, one night after the other (with a little
+    scatter in the start of a night) for `nights_per_season` nights, then nothing until the next season. Sorted."""
+    rng = rng or np.random.default_rng(0)
+    t = []
+    s = 0
+    while len(t) < n_epochs:
+        for night in range(nights_per_season):
+            start = t0 + s * season + night + rng.uniform(-0.05, 0.05)
+            t.extend(start + intra_night * np.arange(per_night))
+        s += 1
+    return np.sort(np.asarray(t[:n_epochs], dtype=np.float64))
+
+
+def config_rv_gappy(n_epochs=10_000, n_walkers=10_000, nuis=False, seed=None):
+    """Round 6 workload `rv_gappy`: ONE planet, an absolute-RV table of nightly runs with seasonal gaps (gappy_epochs: 1e4 epochs = 20 seasons of
+    125 nights x 4 exposures; steps of 0.02 d, ~0.94 d and ~241 d), walkers from config 3's prior with a mass. nuis: per-walker offset and jitter
+    (rv-absolute.jl:172-204's θ_obs) — otherwise the jitter == 0 path with the offset folded into the data."""
+    rng = np.random.default_rng(20260929 + 62 if seed is None else seed)
+    t = gappy_epochs(n_epochs, rng=rng)
+    rv = truth_rv_star(t, TRUTH, 8.0) + rng.normal(0.0, 3.0, n_epochs)
+    table = dict(epoch=t, rv=rv, σ_rv=np.full(n_epochs, 3.0))
+    elems = draw_walkers(rng, n_walkers, with_mass=True)
+    nz = None
+    if nuis:
+        nz = np.zeros((N_NUIS, n_walkers))
+        nz[0] = rng.normal(0.0, 3.0, n_walkers)
+        nz[1] = np.exp(rng.uniform(np.log(0.1), np.log(10.0), n_walkers))
+    return dict(n_epochs=n_epochs, n_walkers=n_walkers, table=table, elems=elems, nuis=nz,
+                theta_example=dict(M=1.2, plx=50.0, planets=dict(b=dict(a=10.0, e=0.3, i=1.0, ω=0.5, Ω=2.0, tp=50000.0, mass=8.0))))
+
+
 def config_small(n_epochs=96, n_walkers=257, seed=7):
     return config_astrom(n_epochs=n_epochs, n_walkers=n_walkers, seed=seed)
 

@@ -114,3 +114,39 @@ def test_no_scalar_load_is_read_before_its_wait():
     import kernel_resources as kr
     bad = kr.scalar_load_hazards()
     assert not bad, bad[:10]
+
+
+def _ins(lines):
+    """[(address, text, branch-target offset)] from 'text' or ('text', target index) items, 4 bytes per instruction."""
+    out = []
+    for k, it in enumerate(lines):
+        txt, tgt = (it, None) if isinstance(it, str) else it
+        out.append((4 * k, txt, None if tgt is None else 4 * tgt))
+    return out
+
+
+def test_hazard_checker_itself():
+    """The checker of the test above, on hand-written instruction lists: (a) a copy of an in-flight tuple ahead of the wait is flagged (what a
+    restructured warm loop compiled to in round 6: a loop-carried tuple copied at the loop head); (b) the early exit's wait on one arm of a
+    diamond whose arm is recorded in an SGPR pair and tested again by the later branch is NOT (the path that skips the wait never reaches the
+    code that reuses the registers); (c) the same diamond with the flag pair overwritten in between IS flagged (nothing known: both arms)."""
+    import kernel_resources as kr
+    a = _ins(["s_load_dwordx8 s[4:11], s[0:1], 0x0", "s_mov_b64 s[20:21], s[4:5]", "s_waitcnt lgkmcnt(0)", "s_endpgm"])
+    assert [b[1] for b in kr.kernel_hazards("a", 0, a)] == [4]
+    diamond = ["s_load_dwordx8 s[20:27], s[0:1], 0x0",          # 0  B in flight
+               "s_andn2_b64 vcc, exec, s[58:59]",                # 1  s[58:59]: early exit?
+               "s_mov_b64 s[58:59], -1",                         # 2
+               ("s_cbranch_vccnz 2", 6),                         # 3  not the early exit: skip the wait
+               "s_mov_b64 s[58:59], 0",                          # 4
+               "s_waitcnt lgkmcnt(0)",                           # 5
+               "v_add_f64 v[0:1], v[0:1], v[2:3]",               # 6  (the sunk tail of the row body)
+               "s_andn2_b64 vcc, exec, s[58:59]",                # 7
+               ("s_cbranch_vccnz 3", 11),                        # 8  early exit -> the code that reuses B's registers
+               "s_waitcnt lgkmcnt(0)",                           # 9  normal path: wait for B, use it
+               "s_endpgm",                                       # 10
+               "s_cselect_b64 s[20:21], -1, 0",                  # 11
+               "s_endpgm"]
+    assert kr.kernel_hazards("b", 0, _ins(diamond)) == []
+    clobbered = list(diamond)
+    clobbered[6] = "s_mov_b64 s[58:59], s[60:61]"
+    assert [b[2] for b in kr.kernel_hazards("c", 0, _ins(clobbered))] == ["s_cselect_b64 s[20:21], -1, 0"]

@@ -137,7 +137,8 @@ def test_warm_loop_every_single_planet_kind(oracle):
 
 def test_warm_entry_test_and_odd_tables(oracle):
     """What keeps a wave in the cold loop, and tables the predictor must survive: (a) one walker of the tile too fast for the cadence —
-    its whole wave stays cold, bit-identical to OCTO_WARM=0; (b) a table with one long gap (dm_max is the table's largest step): cold;
+    its whole wave stays cold, bit-identical to OCTO_WARM=0; (b) a table with one long gap: round 6 — the gap's row alone is solved cold (a scalar
+    branch on the row's key), the rest of the table stays on the warm loop (round 5 took the table's largest step for every row: all cold);
     (c) duplicate epochs (Δt = 0) and an UNSORTED table (negative steps) on the warm loop; (d) an invalid walker (e >= 1, NaN) among valid
     ones: −Inf for it, its neighbours against the oracle."""
     gb = _gpu()
@@ -159,7 +160,10 @@ def test_warm_entry_test_and_odd_tables(oracle):
     tg = t.copy(); tg[n // 2:] += 900.0
     obs = mk(tg)
     warm = _eval(gb, obs, planets, el, None, True, True); cold = _eval(gb, obs, planets, el, None, True, False)
-    assert np.array_equal(warm[0], cold[0]) and np.array_equal(warm[1], cold[1])
+    assert not _same_bits(warm, cold), "a table with one long gap must still take the warm loop"
+    _close("one gap", warm, cold)
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el, None, grad=True, active=act)
+    _cmp_oracle("one gap warm", warm[0], warm[1], None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
     # (c) duplicates and an unsorted table
     td = t.copy(); td[10:13] = td[10]; td[100:140:2], td[101:141:2] = t[101:141:2], t[100:140:2]      # steps of 0, +1.0, -0.5 days
     obs = mk(td)
@@ -274,3 +278,50 @@ def test_dense_fixtures_at_60_digits_warm_and_cold():
                 assert ok, (case["name"], warm, "g_nuis", worst)
             res[warm] = (ll, g_el, g_nu)
         assert not _same_bits(res[True], res[False]), (case["name"], "the warm loop did not run")
+
+
+def test_warm_loop_on_gappy_and_multi_scale_tables(oracle):
+    """Round 6: the step bound is per WAVE (the first entry of the table's ladder of step quantiles that none of the wave's lanes
+    vetoes) and the veto per ROW. (a) an absolute-RV table of nightly runs with seasonal gaps (synth.gappy_epochs: steps of 0.02 d, ~1 d, ~240 d)
+    without nuisances: warm, against cold and the oracle; (b) the same epochs as RA/Dec rows with walkers so fast that only the intra-night steps
+    pass for some tiles (those tiles take a LOWER rung of the ladder, their night-to-night rows go cold) and too fast for any rung in one tile
+    (cold, bit-identical to OCTO_WARM=0); (c) a table longer than WARM_RESTART = 256 rows per wave chunk at OCTO_CHUNK=700: the forced cold rows."""
+    gb = _gpu()
+    rng = np.random.default_rng(61)
+    n, W = 1500, 192
+    t = synth.gappy_epochs(n, per_night=4, nights_per_season=40, rng=rng)
+    planets = [dict(orbit_kind=0, has_mass=True)]
+    el = _dense_walkers(rng, W, 1.0, 40.0, e_hi=0.9)
+    el[8] = rng.uniform(1.0, 15.0, W)
+    rv = synth.truth_rv_star(t, dict(synth.TRUTH), 8.0)
+    obs = [dict(kind=2, planet=-1, epoch=t, y1=rv + rng.normal(0, 3, n), y2=None, s1=np.full(n, 3.0), s2=None, cor=None)]
+    warm = _eval(gb, obs, planets, el, None, True, True); cold = _eval(gb, obs, planets, el, None, True, False)
+    assert not _same_bits(warm, cold), "the gappy RV table did not take the warm loop"
+    _close("gappy rv", warm, cold, g_tol=1e-9)
+    assert np.array_equal(_eval(gb, obs, planets, el, None, False, True)[0], warm[0])
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets, el, None, grad=True, active=synth.active_mask(1, 1, nuis=False))
+    _cmp_oracle("gappy rv warm", warm[0], warm[1], None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
+    # (b) RA/Dec rows at the same epochs; tile 1: periods of 20-60 days (ΔM of a night-to-night step 0.1-0.3 rad: only the 0.02-day rung passes),
+    # tile 2: one walker at a = 0.02 AU (P ~ 1 day: no rung passes)
+    planets1 = [dict(orbit_kind=0, has_mass=False)]
+    ra, dec = synth.truth_radec(t)
+    obs = [dict(kind=0, planet=0, epoch=t, y1=ra + rng.normal(0, 5, n), y2=dec + rng.normal(0, 5, n), s1=np.full(n, 5.0), s2=np.full(n, 7.0), cor=None)]
+    el_b = el.copy(); el_b[8] = 0.0
+    el_b[0, 64:128] = rng.uniform(0.16, 0.3, 64); el_b[1, 64:128] = rng.uniform(0.0, 0.6, 64)
+    el_b[0, 130] = 0.02
+    warm = _eval(gb, obs, planets1, el_b, None, True, True); cold = _eval(gb, obs, planets1, el_b, None, True, False)
+    for lo, name in ((0, "slow tile"), (64, "fast tile: a lower rung")):
+        assert not (np.array_equal(warm[0][lo:lo + 64], cold[0][lo:lo + 64]) and np.array_equal(warm[1][:, lo:lo + 64], cold[1][:, lo:lo + 64])), name
+    assert np.array_equal(warm[0][128:], cold[0][128:]) and np.array_equal(warm[1][:, 128:], cold[1][:, 128:]), "a tile no rung admits must run the cold loop"
+    _close("ladder", warm, cold, g_tol=1e-9)
+    ll_o, g_o, _ = oracle.oracle_eval(obs, planets1, el_b, None, grad=True, active=synth.active_mask(1, 1, mass=False, nuis=False))
+    _cmp_oracle("ladder warm", warm[0], warm[1], None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
+    # (c) long chunks: every 256th row of the table restarts the chain
+    n2 = 2800
+    t2 = 50000.0 + 0.5 * np.arange(n2)
+    ra, dec = synth.truth_radec(t2)
+    obs = [dict(kind=0, planet=0, epoch=t2, y1=ra + rng.normal(0, 5, n2), y2=dec + rng.normal(0, 5, n2), s1=np.full(n2, 5.0), s2=np.full(n2, 7.0), cor=None)]
+    el_c = synth.draw_walkers(rng, 64, 3.0, 60.0); el_c[1] = rng.uniform(0, 0.4, 64)
+    warm = _eval(gb, obs, planets1, el_c, None, True, True, env={"OCTO_CHUNK": "700"}); cold = _eval(gb, obs, planets1, el_c, None, True, False, env={"OCTO_CHUNK": "700"})
+    assert not _same_bits(warm, cold)
+    _close("restart", warm, cold, ll_tol=1e-12, g_tol=1e-10)

@@ -147,6 +147,85 @@ def _sregs(tok):
     return {int(m.group(1))} if m else set()
 
 
+def kernel_hazards(sym, base, ins):
+    """The analysis of ONE kernel: ins = [(address, instruction text, branch-target offset from `base` or None)] in address order."""
+    bad = []
+    addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
+    succ = []
+    for i, (a, txt, tgt) in enumerate(ins):
+        op = txt.split()[0]
+        nxt = [i + 1] if i + 1 < len(ins) else []
+        if op == "s_endpgm":
+            succ.append([])
+        elif op == "s_branch":
+            succ.append([addr_index[base + tgt]] if tgt is not None and base + tgt in addr_index else [])
+        elif op.startswith("s_cbranch"):
+            succ.append(nxt + ([addr_index[base + tgt]] if tgt is not None and base + tgt in addr_index else []))
+        else:
+            succ.append(nxt)
+    # Forward data-flow with a little path sensitivity (round 6): the compiler sometimes puts the early exit's wait on one arm of a
+    # diamond and records which arm ran in an SGPR pair (s_mov_b64 s[a:b], -1 / 0) that a later `s_andn2_b64 vcc, exec, s[a:b]` +
+    # s_cbranch_vcc(n)z tests again. A path-insensitive merge then sees "load pending" on the path that in fact waited. So a state is
+    # (pending registers, the SGPR pairs known to hold -1 or 0, what is known of vcc), an instruction keeps a SET of states, and a
+    # branch on a vcc derived from a known pair follows only the arm that can be taken (exec != 0 inside these uniform loops).
+    state = [set() for _ in ins]
+    state[0].add((frozenset(), frozenset(), None))
+    work = [0]
+    flagged = set()
+    n_states = 0
+    while work:
+        i = work.pop()
+        a, txt, _ = ins[i]
+        parts = re.split(r"[ ,]+", txt)
+        op, args = parts[0], parts[1:]
+        outs = {}      # successor index -> set of states
+        for (pend0, consts0, vcc0) in list(state[i]):
+            pend, consts, vcc = set(pend0), dict(consts0), vcc0
+            take = None      # None: both arms; True: branch taken only; False: fall through only
+            if op.startswith("s_waitcnt"):
+                if "lgkmcnt(0)" in txt:
+                    pend = set()
+            else:
+                used = set().union(*[_sregs(t) for t in args]) if args else set()
+                if pend & used and i not in flagged:
+                    flagged.add(i); bad.append((sym, a, txt))
+                if op.startswith(("s_load_", "s_buffer_load_")) and args:
+                    pend |= _sregs(args[0])
+                # what the instruction writes: its first operand (SALU / VOP3 with an SGPR destination), vcc for e32 compares
+                dst = _sregs(args[0]) if args and not op.startswith(("s_cmp", "s_cbranch", "s_branch", "s_bitcmp", "s_setpc")) else set()
+                for lo in [k for k in consts if k in dst or k + 1 in dst]:
+                    del consts[lo]
+                writes_vcc = (args and args[0] == "vcc") or op.startswith(("v_cmp", "v_div_scale")) and not (args and args[0].startswith("s"))
+                if writes_vcc:
+                    vcc = None
+                m2 = re.fullmatch(r"s\[(\d+):(\d+)\]", args[0]) if args else None
+                if op == "s_mov_b64" and m2 and len(args) == 2 and args[1] in ("-1", "0"):
+                    consts[int(m2.group(1))] = int(args[1])
+                if op in ("s_andn2_b64", "s_and_b64") and len(args) == 3 and args[0] == "vcc" and args[1] == "exec":
+                    m3 = re.fullmatch(r"s\[(\d+):(\d+)\]", args[2])
+                    if m3 and int(m3.group(1)) in consts:
+                        v = consts[int(m3.group(1))]
+                        ones = (v == -1) if op == "s_and_b64" else (v == 0)
+                        vcc = "nz" if ones else "z"
+                if op == "s_cbranch_vccnz" and vcc is not None:
+                    take = vcc == "nz"
+                if op == "s_cbranch_vccz" and vcc is not None:
+                    take = vcc == "z"
+            st = (frozenset(pend), frozenset(consts.items()), vcc)
+            ss = succ[i]
+            if take is not None and op.startswith("s_cbranch") and len(ss) == 2:
+                ss = [ss[1]] if take else [ss[0]]
+            for j in ss:
+                outs.setdefault(j, set()).add(st)
+        for j, sts in outs.items():
+            new = sts - state[j]
+            if new:
+                state[j] |= new; n_states += len(new); work.append(j)
+                if n_states > 2_000_000:
+                    raise RuntimeError(f"scalar_load_hazards: state explosion in {sym}")
+    return bad
+
+
 def scalar_load_hazards(build_dir: Path = BUILD, name_filter: str = "k_main"):
     """[(kernel symbol, address, instruction text)] for every instruction that names a register of a scalar load's destination while that load
     may still be in flight — a forward data-flow over the kernel's control-flow graph (blocks cut at branches and branch targets; a load is
@@ -176,43 +255,7 @@ def scalar_load_hazards(build_dir: Path = BUILD, name_filter: str = "k_main"):
                 tgt = re.search(r"<\S+?\+0x([0-9a-fA-F]+)>", com)
                 kernels[cur][1].append((int(ma.group(1), 16), txt, int(tgt.group(1), 16) if tgt else None))
             for sym, (base, ins) in kernels.items():
-                addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
-                succ = []
-                for i, (a, txt, tgt) in enumerate(ins):
-                    op = txt.split()[0]
-                    nxt = [i + 1] if i + 1 < len(ins) else []
-                    if op == "s_endpgm":
-                        succ.append([])
-                    elif op == "s_branch":
-                        succ.append([addr_index[base + tgt]] if tgt is not None and base + tgt in addr_index else [])
-                    elif op.startswith("s_cbranch"):
-                        succ.append(nxt + ([addr_index[base + tgt]] if tgt is not None and base + tgt in addr_index else []))
-                    else:
-                        succ.append(nxt)
-                state = [None] * len(ins)      # pending registers on entry
-                state[0] = frozenset()
-                work = [0]
-                flagged = set()
-                while work:
-                    i = work.pop()
-                    pend = set(state[i])
-                    a, txt, _ = ins[i]
-                    parts = re.split(r"[ ,]+", txt)
-                    op, args = parts[0], parts[1:]
-                    if op.startswith("s_waitcnt"):
-                        if "lgkmcnt(0)" in txt:
-                            pend = set()
-                    else:
-                        used = set().union(*[_sregs(t) for t in args]) if args else set()
-                        if pend & used and i not in flagged:
-                            flagged.add(i); bad.append((sym, a, txt))
-                        if op.startswith(("s_load_", "s_buffer_load_")) and args:
-                            pend |= _sregs(args[0])
-                    out_state = frozenset(pend)
-                    for j in succ[i]:
-                        merged = out_state if state[j] is None else (state[j] | out_state)
-                        if state[j] is None or merged != state[j]:
-                            state[j] = merged; work.append(j)
+                bad += kernel_hazards(sym, base, ins)
     return bad
 
 if __name__ == "__main__":

@@ -866,10 +866,17 @@ constexpr unsigned main_min_waves() {
 #define OCTO_WARM 1
 #endif
 template <int P, bool GRAD, bool NUIS, int KM, bool FUSED>
+constexpr bool main_warm_plain() {
+    // The nuisance kernels of the kind sets with sep/PA or RV rows: with the 16-dword row buffers of a second pair of prefetching loops they run out
+    // of SGPRs, and the compiler then parks an in-flight prefetch tuple in VGPR lanes (tools/kernel_resources.py: scalar_load_hazards finds it).
+    // Their warm loop reads its rows with plain scalar loads the compiler waits for itself (round 5 built that and found no gain on a probe whose
+    // random epochs vetoed the warm loop through the table-wide bound; with the per-row test — round 6 — an RV table with offset and jitter,
+    // the usual one, runs warm between its gaps).
+    return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL) && NUIS && (KM & (KM_SEPPA | KM_RV));
+}
+template <int P, bool GRAD, bool NUIS, int KM, bool FUSED>
 constexpr bool main_warm() {
-    // (… and not the nuisance kernels of the kind sets with sep/PA or RV rows: with the 16-dword row buffers of a second pair of loops they run
-    // out of SGPRs, and the compiler then parks an in-flight prefetch tuple in VGPR lanes — tools/kernel_resources.py: scalar_load_hazards finds it)
-    return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL) && !(NUIS && (KM & (KM_SEPPA | KM_RV)));
+    return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL);
 }
 
 // The wave's step bound: the first entry of the table's ladder (DevObs::dm_ladder, preferred first) that no lane vetoes, a veto being
@@ -1045,7 +1052,13 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab);
             }
         } else if (main_warm<P, GRAD, NUIS, KM, FUSED>() && warm_loop) {
-            if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
+            if constexpr (main_warm_plain<P, GRAD, NUIS, KM, FUSED>()) {
+                for (int j = 0; j < n_rows; ++j) {
+                    const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
+                    ws.row_ok = (uint32_t)__double2hiint(rw[7]) <= ws.key_hi;
+                    astrom_row<P, GRAD, NUIS, KM, true, true, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab, &ws, rw[6]);
+                }
+            } else if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
                 auto wbody_t = [&](const RowRegs8& r, auto checked) {
                     if constexpr (decltype(checked)::value) ws.row_ok = warm_row_ok<P>(ws, r);
                     astrom_row<P, GRAD, NUIS, KM, true, true, decltype(checked)::value>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3),
@@ -1104,7 +1117,13 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, tab);
             }
         } else if (main_warm<P, GRAD, NUIS, KM, FUSED>() && warm_loop) {
-            if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
+            if constexpr (main_warm_plain<P, GRAD, NUIS, KM, FUSED>()) {
+                for (int j = 0; j < n_rows; ++j) {
+                    const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
+                    ws.row_ok = (uint32_t)__double2hiint(rw[7]) <= ws.key_hi;
+                    rv_row<P, GRAD, NUIS, KM, true, true, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], tab, &ws, rw[6]);
+                }
+            } else if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
                 auto wbody_t = [&](const RowRegs8& r, auto checked) {
                     if constexpr (decltype(checked)::value) ws.row_ok = warm_row_ok<P>(ws, r);
                     rv_row<P, GRAD, NUIS, KM, true, true, decltype(checked)::value>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab,

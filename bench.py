@@ -607,6 +607,11 @@ def main():
                     "north_star words the claim; NOT a bandwidth measurement — it exceeds the 8 TB/s peak because the rows are reused "
                     "by 64 lanes from the scalar cache"}
         res["roofline"] = roof
+        ts = fn.tile_state() if hasattr(fn, "tile_state") else None
+        if ts is not None:      # round 6: the walker-tile sort (octo_tile.h) — on only where its probe says it pays
+            res["tile_sort"] = dict(ts, mode={0: "off", 1: "always", 2: "auto"}.get(fn.get_option(capi.OPT_TILE_SORT), "?"),
+                                    what="walkers grouped into tiles of 64 by how often their rows fail the warm start's a-priori test; a probe every 64th "
+                                         "evaluation prices the sort against its launch and decides")
         if not args.no_extras and cfg is not None and args.workload == "grad":
             # ---- parity of the batch just timed (N > 1: of rank 0's shard)
             try:

@@ -54,6 +54,10 @@ extern "C" {
 #define OCTO_EHIP    2   /* a HIP runtime call failed; see octo_last_error */
 #define OCTO_ENOMEM  3   /* host or device allocation failed */
 #define OCTO_ENODEV  4   /* no usable gfx950 device */
+#define OCTO_ENOTSUP 5   /* a VALID dataset or model that is not on the device path: more planets than OCTO_MAX_PLANETS, marginalised RV / the O'Neil
+                          * prior / HGCA beyond OCTO_MAX_PLANETS_ALL_KINDS planets, an RV table next to a ThieleInnesOrbit planet, a model beyond the size
+                          * limits of octo_model_create. A host-side binding falls back to the reference's own path on THIS status (and on OCTO_ENODEV) —
+                          * not on OCTO_EINVAL (bad input: σ <= 0, non-finite epochs, |cor| >= 1 …), OCTO_EHIP or OCTO_ENOMEM, which are the caller's to see. */
 
 /* ---- observation kinds (one per reference AbstractObs type on the path) -- */
 #define OCTO_ASTROM_RADEC 0  /* PlanetRelAstromObs with (ra, dec, σ_ra, σ_dec[, cor])   */
@@ -191,6 +195,30 @@ int32_t octo_consts_set(octo_ctx* ctx, const octo_consts* c);
 #define OCTO_SMALL_BATCH_DEFAULT 512
 int32_t octo_ctx_set_small_batch(octo_ctx* ctx, int32_t max_walkers);
 const char* octo_last_error(const octo_ctx* ctx);
+
+/* Context options (round 6). The reference evaluates ONE θ at a time and its result is a function of θ alone (src/logdensitymodel.jl:110-146).
+ * The batched throughput kernels keep that to rounding (~1e-15), not bitwise, by default: on tables dense enough for the warm-started row loop a
+ * wave falls back to the cold Kepler starter as a whole, so the last bits of a walker's result depend on the 63 walkers it shares a wave with; the
+ * row partition follows the batch size; and big single-planet batches may be re-tiled by a severity key (below). Results ARE bit-reproducible from
+ * run to run for the same sequence of calls in every mode.
+ *   OCTO_OPT_BATCH_INVARIANT  1: ll(θ) and its gradient are independent of the batch's size and composition, bit for bit — checkpoint / resume, a
+ *                             1-GPU against an 8-GPU rerun of one chain, two batch sizes: the cold row loop, no tile sort, ONE row partition (64 rows
+ *                             per wave) and the throughput kernels for every batch size (no small-batch route: a one-θ call then costs three launches,
+ *                             ~40 µs instead of ~16). Default 0. Costs ~25 % of the throughput on dense tables (round 4's rate).
+ *   OCTO_OPT_WARM_START       0: the cold row loop only (round 4's kernels), everything else as usual. Default 1 (environment OCTO_WARM=0 at
+ *                             octo_ctx_create sets 0).
+ *   OCTO_OPT_TILE_SORT        walkers of big single-planet batches grouped into tiles of 64 by how often their rows would fail the warm start's
+ *                             a-priori test (period against the table's cadence, eccentricity): 0 never, 1 every eligible evaluation, 2 (default)
+ *                             when a probe — every 64th eligible evaluation of a (dataset, batch size) — estimates that it saves more than the sort
+ *                             launch costs. Inputs and outputs keep the caller's order; only the last bits of the results may differ (see above).
+ *   OCTO_OPT_TILE_MIN_WALKERS batches below this size are never sorted (default 2048).
+ * octo_ctx_set_option: OCTO_EINVAL for an unknown option or a value outside its range. */
+#define OCTO_OPT_BATCH_INVARIANT  1
+#define OCTO_OPT_WARM_START       2
+#define OCTO_OPT_TILE_SORT        3
+#define OCTO_OPT_TILE_MIN_WALKERS 4
+int32_t octo_ctx_set_option(octo_ctx* ctx, int32_t option, int64_t value);
+int32_t octo_ctx_get_option(const octo_ctx* ctx, int32_t option, int64_t* value_out);
 
 /* Upload the observation tables (one-time). Observation likelihoods are summed
  * in the order given. OCTO_EINVAL for a non-finite epoch or measurement, an uncertainty that is not finite and > 0, or a

@@ -3,6 +3,7 @@
 // every entry point that evaluates fails with OCTO_ENODEV / OCTO_EHIP when no device is usable.
 #define OCTO_API_TU 1      // this translation unit owns the non-template kernels (octo_model.h, octo_kernels.h)
 #include "octo_host.h"
+#include "octo_tile.h"
 
 using namespace octo;
 
@@ -335,6 +336,7 @@ int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_
 // longer: single-planet D = 11 callback at 768 θ_t 40-41 µs fused against 43 on the three-launch route, 46-48 against 45 at 1 024
 // (tools/r5_midsize_small.py) — the limit there is ctx->small_w_model (768 unless the caller set a limit of its own).
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W, bool model) {
+    if (ctx->opt_invariant) return false;          // OCTO_OPT_BATCH_INVARIANT: one kernel family, one row partition
     if (ds->n_planets > MAXP_T) return false;      // k_small<P> is compiled for 1 … 4 planets
     const int limit = (model && ds->n_planets == 1) ? std::max(ctx->small_w, ctx->small_w_model) : ctx->small_w;
     if (!(W * ds->n_planets <= limit && W <= SMALL_W)) return false;
@@ -342,6 +344,62 @@ bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W, bool
         for (int o = 0; o < ds->n_obs; ++o)
             if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG && ds->h_obs[o].n > SMALL_MARG_ROWS) return false;
     return true;
+}
+
+// The walker-tile sort ahead of a single-planet fused k_main launch (octo_tile.h). Mode 2 (default): every TILE_PROBE_EVERY-th eligible evaluation of
+// a (dataset, batch size) PRICES the sort — k_tile_sort leaves the expected number of cold wave-rows per row, in the order given and sorted,
+// in mapped host memory; the NEXT eligible evaluation waits for that launch (an event; the kernel ran a whole evaluation ago), reads the two numbers
+// and keeps the sort on while  (Δ cold wave-rows per row) x rows x the cost of a cold row > the cost of the launch.  The decision is taken at a fixed
+// point of the call sequence, so a rerun of the same calls makes the same decisions: results stay bit-reproducible run to run.
+constexpr int TILE_PROBE_EVERY = 64;
+constexpr double TILE_COLD_ROW_US = 27.0 * 2.15e-3;      // a cold row costs ~27 more VALU instructions than a warm one, 2.15 ns of a SIMD's issue each (tools/ubench.hip)
+constexpr double TILE_LAUNCH_US = 6.5;                   // the kernel (4-5 µs at 1e4 walkers) + one dependent launch on the stream + the gathers through perm (profiles/r6_tile_trace.txt)
+
+int tile_prepare(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t st) {
+    a.perm = nullptr;
+    if (!a.warm || ctx->tile_mode == 0 || a.W < ctx->tile_min_w || !(ds->tile_dm_ref > 0.0f) || ds->n_planets != 1 ||
+        ds->planets[0].orbit_kind == OCTO_ORBIT_THIELE_INNES)      // (a ThieleInnesOrbit's period needs its constructor: left as drawn)
+        return OCTO_OK;
+    bool probe = false, sort_now = ctx->tile_mode == 1;
+    if (ctx->tile_mode == 2) {
+        if (ctx->tile_ds != ds->serial || ctx->tile_W != a.W) {      // another dataset or batch size: start over (a pending probe of the old shape is dropped)
+            ctx->tile_ds = ds->serial; ctx->tile_W = a.W; ctx->tile_seq = 0; ctx->tile_on = false; ctx->tile_pending = false;
+        }
+        if (ctx->tile_pending) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev_tile));
+            double d = 0.0;
+            for (int k = 0; k < ctx->tile_pending_segs; ++k) d += (double)ctx->h_tile_stats[2 * k] - (double)ctx->h_tile_stats[2 * k + 1];
+            ctx->tile_last_saving_us = d * (double)ds->tile_rows * TILE_COLD_ROW_US / (4.0 * (double)ctx->n_cus);
+            ctx->tile_on = ctx->tile_last_saving_us > 1.3 * TILE_LAUNCH_US;
+            ctx->tile_pending = false;
+        }
+        probe = (ctx->tile_seq % TILE_PROBE_EVERY) == 0;
+        ctx->tile_seq += 1;
+        sort_now = ctx->tile_on;      // (a probe prices the sort, it does not apply it: the same input evaluated twice in a row gives the same bits
+                                      // unless the decision itself changes in between)
+    }
+    if (!sort_now && !probe) return OCTO_OK;
+    const int n_seg = (int)((a.W + TILE_SEG - 1) / TILE_SEG);
+    int rc = grow(ctx, ctx->d_perm, ctx->cap_perm, a.W);
+    if (rc) return rc;
+    if (2 * (int64_t)n_seg > ctx->cap_tile_stats) {
+        if (ctx->h_tile_stats) ctx->retired_host.push_back((void*)ctx->h_tile_stats);
+        ctx->h_tile_stats = nullptr; ctx->cap_tile_stats = 0;
+        const int64_t n = 2 * (int64_t)n_seg + 64;
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_tile_stats, sizeof(float) * (size_t)n, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
+        ctx->cap_tile_stats = n;
+    }
+    if (!ctx->ev_tile) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_tile, hipEventDisableTiming));
+    TileArgs ta;
+    ta.elems = a.elems; ta.ld = a.ld; ta.W = a.W; ta.perm = ctx->d_perm; ta.stats = probe ? ctx->h_tile_stats : nullptr;
+    ta.dm_ref = ds->tile_dm_ref; ta.inv_k_yr = (float)(1.0 / ctx->consts.kepler_year_to_julian_day);
+    hipLaunchKernelGGL(k_tile_sort, dim3((unsigned)n_seg), dim3(TILE_TPB), 0, st, ta);
+    if (probe) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_tile, st));
+        ctx->tile_pending = true; ctx->tile_pending_segs = n_seg; ctx->tile_probes += 1;
+    }
+    if (sort_now) { ctx->tile_sorted_launches += 1; a.perm = ctx->d_perm; }
+    return OCTO_OK;
 }
 
 int drain_timing(octo_ctx* ctx) {
@@ -433,13 +491,15 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
         return OCTO_ENOMEM;
     }
     std::memset(ctx->h_flags, 0, sizeof(uint64_t) * (SMALL_W + 32));
-    if (const char* ev = std::getenv("OCTO_SMALL_W")) ctx->small_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
+    if (const char* ev = std::getenv("OCTO_SMALL_W")) { ctx->small_w = std::min(std::max(std::atoi(ev), 0), SMALL_W); ctx->small_w_model = 0; }      // (as octo_ctx_set_small_batch: the limit holds for the model callback too — ADVICE r5)
     if (const char* ev = std::getenv("OCTO_MAPPED_W")) ctx->mapped_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     if (const char* ev = std::getenv("OCTO_FLAG_W")) ctx->flag_w = std::min(std::max(std::atoi(ev), 0), SMALL_W);
     ctx->env_small_blocks = env_int("OCTO_SMALL_BLOCKS"); ctx->env_small_min_span = env_int("OCTO_SMALL_MIN_SPAN");
     ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST"); ctx->env_kind_all = env_int("OCTO_KIND_ALL"); ctx->env_mainp_tpb = env_int("OCTO_MAINP_TPB");
     if (const char* ev = std::getenv("OCTO_WIDE")) ctx->env_wide = std::atoi(ev);
-    if (const char* ev = std::getenv("OCTO_WARM")) ctx->env_warm = std::atoi(ev);
+    if (const char* ev = std::getenv("OCTO_WARM")) { ctx->env_warm = std::atoi(ev); ctx->opt_warm = ctx->env_warm ? 1 : 0; }
+    if (const char* ev = std::getenv("OCTO_TILE_SORT")) ctx->tile_mode = std::min(std::max(std::atoi(ev), 0), 2);      // experiments: the default of OCTO_OPT_TILE_SORT
+    if (const char* ev = std::getenv("OCTO_TILE_MIN_W")) ctx->tile_min_w = std::max<int64_t>(std::atoll(ev), 64);
     *out = ctx;
     return OCTO_OK;
 }
@@ -457,6 +517,9 @@ int32_t octo_ctx_destroy(octo_ctx* ctx) {
     (void)hipFree(ctx->d_wc); (void)hipFree(ctx->d_valid); (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_marg); (void)hipFree(ctx->d_sctab); (void)hipFree(ctx->d_extra); (void)hipFree(ctx->d_counters);
     (void)hipHostFree(ctx->h_in); (void)hipHostFree(ctx->h_out); (void)hipHostFree(ctx->h_flags);
     (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_out);
+    (void)hipFree(ctx->d_perm); (void)hipHostFree(ctx->h_tile_stats);
+    for (void* q : ctx->retired_host) (void)hipHostFree(q);
+    if (ctx->ev_tile) (void)hipEventDestroy(ctx->ev_tile);
     delete ctx;
     return OCTO_OK;
 }
@@ -507,15 +570,39 @@ int32_t octo_ctx_set_small_batch(octo_ctx* ctx, int32_t max_walkers) {
 
 const char* octo_last_error(const octo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int32_t octo_ctx_set_option(octo_ctx* ctx, int32_t option, int64_t value) {
+    if (!ctx) return OCTO_EINVAL;
+    switch (option) {
+        case OCTO_OPT_BATCH_INVARIANT: if (value != 0 && value != 1) break; ctx->opt_invariant = (int)value; return OCTO_OK;
+        case OCTO_OPT_WARM_START: if (value != 0 && value != 1) break; ctx->opt_warm = (int)value; return OCTO_OK;
+        case OCTO_OPT_TILE_SORT: if (value < 0 || value > 2) break; ctx->tile_mode = (int)value; ctx->tile_seq = 0; ctx->tile_on = false; ctx->tile_pending = false; return OCTO_OK;
+        case OCTO_OPT_TILE_MIN_WALKERS: if (value < 64) break; ctx->tile_min_w = value; return OCTO_OK;
+        default: return fail(ctx, OCTO_EINVAL, "octo_ctx_set_option: unknown option " + std::to_string(option));
+    }
+    return fail(ctx, OCTO_EINVAL, "octo_ctx_set_option: value " + std::to_string(value) + " out of range for option " + std::to_string(option));
+}
+
+int32_t octo_ctx_get_option(const octo_ctx* ctx, int32_t option, int64_t* value_out) {
+    if (!ctx || !value_out) return OCTO_EINVAL;
+    switch (option) {
+        case OCTO_OPT_BATCH_INVARIANT: *value_out = ctx->opt_invariant; return OCTO_OK;
+        case OCTO_OPT_WARM_START: *value_out = ctx->opt_warm; return OCTO_OK;
+        case OCTO_OPT_TILE_SORT: *value_out = ctx->tile_mode; return OCTO_OK;
+        case OCTO_OPT_TILE_MIN_WALKERS: *value_out = ctx->tile_min_w; return OCTO_OK;
+        default: return OCTO_EINVAL;
+    }
+}
+
 int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_obs,
                             const octo_planet_desc* planets, int32_t n_planets, octo_dataset** out) {
     if (!ctx || !out || n_obs < 0 || (n_obs > 0 && !obs) || !planets) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: null argument");
     *out = nullptr;
-    if (n_planets < 1 || n_planets > MAXP) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: 1.." + std::to_string(MAXP) + " planets supported");
+    if (n_planets < 1) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: a dataset needs at least one planet");
+    if (n_planets > MAXP) return fail(ctx, OCTO_ENOTSUP, "octo_dataset_create: 1.." + std::to_string(MAXP) + " planets supported");
     if (n_planets > MAXP_T)      // beyond the templated kernels: the planet-per-wave kernels' kind sets only (octo_mainp.h)
         for (int o = 0; o < n_obs; ++o)
             if (obs[o].kind == OCTO_RV_ABS_MARG || obs[o].kind == OCTO_ONEIL_RADEC || obs[o].kind == OCTO_ONEIL_SEPPA || obs[o].kind == OCTO_HGCA)
-                return fail(ctx, OCTO_EINVAL, "octo_dataset_create: with more than " + std::to_string(MAXP_T) + " planets only relative astrometry and absolute / relative RV tables "
+                return fail(ctx, OCTO_ENOTSUP, "octo_dataset_create: with more than " + std::to_string(MAXP_T) + " planets only relative astrometry and absolute / relative RV tables "
                                               "are supported (no marginalised RV, O'Neil prior or HGCA)");
     for (int p = 0; p < n_planets; ++p)
         if (planets[p].orbit_kind != OCTO_ORBIT_VISUAL_KEP && planets[p].orbit_kind != OCTO_ORBIT_RADVEL &&
@@ -578,7 +665,7 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
         if (!astrom)       // RV of a ThieleInnesOrbit (PlanetOrbits derives i, ω from A, B, F, G for it) is not on this path
             for (int p = 0; p < n_planets; ++p)
                 if (planets[p].orbit_kind == OCTO_ORBIT_THIELE_INNES && (!planet_obs || p == d.planet || planets[p].has_mass))
-                    return bail(OCTO_EINVAL, "octo_dataset_create: RV tables with a ThieleInnesOrbit planet are not supported");
+                    return bail(OCTO_ENOTSUP, "octo_dataset_create: RV tables with a ThieleInnesOrbit planet are not supported");
         if (!planet_obs)   // every planet contributes to absolute RV and requires a mass (rv-absolute.jl:146-155)
             for (int p = 0; p < n_planets; ++p)
                 if (!planets[p].has_mass) return bail(OCTO_EINVAL, "octo_dataset_create: absolute RV needs a mass on every planet");
@@ -684,6 +771,15 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
         }
         ds->n_rows += n;
     }
+    {   // the walker-tile sort's reference step: the preferred rung of the largest table that has a ladder
+        int64_t best = 0;
+        for (int o = 0; o < n_obs; ++o) {
+            const DevObs& h = ds->h_obs[o];
+            if (h.kind == OCTO_HGCA || !(h.dm_ladder[0] > 0.0f)) continue;
+            ds->tile_rows += h.n;
+            if (h.n > best) { best = h.n; ds->tile_dm_ref = h.dm_ladder[0]; }
+        }
+    }
     if (n_obs > 0) {
         if (hipMalloc((void**)&ds->d_obs, sizeof(DevObs) * n_obs) != hipSuccess) return bail(OCTO_ENOMEM, "octo_dataset_create: hipMalloc failed");
         if (hipMemcpy(ds->d_obs, ds->h_obs.data(), sizeof(DevObs) * n_obs, hipMemcpyHostToDevice) != hipSuccess)
@@ -733,6 +829,7 @@ static int eval_impl(octo_ctx* ctx, const octo_dataset* ds, const double* d_elem
     a.n_obs = ds->n_obs; a.n_planets = ds->n_planets;
     for (int p = 0; p < ds->n_planets; ++p) { a.orbit_kind[p] = ds->planets[p].orbit_kind; a.has_mass[p] = ds->planets[p].has_mass; }
     a.elems = d_elems; a.nuis = d_nuis; a.ld = ld; a.W = W;
+    a.warm = (ctx->opt_warm && !ctx->opt_invariant) ? 1 : 0;
     a.ws_in = a.ws_out = 1;
     if (ctx->stage_ws_in > 0) { a.ws_in = ctx->stage_ws_in; a.ws_out = ctx->stage_ws_out; }      // octo_eval's walker-major staging (k_small only)
     a.wc = ctx->d_wc; a.valid = ctx->d_valid; a.ldw = ctx->cap_w; a.sctab = ctx->d_sctab;
@@ -1054,6 +1151,18 @@ static int32_t kepler_solve_host(octo_ctx* ctx, const double* MA, const double* 
     return OCTO_OK;
 }
 
+// Test / measurement hook (not part of the C ABI, like octo_debug_poison_lds; bench.py and tests/test_tile_sort.py bind it by name): the state of the
+// walker-tile sort of this context — launches that were sorted, probes taken, whether the sort is on for the current (dataset, batch size) and the
+// saving the last probe estimated [µs per evaluation].
+int32_t octo_debug_tile_state(octo_ctx* ctx, int64_t* sorted_launches, int64_t* probes, int32_t* on, double* last_saving_us) {
+    if (!ctx) return OCTO_EINVAL;
+    if (sorted_launches) *sorted_launches = ctx->tile_sorted_launches;
+    if (probes) *probes = ctx->tile_probes;
+    if (on) *on = ctx->tile_on ? 1 : 0;
+    if (last_saving_us) *last_saving_us = ctx->tile_last_saving_us;
+    return OCTO_OK;
+}
+
 // Test hook (not part of the C ABI, like octo_debug_poison_lds): k_main's warm-started Kepler step on its own — octo_kernels.h: k_kepler_warm.
 int32_t octo_debug_kepler_warm(octo_ctx* ctx, const double* MA, const double* dM, const double* e, int64_t n, double* sinE_out, double* cosE_out,
                                double* used_warm_out) {
@@ -1158,7 +1267,8 @@ extern "C" {
 int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prior* priors, int32_t D, const octo_source* elem_src,
                           const octo_source* nuis_src, octo_model** out) {
     if (!ctx || !ds || !priors || !elem_src || !out) return fail(ctx, OCTO_EINVAL, "octo_model_create: null argument");
-    if (D < 1 || D > 64) return fail(ctx, OCTO_EINVAL, "octo_model_create: 1 <= D <= 64 supported");
+    if (D < 1) return fail(ctx, OCTO_EINVAL, "octo_model_create: D >= 1");
+    if (D > 64) return fail(ctx, OCTO_ENOTSUP, "octo_model_create: 1 <= D <= 64 supported");
     if (ds->device != ctx->device) return fail(ctx, OCTO_EINVAL, "octo_model_create: dataset lives on another device");
     *out = nullptr;
     const int n_el = ds->n_planets * OCTO_N_EL, n_nu = ds->n_obs * OCTO_N_NUIS;
@@ -1266,14 +1376,14 @@ int32_t octo_model_create(octo_ctx* ctx, const octo_dataset* ds, const octo_prio
     // (the kernel also declares 1 KB of STATIC LDS — sfin, octo_model.h — which counts against the same per-block limits: ADVICE r4)
     const int64_t lds_static = 16 * WAVE;
     if (m->lds_bytes + lds_static > ctx->max_lds)
-        return bail(OCTO_EINVAL, "octo_model_create: the model needs more LDS per block than this device has ((4·D + 6·n_circular)·512 B)");
+        return bail(OCTO_ENOTSUP, "octo_model_create: the model needs more LDS per block than this device has ((4·D + 6·n_circular)·512 B)");
     if (m->lds_bytes + lds_static > 48 * 1024 &&
         (hipFuncSetAttribute((const void*)k_model_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
          hipFuncSetAttribute((const void*)k_model_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
          hipFuncSetAttribute((const void*)k_model_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess ||
          hipFuncSetAttribute((const void*)k_model_fwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes) != hipSuccess)) {
         (void)hipGetLastError();
-        if (m->lds_bytes + lds_static > 64 * 1024) return bail(OCTO_EINVAL, "octo_model_create: cannot raise k_model_fwd's dynamic LDS limit for this model");
+        if (m->lds_bytes + lds_static > 64 * 1024) return bail(OCTO_ENOTSUP, "octo_model_create: cannot raise k_model_fwd's dynamic LDS limit for this model");
     }
     *out = m;
     return OCTO_OK;

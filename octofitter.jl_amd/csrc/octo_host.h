@@ -56,6 +56,8 @@ struct octo_dataset {
     DevObs* d_obs = nullptr;
     std::vector<double*> d_bufs;
     octo_planet_desc planets[MAXP];
+    float tile_dm_ref = 0.0f;            // reference step of the walker-tile sort (octo_tile.h): the preferred rung of the largest table's ladder; 0: none
+    int64_t tile_rows = 0;               // rows of the tables that have a ladder (what a homogeneous tile saves cold rows on)
     uint64_t serial = 0;                 // process-unique id: the contexts key their task-table caches by it (the dataset itself
                                          // is immutable after octo_dataset_create, so contexts may share it without locking)
 };
@@ -115,6 +117,21 @@ struct octo_ctx {
     // environment on a 12 µs path
     int64_t env_small_blocks = 0, env_small_min_span = 0, env_stage_bytes = 0, env_chunk = 0, env_rounds = 0, env_rv_cost = 0, env_kind_all = 0, env_mainp_tpb = 0;
     int env_warm = 1;                           // OCTO_WARM=0: experiments and tests — datasets created by this context never take k_main's warm-started row loop (DevObs::dm_max = 0)
+    // ---- options (octo_ctx_set_option; include/octofitter_hip.h: OCTO_OPT_*)
+    int opt_warm = 1;                           // OCTO_OPT_WARM_START: 0 = every launch of this context takes k_main's cold row loop
+    int opt_invariant = 0;                      // OCTO_OPT_BATCH_INVARIANT: results independent of the batch's size and composition (cold loop, no tile sort,
+                                                // one fixed row partition, no small-batch route)
+    int tile_mode = 2;                          // OCTO_OPT_TILE_SORT: 0 never, 1 every eligible evaluation, 2 when a probe says it pays (octo_api.hip: tile_prepare)
+    int64_t tile_min_w = 2048;                  // OCTO_OPT_TILE_MIN_WALKERS: smaller batches are never sorted (a strong-scaled shard: the launch would cost more than it saves)
+    // the walker-tile sort's state (octo_tile.h)
+    int32_t* d_perm = nullptr; int64_t cap_perm = 0;
+    float* h_tile_stats = nullptr; int64_t cap_tile_stats = 0;      // mapped pinned: k_tile_sort's expected cold wave-rows per row, as given | sorted, per segment
+    hipEvent_t ev_tile = nullptr;
+    bool tile_on = false, tile_pending = false;
+    int tile_pending_segs = 0;
+    int64_t tile_seq = 0, tile_W = 0, tile_sorted_launches = 0, tile_probes = 0;
+    uint64_t tile_ds = 0;
+    double tile_last_saving_us = 0.0;
     int env_wide = 0;                           // OCTO_WIDE: experiments (1: eight-wave k_main blocks for every one-round single-planet launch, -1: never)
     int flag_w = 128;                           // ... and signal completion through per-walker flags the host spins on (OCTO_FLAG_W: experiments)
     int mapped_w = 128;                         // host-buffer calls up to this size let k_small read/write mapped pinned memory; larger
@@ -123,12 +140,14 @@ struct octo_ctx {
     int64_t cap_in = 0, cap_out = 0;
     double *h_in = nullptr, *h_out = nullptr;   // pinned mirrors of d_in / d_out for SMALL batches: one transfer each way instead of
     int64_t cap_hin = 0, cap_hout = 0;          // one per array — what a single-chain sampler's per-gradient latency is made of
+    std::vector<void*> retired_host;            // outgrown mapped-pinned buffers (freed at octo_ctx_destroy: hipHostFree waits for the device)
     std::vector<void*> retired;                 // outgrown scratch buffers: kernels already enqueued may still use them, so they
                                                 // are freed at the next host-blocking point (octo_sync, the end of a host-buffer
                                                 // call, octo_ctx_destroy) instead of by a device-synchronising hipFree mid-stream
     // row partitions ("task tables") of the datasets this context has evaluated, keyed by (dataset serial, plan key)
     std::vector<octo::TaskTable> tables;
     std::map<uint32_t, int> occupancy;          // resident blocks per CU of each k_main variant (P, NUIS, KM) on THIS device
+    std::map<const void*, size_t> lds_raised;   // kernels whose dynamic-LDS limit this context has raised beyond the default 48 KB (raise_dynamic_lds)
     // timing
     int timing_every = 0;                       // 0 = off, n = bracket every n-th evaluation's k_main with events
     bool timing_whole = false;                  // octo_timing_enable(ctx, -1): bracket every host-buffer evaluation WHOLE (copy-in .. last store)
@@ -163,10 +182,22 @@ int grow(octo_ctx* ctx, T*& p, int64_t& cap, int64_t need) {
     return OCTO_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a launch that needs more than the default 48 KB, once per context and kernel
+inline int raise_dynamic_lds(octo_ctx* ctx, const void* fn, size_t lds, const char* what) {
+    if (lds <= 48 * 1024) return OCTO_OK;
+    size_t& r = ctx->lds_raised[fn];
+    if (lds <= r) return OCTO_OK;
+    if (lds > (size_t)ctx->max_lds) return fail(ctx, OCTO_EINVAL, std::string(what) + ": the block shape needs more LDS than this device has");
+    HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    r = lds;
+    return OCTO_OK;
+}
+
 int get_tasks(octo_ctx* ctx, const octo_dataset* ds, int64_t key, TaskTable** out, bool nuis = false, int wpb = WPB);
 int64_t plan_key(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu, bool* wide = nullptr, int blocks8_per_cu = 0);
 int busy(octo_ctx* ctx, const char* what);      // OCTO_EINVAL while an octo_eval_begin of this context is outstanding
 bool small_eligible(const octo_ctx* ctx, const octo_dataset* ds, int64_t W, bool model = false);
+int tile_prepare(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t st);      // octo_tile.h: sets a.perm (or leaves it null)
 
 // Launch of one evaluation for a dataset with P planets (octo_launch.h; instantiated in octo_inst_p<P>.hip).
 template <int P>

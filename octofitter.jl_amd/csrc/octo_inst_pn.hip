@@ -36,12 +36,9 @@ template <bool GRAD, bool NUIS, int KM, int MP_R, int WPE>
 int launch_mainp_shape(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t st) {
     const int P = a.n_planets, tpb = mainp_tpb(ctx, P);
     const size_t lds = mainp_lds_bytes<GRAD, NUIS, KM, MP_R>(P, tpb);
-    static size_t raised = 48 * 1024;      // (per instantiation; contexts of one process share the code object)
-    if (lds > raised) {
-        if (lds > (size_t)ctx->max_lds) return fail(ctx, OCTO_EINVAL, "k_mainp: the block shape needs more LDS than this device has");
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_mainp<GRAD, NUIS, KM, MP_R, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        raised = lds;
-    }
+    // (the raised limit is remembered per CONTEXT — per device and owner thread — not in a function-local static: the attribute belongs to the current
+    // device's copy of the function, and contexts are not synchronised with each other)
+    { int rcl = raise_dynamic_lds(ctx, (const void*)k_mainp<GRAD, NUIS, KM, MP_R, WPE>, lds, "k_mainp"); if (rcl) return rcl; }
     EvalArgs b = a;
     b.n_rblocks = tpb;
     hipLaunchKernelGGL((k_mainp<GRAD, NUIS, KM, MP_R, WPE>), dim3((unsigned)((cols + tpb - 1) / tpb), (unsigned)a.n_tasks), dim3((unsigned)(WAVE * P * tpb)), lds, st, b);
@@ -60,10 +57,13 @@ int launch_finishp_t(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t
     return OCTO_OK;
 }
 template <bool NUIS, int KM>
-int occupancy_t(const octo_ctx* ctx, int P) {
+int occupancy_t(octo_ctx* ctx, int P) {
     // in TILES per CU. (The API counts registers and LDS; what the hardware really places is bounded by its fixed wave -> SIMD order as well: octo_mainp.h)
     const int tpb = mainp_tpb(ctx, P);
     int nb = 0;
+    // the two-tile blocks of 5 / 6 planets ask for more than the default 48 KB: opt in BEFORE the query
+    if (P > 6) (void)raise_dynamic_lds(ctx, (const void*)k_mainp<true, NUIS, KM, mp_rows(8), mp_wpe(8)>, mainp_lds_bytes<true, NUIS, KM, mp_rows(8)>(P, tpb), "k_mainp");
+    else (void)raise_dynamic_lds(ctx, (const void*)k_mainp<true, NUIS, KM, mp_rows(4), mp_wpe(4)>, mainp_lds_bytes<true, NUIS, KM, mp_rows(4)>(P, tpb), "k_mainp");
     hipError_t e = P > 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mainp<true, NUIS, KM, mp_rows(8), mp_wpe(8)>, WAVE * P * tpb, (mainp_lds_bytes<true, NUIS, KM, mp_rows(8)>(P, tpb)))
                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mainp<true, NUIS, KM, mp_rows(4), mp_wpe(4)>, WAVE * P * tpb, (mainp_lds_bytes<true, NUIS, KM, mp_rows(4)>(P, tpb)));
     if (e != hipSuccess || nb < 1) nb = 1;

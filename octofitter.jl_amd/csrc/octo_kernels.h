@@ -83,6 +83,7 @@ struct EvalArgs {
     const int32_t* obs_range;     // [n_obs][2] first and one-past-last task of each observation (tasks are grouped by observation)
     const double* obs_const;      // [n_obs] Σ task_const over the observation's tasks, in task order
     int32_t n_obs, n_tasks, n_planets, n_hblocks;      // n_hblocks: k_small only — extra blocks per walker that compute the HGCA term
+    int32_t warm, pad_w;                        // 1: k_main may take the warm-started row loop (octo_ctx option OCTO_OPT_WARM_START / _BATCH_INVARIANT)
     int32_t task0, n_rblocks;                   // first task of this launch (k_main grid.y is relative to it); k_small: blocks per walker that take row tasks
     int32_t orbit_kind[MAXP];
     int32_t has_mass[MAXP];
@@ -100,6 +101,8 @@ struct EvalArgs {
     double* extra;                // [1 + P*9 + n_obs*3][ldw]: ll and input-gradient of the terms computed outside the epoch loop
                                   // (k_hgca), added by k_finish; or null
     const double* sctab;          // [SCT_N][2] sin/cos grid (octo_device.h: sincos_table), copied to LDS by every k_main block
+    const int32_t* perm;          // [W] or null: walker of each tile position (octo_tile.h: k_tile_sort). Single-planet fused launches only: k_main gathers its
+                                  // tile's inputs through it, the partials stay in tile order, k_finish<1, …, FROM_WC = false> scatters the results back
     int64_t ldw;
     double* ll_out; double* g_elems; double* g_nuis;
     // The tail of the standard parameterisation (octo_model.h; src/logdensitymodel.jl:110-146,169-177) for big batches, run by k_finish right
@@ -883,11 +886,11 @@ constexpr bool main_warm() {
 // ΔM = bound/P > WARM_DM_VETO (thr would fall below WARM_MIN_THR; a NaN — an invalid walker — does not veto). thr = (tol / ΔM³)^(1/5) per lane from
 // that bound (v_log_f32 / v_exp_f32 are base 2). No entry passes: the wave runs the cold loop. The first row of a wave is cold.
 template <int P>
-__device__ __forceinline__ float warm_init(WarmState<P>& ws, const PC (&pc)[P], const DevObs& ob) {
+__device__ __forceinline__ float warm_init(WarmState<P>& ws, const PC (&pc)[P], const DevObs& ob, bool enabled) {
     float bound = 0.0f;
 #pragma unroll
     for (int k = WARM_LADDER - 1; k >= 0; --k) {      // (last to first: the most preferred passing entry is written last)
-        const float d = ob.dm_ladder[k];
+        const float d = enabled ? ob.dm_ladder[k] : 0.0f;
         bool veto = false;
 #pragma unroll
         for (int p = 0; p < P; ++p) veto = veto || (fabsf(d * (float)pc[p].invP) > WARM_DM_VETO);
@@ -937,6 +940,8 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                                                                           // so the row pointer stays scalar (s_load, not global_load)
     const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;          // tail lanes recompute the last walker; results discarded
+    int64_t wsrc = wl;                                  // the walker this tile position holds (octo_tile.h)
+    if constexpr (FUSED && P == 1) { if (a.perm) wsrc = a.perm[wl]; }
     const int task = a.task0 + (int)blockIdx.y;
     const Task tk = a.tasks[task];                      // wave-uniform: scalar loads
     const DevObs ob = a.obs[tk.obs];
@@ -980,7 +985,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         double elv[P][OCTO_N_EL];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + wl;
+            const double* el = a.elems + (int64_t)p * OCTO_N_EL * a.ld + wsrc;
 #pragma unroll
             for (int k = 0; k < OCTO_N_EL; ++k) elv[p][k] = el[(int64_t)k * a.ld];
         }
@@ -1031,7 +1036,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                            ob.kind == OCTO_ONEIL_SEPPA;
 
     if (L::HAS_ASTROM && (!L::HAS_RV || is_astrom)) {
-        const AstromCoef<P> co = astrom_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, ob.kind, ob.planet, ob.has_cor, tk.obs, pc, wl);
+        const AstromCoef<P> co = astrom_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, ob.kind, ob.planet, ob.has_cor, tk.obs, pc, wsrc);
         const crow_t rows = constant_rows((NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE);
         // two rows per trip through two SGPR buffers that swap roles (no copies): B is fetched while A is computed and vice versa
         auto body = [&](const RowRegs& r) {
@@ -1040,7 +1045,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         bool warm_loop = false, warm_unchecked = false;
         WarmState<P> ws;
         if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
-            const float bound = warm_init<P>(ws, pc, ob);
+            const float bound = warm_init<P>(ws, pc, ob, a.warm != 0);
             warm_loop = bound > 0.0f;
             // every row of the task within the wave's bound and no chain longer than WARM_RESTART: the loop without the per-row test (a uniform
             // cadence — config 3 — pays nothing for the gaps other tables have: the test is seven scalar instructions and two branches per row, 1 %)
@@ -1097,7 +1102,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         }
     }
     if (L::HAS_RV && !is_astrom) {
-        const RvCoef<P> co = rv_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, a.marg, a.ldw, ob.kind, ob.planet, tk.obs, pc, wl);
+        const RvCoef<P> co = rv_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, a.marg, a.ldw, ob.kind, ob.planet, tk.obs, pc, wsrc);      // (a.marg: the k_setup route only, where wsrc == wl)
         const crow_t rows = constant_rows((NUIS ? ob.raw : ob.pre) + (int64_t)row_first * ROW_STRIDE);
         auto body = [&](const RowRegs& r) {
             rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab);
@@ -1105,7 +1110,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         bool warm_loop = false, warm_unchecked = false;
         WarmState<P> ws;
         if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
-            const float bound = warm_init<P>(ws, pc, ob);
+            const float bound = warm_init<P>(ws, pc, ob, a.warm != 0);
             warm_loop = bound > 0.0f;
             // every row of the task within the wave's bound and no chain longer than WARM_RESTART: the loop without the per-row test (a uniform
             // cadence — config 3 — pays nothing for the gaps other tables have: the test is seven scalar instructions and two branches per row, 1 %)
@@ -1475,6 +1480,10 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
     static_assert(NGL >= 1, "finish_tile: more planets than waves");
     const int64_t w = tile * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;
+    // wo: the walker this tile position holds (octo_tile.h; the identity without a permutation). The partials are indexed by the POSITION (wl),
+    // everything that belongs to the caller — elements, nuisances, k_hgca's rows, ll, the adjoints, the model's tail — by the walker.
+    int64_t wo = wl;
+    if constexpr (!FROM_WC) { if (a.perm) wo = a.perm[wl]; }
     const int my_p = grp - NGL;                           // >= 0: this wave finishes planet my_p
     double gp[NPL > 0 ? NPL : 1];
 #pragma unroll
@@ -1491,9 +1500,9 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if constexpr (FROM_WC) sma_p[p] = a.wc[((int64_t)p * NWC + WC_A) * a.ldw + wl];
-                else sma_p[p] = setup_planet<true>(a, p, wl).v[WC_A];
-                e_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wl];
-                M_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wl];
+                else sma_p[p] = setup_planet<true>(a, p, wo).v[WC_A];
+                e_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wo];
+                M_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wo];
             }
         }
     }
@@ -1516,10 +1525,10 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
                 fp.si = wc[WC_SINI * a.ldw]; fp.ci = wc[WC_COSI * a.ldw]; fp.sO = wc[WC_SINO * a.ldw]; fp.cO = wc[WC_COSO * a.ldw];
                 fp.sw = wc[WC_SINW * a.ldw]; fp.cw = wc[WC_COSW * a.ldw];
 #pragma unroll
-                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl];
+                for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wo];
                 ok_mine = a.valid[(int64_t)p * a.ldw + wl] != 0;
             } else {
-                const SetupOut so = setup_planet<true>(a, p, wl);      // the same routine, the same values k_setup would have stored
+                const SetupOut so = setup_planet<true>(a, p, wo);      // the same routine, the same values k_setup would have stored
                 fp.sma = so.v[WC_A]; fp.P_d = rcp_nr<2>(so.v[WC_INVP]); fp.beta = so.v[WC_BETA];
                 fp.si = so.v[WC_SINI]; fp.ci = so.v[WC_COSI]; fp.sO = so.v[WC_SINO]; fp.cO = so.v[WC_COSO];
                 fp.sw = so.v[WC_SINW]; fp.cw = so.v[WC_COSW];
@@ -1568,7 +1577,7 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
                 if constexpr (GRAD) { v[8] = vo[L::OFF_ONEIL + 1]; v[9] = vo[L::OFF_ONEIL + 2]; v[10] = vo[L::OFF_ONEIL + 3]; }
             }
             // observations are summed in the order given (system.jl:93,186)
-            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + w : nullptr,
+            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + wo : nullptr, a.extra ? a.extra + wo : nullptr,
                                                 a.ldw, a.c.k_yr, o, v, cst, sma_p, e_p, M_p, w < a.W, oneil_g);
         }
     }
@@ -1587,7 +1596,7 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
     }
     if constexpr (GRAD && !EARLY) derive();
     if (grp == 0) {
-        if (a.extra) ll += a.extra[wl];
+        if (a.extra) ll += a.extra[wo];
         ok_mine = isfinite(ll);
         if constexpr (FROM_WC) {
             if constexpr (!GRAD) {
@@ -1599,10 +1608,10 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
             // finisher wave), every nuisance finite
             if constexpr (!GRAD) {
 #pragma unroll
-                for (int p = 0; p < P; ++p) ok_mine = ok_mine && setup_planet<true>(a, p, wl).ok;
+                for (int p = 0; p < P; ++p) ok_mine = ok_mine && setup_planet<true>(a, p, wo).ok;
             }
             if (a.nuis)
-                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok_mine = ok_mine && isfinite(a.nuis[(int64_t)k * a.ld + wl]);
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok_mine = ok_mine && isfinite(a.nuis[(int64_t)k * a.ld + wo]);
         }
     }
     bool ok = ok_mine;
@@ -1627,10 +1636,10 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
     }
     const bool live = w < a.W;      // (the tile's tail lanes recomputed the last walker: they store nothing)
     if (live && grp == 0) {
-        a.ll_out[w] = ok ? ll : -INFINITY;
+        a.ll_out[wo] = ok ? ll : -INFINITY;
         if constexpr (GRAD && L::N_NU > 0) {
             if (!ok)
-                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + w] = 0.0;
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + wo] = 0.0;
         }
     }
     if constexpr (GRAD) {
@@ -1639,11 +1648,11 @@ __device__ __forceinline__ void finish_tile(const EvalArgs& a, int64_t tile, int
             if (my_p != p || !live) continue;
             // FAST (reciprocal-multiply divisions, as in k_small): the tail of a launch is one wave's dependent chain, and an IEEE
             // FP64 division is a dozen dependent instructions
-            planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
+            planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, a.extra ? a.extra + wo : nullptr, a.ldw, a.c,
                                                             a.orbit_kind[p], a.has_mass[p], p, gmine, L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
         }
     }
-    if (a.mt_lpp) model_tail<P>(a, w, grp, NG);      // block-uniform (a kernel argument)
+    if (a.mt_lpp) model_tail<P>(a, live ? wo : a.W, grp, NG);      // block-uniform (a kernel argument); a dead tail lane passes W: it stores nothing
 }
 
 // ------------------------------------------------------------------------------------ finish_tile_multi (several planets)

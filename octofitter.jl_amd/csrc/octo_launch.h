@@ -152,8 +152,11 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         blocks8_per_cu = nb8 > 0 ? nb8 : 0;
     }
     bool wide = false;
-    const int64_t pkey = MAINP ? plan_key_mainp(ctx, a.W, ds->n_rows, blocks_per_cu)
-                               : plan_key(ctx, a.W, ds->n_rows, blocks_per_cu, (WIDE_OK && !marg_ds && blocks8_per_cu > 0) ? &wide : nullptr, blocks8_per_cu);
+    // OCTO_OPT_BATCH_INVARIANT: ONE row partition whatever the batch size (64 rows per wave, four-wave blocks), so that a walker's sums are formed in
+    // the same order in every batch it is part of
+    const int64_t pkey = ctx->opt_invariant ? (int64_t)-64
+                         : MAINP ? plan_key_mainp(ctx, a.W, ds->n_rows, blocks_per_cu)
+                                 : plan_key(ctx, a.W, ds->n_rows, blocks_per_cu, (WIDE_OK && !marg_ds && blocks8_per_cu > 0) ? &wide : nullptr, blocks8_per_cu);
     int rc0 = get_tasks(ctx, ds, pkey, &tt, NUIS, MAINP ? 1 : (wide ? 2 * WPB : WPB));
     if (rc0) return rc0;
     a.tasks = tt->d_tasks; a.task_const = NUIS ? tt->d_const_raw : tt->d_const_pre;
@@ -193,6 +196,11 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         rc = hgca_term();
         if (rc) return rc;
         if (a.n_tasks > 0) {      // (a dataset without rows — an HGCA table alone, empty tables — is k_finish's closed forms only)
+            // walker tiles made homogeneous for the warm-started loop (octo_tile.h): one sort launch ahead of k_main when it pays
+            if constexpr (P == 1 && !MAINP && main_warm<P, true, NUIS, KM, true>()) {
+                rc = tile_prepare(ctx, ds, a, st);
+                if (rc) return rc;
+            }
             rc = timing_begin();
             if (rc) return rc;
             bool launched = false;

@@ -15,8 +15,9 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "liboctofitter_hip.so"
 
-OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV = 0, 1, 2, 3, 4
-STATUS_NAMES = {0: "OCTO_OK", 1: "OCTO_EINVAL", 2: "OCTO_EHIP", 3: "OCTO_ENOMEM", 4: "OCTO_ENODEV"}
+OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV, OCTO_ENOTSUP = 0, 1, 2, 3, 4, 5
+STATUS_NAMES = {0: "OCTO_OK", 1: "OCTO_EINVAL", 2: "OCTO_EHIP", 3: "OCTO_ENOMEM", 4: "OCTO_ENODEV", 5: "OCTO_ENOTSUP"}
+FALLBACK_STATUSES = (OCTO_ENODEV, OCTO_ENOTSUP)      # what a host-side binding answers by staying on the reference's path; every other status is the caller's to see
 
 ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL, ONEIL_RADEC, ONEIL_SEPPA, HGCA = 0, 1, 2, 3, 4, 5, 6, 7
 HGCA_RA, HGCA_DEC, HGCA_HIP, HGCA_GAIA, HGCA_N_EXTRA = 0, 1, 0, 1, 15
@@ -28,6 +29,7 @@ MAX_PLANETS_ALL_KINDS = 4      # OCTO_MAX_PLANETS_ALL_KINDS: beyond it relative 
 EL_A, EL_E, EL_I, EL_W, EL_O, EL_TP, EL_M, EL_PLX, EL_MASS = range(9)
 NU_JITTER, NU_PLATESCALE, NU_NORTHANGLE = 0, 1, 2
 NU_RV_OFFSET, NU_RV_JITTER, NU_RV_TREND = 0, 1, 2
+OPT_BATCH_INVARIANT, OPT_WARM_START, OPT_TILE_SORT, OPT_TILE_MIN_WALKERS = 1, 2, 3, 4      # octo_ctx_set_option
 
 c_double_p = C.POINTER(C.c_double)
 STREAM_CTX = C.c_void_p(-1)      # OCTO_STREAM_CTX: the context's own stream (NULL = HIP's NULL stream, e.g. torch's default stream)
@@ -129,6 +131,8 @@ _SIGS = {
     "octo_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "octo_consts_set": (C.c_int32, [C.c_void_p, C.POINTER(OctoConsts)]),
     "octo_ctx_set_small_batch": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "octo_ctx_set_option": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int64]),
+    "octo_ctx_get_option": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "octo_host_register": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     "octo_host_unregister": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "octo_last_error": (C.c_char_p, [C.c_void_p]),
@@ -187,7 +191,12 @@ def load_library(path=None):
             "The product path has no CPU fallback.")
     lib = C.CDLL(str(p), mode=C.RTLD_GLOBAL)
     for name, (res, args) in _SIGS.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if path is None and os.environ.get("OCTOFITTER_HIP_LIB"):      # an older build selected for a same-box A/B (tools/): its symbols only
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     if path is None:

@@ -337,6 +337,29 @@ class BatchedLnLike:
     def timing_enable(self, on=True):
         self._check(self.lib.octo_timing_enable(self._ctx, int(on)), "octo_timing_enable")
 
+    def set_option(self, option, value):
+        """octo_ctx_set_option (capi.OPT_*): batch-invariant results, the warm start, the walker-tile sort."""
+        self._check(self.lib.octo_ctx_set_option(self._ctx, int(option), int(value)), "octo_ctx_set_option")
+
+    def get_option(self, option):
+        v = C.c_int64()
+        self._check(self.lib.octo_ctx_get_option(self._ctx, int(option), C.byref(v)), "octo_ctx_get_option")
+        return v.value
+
+    def tile_state(self):
+        """The walker-tile sort of this context (octo_debug_tile_state, a measurement hook outside the C ABI): evaluations that ran sorted, probes
+        taken, whether the sort is on for the current (dataset, batch size), the last probe's estimated saving [µs per evaluation]. None for a
+        library without the hook (an older build selected with OCTOFITTER_HIP_LIB)."""
+        try:
+            f = self.lib.octo_debug_tile_state
+        except AttributeError:
+            return None
+        f.restype = C.c_int32
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        n, pr, on, sv = C.c_int64(), C.c_int64(), C.c_int32(), C.c_double()
+        self._check(f(self._ctx, C.byref(n), C.byref(pr), C.byref(on), C.byref(sv)), "octo_debug_tile_state")
+        return {"evaluations_sorted": n.value, "probes": pr.value, "on": bool(on.value), "last_probe_saving_us": sv.value}
+
     def timing_stats(self):
         """(median_ms, min_ms, max_ms, n) over the individual timed launches since the last reset."""
         med, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
@@ -374,7 +397,11 @@ def accelerate(system: System, θ_example: dict, device: int = 0, consts=None, v
             fn = BatchedLnLike(system, θ_example, device=device, consts=consts)
             system.hip_fallback_reason = None
             return fn
-        except capi.OctoError as ex:      # OCTO_ENODEV, OCTO_EINVAL from octo_dataset_create, OCTO_EHIP / OCTO_ENOMEM at creation
+        except capi.OctoError as ex:
+            # OCTO_ENODEV (no usable device) and OCTO_ENOTSUP (a valid system the device path does not take) are the fallback's reasons; bad input
+            # (OCTO_EINVAL: σ <= 0, non-finite epochs, |cor| >= 1 …), OCTO_EHIP and OCTO_ENOMEM are the caller's to see
+            if ex.status not in capi.FALLBACK_STATUSES:
+                raise
             why = str(ex)
     system.hip_fallback_reason = why
     if verbosity >= 1:

@@ -279,9 +279,10 @@ function accelerate(system::System; device::Integer=0, n_contexts::Integer=Threa
     try
         ctx, ds, entries, columns = _upload(system, eligible, θs; device)
     catch e
-        # OctoError: the library's refusal (no device, a kind set it does not take for this many planets, …); ErrorException: this shim's own
-        # (an orbit type that is not on the HIP path, `_orbit_kind`)
-        (e isa OctoError || e isa ErrorException) || rethrow()
+        # OCTO_ENODEV / OCTO_ENOTSUP: the library's refusal of a VALID system (no device, a kind set it does not take for this many planets, …);
+        # NotOnHIPPath: this shim's own (an orbit type that is not on the HIP path, `_orbit_kind`). Anything else — bad input (OCTO_EINVAL: σ <= 0,
+        # non-finite epochs, |cor| >= 1), OCTO_EHIP, OCTO_ENOMEM, a bug in this file — is the caller's to see (ADVICE r5)
+        is_fallback(e) || rethrow()
         verbosity >= 1 && @info "OctofitterHIP: $(sprint(showerror, e)) — the system stays on the reference's CPU path"
         return system
     end
@@ -390,7 +391,7 @@ function GPUBatchedLikelihood(model; device::Integer=0)
         if !_has_epochs(obs)
             push!(host_terms, (obs, ip, ctxkind)); return
         end
-        _eligible(obs, ip, θs) || error("observation $(likelihoodname(obs)) is not on the HIP path (GP, or a trend_function that is not one θ_obs variable × a function of the epoch); keep using model.ℓπcallback")
+        _eligible(obs, ip, θs) || throw(NotOnHIPPath("observation $(likelihoodname(obs)) is not on the HIP path (GP, or a trend_function that is not one θ_obs variable × a function of the epoch); keep using model.ℓπcallback"))
         push!(eligible, (obs, ip))
     end
     # evaluation order of the generated closure: planet observations planet by planet, then system ones (system.jl:229-235)
@@ -571,7 +572,7 @@ function HIPLogDensityModel(model; device::Integer=0, fallback::Bool=true, verbo
         try
             return _hip_log_density_model(model; device)
         catch e
-            (e isa OctoError || e isa ErrorException) || rethrow()
+            is_fallback(e) || rethrow()
             why = sprint(showerror, e)
         end
     end
@@ -583,18 +584,18 @@ function _hip_log_density_model(model; device::Integer=0)
     g = GPUBatchedLikelihood(model; device)
     # the UnitLengthPrior terms of UniformCircular variables are part of the device model; any other host term is not
     for (obs, _, _) in g.host_terms
-        nameof(typeof(obs)) === :UnitLengthPrior || error("$(typeof(obs)) is evaluated in Julia: use LogDensityModel(accelerate(system)) for this model")
+        nameof(typeof(obs)) === :UnitLengthPrior || throw(NotOnHIPPath("$(typeof(obs)) is evaluated in Julia: use LogDensityModel(accelerate(system)) for this model"))
     end
     dists = _flat_priors(model.system)
-    length(dists) == model.D || error("model has multivariate or discrete priors: not a standard-parameterisation model")
+    length(dists) == model.D || throw(NotOnHIPPath("model has multivariate or discrete priors: not a standard-parameterisation model"))
     priors = OctoPrior[]
     for d in dists
         p = _octo_prior(d)
-        p === nothing && error("prior $(d) has no device counterpart: use LogDensityModel(accelerate(system)) for this model")
+        p === nothing && throw(NotOnHIPPath("prior $(d) has no device counterpart: use LogDensityModel(accelerate(system)) for this model"))
         push!(priors, p)
     end
     srcs = _classify_sources(model, g)
-    srcs === nothing && error("a Derived variable of this model is not one of the standard blocks: use LogDensityModel(accelerate(system))")
+    srcs === nothing && throw(NotOnHIPPath("a Derived variable of this model is not one of the standard blocks: use LogDensityModel(accelerate(system))"))
     n_el = g.n_planets * N_EL
     m = octo_model_create(g.ctx, g.ds, priors, srcs[1:n_el], length(srcs) > n_el ? srcs[n_el+1:end] : nothing)
     lk = ReentrantLock()

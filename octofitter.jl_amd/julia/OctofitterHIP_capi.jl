@@ -9,7 +9,7 @@
 const LIB = get(ENV, "OCTOFITTER_HIP_LIB", "liboctofitter_hip.so")
 
 # ---------------------------------------------------------------------------------------------------- constants of the header
-const OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
+const OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV, OCTO_ENOTSUP = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4), Int32(5)
 const ASTROM_RADEC, ASTROM_SEPPA, RV_ABS, RV_ABS_MARG, RV_REL = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
 const ONEIL_RADEC, ONEIL_SEPPA, HGCA = Int32(5), Int32(6), Int32(7)
 const ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES, ORBIT_KEP = Int32(0), Int32(1), Int32(2), Int32(3)
@@ -67,12 +67,18 @@ struct OctoSource            # mirrors `octo_source`
 end
 
 # ---------------------------------------------------------------------------------------------------- one ccall per exported symbol
-"A non-zero status of the library (include/octofitter_hip.h: OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV) as a Julia exception the shim can catch by kind."
+"A non-zero status of the library (include/octofitter_hip.h: OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV, OCTO_ENOTSUP) as a Julia exception the shim can catch by kind."
 struct OctoError <: Exception
     status::Int32
     what::String
     msg::String
 end
+# What the shim answers by staying on the reference's own path: no usable device, a valid system / model the device path does not take (OCTO_ENOTSUP), or
+# the shim's own refusal of something valid in the reference (NotOnHIPPath: an orbit type, a prior, a Derived expression). Bad input (OCTO_EINVAL),
+# OCTO_EHIP and OCTO_ENOMEM are rethrown.
+struct NotOnHIPPath <: Exception; msg::String; end
+Base.showerror(io::IO, e::NotOnHIPPath) = print(io, e.msg)
+is_fallback(e) = e isa NotOnHIPPath || (e isa OctoError && (e.status == OCTO_ENODEV || e.status == OCTO_ENOTSUP))
 Base.showerror(io::IO, e::OctoError) = print(io, "$(e.what) failed with status $(e.status): $(e.msg)")
 check(ctx, st, what) = st == OCTO_OK ? nothing :
     throw(OctoError(st, what, ctx == C_NULL ? "" : unsafe_string(ccall((:octo_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))))
@@ -88,6 +94,11 @@ end
 octo_ctx_destroy(ctx) = ccall((:octo_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), ctx)
 octo_consts_set(ctx, c::OctoConsts) = check(ctx, ccall((:octo_consts_set, LIB), Int32, (Ptr{Cvoid}, Ref{OctoConsts}), ctx, c), "octo_consts_set")
 octo_ctx_set_small_batch(ctx, n::Integer) = check(ctx, ccall((:octo_ctx_set_small_batch, LIB), Int32, (Ptr{Cvoid}, Int32), ctx, n), "octo_ctx_set_small_batch")
+# Context options (include/octofitter_hip.h: OCTO_OPT_*). OCTO_OPT_BATCH_INVARIANT = 1 gives the reference's per-θ determinism (src/logdensitymodel.jl:110-146):
+# ll(θ) bit-identical whatever batch θ is evaluated in.
+const OCTO_OPT_BATCH_INVARIANT, OCTO_OPT_WARM_START, OCTO_OPT_TILE_SORT, OCTO_OPT_TILE_MIN_WALKERS = Int32(1), Int32(2), Int32(3), Int32(4)
+octo_ctx_set_option(ctx, option::Integer, value::Integer) = check(ctx, ccall((:octo_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Int32, Int64), ctx, option, value), "octo_ctx_set_option")
+octo_ctx_get_option(ctx, option::Integer) = (v = Ref{Int64}(0); check(ctx, ccall((:octo_ctx_get_option, LIB), Int32, (Ptr{Cvoid}, Int32, Ref{Int64}), ctx, option, v), "octo_ctx_get_option"); v[])
 # Page-lock and map an Array the caller keeps alive (elements, log-likelihoods, gradients of a big batch): later host-buffer calls
 # whose buffers are all registered skip the copy engine. `GC.@preserve` the array for as long as it is registered; unregister before it is freed.
 octo_host_register(ctx, a::Array{Float64}) = check(ctx, ccall((:octo_host_register, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), ctx, pointer(a), sizeof(a)), "octo_host_register")

@@ -34,7 +34,7 @@ def poison(ctx):
 
 
 class GpuPath:
-    def __init__(self, obs_tables, planets, device=0, consts=None, small_batch=None):
+    def __init__(self, obs_tables, planets, device=0, consts=None, small_batch=None, options=None):
         if small_batch is None:
             small_batch = DEFAULT_SMALL_BATCH
         self.lib = capi.load_library()
@@ -46,6 +46,8 @@ class GpuPath:
             self._chk(self.lib.octo_consts_set(self.ctx, C.byref(consts)))
         if small_batch is not None:      # 0: force the throughput kernels (lane = walker) also for tiny batches
             self._chk(self.lib.octo_ctx_set_small_batch(self.ctx, int(small_batch)))
+        for opt, val in (options or {}).items():      # octo_ctx_set_option (capi.OPT_*)
+            self._chk(self.lib.octo_ctx_set_option(self.ctx, int(opt), int(val)))
         obs_arr, keep = capi.pack_obs(obs_tables)
         pl_arr = capi.pack_planets(planets)
         self.ds = C.c_void_p()
@@ -68,6 +70,14 @@ class GpuPath:
                                      capi._dptr(ll), capi._dptr(g_el), capi._dptr(g_nu)))
         return ll, g_el, g_nu
 
+    def tile_state(self):
+        """(sorted launches, probes, sort on?, the last probe's estimated saving in µs) — octo_debug_tile_state, a test hook."""
+        n, pr, on, sv = C.c_int64(), C.c_int64(), C.c_int32(), C.c_double()
+        self.lib.octo_debug_tile_state.restype = C.c_int32
+        self.lib.octo_debug_tile_state.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        self._chk(self.lib.octo_debug_tile_state(self.ctx, C.byref(n), C.byref(pr), C.byref(on), C.byref(sv)))
+        return n.value, pr.value, bool(on.value), sv.value
+
     def close(self):
         if self.ds:
             self.lib.octo_dataset_destroy(self.ds); self.ds = None
@@ -81,6 +91,6 @@ class GpuPath:
         self.close()
 
 
-def gpu_eval(obs_tables, planets, elems, nuis=None, grad=True, consts=None, small_batch=None):
-    with GpuPath(obs_tables, planets, consts=consts, small_batch=small_batch) as g:
+def gpu_eval(obs_tables, planets, elems, nuis=None, grad=True, consts=None, small_batch=None, options=None):
+    with GpuPath(obs_tables, planets, consts=consts, small_batch=small_batch, options=options) as g:
         return g.eval(elems, nuis, grad)

@@ -156,7 +156,7 @@ def test_julia_constants_match_the_header():
                                                                                          "OCTO_PRIOR_TRUNCNORMAL", "OCTO_PRIOR_SINE"],
         "SRC_CONST, SRC_THETA, SRC_CIRCULAR, SRC_TPERI": ["OCTO_SRC_CONST", "OCTO_SRC_THETA", "OCTO_SRC_CIRCULAR", "OCTO_SRC_TPERI"],
         "SRC_FLAG_UNITLEN, SRC_FLAG_TI": ["OCTO_SRC_FLAG_UNITLEN", "OCTO_SRC_FLAG_TI"],
-        "OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV": ["OCTO_OK", "OCTO_EINVAL", "OCTO_EHIP", "OCTO_ENOMEM", "OCTO_ENODEV"],
+        "OCTO_OK, OCTO_EINVAL, OCTO_EHIP, OCTO_ENOMEM, OCTO_ENODEV, OCTO_ENOTSUP": ["OCTO_OK", "OCTO_EINVAL", "OCTO_EHIP", "OCTO_ENOMEM", "OCTO_ENODEV", "OCTO_ENOTSUP"],
     }
     for lhs, names in groups.items():
         m = re.search(r"const " + re.escape(lhs) + r"\s*=\s*(.+)", txt)
@@ -258,10 +258,15 @@ def test_julia_shim_falls_back_instead_of_throwing():
     # accelerate: the three branches, each returning `system`
     acc = re.search(r"function accelerate\(system::System;.*?\n(.*?)\n    n_in = ", main, re.S).group(1)
     assert re.search(r"why = _not_on_device\(system\)\s+if why !== nothing.*?@info.*?return system\s+end", acc, re.S)
-    assert re.search(r"try\s+ctx, ds, entries, columns = _upload\(.*?catch e\s.*?\(e isa OctoError \|\| e isa ErrorException\) \|\| rethrow\(\).*?@info.*?return system\s+end", acc, re.S)
+    assert re.search(r"try\s+ctx, ds, entries, columns = _upload\(.*?catch e\s.*?is_fallback\(e\) \|\| rethrow\(\).*?@info.*?return system\s+end", acc, re.S)
     slots = re.search(r"for _ in 2:max\(1, n_contexts\)(.*?)\n    end\n", main, re.S).group(1)
     assert "octo_ctx_destroy(c)" in slots and "e isa OctoError || rethrow()" in slots and "break" in slots
+    # the fallback answers ONLY "no device" / "a valid system that is not on the device path" / the shim's own NotOnHIPPath — bad input
+    # (OCTO_EINVAL), OCTO_EHIP, OCTO_ENOMEM and plain ErrorExceptions (bugs) are rethrown
+    capi_txt = JULIA_CAPI.read_text()
+    assert re.search(r"is_fallback\(e\) = e isa NotOnHIPPath \|\| \(e isa OctoError && \(e.status == OCTO_ENODEV \|\| e.status == OCTO_ENOTSUP\)\)", capi_txt)
+    assert "ErrorException" not in main.replace("# ", "")
     # HIPLogDensityModel: returns the reference's model
     h = re.search(r"function HIPLogDensityModel\(model;.*?\n(.*?)\nend\n", main, re.S).group(1)
-    assert "_not_on_device(model.system)" in h and "e isa OctoError || e isa ErrorException" in h and "@info" in h and h.rstrip().endswith("return model")
+    assert "_not_on_device(model.system)" in h and "is_fallback(e) || rethrow()" in h and "@info" in h and h.rstrip().endswith("return model")
     assert "fallback || return _hip_log_density_model(model; device)" in h

@@ -355,6 +355,17 @@ constexpr int TILE_PROBE_EVERY = 64;
 constexpr double TILE_COLD_ROW_US = 27.0 * 2.15e-3;      // a cold row costs ~27 more VALU instructions than a warm one, 2.15 ns of a SIMD's issue each (tools/ubench.hip)
 constexpr double TILE_LAUNCH_US = 6.5;                   // the kernel (4-5 µs at 1e4 walkers) + one dependent launch on the stream + the gathers through perm (profiles/r6_tile_trace.txt)
 
+// read the pending probe: wait for its launch, sum the segments' two numbers, decide
+static int tile_settle(octo_ctx* ctx, const octo_dataset* ds) {
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_tile));
+    double d = 0.0;
+    for (int k = 0; k < ctx->tile_pending_segs; ++k) d += (double)ctx->h_tile_stats[2 * k] - (double)ctx->h_tile_stats[2 * k + 1];
+    ctx->tile_last_saving_us = d * (double)ds->tile_rows * TILE_COLD_ROW_US / (4.0 * (double)ctx->n_cus);
+    ctx->tile_on = ctx->tile_last_saving_us > 1.3 * TILE_LAUNCH_US;
+    ctx->tile_pending = false;
+    return OCTO_OK;
+}
+
 int tile_prepare(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t st) {
     a.perm = nullptr;
     if (!a.warm || ctx->tile_mode == 0 || a.W < ctx->tile_min_w || !(ds->tile_dm_ref > 0.0f) || ds->n_planets != 1 ||
@@ -365,14 +376,7 @@ int tile_prepare(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t
         if (ctx->tile_ds != ds->serial || ctx->tile_W != a.W) {      // another dataset or batch size: start over (a pending probe of the old shape is dropped)
             ctx->tile_ds = ds->serial; ctx->tile_W = a.W; ctx->tile_seq = 0; ctx->tile_on = false; ctx->tile_pending = false;
         }
-        if (ctx->tile_pending) {
-            HIPCHK(ctx, hipEventSynchronize(ctx->ev_tile));
-            double d = 0.0;
-            for (int k = 0; k < ctx->tile_pending_segs; ++k) d += (double)ctx->h_tile_stats[2 * k] - (double)ctx->h_tile_stats[2 * k + 1];
-            ctx->tile_last_saving_us = d * (double)ds->tile_rows * TILE_COLD_ROW_US / (4.0 * (double)ctx->n_cus);
-            ctx->tile_on = ctx->tile_last_saving_us > 1.3 * TILE_LAUNCH_US;
-            ctx->tile_pending = false;
-        }
+        if (ctx->tile_pending) { int rcd = tile_settle(ctx, ds); if (rcd) return rcd; }
         probe = (ctx->tile_seq % TILE_PROBE_EVERY) == 0;
         ctx->tile_seq += 1;
         sort_now = ctx->tile_on;      // (a probe prices the sort, it does not apply it: the same input evaluated twice in a row gives the same bits
@@ -397,6 +401,14 @@ int tile_prepare(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t
     if (probe) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_tile, st));
         ctx->tile_pending = true; ctx->tile_pending_segs = n_seg; ctx->tile_probes += 1;
+        if (ctx->tile_seq == 1) {
+            // The FIRST probe of a (dataset, batch size) is read at once (one host wait, once per shape), so that the decision already holds for the
+            // evaluation it was taken on: the same inputs then give the same bits on every call of a context's life — later probes (read one
+            // evaluation late, without a wait) can only change the decision when the inputs have changed.
+            int rcd = tile_settle(ctx, ds);
+            if (rcd) return rcd;
+            sort_now = ctx->tile_on;
+        }
     }
     if (sort_now) { ctx->tile_sorted_launches += 1; a.perm = ctx->d_perm; }
     return OCTO_OK;

@@ -633,9 +633,52 @@ def dense_cases():
     print("wrote", p, p.stat().st_size, "bytes")
 
 
+def gappy_cases():
+    """tests/golden/gappy.json — F16 (round 6): tables with GAPS, at 60 digits. Nightly runs with seasonal gaps (steps of 0.02 d,
+    ~1 d and ~300 d): k_main's warm-started row loop now takes its step bound per wave from a ladder of the table's step quantiles and sends the
+    rows beyond it to the cold starter behind a scalar branch (round 5 took the table's largest step for every row: such a table ran cold).
+    F16a: absolute RV, no nuisances (the prefetching warm loop with the per-row test); F16b: the same table with per-walker offset / jitter / trend
+    (the nuisance kernels' warm loop, plain scalar row loads); F16c: RA/Dec at the same epochs with one walker so fast that the wave takes the
+    intra-night rung of the ladder (its night-to-night rows go cold). The root of Kepler's equation is unique: the 60-digit values know nothing of
+    starters. Epochs sorted, as the reference's constructors leave them (src/likelihoods/relative-astrometry.jl:46-47, rv-absolute.jl:98-99)."""
+    rng = np.random.default_rng(20260929 + 81)
+    out = []
+    W = 6
+    t = []
+    for season in range(3):
+        for night in range(14):
+            start = 50000.0 + 330.0 * season + night + rng.uniform(-0.05, 0.05)
+            t.extend(start + 0.02 * np.arange(3))
+    t = np.sort(np.asarray(t))
+    n = t.size
+    def walkers(a_lo, a_hi, mass=False):
+        a = np.exp(rng.uniform(np.log(a_lo), np.log(a_hi), W)); e = rng.uniform(0.0, 0.9, W)
+        el = np.stack([a, e, np.arccos(rng.uniform(-1, 1, W)), rng.uniform(0, 6.28, W), rng.uniform(0, 6.28, W),
+                       50000.0 + rng.uniform(2.0, 12.0, W), rng.normal(1.2, 0.05, W), rng.normal(50.0, 0.5, W), rng.uniform(1, 20, W) if mass else np.zeros(W)])
+        el[1, 0] = 0.85; el[0, 0] = a_lo * 1.05      # the fastest orbit, eccentric, periastron inside the first run
+        el[1, 1] = 0.0
+        return el
+    el = walkers(1.1, 20.0, mass=True)
+    rv = rng.normal(0, 30, n)
+    out.append(run_case("F16_gappy_rv", [VISM], [rvtab("RV_ABS", -1, t, rv, [3.0] * n)], el, None,
+                        "absolute RV in nightly runs with seasonal gaps, no nuisances: k_main<1, ·, false, RADEC|RVABS> warm loop with the per-row test"))
+    nu = col(rng.normal(0, 5, W), np.exp(rng.uniform(np.log(0.2), np.log(6), W)), rng.normal(0, 2, W))
+    tab = rvtab("RV_ABS", -1, t, rv, rng.uniform(2, 5, n))
+    tab["extra"] = list(map(float, (t - 50300.0) / 100.0))
+    out.append(run_case("F16_gappy_rv_nuisances", [VISM], [tab], el, nu,
+                        "the same epochs with per-walker offset / jitter / trend: the nuisance kernels' warm loop (plain scalar row loads)"))
+    el = walkers(1.1, 20.0)
+    el[0, 2] = 0.2; el[1, 2] = 0.3      # P ~ 30 days: only the intra-night steps pass the wave's veto — the wave takes that rung
+    out.append(run_case("F16_gappy_radec_fast_walker", [VIS], [astrom(0, t, rng.normal(0, 200, n), rng.normal(0, 200, n), [5.0] * n, [7.0] * n)], el, None,
+                        "RA/Dec at the same epochs, one walker with a 30-day period: the wave takes the intra-night rung, night-to-night rows go cold"))
+    p = ROOT / "tests" / "golden" / "gappy.json"
+    p.write_text(json.dumps(dict(consts=C, cases=out, generator="oracle/make_golden.py gappy_cases (mpmath dps=%d)" % mp.mp.dps), indent=0))
+    print("wrote", p, p.stat().st_size, "bytes")
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(ROOT / "oracle"))
-    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only", "--kep-only", "--trend-only", "--dense-only") if f in sys.argv]
+    only = [f for f in ("--ofti-only", "--model-only", "--hgca-only", "--ti-only", "--config1-only", "--kep-only", "--trend-only", "--dense-only", "--gappy-only") if f in sys.argv]
     if not only:
         main()
     if not only or "--ofti-only" in only:
@@ -654,3 +697,5 @@ if __name__ == "__main__":
         trend_cases()
     if not only or "--dense-only" in only:
         dense_cases()
+    if not only or "--gappy-only" in only:
+        gappy_cases()

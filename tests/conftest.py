@@ -56,6 +56,8 @@ def golden():
         g["cases"] = g["cases"] + json.load(f)["cases"]
     with open(ROOT / "tests" / "golden" / "dense.json") as f:     # F14: dense tables (k_main's warm-started row loop); F15: six planets (k_mainp) (--dense-only)
         g["cases"] = g["cases"] + json.load(f)["cases"]
+    with open(ROOT / "tests" / "golden" / "gappy.json") as f:     # F16: tables with gaps (the warm loop's per-wave bound and per-row test) (--gappy-only)
+        g["cases"] = g["cases"] + json.load(f)["cases"]
     return g
 
 

@@ -528,12 +528,12 @@ def test_c_abi_argument_checking_and_strides(pkg, oracle):
         assert b"octo_dataset_create" in lib.octo_last_error(ctx)
     arr, keep = capi.pack_obs([tab])
     n_many = capi.MAX_PLANETS + 1      # (round 5: up to OCTO_MAX_PLANETS = 8 planets on the planet-per-wave kernels)
-    assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)] * n_many), n_many, C.byref(ds)) == capi.OCTO_EINVAL
+    assert lib.octo_dataset_create(ctx, arr, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)] * n_many), n_many, C.byref(ds)) == capi.OCTO_ENOTSUP      # (a VALID system that is not on the device path: round 6)
     rv = dict(kind=2, planet=-1, epoch=t["epoch"], y1=t["ra"], y2=None, s1=t["σ_ra"], s2=None, cor=None)
     arr2, keep2 = capi.pack_obs([rv])
     assert lib.octo_dataset_create(ctx, arr2, 1, capi.pack_planets([dict(orbit_kind=0, has_mass=False)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
     # RV tables with a ThieleInnesOrbit planet; HGCA without its catalogue numbers, with bad row codes, with a mass-less planet
-    assert lib.octo_dataset_create(ctx, arr2, 1, capi.pack_planets([dict(orbit_kind=2, has_mass=True)]), 1, C.byref(ds)) == capi.OCTO_EINVAL
+    assert lib.octo_dataset_create(ctx, arr2, 1, capi.pack_planets([dict(orbit_kind=2, has_mass=True)]), 1, C.byref(ds)) == capi.OCTO_ENOTSUP
     hg = dict(kind=7, planet=-1, epoch=t["epoch"][:4], y1=np.array([0., 1, 0, 1]), y2=np.array([0., 0, 1, 1]), s1=None, s2=None, cor=None,
               extra=np.array([1., 1, .1, .1, 0] * 3))
     for bad in (dict(hg, extra=None), dict(hg, extra=np.ones(7)), dict(hg, y1=np.array([0., 2, 0, 1])), dict(hg, extra=np.array([1., 1, .1, .1, 1.5] * 3))):
@@ -794,7 +794,7 @@ def test_planet_per_wave_kernels_vs_oracle(oracle, P):
 
 def test_more_than_four_planets_refuses_the_other_kinds(pkg):
     """Beyond OCTO_MAX_PLANETS_ALL_KINDS the library takes relative astrometry and absolute / relative RV only: marginalised RV, the O'Neil
-    prior and HGCA are refused at octo_dataset_create (OCTO_EINVAL — the shim then keeps the system on the reference's path), and so are
+    prior and HGCA are refused at octo_dataset_create (OCTO_ENOTSUP: valid, not on the device path — the shim then keeps the system on the reference's path), and so are
     more than OCTO_MAX_PLANETS planets."""
     gb = _gpu()
     capi = pkg.capi
@@ -806,6 +806,6 @@ def test_more_than_four_planets_refuses_the_other_kinds(pkg):
     for obs, n in (([rv], 5), ([on], 5), ([ok], capi.MAX_PLANETS + 1)):
         with pytest.raises(capi.OctoError) as ei:
             gb.GpuPath(obs, pl(n))
-        assert ei.value.status == capi.OCTO_EINVAL
+        assert ei.value.status == capi.OCTO_ENOTSUP
     gb.GpuPath([ok], pl(5)).close()
     gb.GpuPath([rv, on], pl(4)).close()

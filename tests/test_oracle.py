@@ -129,7 +129,7 @@ def test_reference_dump_if_present(oracle, golden):
     dump = json.loads(dump_path.read_text())
     checked = 0
     for case in golden["cases"]:
-        for file in ("fixtures.json", "kep.json", "trend.json", "dense.json"):
+        for file in ("fixtures.json", "kep.json", "trend.json", "dense.json", "gappy.json"):
             r = dump.get(f"{file}/{case['name']}")
             if r is None:
                 continue

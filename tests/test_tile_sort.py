@@ -128,8 +128,8 @@ def test_sorted_tiles_with_nuisances_rv_and_the_model_tail(pkg, oracle):
 
 
 def test_auto_mode_sorts_only_where_it_pays(pkg):
-    """OCTO_OPT_TILE_SORT = 2 (the default): the first eligible evaluation of a (dataset, batch size) prices the sort (without applying it), the
-    second reads the price and the sort is on from there — or not. Config 3's prior (a ~ LogU(1, 100) AU at a daily cadence: no lane vetoes, 8 % of the wave-rows fall back as drawn, 4 % sorted) on a table of
+    """OCTO_OPT_TILE_SORT = 2 (the default): the first eligible evaluation of a (dataset, batch size) prices the sort and reads the price at once
+    (one host wait per shape), so the decision holds from that very evaluation: the same inputs give the same bits on every call. Config 3's prior (a ~ LogU(1, 100) AU at a daily cadence: no lane vetoes, 8 % of the wave-rows fall back as drawn, 4 % sorted) on a table of
     2 000 rows: the saving is below the cost of the launch -> off. The same table with a ~ LogU(0.3, 100) AU (14 % of the lanes veto: every wave cold
     as drawn) -> on. Deterministic: the same calls make the same decisions."""
     gb = _gpu()
@@ -143,13 +143,12 @@ def test_auto_mode_sorts_only_where_it_pays(pkg):
             with gb.GpuPath(obs, [dict(orbit_kind=0, has_mass=False)], small_batch=0) as g:
                 outs = [g.eval(cfg["elems"], None, grad=True) for _ in range(4)]
                 states.append(g.tile_state())
-                # the first evaluation ran as drawn (and priced the sort); the later ones follow the decision; all agree to rounding
+                # every evaluation of the same inputs returns the same bits, the first one included
                 for o in outs[1:]:
-                    assert np.all(rel_err(o[0][np.isfinite(o[0])], outs[0][0][np.isfinite(o[0])], 1.0) < 1e-12)
-                assert np.array_equal(outs[2][0], outs[3][0]) and np.array_equal(outs[2][1], outs[3][1])
+                    assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
         n_sorted, probes, on, saving = states[0]
         assert states[0] == states[1], "the probe's decision must not depend on the run"
-        assert probes == 1 and on == expect_on and n_sorted == (3 if expect_on else 0), (a_lo, states[0])
+        assert probes == 1 and on == expect_on and n_sorted == (4 if expect_on else 0), (a_lo, states[0])
         assert (saving > 1.3 * 6.5) == expect_on, (a_lo, saving)
 
 

@@ -253,7 +253,7 @@ def test_warm_step_device_routine_over_the_elliptic_domain(pkg):
 
 
 def test_dense_fixtures_at_60_digits_warm_and_cold():
-    """tests/golden/dense.json F14 (oracle/make_golden.py --dense-only: the independent 60-digit oracle on dense tables — a Newton solve of Kepler's
+    """tests/golden/dense.json F14 and gappy.json F16 (oracle/make_golden.py --dense-only / --gappy-only: the independent 60-digit oracle on dense tables and on tables with gaps — a Newton solve of Kepler's
     equation at 60 digits knows nothing of starters): the throughput kernels with the warm-started loop AND with OCTO_WARM=0 against the
     same numbers at the golden-vector bars (1e-12 on ll; gradients within 1e-9 of their 60-digit values + cancellation scale), and the warm
     loop really ran (the two launches differ in their last bits)."""
@@ -262,8 +262,10 @@ def test_dense_fixtures_at_60_digits_warm_and_cold():
     from conftest import case_tables
     from test_gpu_parity import LL_RTOL, G_RTOL, G_CANCEL, grad_ok
     gb = _gpu()
-    cases = [c for c in json.loads((Path(__file__).resolve().parent / "golden" / "dense.json").read_text())["cases"] if c["name"].startswith("F14")]
-    assert len(cases) == 3
+    gdir = Path(__file__).resolve().parent / "golden"
+    cases = [c for c in json.loads((gdir / "dense.json").read_text())["cases"] if c["name"].startswith("F14")]
+    cases += [c for c in json.loads((gdir / "gappy.json").read_text())["cases"] if c["name"].startswith("F16")]      # round 6: tables with gaps
+    assert len(cases) == 6
     for case in cases:
         obs, planets, elems, nuis = case_tables(case)
         res = {}

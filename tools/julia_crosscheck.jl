@@ -136,7 +136,7 @@ out = Dict{String,Any}("octofitter_version" => string(pkgversion(Octofitter)), "
                                            "rad2as" => PlanetOrbits.rad2as, "mjup2msol" => Octofitter.mjup2msol))
 out["model.json/D11_reference_test_model"] = model_dump(golden("model.json")["cases"][1])
 out["config1.json/config1_D11_50_epochs"] = model_dump(golden("config1.json")["cases"][1])
-for file in ("fixtures.json", "kep.json", "trend.json", "dense.json"), case in golden(file)["cases"]      # dense.json: F14 (dense tables: the warm-started row loop); its six-planet F15 is skipped like every multi-planet case
+for file in ("fixtures.json", "kep.json", "trend.json", "dense.json", "gappy.json"), case in golden(file)["cases"]      # gappy.json: F16 (tables with gaps: the warm loop's per-row test); dense.json: F14 (dense tables: the warm-started row loop); its six-planet F15 is skipped like every multi-planet case
     r = try run_case(case) catch err; @warn "case failed" case["name"] err; nothing end
     r === nothing || (out["$file/$(case["name"])"] = r)
 end

@@ -858,6 +858,10 @@ constexpr unsigned main_min_waves() {
     // rows carry their own (fourth-order) copy of the correction a CU holds two such blocks, at 80 (two dwords parked outside the loop) three —
     // 1 250 walkers x 1e4 epochs: 49.9 -> 48.9 µs per step (profiles/r5_d4_ab.txt). The four-wave kernel keeps its 84 (five waves: 280 µs against 285).
     if (NWV == 2 * WPB && P == 1 && GRAD && !NUIS && (KM & ~KM_COR) == KM_RADEC) return 6u;
+#ifdef OCTO_P2_WAVES
+    // experiment: two planets with nuisances, gradient — 172-186 VGPRs left alone (two waves per SIMD); three waves need <= 168
+    if (P == 2 && GRAD && NUIS && !(KM & (KM_MARG | KM_ONEIL))) return (unsigned)OCTO_P2_WAVES;
+#endif
     return 1u;
 }
 

@@ -16,6 +16,8 @@ itself (which bijector a bounded prior gets, the sign of an offset): that stays 
   Thiele-Innes   the ThieleInnesOrbit planet = the Campbell orbit through the textbook constants A, B, F, G
   marginal RV    scipy.integrate.quad over the zero point: the reference's ll is 2·log(integral) − log 2π (rv-absolute-margin.jl:140-185)
   tperi          θ_at_epoch_to_tperi by its meaning — the position angle at the epoch IS θ — with brentq over the orbit, not by its formula
+  O'Neil prior   2·log(Σ|t_j|·∛P/√(1−e²)) = 2·log(3·Σ|det ∂(x, y)/∂(P, e)|) with the determinant from 40-digit central differences (prior-observable.jl:78-137)
+  HGCA           the model proper motions as time derivatives of the star's reflex offset, read off the likelihood's parabolas (hgca.jl:155-400)
   Each also runs against the HIP path itself under -m gpu (both kernel families), so the product is held to third-party numbers directly.
 """
 import numpy as np
@@ -621,3 +623,131 @@ def test_gpu_unit_length_prior_vs_scipy_lognorm(pkg, oracle):
     finally:
         m.close()
 
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 6: the last two unpinned rules
+def _oneil_case(oracle):
+    """The O'Neil et al. (2019) observable-based prior (src/likelihoods/prior-observable.jl:78-137) BY ITS MEANING. The reference adds
+    2·log(Σ_j |t_j| · ∛P / √(1−e²)) with t_j = 3M(e + cos E) + 2(−2 + e² + e cos E) sin E, P the period in Julian years. That expression is −3 times
+    the Jacobian determinant ∂(x, y)/∂(P, e) of the orbital-plane position (x, y) = P^(2/3)·(cos E − e, √(1−e²) sin E) at the epoch — the
+    observables against the parameters the prior is meant to flatten — so the term is 2·log(3·Σ_j |det J_j|). Here det J_j comes from central
+    differences at 40 digits (mpmath) of (x, y) written out from Kepler's equation alone; epochs within half a period of tp, so that the
+    reference's wrapped mean anomaly is the unwrapped one."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    c = oracle.oracle_consts()
+    rng = np.random.default_rng(23)
+    cases = []
+    for _ in range(6):
+        a, e, M_tot = rng.uniform(2, 30), rng.uniform(0.05, 0.85), rng.uniform(0.6, 2.0)
+        period_d = np.sqrt(a ** 3 / M_tot) * c.kepler_year_to_julian_day
+        tp = 50000.0 + rng.uniform(0, 500)
+        t = tp + period_d * rng.uniform(-0.45, 0.45, 5)
+        el = np.array([a, e, rng.uniform(0.2, 2.9), rng.uniform(0, 6.28), rng.uniform(0, 6.28), tp, M_tot, rng.uniform(20, 60), 0.0])
+
+        def xy(P, ee, tau):
+            Mm = 2 * mp.pi * tau / P
+            E = Mm + ee * mp.sin(Mm)
+            for _ in range(80):
+                E = E - (E - ee * mp.sin(E) - Mm) / (1 - ee * mp.cos(E))
+            s = P ** (mp.mpf(2) / 3)
+            return s * (mp.cos(E) - ee), s * mp.sqrt(1 - ee * ee) * mp.sin(E)
+        P_yr = mp.mpf(float(period_d)) / mp.mpf("365.25")
+        h = mp.mpf("1e-18")
+        tot = mp.mpf(0)
+        for tj in t:
+            tau = mp.mpf(float(tj - tp)) / mp.mpf("365.25")
+            xp, yp = xy(P_yr + h, mp.mpf(float(e)), tau); xm, ym = xy(P_yr - h, mp.mpf(float(e)), tau)
+            xe, ye = xy(P_yr, mp.mpf(float(e)) + h, tau); xf, yf = xy(P_yr, mp.mpf(float(e)) - h, tau)
+            det = ((xp - xm) * (ye - yf) - (xe - xf) * (yp - ym)) / (4 * h * h)
+            tot += abs(det)
+        ref = float(2 * mp.log(3 * tot))
+        n = t.size
+        cols = dict(planet=0, epoch=t, y1=rng.normal(0, 300, n), y2=rng.normal(0, 300, n), s1=np.full(n, 5.0), s2=np.full(n, 7.0), cor=None, extra=None)
+        cases.append((el, cols, ref))
+    return cases
+
+
+def test_oneil_prior_is_the_jacobian_of_the_orbital_plane_position(oracle):
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    for el, cols, ref in _oneil_case(oracle):
+        ll5, _, _ = oracle.oracle_eval([dict(kind=5, **cols)], planets, el[:, None], None, grad=False)
+        ll0, _, _ = oracle.oracle_eval([dict(kind=0, **cols)], planets, el[:, None], None, grad=False)
+        assert abs((ll5[0] - ll0[0]) - ref) < 1e-9 * max(1.0, abs(ref)), (ll5[0] - ll0[0], ref)
+
+
+@pytest.mark.gpu
+def test_gpu_oneil_prior_is_the_jacobian_of_the_orbital_plane_position(oracle):
+    import gpu_binding
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    for el, cols, ref in _oneil_case(oracle):
+        for small, W in ((None, 1), (0, 70)):
+            ll5, _, _ = gpu_binding.gpu_eval([dict(kind=5, **cols)], planets, np.repeat(el[:, None], W, axis=1), None, grad=True, small_batch=small)
+            ll0, _, _ = gpu_binding.gpu_eval([dict(kind=0, **cols)], planets, np.repeat(el[:, None], W, axis=1), None, grad=True, small_batch=small)
+            assert np.all(np.abs((ll5 - ll0) - ref) < 1e-9 * max(1.0, abs(ref))), ((ll5 - ll0)[0], ref)
+
+
+def _hgca_case(oracle):
+    """HGCAInstantaneousObs (src/likelihoods/hgca.jl:155-400) BY ITS MEANING: the model's proper motions are those of the STAR — the reflex of the
+    companion about the barycentre, −(m·mjup2msol/M)·(the companion's sky offset) — and `pmra` / `pmdec` are the TIME DERIVATIVES of that offset in
+    mas per Julian year. With one RA and one Dec row per mission the three model values ln_like compares with the catalogue are
+        hip: pm(t_h) + pm_sys,    hg: (R(t_g) − R(t_h)) / (t_g − t_h)·365.25 + pm_sys,    gaia: pm(t_g) + pm_sys      (hgca.jl:160-215, 288-376)
+    with R(t) the star's offset [mas] (ln_like reads simulate's INDIVIDUAL values; the vectors μ_h, μ_hg, μ_g re-framed by the Gaia-epoch reflex motion,
+    hgca.jl:380-390, are returned next to them and not used by it). R comes from the oracle's orbit solution (pinned against scipy's root finder and the reference's tutorial
+    table), pm from central differences of it — not from the closed form the restatement recalls. The model values are read off the likelihood as
+    the vertices of its parabolas in the catalogue values (three evaluations each, correlations 0)."""
+    c = oracle.oracle_consts()
+    rng = np.random.default_rng(29)
+    out = []
+    for _ in range(4):
+        a, e = rng.uniform(4, 25), rng.uniform(0.0, 0.7)
+        el = np.array([a, e, rng.uniform(0.2, 2.9), rng.uniform(0, 6.28), rng.uniform(0, 6.28), 50000.0 + rng.uniform(0, 9000), rng.uniform(0.7, 1.8), rng.uniform(15, 70),
+                       rng.uniform(5, 60)])
+        f = -el[8] * c.mjup2msol / el[6]
+        t_h = np.array([48348.0 + rng.uniform(-40, 40), 48348.0 + rng.uniform(-40, 40)])      # RA row, Dec row of Hipparcos
+        t_g = np.array([57388.0 + rng.uniform(-40, 40), 57388.0 + rng.uniform(-40, 40)])
+        R = lambda tt, k: f * oracle.oracle_orbitsolve(el, tt)["raoff" if k == 0 else "decoff"]
+        period_d = np.sqrt(a ** 3 / el[6]) * c.kepler_year_to_julian_day
+        h = 2e-4 * period_d * (1 - e) ** 1.5
+        pm = lambda tt, k: (R(tt + h, k) - R(tt - h, k)) / (2 * h) * 365.25                    # mas per Julian year
+        pm_sys = np.array([rng.normal(0, 20), rng.normal(0, 20)])
+        mu_h = np.array([pm(t_h[k], k) + pm_sys[k] for k in (0, 1)])
+        mu_hg = np.array([(R(t_g[k], k) - R(t_h[k], k)) / (t_g[k] - t_h[k]) * 365.25 + pm_sys[k] for k in (0, 1)])
+        mu_g = np.array([pm(t_g[k], k) + pm_sys[k] for k in (0, 1)])
+        obs = dict(kind=7, planet=-1, epoch=np.array([t_h[0], t_h[1], t_g[0], t_g[1]]), y1=np.array([0., 1, 0, 1]), y2=np.array([0., 0, 1, 1]), s1=None, s2=None, cor=None)
+        nuis = np.array([[pm_sys[0]], [pm_sys[1]], [0.0]])
+        scale = max(np.abs(pm(t_h[0], 0)), np.abs(pm(t_h[1], 1)), 1e-3)
+        out.append((el, obs, nuis, np.concatenate([mu_h, mu_hg, mu_g]), scale))
+    return out
+
+
+def _hgca_model_values(evaluate, obs, sig=0.7):
+    """The six model values (μ_hip, μ_hg, μ_gaia: ra, dec each) from the likelihood: vertex of ll as a function of each catalogue value."""
+    base = np.array([0.0, 0.0, sig, sig, 0.0] * 3)
+    vals = []
+    for k in range(3):
+        for ax in (0, 1):
+            f = []
+            for d in (-1.0, 0.0, 1.0):
+                ex = base.copy(); ex[5 * k + ax] = d
+                f.append(evaluate(dict(obs, extra=ex)))
+            vals.append(-(f[2] - f[0]) / (2 * (f[2] - 2 * f[1] + f[0])))
+    return np.array(vals)
+
+
+def test_hgca_proper_motions_are_time_derivatives_of_the_stars_reflex_position(oracle):
+    planets = [dict(orbit_kind=0, has_mass=True)]
+    for el, obs, nuis, ref, scale in _hgca_case(oracle):
+        got = _hgca_model_values(lambda o: oracle.oracle_eval([o], planets, el[:, None], nuis, grad=False)[0][0], obs)
+        assert np.all(np.abs(got - ref) < 2e-6 * scale + 1e-9 * np.abs(ref)), (got, ref)
+
+
+@pytest.mark.gpu
+def test_gpu_hgca_proper_motions_are_time_derivatives_of_the_stars_reflex_position(oracle):
+    import gpu_binding
+    planets = [dict(orbit_kind=0, has_mass=True)]
+    for el, obs, nuis, ref, scale in _hgca_case(oracle):
+        for small, W in ((None, 1), (0, 70)):
+            ev = lambda o: gpu_binding.gpu_eval([o], planets, np.repeat(el[:, None], W, axis=1), np.repeat(nuis, W, axis=1), grad=True, small_batch=small)[0][W - 1]
+            got = _hgca_model_values(ev, obs)
+            assert np.all(np.abs(got - ref) < 2e-6 * scale + 1e-9 * np.abs(ref)), (small, got, ref)

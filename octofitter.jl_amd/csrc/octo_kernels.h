@@ -486,6 +486,11 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
                                            const AstromCoef<P>& co, double t, double y1, double y2, double c3, double c4, double c5,
                                            const SinCosTab& tab, WarmState<P>* ws = nullptr, double dm = 0.0) {
     using L = Layout<P, GRAD, NUIS, KM>;
+    // DEFER (k_main's mapping, lane = walker: round 6): every factor of an adjoint sum that is constant over the table's rows for one walker — the
+    // planet's coefficient f_p, the jitter, the platescale in front of the northangle term — is applied ONCE per wave after the row loop
+    // (astrom_finish_sums) instead of once per row; the ∂/∂(m/M) sum is accumulated for every planet and dropped afterwards where it does not
+    // apply (two selects per planet and row before). 11 VALU instructions per two-planet nuisance row less; the value path is untouched.
+    constexpr bool DEFER = TAB;
     const double (&f)[P] = co.f;
     const double jit = co.jit, j2 = co.j2, ps = co.ps, na = co.na, sn = co.sn, cn = co.cn;
     const bool seppa = co.seppa, oneil = co.oneil;
@@ -573,7 +578,9 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
     } else {
         const double v1 = fma(c3, c3, j2), v2 = fma(c4, c4, j2);   // hypot(σ, jitter)², :234-235
         const double v12 = v1 * v2;
-        const double iv12 = rcp_nr<2>(v12);                       // one reciprocal for 1/v1 and 1/v2
+        // one reciprocal for 1/v1 and 1/v2; k_main (DEFER) takes ONE Newton step on v_rcp_f64 — 2^-46 = 1.4e-14 relative on a row's χ² term, three
+        // orders below the golden-vector bar — k_small keeps two
+        const double iv12 = rcp_nr<DEFER ? 1 : 2>(v12);
         const double iv1 = iv12 * v2, iv2 = iv12 * v1;
         double a1, a2;                                             // Σ⁻¹ r
         if (L::HAS_COR && co.has_cor) {
@@ -593,13 +600,15 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
         acc[L::OFF_S] = fma(r1, a1, fma(r2, a2, acc[L::OFF_S]));
         g1 = -a1; g2 = -a2;
         if constexpr (GRAD) {
-            acc[L::OFF_NU + OCTO_NU_JITTER] += jit * fma(fma(r1, a1, -1.0), iv1, fma(r2, a2, -1.0) * iv2);
+            if constexpr (DEFER) acc[L::OFF_NU + OCTO_NU_JITTER] += fma(fma(r1, a1, -1.0), iv1, fma(r2, a2, -1.0) * iv2);      // × jitter after the loop
+            else acc[L::OFF_NU + OCTO_NU_JITTER] += jit * fma(fma(r1, a1, -1.0), iv1, fma(r2, a2, -1.0) * iv2);
             if (seppa) {
                 acc[L::OFF_NU + OCTO_NU_PLATESCALE] = fma(g2, y2, acc[L::OFF_NU + OCTO_NU_PLATESCALE]);
                 acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += g1;
             } else {
                 acc[L::OFF_NU + OCTO_NU_PLATESCALE] += g1 * u1 + g2 * u2;
-                acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += ps * (g1 * u2 - g2 * u1);
+                if constexpr (DEFER) acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += g1 * u2 - g2 * u1;      // × platescale after the loop
+                else acc[L::OFF_NU + OCTO_NU_NORTHANGLE] += ps * (g1 * u2 - g2 * u1);
             }
         }
     }
@@ -616,15 +625,17 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             double* g = &acc[L::OFF_PL + p * L::PL_N];
-            const double ra_f = (P == 1) ? rab : f[p] * rab, de_f = (P == 1) ? deb : f[p] * deb;
+            const double ra_f = (P == 1 || DEFER) ? rab : f[p] * rab, de_f = (P == 1 || DEFER) ? deb : f[p] * deb;      // DEFER: × f_p after the loop
             g[L::U1] = fma(s[p].cE, ra_f, g[L::U1]);
             g[L::U2] = fma(s[p].sE, ra_f, g[L::U2]);
             g[L::U3] = fma(s[p].cE, de_f, g[L::U3]);
             g[L::U4] = fma(s[p].sE, de_f, g[L::U4]);
             g[L::U5] += ra_f;
             g[L::U6] += de_f;
-            if constexpr (P > 1)
-                g[L::GC] += (p == co.planet) ? 0.0 : ((f[p] != 0.0) ? fma(rab, rap[p], deb * dep[p]) : 0.0);
+            if constexpr (P > 1) {
+                if constexpr (DEFER) g[L::GC] += fma(rab, rap[p], deb * dep[p]);      // dropped after the loop for the attached planet and for f_p = 0
+                else g[L::GC] += (p == co.planet) ? 0.0 : ((f[p] != 0.0) ? fma(rab, rap[p], deb * dep[p]) : 0.0);
+            }
             // Ē = r̄a·∂ra/∂E + d̄ec·∂dec/∂E ;  M̄ = Ē/(1 − e cos E)
             const double dra = fma(pc[p].cGb, s[p].cE, -(pc[p].cB * s[p].sE));
             const double dde = fma(pc[p].cFb, s[p].cE, -(pc[p].cA * s[p].sE));
@@ -639,6 +650,7 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
 template <int P>
 struct RvCoef {
     double gc[P];                   // coefficient of K_p·V_p in the RV model
+    double gK[P];                   // gc_p·K_p
     double ib2[P];                  // 1/β² of each planet (the gradient's closed forms)
     double off, jit, j2, mu_hat, iA;
     double trend;                   // coefficient of the table's trend basis column (OCTO_NU_RV_TREND)
@@ -662,7 +674,7 @@ __device__ __forceinline__ RvCoef<P> rv_coef_vals(double off, double jit, double
             c.gc[p] = c.rel ? ((p == ob_planet) ? 1.0 : ((pc[p].a < a_this) ? -pc[p].mu : 0.0)) : -pc[p].mu;
     }
 #pragma unroll
-    for (int p = 0; p < P; ++p) c.ib2[p] = GRAD ? 1.0 / (pc[p].beta * pc[p].beta) : 0.0;
+    for (int p = 0; p < P; ++p) { c.ib2[p] = GRAD ? 1.0 / (pc[p].beta * pc[p].beta) : 0.0; c.gK[p] = c.gc[p] * pc[p].K; }
     c.marg = (KM & KM_MARG) && ob_kind == OCTO_RV_ABS_MARG;
     c.off = 0.0; c.jit = 0.0; c.j2 = 0.0; c.trend = 0.0;
     if constexpr (NUIS) {
@@ -696,6 +708,10 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
                                        const RvCoef<P>& co, double t, double rv, double c2, double basis, const SinCosTab& tab,
                                        WarmState<P>* ws = nullptr, double dm = 0.0) {
     using L = Layout<P, GRAD, NUIS, KM>;
+    // DEFER (k_main's mapping: round 6, as in astrom_row): every planet sum of an RV row is linear in rvb·(a function of the solution) with a factor
+    // gc_p·K_p, gc_p or K_p that is constant over the rows — applied once per wave after the loop (rv_finish_sums); ∂/∂K and ∂/∂(m/M) are the SAME
+    // sum Σ V·rvb. Six VALU instructions per planet and row less.
+    constexpr bool DEFER = TAB;
     const double (&gc)[P] = co.gc;
     const bool rel = co.rel, marg = co.marg;
     const double jit = co.jit, j2 = co.j2, mu_hat = co.mu_hat, iA = co.iA;
@@ -711,11 +727,11 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
         cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
         snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
         V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
-        model = fma(gc[p] * pc[p].K, V[p], model);
+        model = fma(DEFER ? co.gK[p] : gc[p] * pc[p].K, V[p], model);      // (co.gK is the same product, formed once per wave: the value is unchanged)
     }
     const double resid = rv - model;
     double iv, var = 1.0;
-    if constexpr (NUIS) { var = fma(c2, c2, j2); iv = rcp_nr<2>(var); lp.mul(var); } else { iv = c2; }
+    if constexpr (NUIS) { var = fma(c2, c2, j2); iv = rcp_nr<DEFER ? 1 : 2>(var); lp.mul(var); } else { iv = c2; }      // (one Newton step in k_main: 1.4e-14, as in astrom_row)
     double rvb;   // ∂ll/∂model
     if (L::HAS_MARG && marg) {
         // rv-absolute-margin.jl:171-180
@@ -727,7 +743,8 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
         const double dm = resid - mu_hat;
         rvb = 2.0 * dm * iv;
         if constexpr (GRAD && NUIS) {
-            acc[L::OFF_NU + OCTO_NU_RV_JITTER] += 2.0 * jit * iv * (dm * dm * iv - 1.0 + iv * iA);
+            if constexpr (DEFER) acc[L::OFF_NU + OCTO_NU_RV_JITTER] += iv * (dm * dm * iv - 1.0 + iv * iA);      // × 2·jitter after the loop
+            else acc[L::OFF_NU + OCTO_NU_RV_JITTER] += 2.0 * jit * iv * (dm * dm * iv - 1.0 + iv * iA);
             acc[L::OFF_NU + OCTO_NU_RV_TREND] = fma(rvb, basis, acc[L::OFF_NU + OCTO_NU_RV_TREND]);
         }
     } else {
@@ -735,7 +752,8 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
         rvb = resid * iv;
         if constexpr (GRAD && NUIS) {
             acc[L::OFF_NU + OCTO_NU_RV_OFFSET] += rvb;
-            acc[L::OFF_NU + OCTO_NU_RV_JITTER] += jit * iv * (resid * resid * iv - 1.0);
+            if constexpr (DEFER) acc[L::OFF_NU + OCTO_NU_RV_JITTER] += iv * (resid * resid * iv - 1.0);      // × jitter after the loop
+            else acc[L::OFF_NU + OCTO_NU_RV_JITTER] += jit * iv * (resid * resid * iv - 1.0);
             acc[L::OFF_NU + OCTO_NU_RV_TREND] = fma(rvb, basis, acc[L::OFF_NU + OCTO_NU_RV_TREND]);
         }
     }
@@ -743,10 +761,16 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             double* g = &acc[L::OFF_PL + p * L::PL_N];
-            g[L::GK] = fma(gc[p] * V[p], rvb, g[L::GK]);
-            const bool via_mu = rel ? (p != co.planet && gc[p] != 0.0) : true;
-            g[L::GC] += via_mu ? -(pc[p].K * V[p] * rvb) : 0.0;
-            const double Vb = gc[p] * pc[p].K * rvb;
+            double Vb;
+            if constexpr (DEFER) {
+                g[L::GK] = fma(V[p], rvb, g[L::GK]);      // Σ V·rvb: × gc_p for ∂/∂K, × −K_p for ∂/∂(m/M), after the loop
+                Vb = rvb;                                  // … and × gc_p·K_p for the four sums below
+            } else {
+                g[L::GK] = fma(gc[p] * V[p], rvb, g[L::GK]);
+                const bool via_mu = rel ? (p != co.planet && gc[p] != 0.0) : true;
+                g[L::GC] += via_mu ? -(pc[p].K * V[p] * rvb) : 0.0;
+                Vb = gc[p] * pc[p].K * rvb;
+            }
             // V = cos(ν+ω) + e cos ω with cos ν = (cE − e)/D, sin ν = β sE/D, D = 1 − e cE, in closed form:
             //   ∂V/∂ω = −sin(ν+ω) − e sin ω,   ∂V/∂E = −β sin(ν+ω)/D,   ∂V/∂e at fixed E = cos ω − sin ν · sin(ν+ω)/β²
             const double S = fma(snu[p], pc[p].cw, cnu[p] * pc[p].sw);      // sin(ν+ω)
@@ -759,6 +783,45 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
             g[L::GE] += eb;
             g[L::GM] += Mb;
             g[L::GT] = fma(Mb, s[p].dt, g[L::GT]);
+        }
+    }
+}
+
+// What astrom_row<…, DEFER> / rv_row<…, DEFER> left out of the rows: applied once per wave (one task = one table, so the factors are the same for
+// every row the sums hold).
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ void astrom_finish_sums(AccArr<P, GRAD, NUIS, KM>& acc, const AstromCoef<P>& co) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    if constexpr (GRAD) {
+        if constexpr (L::N_NU > 0) {
+            acc[L::OFF_NU + OCTO_NU_JITTER] *= co.jit;
+            acc[L::OFF_NU + OCTO_NU_NORTHANGLE] *= co.seppa ? 1.0 : co.ps;
+        }
+        if constexpr (P > 1) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double* g = &acc[L::OFF_PL + p * L::PL_N];
+                const double fp = co.f[p];
+                g[L::U1] *= fp; g[L::U2] *= fp; g[L::U3] *= fp; g[L::U4] *= fp; g[L::U5] *= fp; g[L::U6] *= fp;
+                g[L::GE] *= fp; g[L::GM] *= fp; g[L::GT] *= fp;
+                g[L::GC] = (p == co.planet || fp == 0.0) ? 0.0 : g[L::GC];
+            }
+        }
+    }
+}
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ void rv_finish_sums(AccArr<P, GRAD, NUIS, KM>& acc, const RvCoef<P>& co, const PC (&pc)[P]) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    if constexpr (GRAD && L::HAS_RV) {
+        if constexpr (L::N_NU > 0) acc[L::OFF_NU + OCTO_NU_RV_JITTER] *= (L::HAS_MARG && co.marg) ? 2.0 * co.jit : co.jit;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double* g = &acc[L::OFF_PL + p * L::PL_N];
+            const double svr = g[L::GK];                                                   // Σ V·rvb
+            const bool via_mu = co.rel ? (p != co.planet && co.gc[p] != 0.0) : true;
+            g[L::GK] = co.gc[p] * svr;
+            g[L::GC] = via_mu ? -(pc[p].K * svr) : 0.0;
+            g[L::GW] *= co.gK[p]; g[L::GE] *= co.gK[p]; g[L::GM] *= co.gK[p]; g[L::GT] *= co.gK[p];
         }
     }
 }
@@ -1104,6 +1167,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)");      // the normal exit's spare prefetch (of the shapes tried, this one keeps the loop's registers: 105 VALU per row)
         }
+        astrom_finish_sums<P, GRAD, NUIS, KM>(acc, co);
     }
     if (L::HAS_RV && !is_astrom) {
         const RvCoef<P> co = rv_coef<P, GRAD, NUIS, KM>(a.nuis, a.ld, a.marg, a.ldw, ob.kind, ob.planet, tk.obs, pc, wsrc);      // (a.marg: the k_setup route only, where wsrc == wl)
@@ -1165,6 +1229,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)");
         }
+        rv_finish_sums<P, GRAD, NUIS, KM>(acc, co, pc);
     }
     if constexpr (NUIS) {
         // Σ log|Σ_row| (astrometry), Σ log var (RV), Σ log(2π var) (marginalised RV, rv-absolute-margin.jl:179) of this wave's rows

@@ -509,6 +509,7 @@ int32_t octo_ctx_create(octo_ctx** out, int32_t device_id) {
     ctx->env_small_blocks = env_int("OCTO_SMALL_BLOCKS"); ctx->env_small_min_span = env_int("OCTO_SMALL_MIN_SPAN");
     ctx->env_stage_bytes = env_int("OCTO_STAGE_BYTES"); ctx->env_chunk = env_int("OCTO_CHUNK"); ctx->env_rounds = env_int("OCTO_ROUNDS"); ctx->env_rv_cost = env_int("OCTO_RV_COST"); ctx->env_kind_all = env_int("OCTO_KIND_ALL"); ctx->env_mainp_tpb = env_int("OCTO_MAINP_TPB");
     if (const char* ev = std::getenv("OCTO_WIDE")) ctx->env_wide = std::atoi(ev);
+    if (const char* ev = std::getenv("OCTO_FIN_FUSED")) ctx->env_no_fin_fused = std::atoi(ev) ? 0 : 1;
     if (const char* ev = std::getenv("OCTO_WARM")) { ctx->env_warm = std::atoi(ev); ctx->opt_warm = ctx->env_warm ? 1 : 0; }
     if (const char* ev = std::getenv("OCTO_TILE_SORT")) ctx->tile_mode = std::min(std::max(std::atoi(ev), 0), 2);      // experiments: the default of OCTO_OPT_TILE_SORT
     if (const char* ev = std::getenv("OCTO_TILE_MIN_W")) ctx->tile_min_w = std::max<int64_t>(std::atoll(ev), 64);

@@ -132,6 +132,7 @@ struct octo_ctx {
     int64_t tile_seq = 0, tile_W = 0, tile_sorted_launches = 0, tile_probes = 0;
     uint64_t tile_ds = 0;
     double tile_last_saving_us = 0.0;
+    int env_no_fin_fused = 0;                   // OCTO_FIN_FUSED=0: experiments and tests — one-task launches keep the k_finish launch
     int env_wide = 0;                           // OCTO_WIDE: experiments (1: eight-wave k_main blocks for every one-round single-planet launch, -1: never)
     int flag_w = 128;                           // ... and signal completion through per-walker flags the host spins on (OCTO_FLAG_W: experiments)
     int mapped_w = 128;                         // host-buffer calls up to this size let k_small read/write mapped pinned memory; larger

@@ -83,7 +83,8 @@ struct EvalArgs {
     const int32_t* obs_range;     // [n_obs][2] first and one-past-last task of each observation (tasks are grouped by observation)
     const double* obs_const;      // [n_obs] Σ task_const over the observation's tasks, in task order
     int32_t n_obs, n_tasks, n_planets, n_hblocks;      // n_hblocks: k_small only — extra blocks per walker that compute the HGCA term
-    int32_t warm, pad_w;                        // 1: k_main may take the warm-started row loop (octo_ctx option OCTO_OPT_WARM_START / _BATCH_INVARIANT)
+    int32_t warm, fin_fused;                    // warm 1: k_main may take the warm-started row loop (octo_ctx option OCTO_OPT_WARM_START / _BATCH_INVARIANT);
+                                                // fin_fused 1: the launch has ONE task and k_main's blocks finish their own tile (fin_in_main): no partials, no k_finish
     int32_t task0, n_rblocks;                   // first task of this launch (k_main grid.y is relative to it); k_small: blocks per walker that take row tasks
     int32_t orbit_kind[MAXP];
     int32_t has_mass[MAXP];
@@ -991,7 +992,22 @@ __device__ __forceinline__ bool warm_row_ok(const WarmState<P>& ws, const Row& r
 // waves per block buy six waves per SIMD with the SAME number of blocks — table fills, orbit-constructor pieces, partials and k_finish work
 // unchanged — where twice as many 4-wave blocks paid all of those twice (profiles/r4_chunk_sweep_1250.txt: no gain). 1 250 walkers x 1e4
 // epochs: 53.25 -> 51.8 µs per step (same box, profiles/r4_wide_ab.txt); the planner (plan_key) offers it only while a wave keeps >= 32 rows.
-template <int P, bool GRAD, bool NUIS, int KM, bool FUSED = false, int NWV = WPB>
+// The finish of a ONE-TASK launch inside k_main (round 6; defined behind planet_finish below): a mid-size callback — 1 024 θ_t x 50
+// epochs: a Pigeons round, a guess_starting_position chunk — is three mostly-fixed-cost kernels (k_model_fwd 11.7 µs, k_main ~8, k_finish ~9). Its
+// table is one task, so after the LDS combine wave 0 of a k_main block already holds its tile's complete sums: it runs the per-walker tail itself
+// (and all four waves the model's tail) — no partials, no k_finish launch. Round 3 measured a fused finish for EVERY launch and dropped it (one block
+// gathering 87 tasks' partials); with a single task there is nothing to gather. Same routines on the same sums: bit-identical to the two-launch route.
+template <int P, bool GRAD, bool NUIS, int KM, bool FUSED, int NWV>
+constexpr bool main_fin_fused() {
+    // (compiled into the three kind sets a one-table dataset can have — RA/Dec, RA/Dec + cor, RA/Dec | absolute RV: 8 KB of code per variant)
+    return FUSED && P == 1 && NWV == WPB && (KM == KM_RADEC || KM == (KM_RADEC | KM_COR) || KM == (KM_RADEC | KM_RVABS));
+}
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ void fin_in_main(const EvalArgs& a, const AccArr<P, GRAD, NUIS, KM>& acc, int64_t w, int64_t wo, int wv);
+
+// FINF: the instantiation that carries fin_in_main — a kernel of its own (launched for one-task launches only), so that the finish's registers and
+// 8 KB of code are not every launch's: compiled into the standard kernel it took config 3's k_main from 84 to 93 VGPRs and cost it 0.5 %.
+template <int P, bool GRAD, bool NUIS, int KM, bool FUSED = false, int NWV = WPB, bool FINF = false>
 __attribute__((amdgpu_waves_per_eu(main_min_waves<P, GRAD, NUIS, KM, NWV>())))
 static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
     using L = Layout<P, GRAD, NUIS, KM>;
@@ -1009,6 +1025,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
     const int64_t wl = w < a.W ? w : a.W - 1;          // tail lanes recompute the last walker; results discarded
     int64_t wsrc = wl;                                  // the walker this tile position holds (octo_tile.h)
     if constexpr (FUSED && P == 1) { if (a.perm) wsrc = a.perm[wl]; }
+    static_assert(!FINF || main_fin_fused<P, GRAD, NUIS, KM, FUSED, NWV>(), "k_main<…, FINF>: a kind set fin_in_main is compiled for");
     const int task = a.task0 + (int)blockIdx.y;
     const Task tk = a.tasks[task];                      // wave-uniform: scalar loads
     const DevObs ob = a.obs[tk.obs];
@@ -1145,7 +1162,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                         A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                         wbody_t(B, checked);
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)");
+                    row_drain(A);      // the normal exit's spare prefetch sits in A: the wait names the tuple, so its registers stay allocated until it has landed
                 };
                 if (n_rows > 0) {
                     if (warm_unchecked) wloop(std::false_type{});
@@ -1165,7 +1182,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                 body(B);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)");      // the normal exit's spare prefetch (of the shapes tried, this one keeps the loop's registers: 105 VALU per row)
+            row_drain(A);      // the normal exit's spare prefetch (in A; named, so that nothing is allocated over it before it lands)
         }
         astrom_finish_sums<P, GRAD, NUIS, KM>(acc, co);
     }
@@ -1211,7 +1228,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                         A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                         wbody_t(B, checked);
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)");
+                    row_drain(A);      // the normal exit's spare prefetch sits in A: the wait names the tuple, so its registers stay allocated until it has landed
                 };
                 if (n_rows > 0) {
                     if (warm_unchecked) wloop(std::false_type{});
@@ -1227,7 +1244,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                 body(B);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)");
+            row_drain(A);
         }
         rv_finish_sums<P, GRAD, NUIS, KM>(acc, co, pc);
     }
@@ -1261,6 +1278,10 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 for (int k = 0; k < L::NACC; ++k) acc[k] += lds[((q - q0) * L::NACC + k) * WAVE + lane];
             }
         }
+    }
+    if constexpr (FINF) {      // the launch has ONE task: this block finishes its tile itself
+        fin_in_main<P, GRAD, NUIS, KM>(a, acc, w, wsrc, wv);
+        return;
     }
     if (wv == 0 && w < a.W) {
         double* out = a.partials + (int64_t)task * L::NACC * a.ldw + w;
@@ -1499,6 +1520,44 @@ __device__ __forceinline__ void model_tail_n(const EvalArgs& a, int64_t w, int g
 }
 template <int P>
 __device__ __forceinline__ void model_tail(const EvalArgs& a, int64_t w, int grp, int n_waves) { model_tail_n(a, w, grp, n_waves, P); }
+
+// fin_in_main (declared ahead of k_main): the per-walker tail of a one-task launch, by wave 0 of the k_main block that holds the tile's sums. What
+// finish_tile does with one task's partials — obs_finish, validity, planet_finish, then the model's tail over the block's waves — on the same numbers.
+template <int P, bool GRAD, bool NUIS, int KM>
+__device__ __forceinline__ void fin_in_main(const EvalArgs& a, const AccArr<P, GRAD, NUIS, KM>& acc, int64_t w, int64_t wo, int wv) {
+    using L = Layout<P, GRAD, NUIS, KM>;
+    static_assert(P == 1 && !L::HAS_ONEIL && !L::HAS_MARG, "fin_in_main: single-planet kind sets without O'Neil / marginalised-RV sums");
+    const bool live = w < a.W;
+    if (wv == 0) {
+        double v[NOBS_ACC];
+#pragma unroll
+        for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
+        v[0] = acc[L::OFF_S];
+        if constexpr (L::N_NU > 0) { v[4] = acc[L::OFF_NU + 0]; v[5] = acc[L::OFF_NU + 1]; v[6] = acc[L::OFF_NU + 2]; }
+        double sma_p[P] = {0.0}, e_p[P] = {0.0}, M_p[P] = {1.0};
+        double og[oneil_slots<P, GRAD, NUIS, KM>()] = {0.0};
+        const double ll = obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + wo : nullptr, nullptr, a.ldw, a.c.k_yr, 0, v, a.obs_const[0],
+                                                        sma_p, e_p, M_p, live, og);
+        const SetupOut so = setup_planet<true>(a, 0, wo);      // the same routine k_finish<FROM_WC = false> derives its constants with
+        bool ok = isfinite(ll) && so.ok;
+        if (a.nuis)
+            for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok = ok && isfinite(a.nuis[(int64_t)k * a.ld + wo]);
+        if (live) {
+            a.ll_out[wo] = ok ? ll : -INFINITY;
+            if constexpr (GRAD && L::N_NU > 0) {
+                if (!ok)
+                    for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + wo] = 0.0;
+            }
+            if constexpr (GRAD) {
+                FinPC fp;
+                fp.sma = so.v[WC_A]; fp.P_d = rcp_nr<2>(so.v[WC_INVP]); fp.beta = so.v[WC_BETA];
+                fp.si = so.v[WC_SINI]; fp.ci = so.v[WC_COSI]; fp.sO = so.v[WC_SINO]; fp.cO = so.v[WC_COSO]; fp.sw = so.v[WC_SINW]; fp.cw = so.v[WC_COSW];
+                planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(so.el, a.g_elems + wo, a.ld, nullptr, a.ldw, a.c, a.orbit_kind[0], a.has_mass[0], 0, &acc[L::OFF_PL], nullptr, fp, ok);
+            }
+        }
+    }
+    if (a.mt_lpp) model_tail<P>(a, live ? wo : a.W, wv, WPB);      // block-uniform (a kernel argument)
+}
 
 // ------------------------------------------------------------------------------------ finish_tile / k_finish
 // The per-walker tail for one tile of 64 walkers, run by NG waves. It is a latency chain (a tile's partials were written by other CUs;

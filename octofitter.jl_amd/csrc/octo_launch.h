@@ -87,8 +87,9 @@ int launch_small(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, const Small
 // table's kind is block-uniform, so a wider set costs a one-θ call nothing it can measure — profiles/r4_small_kindsets_ab.txt — while
 // every set costs ~1 MB of code over the four planet counts): RA/Dec alone; + sep/PA and cor; + absolute / relative RV; everything
 // (O'Neil priors and marginalised RV).
-constexpr int small_kind_set(int km_rows) {
-    if (km_rows == KM_RADEC) return KM_RADEC;
+constexpr int small_kind_set(int km_rows, int n_planets = 1) {
+    // (three and four planets: RA/Dec alone rides the sep/PA + cor set — 0.8 MB of code for a branch a one-θ call cannot measure; round 6)
+    if (km_rows == KM_RADEC) return n_planets >= 3 ? (KM_RADEC | KM_SEPPA | KM_COR) : KM_RADEC;
     if ((km_rows & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0) return KM_RADEC | KM_SEPPA | KM_COR;
     if ((km_rows & (KM_MARG | KM_ONEIL)) == 0) return KM_ALL & ~KM_MARG & ~KM_ONEIL;
     return KM_ALL;
@@ -99,7 +100,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
     // KMD: the dataset's kind set, possibly with KM_HGCA. The epoch-loop kernels never see that bit (KM below); k_small does, when it is
     // compiled with nuisances (an HGCA table without `nuis` is refused at run time, so the nuisance-free variants need no HGCA twin).
     constexpr int KM = KMD & ~KM_HGCA;
-    constexpr int KSR = small_kind_set(KM);
+    constexpr int KSR = small_kind_set(KM, P);
     constexpr int KS = !(NUIS && (KMD & KM_HGCA)) ? KSR      // with an HGCA table: relative astrometry alone, or everything
                        : ((KSR & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0 ? (KM_RADEC | KM_SEPPA | KM_COR | KM_HGCA) : (KM_ALL | KM_HGCA));
     using L = Layout<P, GRAD, NUIS, KM>;
@@ -218,11 +219,26 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
                 launched = true;
             }
             if constexpr (!MAINP) {
-                if (!launched)
-                    hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
-                                       (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+                if (!launched) {
+                    // ONE task (a table of a few dozen rows: a mid-size callback), one table, nothing from k_hgca: the k_main blocks finish their own
+                    // tiles (octo_kernels.h: fin_in_main) — no partials, no k_finish launch
+                    if constexpr (main_fin_fused<P, GRAD, NUIS, KM, true, WPB>()) {
+                        if (a.n_tasks == 1 && ds->n_obs == 1 && ds->n_hgca == 0 && !ctx->env_no_fin_fused) a.fin_fused = 1;
+                        if (a.fin_fused)
+                            hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true, WPB, true>), dim3((unsigned)cols, 1u), dim3(WAVE * WPB),
+                                               (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+                    }
+                    if (!a.fin_fused)
+                        hipLaunchKernelGGL((k_main<P, GRAD, NUIS, KM, true>), dim3((unsigned)cols, (unsigned)a.n_tasks), dim3(WAVE * WPB),
+                                           (fused_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
+                }
             }
             if (e1) HIPCHK(ctx, hipEventRecord(e1, st));
+            if (a.fin_fused) {
+                HIPCHK(ctx, hipGetLastError());
+                ctx->mt_applied = a.mt_lpp != nullptr;
+                return OCTO_OK;
+            }
         }
         hipLaunchKernelGGL((k_finish<P, GRAD, NUIS, KM, false>), dim3((unsigned)cols), dim3(WAVE * fin_waves<P, GRAD, NUIS, KM>()), (fin_lds_bytes<P, GRAD, NUIS, KM>()), st, a);
         HIPCHK(ctx, hipGetLastError());

@@ -47,13 +47,13 @@ def test_latency_kernels_have_no_scratch_and_no_vgpr_spills(rows):
 # The nuisance-free single-planet RA/Dec gradient kernels: rounds 2-4 held them to 72 VGPRs (seven waves per SIMD) with 12-16 bytes parked outside
 # the row loop; since round 5's warm-started loop they keep the 79 registers they want (six waves, 2-3 % faster: octo_kernels.h: main_min_waves) and the
 # budget below — nothing in the loop, at most a few dwords outside it — now simply holds them to no spills worth the name.
-SEVEN_WAVES = re.compile(r"k_main<1, true, false, (1|33), (true|false), (4|8)>")
+SEVEN_WAVES = re.compile(r"k_main<1, true, false, (1|33), (true|false), (4|8), (true|false)>")
 
 
 # The four-planet gradient kernels are held to 256 VGPRs = two waves per SIMD (main_min_waves): left alone they take 312-339 registers, ONE wave
 # per SIMD, and run at 0.21 of the FP64 peak. Held, they park 2-23 doubles per row in scratch memory and are 18 % faster (same-box A/B,
 # profiles/r4_p4_waves_ab.txt). Deliberate; the budget below keeps the parking from growing unnoticed.
-FOUR_PLANETS_TWO_WAVES = re.compile(r"k_main<4, true, (true|false), \d+, (true|false), 4>")
+FOUR_PLANETS_TWO_WAVES = re.compile(r"k_main<4, true, (true|false), \d+, (true|false), 4, false>")
 
 
 # The planet-per-wave kernels (octo_mainp.h, round 5) are held to three (4-6 planets) or four (7-8) waves per SIMD: the nuisance gradient variants

@@ -40,6 +40,28 @@ def test_eval_multi_splits_a_host_batch(pkg, oracle):
     planets = [dict(orbit_kind=0, has_mass=False)]
     ref = gb.gpu_eval(obs, planets, cfg["elems"], None, grad=True, small_batch=0)      # throughput kernels for the batch and for every slice
     n_vis = _device_count()
+    # Round 6: the same split on a DENSE table — daily cadence, the warm-started loop — where a walker's last bits
+    # depend on its wave's neighbours and on the batch's row partition: to rounding by default, BITWISE with OCTO_OPT_BATCH_INVARIANT on every context
+    # (a 1-GPU against an N-GPU rerun of one chain, checkpoint / resume).
+    obs_d = [dict(obs[0], epoch=t["epoch"])]
+    for inv in (0, 1):
+        opts = {capi.OPT_BATCH_INVARIANT: inv}
+        ref_d = gb.gpu_eval(obs_d, planets, cfg["elems"], None, grad=True, small_batch=0, options=opts)
+        paths = [gb.GpuPath(obs_d, planets, device=0, small_batch=0, options=opts) for _ in range(3)]
+        ctxs = (C.c_void_p * 3)(*[p.ctx for p in paths]); dss = (C.c_void_p * 3)(*[p.ds for p in paths])
+        el = np.ascontiguousarray(cfg["elems"]); W = el.shape[1]
+        ll = np.full(W, np.nan); g = np.full_like(el, np.nan)
+        assert lib.octo_eval_multi(ctxs, dss, 3, capi._dptr(el), None, W, W, capi._dptr(ll), capi._dptr(g), None) == 0
+        ok = np.isfinite(ref_d[0])
+        if inv:
+            assert np.array_equal(ll, ref_d[0]) and np.array_equal(g, ref_d[1]), "OCTO_OPT_BATCH_INVARIANT: split and unsplit must agree bit for bit"
+        else:
+            assert np.array_equal(np.isfinite(ll), ok)
+            assert np.max(np.abs(ll[ok] - ref_d[0][ok]) / np.maximum(1.0, np.abs(ref_d[0][ok]))) < 1e-12
+            sc = np.maximum(np.abs(ref_d[1][:8, ok]).max(axis=1, keepdims=True), 1e-300)
+            assert np.max(np.abs(g[:8, ok] - ref_d[1][:8, ok]) / sc) < 1e-11
+        for p in paths:
+            p.close()
     for devices in ([0, 0], [0, 0, 0], list(range(n_vis)) if n_vis > 1 else [0]):
         paths = [gb.GpuPath(obs, planets, device=d, small_batch=0) for d in devices]
         n = len(paths)

@@ -210,3 +210,66 @@ def test_model_callback_fused_launch_vs_oracle(pkg, oracle, W):
         gref = np.asarray(case["grad"])[:, :n0]
         assert np.all(np.abs(res[None][1][:, :n0] - gref) <= 1e-9 * np.abs(gref) + 1e-10 * np.abs(gref).max(axis=1, keepdims=True))
         assert np.all(np.abs(res[None][0] - res[0][0]) <= 1e-13 * np.abs(res[0][0]))
+
+
+@pytest.mark.gpu
+def test_one_task_launch_finishes_inside_k_main(pkg, oracle):
+    """Round 6: a mid-size batch on a short table — 1 024 walkers x 50 epochs, a Pigeons round or a guess_starting_position chunk — is ONE
+    task, and the k_main blocks finish their own tiles (octo_kernels.h: fin_in_main): no partials, no k_finish launch. Same routines on the same sums:
+    BIT-identical to the two-launch route (OCTO_FIN_FUSED=0 at context creation), with and without nuisances, forward-only, with invalid walkers and a
+    ragged last tile; against the oracle; and through the whole callback (octo_model_logpost_device: the model's tail runs in the same blocks)."""
+    import os
+    import gpu_binding as gb
+    import synth
+    from test_gpu_parity import _cmp_oracle
+    rng = np.random.default_rng(91)
+    n, W = 50, 1000
+    t = 50000.0 + 20.0 * np.arange(n)
+    ra, dec = synth.truth_radec(t)
+    planets = [dict(orbit_kind=0, has_mass=False)]
+    el = synth.draw_walkers(rng, W)
+    el[1, 5] = 1.2; el[0, 77] = np.nan; el[6, 999] = -1.0
+    nuis = np.stack([rng.uniform(0, 3, W), rng.normal(1, 0.01, W), rng.normal(0, 0.02, W)])
+    nuis[0, 300] = np.inf
+
+    def both(obs, nz, grad):
+        out = []
+        for fused in ("1", "0"):
+            os.environ["OCTO_FIN_FUSED"] = fused
+            try:
+                out.append(gb.gpu_eval(obs, planets, el, nz, grad=grad, small_batch=0))
+            finally:
+                os.environ.pop("OCTO_FIN_FUSED")
+        return out
+    for cor in (None, rng.uniform(-0.5, 0.5, n)):
+        obs = [dict(kind=0, planet=0, epoch=t, y1=ra + rng.normal(0, 5, n), y2=dec + rng.normal(0, 5, n), s1=np.full(n, 5.0), s2=np.full(n, 7.0), cor=cor)]
+        for nz in (None, nuis):
+            a, b = both(obs, nz, True)
+            assert all((x is None and y is None) or np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)), ("fused finish differs from k_finish", cor is None, nz is None)
+            af, _ = both(obs, nz, False)
+            assert np.array_equal(af[0], a[0])
+            bad = [5, 77, 999] + ([300] if nz is not None else [])
+            assert np.isneginf(a[0][bad]).all() and np.all(a[1][:, bad] == 0.0)
+            ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, el, nz, grad=True, active=synth.active_mask(1, 1, mass=False, nuis=nz is not None))
+            _cmp_oracle("fused finish", a[0], a[1], a[2], ll_o, g_o, gn_o)
+    # the whole callback
+    import torch
+    tbl = dict(epoch=t, ra=ra, dec=dec, σ_ra=np.full(n, 5.0), σ_dec=np.full(n, 7.0))
+    res = []
+    for fused in ("1", "0"):
+        os.environ["OCTO_FIN_FUSED"] = fused
+        try:
+            b = pkg.Planet(name="b", basis="Visual{KepOrbit}", observations=[pkg.PlanetRelAstromObs(tbl, name="astrom")],
+                           variables=pkg.variables(a=pkg.LogUniform(1, 100), e=pkg.Uniform(0.0, 0.99), i=pkg.Sine(), ω=pkg.UniformCircular(),
+                                                   Ω=pkg.UniformCircular(), θ=pkg.UniformCircular(), tp=pkg.θ_at_epoch_to_tperi("θ", 50000)))
+            model = pkg.LogDensityModel(pkg.System(name="mid", companions=[b], variables=pkg.variables(M=pkg.truncated(pkg.Normal(1.2, 0.1), lower=0.1),
+                                                                                                         plx=pkg.truncated(pkg.Normal(50.0, 0.02), lower=0.1))))
+        finally:
+            os.environ.pop("OCTO_FIN_FUSED")
+        th = model.link(model.sample_priors(np.random.default_rng(6), 1024))
+        th[2, 9] = np.nan
+        lp, g = model.logpost_device(torch.tensor(th, device="cuda"), grad=True)
+        res.append((lp.cpu().numpy(), g.cpu().numpy()))
+        model.close()
+    assert np.array_equal(res[0][0], res[1][0], equal_nan=True) and np.array_equal(res[0][1], res[1][1], equal_nan=True)
+    assert np.isfinite(res[0][0]).sum() > 900

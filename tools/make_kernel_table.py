@@ -10,22 +10,22 @@ PEAK_TF = 78.6
 # workload -> (kernels of interest: substring -> (evaluations per launch, row-waves per launch, solves per evaluation))
 E4 = 10_000
 WORK = {
-    "two_planet": {"k_main<2, true, true, 5, true, 4>": (5000 * 4096, 5000 * 64, 2), "k_finish<2, true, true, 5, false>": (5000 * 4096, None, 2)},
-    "nuis": {"k_main<1, true, true, 1, true, 4>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, true, 1, false>": (E4 * E4, None, 1)},
-    "fwd": {"k_main<1, false, false, 1, true, 4>": (E4 * E4, E4 * 157, 1), "k_finish<1, false, false, 1, false>": (E4 * E4, None, 1)},
+    "two_planet": {"k_main<2, true, true, 5, true, 4, false>": (5000 * 4096, 5000 * 64, 2), "k_finish<2, true, true, 5, false>": (5000 * 4096, None, 2)},
+    "nuis": {"k_main<1, true, true, 1, true, 4, false>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, true, 1, false>": (E4 * E4, None, 1)},
+    "fwd": {"k_main<1, false, false, 1, true, 4, false>": (E4 * E4, E4 * 157, 1), "k_finish<1, false, false, 1, false>": (E4 * E4, None, 1)},
     "ofti": {"k_ofti_main": (E4 * E4, E4 * 157, 1), "k_ofti_finish": (E4 * E4, None, 1)},
     "logpost": {"k_model_fwd<true, false>": (E4 * E4, None, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
-    "three_planet": {"k_main<3, true, true, 5, true, 4>": (6250 * 4096, 6250 * 64, 3), "k_finish<3, true, true, 5, false>": (6250 * 4096, None, 3)},
+    "three_planet": {"k_main<3, true, true, 5, true, 4, false>": (6250 * 4096, 6250 * 64, 3), "k_finish<3, true, true, 5, false>": (6250 * 4096, None, 3)},
     # round 5: four planets and more on the planet-per-wave kernel (octo_mainp.h) — a block is P waves, so a tile-row is P row-waves
     "four_planet": {"k_mainp<true, true, 55, 4, 3>": (7500 * 4096, 7500 * 64 * 4, 4), "k_finish<4, true, true, 5, false>": (7500 * 4096, None, 4)},
     "five_planet": {"k_mainp<true, true, 55, 4, 3>": (8750 * 4096, 8750 * 64 * 5, 5), "k_finishp<true, true, 55>": (8750 * 4096, None, 5)},
     "eight_planet": {"k_mainp<true, true, 55, 2, 4>": (12500 * 4096, 12500 * 64 * 8, 8), "k_finishp<true, true, 55>": (12500 * 4096, None, 8)},
     # the per-GPU share of config 3 on 8 GPUs (1 250 walkers = 20 tiles): the eight-wave block of one-round launches
-    "shard_1250": {"k_main<1, true, false, 1, true, 8>": (E4 * 1250, E4 * 20, 1), "k_finish<1, true, false, 1, false>": (E4 * 1250, None, 1)},
-    "shard_2500": {"k_main<1, true, false, 1, true, 4>": (E4 * 2500, E4 * 40, 1), "k_finish<1, true, false, 1, false>": (E4 * 2500, None, 1)},
+    "shard_1250": {"k_main<1, true, false, 1, true, 8, false>": (E4 * 1250, E4 * 20, 1), "k_finish<1, true, false, 1, false>": (E4 * 1250, None, 1)},
+    "shard_2500": {"k_main<1, true, false, 1, true, 4, false>": (E4 * 2500, E4 * 40, 1), "k_finish<1, true, false, 1, false>": (E4 * 2500, None, 1)},
     "small_w1": {"k_small<1, true, false, 1, false>": (E4 * 1, E4 * 1 / 64.0, 1)},
     "small_w512": {"k_small<1, true, false, 1, false>": (E4 * 512, E4 * 512 / 64.0, 1)},
-    "config3": {"k_main<1, true, false, 1, true, 4>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
+    "config3": {"k_main<1, true, false, 1, true, 4, false>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
 }
 
 

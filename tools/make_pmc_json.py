@@ -8,14 +8,14 @@ sources so that bench.py can refuse figures collected for a different kernel.
 Round 5: the per-GPU launch shapes of a strong-scaled run (SURVEY 8d "Scaling runs": 1e4 walkers split over 2 / 4 / 8 GPUs) get their own
 counter passes (gpurun_out/<tag>/w5000, w2500, w1250: the same bench command with --walkers W) and land under "shapes" keyed by the
 walkers per launch; bench.py picks the entry of the shape it launched. The kernel of a shape is whichever k_main instantiation the
-planner chose for it (the eight-wave block k_main<1, true, false, 1, true, 8> for one-round launches)."""
+planner chose for it (the eight-wave block k_main<1, true, false, 1, true, 8, false> for one-round launches)."""
 import glob, json, re, sqlite3, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from __graft_entry__ import kernel_source_hash
 
-KERNEL = "k_main<1, true, false, 1, true, 4>"      # (P, GRAD, NUIS, KM, FUSED, waves per block)
+KERNEL = "k_main<1, true, false, 1, true, 4, false>"      # (P, GRAD, NUIS, KM, FUSED, waves per block)
 W, E = 10_000, 10_000
 SHARD_WALKERS = (5_000, 2_500, 1_250)
 
@@ -69,7 +69,7 @@ def kernel_avg_us(src, KERNEL=KERNEL, W=W, sub="stats"):
             rows = con.execute("select name, grid_x, grid_y, count(*), avg(duration) / 1e3 from kernels group by name, grid_x, grid_y").fetchall()
         except sqlite3.Error:
             continue
-        wg = 64 * int(KERNEL.rstrip(">").split(",")[-1])
+        wg = 64 * int(KERNEL.rstrip(">").split(",")[-2])      # (…, waves per block, FINF)
         rows = [r for r in rows if KERNEL in r[0] and r[1] == cols * wg]
         if rows:
             r = max(rows, key=lambda r: r[3])

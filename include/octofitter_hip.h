@@ -407,6 +407,12 @@ int32_t octo_pt_step_device(octo_ctx* ctx, const double* d_ll_local, double* d_l
                             const double* d_beta, int32_t* d_slot2rep, int32_t n_temps, int64_t n_chains,
                             int32_t parity, uint64_t seed, uint64_t step, int32_t* d_accepted, void* hip_stream);
 
+/* The same step on HOST arrays (blocking): ll_local [n_temps/world][n_chains], beta [n_temps], slot2rep [n_chains][n_temps] in/out, accepted
+ * [n_temps] in/out or NULL — for a driver whose replicas live in host memory (Julia Vectors: julia/OctofitterHIP.jl: octofit_pigeons_hip; its
+ * executable twin is host/tempering.py: TemperedSwap.swap_step_host). */
+int32_t octo_pt_step(octo_ctx* ctx, const double* ll_local, const double* beta, int32_t* slot2rep, int32_t n_temps, int64_t n_chains,
+                     int32_t parity, uint64_t seed, uint64_t step, int32_t* accepted);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,39 @@ int32_t octo_pt_step_device(octo_ctx* ctx, const double* d_ll_local, double* d_l
     return octo_pt_swap_device(ctx, d_all, d_beta, d_slot2rep, n_temps, n_chains, parity, seed, step, d_accepted, hip_stream);
 }
 
+// The same step on HOST arrays (round 6): what a driver without a device-array package calls — the reference's host language has
+// its replicas' log-likelihoods in a Vector (ext/OctofitterPigeonsExt/OctofitterPigeonsExt.jl:76-128 leaves the replicas to Pigeons.jl, one model(θ) at a
+// time). ll_local [n_temps/world][n_chains], beta [n_temps], slot2rep [n_chains][n_temps] in/out, accepted [n_temps] in/out or NULL. Staged through
+// the context's scratch on its own stream: three small copies in, the all-gather (world > 1) and the swap kernel, two copies out, one wait.
+int32_t octo_pt_step(octo_ctx* ctx, const double* ll_local, const double* beta, int32_t* slot2rep, int32_t n_temps, int64_t n_chains, int32_t parity,
+                     uint64_t seed, uint64_t step, int32_t* accepted) {
+    if (!ctx || !ll_local || !beta || !slot2rep) return fail(ctx, OCTO_EINVAL, "octo_pt_step: null argument");
+    const int world = ctx->comm_world;
+    if (n_temps < 2 || n_chains < 1 || n_temps % world) return fail(ctx, OCTO_EINVAL, "octo_pt_step: n_temps must be >= 2 and divide evenly over the ranks");
+    if (world > 1 && !ctx->comm) return fail(ctx, OCTO_EINVAL, "octo_pt_step: call octo_comm_create first");
+    { int rcb = busy(ctx, "octo_pt_step"); if (rcb) return rcb; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t n_loc = (int64_t)(n_temps / world) * n_chains, n_all = (int64_t)n_temps * n_chains;
+    // one device block: [ll_local | ll_all | beta] doubles, then [slot2rep | accepted] int32 (in doubles' worth of space)
+    const int64_t n_d = n_loc + n_all + n_temps, n_i = n_all + n_temps;
+    int rc = grow(ctx, ctx->d_in, ctx->cap_in, n_d + (n_i + 1) / 2);
+    if (rc) return rc;
+    double* d_loc = ctx->d_in; double* d_all = d_loc + n_loc; double* d_beta = d_all + n_all;
+    int32_t* d_s2r = reinterpret_cast<int32_t*>(d_beta + n_temps); int32_t* d_acc = d_s2r + n_all;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(d_loc, ll_local, sizeof(double) * (size_t)n_loc, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(d_beta, beta, sizeof(double) * (size_t)n_temps, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(d_s2r, slot2rep, sizeof(int32_t) * (size_t)n_all, hipMemcpyHostToDevice, st));
+    if (accepted) HIPCHK(ctx, hipMemcpyAsync(d_acc, accepted, sizeof(int32_t) * (size_t)n_temps, hipMemcpyHostToDevice, st));
+    else HIPCHK(ctx, hipMemsetAsync(d_acc, 0, sizeof(int32_t) * (size_t)n_temps, st));
+    rc = octo_pt_step_device(ctx, d_loc, d_all, d_beta, d_s2r, n_temps, n_chains, parity, seed, step, d_acc, OCTO_STREAM_CTX);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(slot2rep, d_s2r, sizeof(int32_t) * (size_t)n_all, hipMemcpyDeviceToHost, st));
+    if (accepted) HIPCHK(ctx, hipMemcpyAsync(accepted, d_acc, sizeof(int32_t) * (size_t)n_temps, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return OCTO_OK;
+}
+
 int32_t octo_eval_multi(octo_ctx* const* ctxs, const octo_dataset* const* dss, int32_t n_dev, const double* elems, const double* nuis,
                         int64_t ld, int64_t W, double* ll_out, double* g_elems, double* g_nuis) {
     if (!ctxs || !dss || n_dev < 1) return OCTO_EINVAL;

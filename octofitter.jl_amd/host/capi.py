@@ -152,6 +152,8 @@ _SIGS = {
     "octo_comm_destroy": (C.c_int32, [C.c_void_p]),
     "octo_pt_step_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                         C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "octo_pt_step": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int32, C.c_uint64, C.c_uint64,
+                                 C.POINTER(C.c_int32)]),
     "octo_eval_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "octo_sync": (C.c_int32, [C.c_void_p]),

@@ -77,6 +77,25 @@ class TemperedSwap:
         b = self.beta[rep2slot[:, self.lo:self.hi].long()]        # [n_chains, n_local]
         return b.t().contiguous().reshape(-1)
 
+    def swap_step_host(self, ll_local, step):
+        """The communication step on HOST arrays (octo_pt_step): the executable twin of julia/OctofitterHIP.jl: octofit_pigeons_hip's swap — a driver whose
+        replicas live in host memory. ll_local: numpy [n_local_temps * n_chains]; returns slot2rep as numpy [n_chains, n_temps] (kept on the object
+        as `slot2rep_host`; `accepted_host` counts acceptances per slot). Same seed, same step -> the same permutation as swap_step on every rank."""
+        import ctypes as C
+        import numpy as np
+        if not self._comm_ready:
+            raise RuntimeError("call create_comm() on every rank before the first swap_step_host")
+        if not hasattr(self, "slot2rep_host"):
+            self.slot2rep_host = np.ascontiguousarray(np.tile(np.arange(self.n_temps, dtype=np.int32), (self.n_chains, 1)))
+            self.accepted_host = np.zeros(self.n_temps, dtype=np.int32)
+            self.beta_host = np.ascontiguousarray(self.beta.detach().cpu().numpy(), dtype=np.float64)
+        ll = np.ascontiguousarray(ll_local, dtype=np.float64)
+        i32p = C.POINTER(C.c_int32)
+        self.fn._check(self.fn.lib.octo_pt_step(self.fn._ctx, ll.ctypes.data_as(C.POINTER(C.c_double)), self.beta_host.ctypes.data_as(C.POINTER(C.c_double)),
+                                                self.slot2rep_host.ctypes.data_as(i32p), self.n_temps, self.n_chains, int(step) % 2, C.c_uint64(self.seed),
+                                                C.c_uint64(int(step)), self.accepted_host.ctypes.data_as(i32p)), "octo_pt_step")
+        return self.slot2rep_host
+
     def swap_step(self, ll_local, step):
         """ll_local: [n_local_temps * n_chains] log-likelihoods of this rank's replicas. Returns slot2rep."""
         import ctypes as C

@@ -662,5 +662,76 @@ function rejection_evaluate_likelihoods(model::HIPLogDensityModel, prior_samples
     return map(x -> isfinite(x) ? x : -Inf, ll)
 end
 
+# ---------------------------------------------------------------------------------------------------- parallel tempering, batched (BASELINE config 5)
+# `octofit_pigeons` (ext/OctofitterPigeonsExt/OctofitterPigeonsExt.jl:76-128) builds Pigeons.Inputs and leaves the replicas to Pigeons.jl, whose explorers
+# call model(θ) ONE replica at a time (:10-12). This driver owns the loop instead, so that every exploration step evaluates ALL local replicas as one
+# [D][W] batch on the device and every communication step is one collective:
+#   protocol (shared with host/tempering.py: TemperedSwap, its executable twin — tests/test_multi_gpu.py::test_host_swap_step_is_the_device_swap_step):
+#   * one process per GPU; temperatures (replicas) split contiguously over the ranks, every rank holds all `n_chains` independent chains of its replicas:
+#     local walker w = r_local·n_chains + c  (column w of θ_t, 1-based w + 1 in Julia);
+#   * bootstrap: rank 0 draws the 128-byte id (octo_comm_unique_id), `bcast_id` carries it to the others (MPI.Bcast!, a file, a socket), every rank joins
+#     with octo_comm_create(ctx, id, rank, world); world = 1 needs no id and no RCCL;
+#   * exploration: a random-walk Metropolis step on θ_t for every local replica at its current β — log u < (ℓprior′ + β ℓ′) − (ℓprior + β ℓ) — with
+#     ℓπ = octo_model_logpost! on the whole batch and ℓprior from the reference's own make_ln_prior_transformed, so ℓ = ℓπ − ℓprior (Pigeons' reference chain
+#     is the prior, OctofitterPigeonsExt.jl:61-67);
+#   * communication: octo_pt_step(ctx, ℓ_local, β, slot2rep, …, parity = scan % 2, seed, scan, accepted): all-gather of the local ℓ (RCCL) + the
+#     deterministic neighbour swap of β LABELS (states never move) — same seed and scan on every rank, so every rank ends with the same slot2rep.
+# Returns (θ_t, ℓπ, slot2rep, accepted, β) of this rank; slot2rep[c, t] = the replica that sits at ladder slot t of chain c.
+function octofit_pigeons_hip(hm::HIPLogDensityModel; n_rounds::Integer=8, n_temps::Integer=16, n_chains::Integer=64, seed::Integer=1,
+                             explorer_steps::Integer=3, step_size::Real=0.05, rank::Integer=0, world::Integer=1,
+                             bcast_id=identity, rng::Random.AbstractRNG=Random.Xoshiro(seed + rank), verbosity::Integer=1)
+    n_temps % world == 0 || error("n_temps must divide evenly over the ranks")
+    ctx, D = hm.batched.ctx, hm.D
+    id = world > 1 ? bcast_id(rank == 0 ? octo_comm_unique_id() : zeros(UInt8, 128)) : nothing
+    octo_comm_create(ctx, id, rank, world)
+    n_loc = n_temps ÷ world
+    W = n_loc * n_chains
+    β = collect(range(1.0, 0.0; length=n_temps)) .^ 3                                   # β_1 = 1: the target; the last slot is the prior
+    slot2rep = Matrix{Int32}(undef, n_temps, n_chains)                                  # column-major [t, c] = the C ABI's [n_chains][n_temps]
+    for c in 1:n_chains, t in 1:n_temps
+        slot2rep[t, c] = t - 1
+    end
+    accepted = zeros(Int32, n_temps)
+    θ = Matrix{Float64}(undef, W, D)                                                    # column d = row d of the C ABI's [D][ld = W]
+    for w in 1:W
+        θ[w, :] .= hm.link(hm.sample_priors(rng))
+    end
+    θ′ = similar(θ); ℓπ = Vector{Float64}(undef, W); ℓπ′ = similar(ℓπ)
+    ln_prior_transformed = Octofitter.make_ln_prior_transformed(hm.system)             # the reference's own prior density (src/logdensitymodel.jl:47,128)
+    ℓprior(θm, w) = ln_prior_transformed(hm.invlink(θm[w, :]), true)
+    lpr = [ℓprior(θ, w) for w in 1:W]; lpr′ = similar(lpr)
+    lock(hm.lock) do; octo_model_logpost!(ctx, hm.m, θ, ℓπ, nothing); end
+    ℓ = ℓπ .- lpr
+    try
+        scan = 0
+        for round in 1:n_rounds, _ in 1:2^round
+            scan += 1
+            # β of every local walker under the current labels: replica r (0-based, global) of chain c sits at the slot t with slot2rep[t, c] == r
+            βw = Vector{Float64}(undef, W)
+            for c in 1:n_chains, t in 1:n_temps
+                r = Int(slot2rep[t, c]) - rank * n_loc
+                0 <= r < n_loc && (βw[r * n_chains + c] = β[t])
+            end
+            for _ in 1:explorer_steps
+                θ′ .= θ .+ step_size .* randn(rng, W, D)
+                lock(hm.lock) do; octo_model_logpost!(ctx, hm.m, θ′, ℓπ′, nothing); end   # ONE batched evaluation of every local replica
+                for w in 1:W
+                    lpr′[w] = ℓprior(θ′, w)
+                    ℓ′ = ℓπ′[w] - lpr′[w]
+                    if isfinite(ℓπ′[w]) && log(rand(rng)) < (lpr′[w] + βw[w] * ℓ′) - (lpr[w] + βw[w] * ℓ[w])
+                        θ[w, :] .= view(θ′, w, :); ℓπ[w] = ℓπ′[w]; lpr[w] = lpr′[w]; ℓ[w] = ℓ′
+                    end
+                end
+            end
+            octo_pt_step(ctx, ℓ, β, slot2rep, n_temps, n_chains, scan % 2, UInt64(seed), UInt64(scan), accepted)
+        end
+        verbosity >= 1 && @info "octofit_pigeons_hip: rank $rank of $world, $scan scans, swap acceptances per slot $(accepted)"
+    finally
+        octo_comm_destroy(ctx)
+    end
+    return (; θ_t=θ, ℓπ, slot2rep, accepted, β)
+end
+
+export octofit_pigeons_hip
 export accelerate, HIPObs, HIPLogDensityModel, GPUBatchedLikelihood, ln_like_batch, pointwise_like_batch, rejection_evaluate_likelihoods
 end # module

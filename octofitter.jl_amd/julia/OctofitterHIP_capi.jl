@@ -217,6 +217,9 @@ octo_pt_step_device(ctx, d_ll_local, d_ll_all, d_beta, d_slot2rep, n_temps, n_ch
     check(ctx, ccall((:octo_pt_step_device, LIB), Int32,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Int32, Int64, Int32, UInt64, UInt64, Ptr{Int32}, Ptr{Cvoid}),
         ctx, d_ll_local, d_ll_all, d_beta, d_slot2rep, n_temps, n_chains, parity, seed, step, d_accepted, stream), "octo_pt_step_device")
+octo_pt_step(ctx, ll_local::Vector{Float64}, beta::Vector{Float64}, slot2rep::Matrix{Int32}, n_temps, n_chains, parity, seed, step, accepted::Vector{Int32}) =
+    check(ctx, ccall((:octo_pt_step, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Int32, Int64, Int32, UInt64, UInt64, Ptr{Int32}),
+        ctx, ll_local, beta, slot2rep, n_temps, n_chains, parity, seed, step, accepted), "octo_pt_step")
 octo_pt_swap_device(ctx, d_ll_by_replica, d_beta, d_slot2rep, n_temps, n_chains, parity, seed, step, d_accepted, stream=STREAM_CTX) =
     check(ctx, ccall((:octo_pt_swap_device, LIB), Int32,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Int32, Int64, Int32, UInt64, UInt64, Ptr{Int32}, Ptr{Cvoid}),

@@ -31,7 +31,7 @@ static const char* SYMBOLS[] = {
     "octo_eval_device", "octo_sync", "octo_kepler_solve", "octo_ofti_create", "octo_ofti_destroy", "octo_ofti_eval", "octo_ofti_eval_device",
     "octo_model_create", "octo_model_destroy", "octo_model_logpost", "octo_model_logpost_device", "octo_timing_enable", "octo_timing_read",
     "octo_timing_stats", "octo_pt_swap_device", "octo_comm_unique_id", "octo_comm_create", "octo_comm_destroy", "octo_pt_step_device", "octo_host_register", "octo_host_unregister", "octo_kepler_solve_table",
-    "octo_ctx_set_option", "octo_ctx_get_option"};
+    "octo_ctx_set_option", "octo_ctx_get_option", "octo_pt_step"};
 
 int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "layout";

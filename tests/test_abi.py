@@ -270,3 +270,45 @@ def test_julia_shim_falls_back_instead_of_throwing():
     h = re.search(r"function HIPLogDensityModel\(model;.*?\n(.*?)\nend\n", main, re.S).group(1)
     assert "_not_on_device(model.system)" in h and "is_fallback(e) || rethrow()" in h and "@info" in h and h.rstrip().endswith("return model")
     assert "fallback || return _hip_log_density_model(model; device)" in h
+
+
+def test_julia_pigeons_driver_calls_what_is_bound_and_follows_the_shared_protocol():
+    """the batched parallel-tempering driver of julia/OctofitterHIP.jl (octofit_pigeons_hip) cannot run here, so it is held
+    statically: every octo_* call in its body is a wrapper the ccall layer defines, with that wrapper's positional arity; the reference function it
+    reaches for exists (tests/golden/julia_api_names.json); and the protocol constants it shares with its executable twin host/tempering.py
+    (TemperedSwap: the ladder, the walker layout r_local·n_chains + c, parity = scan % 2, the [n_chains][n_temps] label matrix) agree."""
+    main = (ROOT / "octofitter.jl_amd" / "julia" / "OctofitterHIP.jl").read_text()
+    capi_txt = JULIA_CAPI.read_text()
+    body = re.search(r"function octofit_pigeons_hip\(.*?\n(.*?)\nend\n\nexport octofit_pigeons_hip", main, re.S).group(1)
+
+    def arity(sig):      # top-level commas of an argument list, keyword part (after ';') dropped
+        sig = sig.split(";")[0]
+        depth, n, cur = 0, 0, ""
+        for ch in sig:
+            depth += ch in "([{"; depth -= ch in ")]}"
+            if ch == "," and depth == 0:
+                n += bool(cur.strip()); cur = ""
+            else:
+                cur += ch
+        return n + bool(cur.strip())
+
+    def call_args(text, start):
+        depth, j = 1, start
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[j], 0); j += 1
+        return text[start:j - 1]
+    defs = {}
+    for m in re.finditer(r"^(?:function )?(octo_\w+!?)\(", capi_txt, re.M):
+        defs.setdefault(m.group(1), set()).add(arity(call_args(capi_txt, m.end())))
+    calls = [(m.group(1), arity(call_args(body, m.end()))) for m in re.finditer(r"\b(octo_\w+!?)\(", body)]
+    assert {c[0] for c in calls} >= {"octo_comm_unique_id", "octo_comm_create", "octo_model_logpost!", "octo_pt_step", "octo_comm_destroy"}, calls
+    for name, n in calls:
+        assert name in defs, f"octofit_pigeons_hip calls {name}, which OctofitterHIP_capi.jl does not define"
+        assert n in defs[name] or any(n <= d for d in defs[name]), (name, n, defs[name])      # (trailing defaulted arguments may be omitted)
+    man = json.loads((ROOT / "tests" / "golden" / "julia_api_names.json").read_text())
+    assert "make_ln_prior_transformed" in man["names"], "the reference's prior density constructor the driver calls (src/logdensitymodel.jl:47)"
+    twin = (ROOT / "octofitter.jl_amd" / "host" / "tempering.py").read_text()
+    assert "range(1.0, 0.0; length=n_temps)) .^ 3" in body and "linspace(1.0, 0.0, self.n_temps, dtype=torch.float64) ** 3" in twin      # the same ladder
+    assert "r * n_chains + c" in body and "r_local * n_chains + c" in twin                                                                # the same walker layout
+    assert "scan % 2" in body and "int(step) % 2" in twin                                                                                 # the same parity rule
+    assert "octo_pt_step(" in twin.replace("lib.octo_pt_step(", "octo_pt_step(")

@@ -319,3 +319,30 @@ def test_lifecycle_returns_every_byte_of_device_memory(pkg):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 <= 8 << 20, f"device memory not returned: {(free0 - free1) / 2**20:.1f} MiB after 40 create/use/destroy cycles"
+
+
+def test_host_swap_step_is_the_device_swap_step(pkg):
+    """octo_pt_step (HOST arrays: the communication step of julia/OctofitterHIP.jl: octofit_pigeons_hip, through its executable twin
+    TemperedSwap.swap_step_host) against octo_pt_step_device on the same log-likelihoods, seeds and steps: identical label matrices and
+    acceptance counts after every step, with and without the one-rank RCCL communicator."""
+    import torch
+    from octofitter_jl_amd.host.tempering import TemperedSwap
+    cfg = synth.config_astrom(n_epochs=50, n_walkers=64, seed=35)
+    obs_m, planet = synth.to_mirror(pkg, cfg)
+    dev = torch.device("cuda", 0)
+    n_temps, chains = 8, 37
+    for force_rccl in (False, True):
+        fn_d = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
+        fn_h = pkg.make_ln_like(pkg.System(name="s", companions=[planet]), cfg["theta_example"])
+        pt_d = TemperedSwap(fn_d, n_temps_total=n_temps, n_chains=chains, rank=0, world=1, device=dev, seed=11)
+        pt_h = TemperedSwap(fn_h, n_temps_total=n_temps, n_chains=chains, rank=0, world=1, device=dev, seed=11)
+        pt_d.create_comm(force_rccl=force_rccl); pt_h.create_comm(force_rccl=force_rccl)
+        rng = np.random.default_rng(4)
+        for step in range(1, 9):
+            ll = rng.normal(0, 3, n_temps * chains)
+            s_d = pt_d.swap_step(torch.tensor(ll, device=dev), step).cpu().numpy()
+            s_h = pt_h.swap_step_host(ll, step)
+            assert np.array_equal(s_d, s_h), (force_rccl, step)
+        assert np.array_equal(pt_d.accepted.cpu().numpy(), pt_h.accepted_host) and pt_h.accepted_host.sum() > 0
+        fn_d.lib.octo_comm_destroy(fn_d._ctx); fn_h.lib.octo_comm_destroy(fn_h._ctx)
+        fn_d.close(); fn_h.close()

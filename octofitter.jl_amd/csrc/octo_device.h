@@ -394,6 +394,30 @@ __device__ __forceinline__ KSol kepler_solve(double t, const PC& pc, const SinCo
 // The warm-started solve (KWarm above). st: the previous row's solution of this (walker, planet), updated; thr: the lane's bound on 1/D;
 // dm = 2π (t − t of the previous row), wave-uniform (row record slot 6); row_ok: the row's own step is within the wave's bound (scalar: slot 7
 // against WarmState::key_hi). A wave's first row enters with st.invD = +Inf: cold.
+// The warm step alone, UNCONDITIONAL (round 6: the two-planet kernels' "last planet always warm" loop): for a wave whose lanes all pass the a-priori test on
+// every row — 1/(1 − e) < thr: the bound holds at periastron itself — and whose task has no row beyond the wave's step bound, there is nothing to test
+// and nothing to fall back to: no ballot, no branch, the two planets' solves stay in one basic block.
+template <int INV_NR>
+__device__ __forceinline__ KSol kepler_warm_step(double t, const PC& pc, KWarm& st, double dm) {
+    static_assert(INV_NR >= 0, "the warm start needs 1/(1 − e cos E) of every row");
+    KSol s;
+    s.dt = t - pc.tp;
+    const double dM = dm * pc.invP;
+    const double x = dM * st.invD;
+    const double z = x * st.invD;
+    const double dE = fma(-((pc.he * st.sE) * z), x, x);
+    const double u = dE * dE;
+    const double sr = dE * fma(u, fma(u, fma(u, OCTO_KT[22], OCTO_KT[17]), OCTO_KT[18]), 1.0);
+    const double cm1 = u * fma(u, fma(u, fma(u, OCTO_KT[23], OCTO_KT[19]), OCTO_KT[20]), -0.5);
+    const double ds = fma(st.sE, cm1, st.cE * sr);
+    const double s1 = st.sE + ds;
+    const double c1 = fma(st.cE, cm1, fma(-st.sE, sr, st.cE));
+    const double f0 = fma(-pc.e, ds, dE - dM);
+    kepler_correct<INV_NR, true>(s, pc, 0.0, s1, c1, f0);
+    st.sE = s.sE; st.cE = s.cE; st.invD = s.invD;
+    return s;
+}
+
 template <int INV_NR>
 __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const SinCosTab& tab, KWarm& st, double thr, double dm, bool row_ok = true) {
     static_assert(INV_NR >= 0, "the warm start needs 1/(1 − e cos E) of every row");

@@ -102,8 +102,8 @@ struct EvalArgs {
     double* extra;                // [1 + P*9 + n_obs*3][ldw]: ll and input-gradient of the terms computed outside the epoch loop
                                   // (k_hgca), added by k_finish; or null
     const double* sctab;          // [SCT_N][2] sin/cos grid (octo_device.h: sincos_table), copied to LDS by every k_main block
-    const int32_t* perm;          // [W] or null: walker of each tile position (octo_tile.h: k_tile_sort). Single-planet fused launches only: k_main gathers its
-                                  // tile's inputs through it, the partials stay in tile order, k_finish<1, …, FROM_WC = false> scatters the results back
+    const int32_t* perm;          // [W] or null: walker of each tile position (octo_tile.h: k_tile_sort). One- and two-planet fused launches only: k_main gathers its
+                                  // tile's inputs through it, the partials stay in tile order, k_finish<P <= 2, …, FROM_WC = false> scatters the results back
     int64_t ldw;
     double* ll_out; double* g_elems; double* g_nuis;
     // The tail of the standard parameterisation (octo_model.h; src/logdensitymodel.jl:110-146,169-177) for big batches, run by k_finish right
@@ -482,7 +482,8 @@ __device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ 
 template <int P>
 struct WarmState { KWarm st[P]; double thr[P]; uint32_t key_hi; bool row_ok; };
 
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true>
+// WLAST (round 6, P >= 2): the LAST planet takes the unconditional warm step (octo_device.h: kepler_warm_step) from ws->st[P − 1], the others the cold solve.
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true, bool WLAST = false>
 __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                            const AstromCoef<P>& co, double t, double y1, double y2, double c3, double c4, double c5,
                                            const SinCosTab& tab, WarmState<P>* ws = nullptr, double dm = 0.0) {
@@ -501,6 +502,7 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if constexpr (WARM) s[p] = kepler_solve_warm<1>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
+        else if constexpr (WLAST) { if (p == P - 1) s[p] = kepler_warm_step<1>(t, pc[p], ws->st[p], dm); else s[p] = kepler_solve<1, TAB>(t, pc[p], tab); }
         else s[p] = kepler_solve<1, TAB>(t, pc[p], tab);
         rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
         dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
@@ -704,7 +706,7 @@ __device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, in
     return rv_coef_vals<P, GRAD, NUIS, KM>(off, jit, trend, margp, ldw, ob_kind, ob_planet, obs_index, pc, wl);
 }
 
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true>
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true, bool WLAST = false>
 __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                        const RvCoef<P>& co, double t, double rv, double c2, double basis, const SinCosTab& tab,
                                        WarmState<P>* ws = nullptr, double dm = 0.0) {
@@ -724,6 +726,7 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if constexpr (WARM) s[p] = kepler_solve_warm<2>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
+        else if constexpr (WLAST) { if (p == P - 1) s[p] = kepler_warm_step<2>(t, pc[p], ws->st[p], dm); else s[p] = kepler_solve<2, TAB>(t, pc[p], tab); }
         else s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
         cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
         snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
@@ -950,6 +953,30 @@ constexpr bool main_warm() {
     return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL);
 }
 
+// Two planets (round 6): the LAST planet — the outer one in the usual order — takes the unconditional warm step in waves where it is provably safe on
+// every row (warm_last_init), the other the cold solve, both in one basic block. Config 4's outer planet (a ~ 8-40 AU at a 4-day cadence) qualifies in
+// every tile whose 64 lanes have e < ~0.87 — which is most tiles once the walkers are tiled by that planet's severity (octo_tile.h).
+template <int P, bool GRAD, bool NUIS, int KM, bool FUSED>
+constexpr bool main_warm_last() { return OCTO_WARM && FUSED && P == 2 && !(KM & (KM_ONEIL | KM_MARG)); }
+
+// the step bound as in warm_init, and the wave qualifies only if every lane's bound on 1/D holds at periastron itself: 1/(1 − e) < thr
+__device__ __forceinline__ float warm_last_init(KWarm& st, const PC& pc, const DevObs& ob, bool enabled) {
+    float bound = 0.0f;
+#pragma unroll
+    for (int k = WARM_LADDER - 1; k >= 0; --k) {
+        const float d = enabled ? ob.dm_ladder[k] : 0.0f;
+        const bool veto = fabsf(d * (float)pc.invP) > WARM_DM_VETO;
+        if (d > 0.0f && __builtin_amdgcn_ballot_w64(veto) == 0) bound = d;
+    }
+    const float dmx = fabsf(bound * (1.0f + 0x1p-18f) * (float)pc.invP);
+    const float th = __builtin_amdgcn_exp2f(0.2f * (__builtin_amdgcn_logf((float)WARM_TOL) - 3.0f * __builtin_amdgcn_logf(dmx)));
+    const bool unsafe = !(__builtin_amdgcn_rcpf(pc.omef) * 1.0001f < th);      // (a NaN — an invalid walker — counts as safe: its sums are discarded)
+    const bool nanlane = !(pc.e == pc.e) || !(pc.invP == pc.invP);
+    if (__builtin_amdgcn_ballot_w64(unsafe && !nanlane) != 0) bound = 0.0f;
+    st.sE = 0.0; st.cE = 1.0; st.invD = 1.0;
+    return bound;
+}
+
 // The wave's step bound: the first entry of the table's ladder (DevObs::dm_ladder, preferred first) that no lane vetoes, a veto being
 // ΔM = bound/P > WARM_DM_VETO (thr would fall below WARM_MIN_THR; a NaN — an invalid walker — does not veto). thr = (tol / ΔM³)^(1/5) per lane from
 // that bound (v_log_f32 / v_exp_f32 are base 2). No entry passes: the wave runs the cold loop. The first row of a wave is cold.
@@ -1024,7 +1051,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
     const int64_t w = (int64_t)blockIdx.x * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;          // tail lanes recompute the last walker; results discarded
     int64_t wsrc = wl;                                  // the walker this tile position holds (octo_tile.h)
-    if constexpr (FUSED && P == 1) { if (a.perm) wsrc = a.perm[wl]; }
+    if constexpr (FUSED && P <= 2) { if (a.perm) wsrc = a.perm[wl]; }
     static_assert(!FINF || main_fin_fused<P, GRAD, NUIS, KM, FUSED, NWV>(), "k_main<…, FINF>: a kind set fin_in_main is compiled for");
     const int task = a.task0 + (int)blockIdx.y;
     const Task tk = a.tasks[task];                      // wave-uniform: scalar loads
@@ -1135,7 +1162,33 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
             // cadence — config 3 — pays nothing for the gaps other tables have: the test is seven scalar instructions and two branches per row, 1 %)
             warm_unchecked = warm_loop && tk.key_max <= bound && tk.chunk <= WARM_RESTART;
         }
-        if constexpr (!ROW_PREFETCH) {
+        bool warm_last = false;
+        if constexpr (main_warm_last<P, GRAD, NUIS, KM, FUSED>()) {
+            const float bound = warm_last_init(ws.st[P - 1], pc[P - 1], ob, a.warm != 0);
+            warm_last = bound > 0.0f && tk.key_max <= bound && tk.chunk <= WARM_RESTART && n_rows > 0;
+        }
+        if (main_warm_last<P, GRAD, NUIS, KM, FUSED>() && warm_last) {
+            if constexpr (main_warm_last<P, GRAD, NUIS, KM, FUSED>()) {
+                // seed: the last planet's cold solution at the wave's first epoch; the first row then advances by a step of 0
+                {
+                    const KSol s0 = kepler_solve<2, true>(rows[0], pc[P - 1], tab);
+                    ws.st[P - 1].sE = s0.sE; ws.st[P - 1].cE = s0.cE; ws.st[P - 1].invD = s0.invD;
+                }
+                auto lbody = [&](const RowRegs8& r, bool first) {
+                    astrom_row<P, GRAD, NUIS, KM, true, false, true, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4),
+                                                                           row_get(r, 5), tab, &ws, first ? 0.0 : row_get(r, 6));
+                };
+                RowRegs8 A = row_issue8(rows);
+                for (int j = 0; j < n_rows; j += 2) {
+                    RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
+                    lbody(A, j == 0);
+                    if (j + 1 >= n_rows) { row_drain(B); break; }
+                    A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
+                    lbody(B, false);
+                }
+                row_drain(A);
+            }
+        } else if constexpr (!ROW_PREFETCH) {
             for (int j = 0; j < n_rows; ++j) {
                 const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
                 astrom_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab);
@@ -1201,7 +1254,32 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
             // cadence — config 3 — pays nothing for the gaps other tables have: the test is seven scalar instructions and two branches per row, 1 %)
             warm_unchecked = warm_loop && tk.key_max <= bound && tk.chunk <= WARM_RESTART;
         }
-        if constexpr (!ROW_PREFETCH) {
+        bool warm_last = false;
+        if constexpr (main_warm_last<P, GRAD, NUIS, KM, FUSED>()) {
+            const float bound = warm_last_init(ws.st[P - 1], pc[P - 1], ob, a.warm != 0);
+            warm_last = bound > 0.0f && tk.key_max <= bound && tk.chunk <= WARM_RESTART && n_rows > 0;
+        }
+        if (main_warm_last<P, GRAD, NUIS, KM, FUSED>() && warm_last) {
+            if constexpr (main_warm_last<P, GRAD, NUIS, KM, FUSED>()) {
+                {
+                    const KSol s0 = kepler_solve<2, true>(rows[0], pc[P - 1], tab);
+                    ws.st[P - 1].sE = s0.sE; ws.st[P - 1].cE = s0.cE; ws.st[P - 1].invD = s0.invD;
+                }
+                auto lbody = [&](const RowRegs8& r, bool first) {
+                    rv_row<P, GRAD, NUIS, KM, true, false, true, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab, &ws,
+                                                                       first ? 0.0 : row_get(r, 6));
+                };
+                RowRegs8 A = row_issue8(rows);
+                for (int j = 0; j < n_rows; j += 2) {
+                    RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
+                    lbody(A, j == 0);
+                    if (j + 1 >= n_rows) { row_drain(B); break; }
+                    A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
+                    lbody(B, false);
+                }
+                row_drain(A);
+            }
+        } else if constexpr (!ROW_PREFETCH) {
             for (int j = 0; j < n_rows; ++j) {
                 const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
                 rv_row<P, GRAD, NUIS, KM, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], NUIS ? rw[3] : 0.0, tab);
@@ -1818,6 +1896,8 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
     constexpr int UNR_P = 4;                                       // ... and a planet wave (PL_N columns each)
     const int64_t w = tile * WAVE + lane;
     const int64_t wl = w < a.W ? w : a.W - 1;
+    int64_t wo = wl;      // the walker this tile position holds (octo_tile.h; as in finish_tile): the partials by position, everything of the caller's by walker
+    if constexpr (!FROM_WC && P == 2) { if (a.perm) wo = a.perm[wl]; }
     const int role_p = grp == 0 ? -1 : (grp - 1) / NWR;           // the planet this wave works for
     const int sub = grp == 0 ? 0 : (grp - 1) % NWR;
     const int my_p = (grp > 0 && sub == 0) ? role_p : -1;        // >= 0: this wave finishes planet my_p
@@ -1842,9 +1922,9 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if constexpr (FROM_WC) sma_p[p] = a.wc[((int64_t)p * NWC + WC_A) * a.ldw + wl];
-                else sma_p[p] = setup_planet<true>(a, p, wl).v[WC_A];
-                e_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wl];
-                M_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wl];
+                else sma_p[p] = setup_planet<true>(a, p, wo).v[WC_A];
+                e_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_E) * a.ld + wo];
+                M_p[p] = a.elems[((int64_t)p * OCTO_N_EL + OCTO_EL_M) * a.ld + wo];
             }
         }
         for (int o = 0; o < a.n_obs; ++o) {
@@ -1872,10 +1952,10 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
                 if constexpr (GRAD) { v[8] = vo[L::OFF_ONEIL + 1]; v[9] = vo[L::OFF_ONEIL + 2]; v[10] = vo[L::OFF_ONEIL + 3]; }
             }
             // observations are summed in the order given (system.jl:93,186)
-            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + w : nullptr,
+            ll += obs_finish<P, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + wo : nullptr, a.extra ? a.extra + wo : nullptr,
                                                 a.ldw, a.c.k_yr, o, v, a.obs_const[o], sma_p, e_p, M_p, w < a.W, oneil_g);
         }
-        if (a.extra) ll += a.extra[wl];
+        if (a.extra) ll += a.extra[wo];
         ok_mine = isfinite(ll);
         if constexpr (FROM_WC) {
             if constexpr (!GRAD) {
@@ -1887,10 +1967,10 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
             // finisher wave), every nuisance finite
             if constexpr (!GRAD) {
 #pragma unroll
-                for (int p = 0; p < P; ++p) ok_mine = ok_mine && setup_planet<true>(a, p, wl).ok;
+                for (int p = 0; p < P; ++p) ok_mine = ok_mine && setup_planet<true>(a, p, wo).ok;
             }
             if (a.nuis)
-                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok_mine = ok_mine && isfinite(a.nuis[(int64_t)k * a.ld + wl]);
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) ok_mine = ok_mine && isfinite(a.nuis[(int64_t)k * a.ld + wo]);
         }
     } else if constexpr (GRAD) {
         // ---- planet role_p's running sums over every task; the group's first wave derives the planet's constants meanwhile
@@ -1916,7 +1996,7 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
                 for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl];
                 ok_mine = a.valid[(int64_t)p * a.ldw + wl] != 0;
             } else {
-                const SetupOut so = setup_planet<true>(a, p, wl);      // the same routine, the same values k_setup would have stored
+                const SetupOut so = setup_planet<true>(a, p, wo);      // the same routine, the same values k_setup would have stored
                 fp.sma = so.v[WC_A]; fp.P_d = rcp_nr<2>(so.v[WC_INVP]); fp.beta = so.v[WC_BETA];
                 fp.si = so.v[WC_SINI]; fp.ci = so.v[WC_COSI]; fp.sO = so.v[WC_SINO]; fp.cO = so.v[WC_COSO];
                 fp.sw = so.v[WC_SINW]; fp.cw = so.v[WC_COSW];
@@ -1962,21 +2042,21 @@ __device__ __forceinline__ void finish_tile_multi(const EvalArgs& a, int64_t til
     }
     const bool live = w < a.W;
     if (live && grp == 0) {
-        a.ll_out[w] = ok ? ll : -INFINITY;
+        a.ll_out[wo] = ok ? ll : -INFINITY;
         if constexpr (GRAD && L::N_NU > 0) {
             if (!ok)
-                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + w] = 0.0;
+                for (int k = 0; k < a.n_obs * OCTO_N_NUIS; ++k) a.g_nuis[(int64_t)k * a.ld + wo] = 0.0;
         }
     }
     if constexpr (GRAD) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             if (my_p != p || !live) continue;
-            planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
+            planet_finish<P, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + wo, a.ld, a.extra ? a.extra + wo : nullptr, a.ldw, a.c,
                                                             a.orbit_kind[p], a.has_mass[p], p, gp, L::HAS_ONEIL ? &oneil_g[p * 6] : nullptr, fp, ok);
         }
     }
-    if (a.mt_lpp) model_tail<P>(a, w, grp, (fin_waves<P, GRAD, NUIS, KM>()));
+    if (a.mt_lpp) model_tail<P>(a, live ? wo : a.W, grp, (fin_waves<P, GRAD, NUIS, KM>()));
 }
 
 // one block per tile of 64 walkers. FROM_WC = false: after a k_main launch that derived the constants itself.

@@ -198,7 +198,7 @@ int launch_all(octo_ctx* ctx, const octo_dataset* cds, EvalArgs& a, const SmallM
         if (rc) return rc;
         if (a.n_tasks > 0) {      // (a dataset without rows — an HGCA table alone, empty tables — is k_finish's closed forms only)
             // walker tiles made homogeneous for the warm-started loop (octo_tile.h): one sort launch ahead of k_main when it pays
-            if constexpr (P == 1 && !MAINP && main_warm<P, true, NUIS, KM, true>()) {
+            if constexpr (!MAINP && ((P == 1 && main_warm<P, true, NUIS, KM, true>()) || main_warm_last<P, true, NUIS, KM, true>())) {
                 rc = tile_prepare(ctx, ds, a, st);
                 if (rc) return rc;
             }

@@ -194,3 +194,41 @@ def test_batch_invariant_option_is_bitwise(pkg, oracle):
         assert g.lib.octo_ctx_set_option(g.ctx, 99, 0) == capi.OCTO_EINVAL
         assert g.lib.octo_ctx_set_option(g.ctx, capi.OPT_TILE_MIN_WALKERS, 4096) == 0
         assert g.lib.octo_ctx_get_option(g.ctx, capi.OPT_TILE_MIN_WALKERS, __import__("ctypes").byref(v)) == 0 and v.value == 4096
+
+
+def test_two_planets_last_planet_always_warm_and_sorted_tiles(pkg, oracle):
+    """Round 6: the two-planet kernels carry a loop in which the LAST planet takes the unconditional warm step (no ballot, no branch:
+    both planets' solves in one basic block) — taken by waves whose 64 lanes are provably safe on every row, 1/(1 − e) < thr — and the walker tiles are
+    sorted by that planet's severity so that most tiles qualify. Config 4 in small (RA/Dec on the outer planet + absolute RV, nuisances, inner-barycentre
+    term): (a) outer eccentricities below 0.7 — every wave qualifies as drawn: against the cold loop (OCTO_OPT_WARM_START = 0) and the oracle;
+    (b) as drawn (e up to 0.95: no wave qualifies unsorted) with the sort forced on: equal to the unsorted, cold evaluation to rounding, every walker at
+    its own column, invalid walkers included; forward-only == the value returned with a gradient."""
+    gb = _gpu()
+    capi = pkg.capi
+    c4 = synth.config_two_planet(n_astrom=300, n_rv=260, n_walkers=2300, seed=77)
+    obs = [dict(kind=0, planet=1, epoch=c4["astrom"]["epoch"], y1=c4["astrom"]["ra"], y2=c4["astrom"]["dec"], s1=c4["astrom"]["σ_ra"], s2=c4["astrom"]["σ_dec"], cor=None),
+           dict(kind=2, planet=-1, epoch=c4["rv"]["epoch"], y1=c4["rv"]["rv"], y2=None, s1=c4["rv"]["σ_rv"], s2=None, cor=None)]
+    planets = [dict(orbit_kind=0, has_mass=True)] * 2
+    el, nuis = c4["elems"].copy(), c4["nuis"]
+    W = el.shape[1]
+    idx = np.arange(0, W, 31)
+    for nz in (nuis, None):
+        # (a) every wave safe as drawn
+        el_a = el.copy(); el_a[9 + 1] *= 0.7 / 0.95
+        warm = gb.gpu_eval(obs, planets, el_a, nz, grad=True, small_batch=0, options=_opts(capi, 0))
+        cold = gb.gpu_eval(obs, planets, el_a, nz, grad=True, small_batch=0, options={capi.OPT_TILE_SORT: 0, capi.OPT_WARM_START: 0})
+        assert not (np.array_equal(warm[0], cold[0]) and np.array_equal(warm[1], cold[1])), "the last-planet warm loop did not run"
+        _close("last planet warm vs cold", warm, cold)
+        fwd = gb.gpu_eval(obs, planets, el_a, nz, grad=False, small_batch=0, options=_opts(capi, 0))
+        assert np.array_equal(fwd[0], warm[0])
+        ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, el_a[:, idx], None if nz is None else nz[:, idx], grad=True)
+        _cmp_oracle("last planet warm vs oracle", warm[0][idx], warm[1][:, idx], None if nz is None else warm[2][:, idx], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)
+        # (b) as drawn + invalid walkers, sort forced on
+        el_b = el.copy(); el_b[1, 7] = 1.1; el_b[9, 500] = np.nan; el_b[9 + 6, 2299] = -2.0
+        srt = gb.gpu_eval(obs, planets, el_b, nz, grad=True, small_batch=0, options=_opts(capi, 1))
+        uns = gb.gpu_eval(obs, planets, el_b, nz, grad=True, small_batch=0, options={capi.OPT_TILE_SORT: 0, capi.OPT_WARM_START: 0})
+        assert np.isneginf(srt[0][[7, 500, 2299]]).all()
+        _close("two planets sorted vs as drawn", srt, uns)
+        assert not (np.array_equal(srt[0], uns[0]) and np.array_equal(srt[1], uns[1]))
+        ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, el_b[:, idx], None if nz is None else nz[:, idx], grad=True)
+        _cmp_oracle("two planets sorted vs oracle", srt[0][idx], srt[1][:, idx], None if nz is None else srt[2][:, idx], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)

@@ -25,6 +25,10 @@ WORK = {
     "shard_2500": {"k_main<1, true, false, 1, true, 4, false>": (E4 * 2500, E4 * 40, 1), "k_finish<1, true, false, 1, false>": (E4 * 2500, None, 1)},
     "small_w1": {"k_small<1, true, false, 1, false>": (E4 * 1, E4 * 1 / 64.0, 1)},
     "small_w512": {"k_small<1, true, false, 1, false>": (E4 * 512, E4 * 512 / 64.0, 1)},
+    # round 6: the non-uniform workloads (tests/synth.py: config_wide_prior, config_rv_gappy) and the tile sort that wide_prior turns on
+    "wide_prior": {"k_main<1, true, false, 1, true, 4, false>": (E4 * E4, E4 * 157, 1), "k_tile_sort": (E4 * E4, None, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
+    "rv_gappy": {"k_main<1, true, false, 5, true, 4, false>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, false, 5, false>": (E4 * E4, None, 1)},
+    "rv_gappy_nuis": {"k_main<1, true, true, 5, true, 4, false>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, true, 5, false>": (E4 * E4, None, 1)},
     "config3": {"k_main<1, true, false, 1, true, 4, false>": (E4 * E4, E4 * 157, 1), "k_finish<1, true, false, 1, false>": (E4 * E4, None, 1)},
 }
 

@@ -23,6 +23,9 @@ run() {   # run <name> <command...>
 run two_planet $B --workload two_planet
 run nuis $B --workload nuis
 run fwd $B --workload fwd
+run wide_prior $B --workload wide_prior
+run rv_gappy $B --workload rv_gappy
+run rv_gappy_nuis $B --workload rv_gappy_nuis
 run ofti $B --workload ofti
 run logpost $B --workload logpost
 run three_planet python $ROOT/tools/multi_planet_steps.py 3 60

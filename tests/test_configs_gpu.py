@@ -344,7 +344,7 @@ def test_bench_shard_shape_has_its_own_roofline():
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     roof = d["roofline"]
     assert roof["frac"] is not None and 0.1 < roof["frac"] <= 1.0, roof.get("note")
-    assert roof["launch_shape"] == {"walkers": 1250, "rows": 10000, "pmc_walkers": 1250} and roof["kernel"].endswith(", 8>") and "pmc_note" not in roof
+    assert roof["launch_shape"] == {"walkers": 1250, "rows": 10000, "pmc_walkers": 1250} and roof["kernel"].endswith(", 8, false>") and "pmc_note" not in roof
     assert 0.02 < roof["kernel_avg_ms"] < 0.09 and roof["traffic"] > 1e5
 
 

@@ -208,12 +208,15 @@ constexpr int64_t SMALL_MARG_ROWS = 16384;      // longest marginalised-RV table
 constexpr int64_t SMALL_KEY = (int64_t)1 << 40;   // get_tasks keys at or below −SMALL_KEY: k_small's row partition
 constexpr int64_t STAGE_DMA_BYTES = 1 << 20;   // host-buffer calls up to this size (inputs + outputs) are staged in pinned memory
 
-// The planet-per-wave kernels (octo_mainp.h), instantiated ONCE in octo_inst_pn.hip for the two kind sets they are compiled for: km_p = 35
-// (RA/Dec, sep/PA, cor) or 55 (+ absolute and relative RV). launch_mainp: k_mainp on a planned grid; launch_finishp: k_finishp (P > MAXP_T).
+// The planet-per-wave kernels (octo_mainp.h), instantiated ONCE in octo_inst_pn.hip for the kind sets they are compiled for: km_p = 35
+// (RA/Dec, sep/PA, cor), 55 (+ absolute and relative RV) or 63 (+ marginalised RV: round 6, more than four planets only). launch_mainp: k_mainp on a planned grid; launch_finishp: k_finishp (P > MAXP_T).
 int mainp_occupancy(octo_ctx* ctx, bool nuis, int km_p, int P);
 int launch_mainp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st);
 int launch_finishp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st);
-constexpr int mainp_kind_set(int km) { return (km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0 ? (KM_RADEC | KM_SEPPA | KM_COR) : (KM_ALL & ~KM_MARG & ~KM_ONEIL); }
+constexpr int mainp_kind_set(int km) {
+    return (km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0 ? (KM_RADEC | KM_SEPPA | KM_COR) : ((km & KM_MARG) ? (KM_ALL & ~KM_ONEIL) : (KM_ALL & ~KM_MARG & ~KM_ONEIL));
+}
+int launch_margp(octo_ctx* ctx, bool nuis, int km_p, const EvalArgs& a, hipStream_t st);      // k_marg for the planet-per-wave kernels' forward partials
 // more planets than the templated kernels are compiled for: planner + k_mainp + k_finishp (octo_inst_pn.hip)
 int dispatch_many(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st);
 int64_t plan_key_mainp(const octo_ctx* ctx, int64_t W, int64_t n_rows, int blocks_per_cu);

@@ -18,7 +18,7 @@ int64_t plan_key_mainp(const octo_ctx* ctx, int64_t W, int64_t n_rows, int block
 }
 
 namespace {
-constexpr int KA = KM_RADEC | KM_SEPPA | KM_COR, KB = KM_ALL & ~KM_MARG & ~KM_ONEIL;
+constexpr int KA = KM_RADEC | KM_SEPPA | KM_COR, KB = KM_ALL & ~KM_MARG & ~KM_ONEIL, KC = KM_ALL & ~KM_ONEIL;      // KC (round 6): + marginalised RV, more than four planets only
 
 // Tiles per block (octo_mainp.h), from the probes of tools/r5_tpb_ab.sh (profiles/r5_tpb_ab.txt): two for 5 and 6 planets — ten waves (3, 3, 2, 2 per SIMD)
 // and twelve (3 each): 1.70 -> 1.15 ms and 1.80 -> 1.16 ms per step of the probe; one for 4 and 8 planets (whole multiples of four waves already) and for
@@ -73,14 +73,24 @@ int occupancy_t(octo_ctx* ctx, int P) {
 }
 }  // namespace
 
+#define OCTO_PN_DISPATCH_K(FN, K, ...)                                                                              \
+    (grad ? (nuis ? FN<true, true, K>(__VA_ARGS__) : FN<true, false, K>(__VA_ARGS__))                                \
+          : (nuis ? FN<false, true, K>(__VA_ARGS__) : FN<false, false, K>(__VA_ARGS__)))
 #define OCTO_PN_DISPATCH(FN, ...)                                                                                   \
-    (km_p == KA ? (grad ? (nuis ? FN<true, true, KA>(__VA_ARGS__) : FN<true, false, KA>(__VA_ARGS__))              \
-                        : (nuis ? FN<false, true, KA>(__VA_ARGS__) : FN<false, false, KA>(__VA_ARGS__)))           \
-                : (grad ? (nuis ? FN<true, true, KB>(__VA_ARGS__) : FN<true, false, KB>(__VA_ARGS__))              \
-                        : (nuis ? FN<false, true, KB>(__VA_ARGS__) : FN<false, false, KB>(__VA_ARGS__))))
+    (km_p == KA ? OCTO_PN_DISPATCH_K(FN, KA, __VA_ARGS__) : (km_p == KB ? OCTO_PN_DISPATCH_K(FN, KB, __VA_ARGS__) : OCTO_PN_DISPATCH_K(FN, KC, __VA_ARGS__)))
 
 int mainp_occupancy(octo_ctx* ctx, bool nuis, int km_p, int P) {
-    return km_p == KA ? (nuis ? occupancy_t<true, KA>(ctx, P) : occupancy_t<false, KA>(ctx, P)) : (nuis ? occupancy_t<true, KB>(ctx, P) : occupancy_t<false, KB>(ctx, P));
+    if (km_p == KA) return nuis ? occupancy_t<true, KA>(ctx, P) : occupancy_t<false, KA>(ctx, P);
+    if (km_p == KB) return nuis ? occupancy_t<true, KB>(ctx, P) : occupancy_t<false, KB>(ctx, P);
+    return nuis ? occupancy_t<true, KC>(ctx, P) : occupancy_t<false, KC>(ctx, P);
+}
+// k_marg on the forward partials of the planet-per-wave kernels (their layout is Layout<2, false, ·, ·> for every P: no planet sums without a gradient)
+int launch_margp(octo_ctx* ctx, bool nuis, int km_p, const EvalArgs& a, hipStream_t st) {
+    if (km_p != KC) return fail(ctx, OCTO_EINVAL, "internal: k_marg requested for a kind set without marginalised RV");
+    const dim3 g((unsigned)((a.W + 255) / 256));
+    if (nuis) hipLaunchKernelGGL((k_marg<2, true, KC>), g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_marg<2, false, KC>), g, dim3(256), 0, st, a);
+    return OCTO_OK;
 }
 int launch_mainp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st) {
     return OCTO_PN_DISPATCH(launch_mainp_t, ctx, cols, a, st);
@@ -92,7 +102,7 @@ int launch_finishp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, 
 // A dataset of MAXP_T < P <= MAXP planets: always the throughput kernels (no k_small<P> there), k_mainp -> k_finishp on one stream.
 int dispatch_many(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st) {
     if (sm) return fail(ctx, OCTO_EINVAL, "internal: fused model launch requested for a dataset of more than four planets");
-    if (ds->kind_mask & (KM_MARG | KM_ONEIL | KM_HGCA)) return fail(ctx, OCTO_EINVAL, "internal: kind set outside the planet-per-wave kernels");
+    if (ds->kind_mask & (KM_ONEIL | KM_HGCA)) return fail(ctx, OCTO_EINVAL, "internal: kind set outside the planet-per-wave kernels");
     const int P = ds->n_planets;
     const int km_p = mainp_kind_set(ds->kind_mask);
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
@@ -120,6 +130,29 @@ int dispatch_many(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad,
             }
             hipEvent_t e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second; ctx->ev_used++;
             HIPCHK(ctx, hipEventRecord(e0, st));
+        }
+        if (grad && (ds->kind_mask & KM_MARG)) {
+            // marginalised RV with a gradient (rv-absolute-margin.jl:140-185): r̄v = 2 (r − μ̂)/var needs μ̂ = −B/2A of the WHOLE table first — a forward
+            // pre-pass over that table's tasks, k_marg, then the gradient pass (k_main's flow for these tables; the forward partials fit in the gradient buffer)
+            rc = grow(ctx, ctx->d_marg, ctx->cap_marg, (int64_t)a.n_obs * 2 * a.ldw);
+            if (rc) return rc;
+            a.marg = nullptr; a.marg_out = ctx->d_marg;
+            const Task* tks = tt->h_tasks.data();
+            for (int t0 = 0; t0 < tt->n_tasks;) {
+                const int o = tks[t0].obs;
+                int t1 = t0;
+                while (t1 < tt->n_tasks && tks[t1].obs == o) ++t1;
+                if (ds->h_obs[o].kind == OCTO_RV_ABS_MARG) {
+                    EvalArgs b = a;
+                    b.task0 = t0; b.n_tasks = t1 - t0;
+                    rc = launch_mainp(ctx, false, nuis, km_p, cols, b, st);
+                    if (rc) return rc;
+                }
+                t0 = t1;
+            }
+            rc = launch_margp(ctx, nuis, km_p, a, st);
+            if (rc) return rc;
+            a.marg = ctx->d_marg;
         }
         rc = launch_mainp(ctx, grad, nuis, km_p, cols, a, st);
         if (rc) return rc;

@@ -20,7 +20,10 @@
 // buffers suffice. Per row and tile that is P solves + ONE density + P adjoint updates — the instruction count of k_main<P> — spread over P
 // SIMDs at ~100 VGPRs per lane, no scratch, and P is a RUN-TIME block shape: the partials keep k_main's layout (Layout<2>'s offsets hold
 // for every P >= 2), so k_finish<3>, k_finish<4> read them unchanged, and k_finishp below finishes any P up to OCTO_MAX_PLANETS.
-// Kind sets: everything but marginalised RV and the O'Neil prior (they keep k_main<P>, P <= 4).
+// Kind sets: everything but the O'Neil prior (it keeps k_main<P>, P <= 4). Marginalised RV (round 6, for systems of more than four planets — the usual RV
+// likelihood of a many-planet RV fit): the owning wave of a row accumulates the three sums A = Σ 1/var, B = Σ −2 r/var, C = Σ r²/var of
+// rv-absolute-margin.jl:171-180 with the observation's other sums; a gradient takes the two-pass flow of k_main (forward pre-pass over that table's tasks,
+// k_marg for μ̂ = −B/2A and A per walker, then the gradient pass with r̄v = 2 (r − μ̂)/var).
 #pragma once
 #include "octo_kernels.h"
 
@@ -62,7 +65,7 @@ template <bool GRAD, bool NUIS, int KM, int MP_R, int WPE>
 __attribute__((amdgpu_waves_per_eu(WPE)))
 static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
     using L = LayoutP<GRAD, NUIS, KM>;
-    static_assert(!(KM & (KM_MARG | KM_ONEIL)), "k_mainp: marginalised RV and the O'Neil prior stay on k_main<P>");
+    static_assert(!(KM & KM_ONEIL), "k_mainp: the O'Neil prior stays on k_main<P>");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int P = a.n_planets;                                             // = waves per tile
@@ -107,6 +110,7 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
     }
     const bool is_astrom = !L::HAS_RV || ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA;
     const bool rel = (KM & KM_RVREL) && ob.kind == OCTO_RV_REL;
+    const bool marg = (KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG;
     // the semi-major axis of the planet the table is attached to, through LDS (relative-astrometry.jl:120-123, rv-relative.jl:148-152: strictly inner)
     contrib[wv * WAVE + lane] = pc.a;
     __syncthreads();                                                       // (also: table filled)
@@ -127,6 +131,11 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
     const double jit = is_astrom ? n0 : n1, j2 = jit * jit;
     const bool seppa = (KM & KM_SEPPA) && ob.kind == OCTO_ASTROM_SEPPA;
     const double ib2 = GRAD ? 1.0 / (pc.beta * pc.beta) : 0.0;
+    double mu_hat = 0.0, iA = 0.0;                                         // marginalised RV, gradient pass: the pre-pass's μ̂ and 1/A of this walker (k_marg)
+    if constexpr (GRAD && L::HAS_MARG) {
+        if (marg && a.marg) { mu_hat = a.marg[((int64_t)tk.obs * 2 + 0) * a.ldw + wl]; iA = 1.0 / a.marg[((int64_t)tk.obs * 2 + 1) * a.ldw + wl]; }
+    }
+    int n_owned = 0;                                                       // rows this wave owned (marginalised RV with nuisances: Σ log 2π var)
 
     double ao[L::OFF_PL];                                                  // the observation's sums over the rows this wave owns
 #pragma unroll
@@ -239,16 +248,31 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
             } else if constexpr (L::HAS_RV) {
                 // rv-absolute.jl:143-204, rv-relative.jl:131-210
                 const double rv = rw[1], c2 = rw[2], basis = NUIS ? rw[3] : 0.0;
-                const double model = (NUIS ? fma(n2, basis, n0) : 0.0) + m0;
+                const double model = (NUIS ? fma(n2, basis, marg ? 0.0 : n0) : 0.0) + m0;      // (a marginalised table has no offset: rv-absolute-margin.jl:111)
                 const double resid = rv - model;
                 double iv;
                 if constexpr (NUIS) { const double var = fma(c2, c2, j2); iv = rcp_nr<2>(var); lp.mul(var); } else { iv = c2; }
-                ao[L::OFF_S] = fma(resid * resid, iv, ao[L::OFF_S]);
-                b0 = resid * iv;
-                if constexpr (GRAD && NUIS) {
-                    ao[L::OFF_NU + OCTO_NU_RV_OFFSET] += b0;
-                    ao[L::OFF_NU + OCTO_NU_RV_JITTER] += jit * iv * (resid * resid * iv - 1.0);
-                    ao[L::OFF_NU + OCTO_NU_RV_TREND] = fma(b0, basis, ao[L::OFF_NU + OCTO_NU_RV_TREND]);
+                n_owned += 1;
+                if (L::HAS_MARG && marg) {
+                    if constexpr (L::HAS_MARG) {      // rv-absolute-margin.jl:171-180
+                        ao[L::OFF_MARG + 0] += iv;
+                        ao[L::OFF_MARG + 1] = fma(-2.0 * resid, iv, ao[L::OFF_MARG + 1]);
+                        ao[L::OFF_MARG + 2] = fma(resid * resid, iv, ao[L::OFF_MARG + 2]);
+                    }
+                    const double dmv = resid - mu_hat;
+                    b0 = 2.0 * dmv * iv;
+                    if constexpr (GRAD && NUIS) {
+                        ao[L::OFF_NU + OCTO_NU_RV_JITTER] += 2.0 * jit * iv * (dmv * dmv * iv - 1.0 + iv * iA);
+                        ao[L::OFF_NU + OCTO_NU_RV_TREND] = fma(b0, basis, ao[L::OFF_NU + OCTO_NU_RV_TREND]);
+                    }
+                } else {
+                    ao[L::OFF_S] = fma(resid * resid, iv, ao[L::OFF_S]);
+                    b0 = resid * iv;
+                    if constexpr (GRAD && NUIS) {
+                        ao[L::OFF_NU + OCTO_NU_RV_OFFSET] += b0;
+                        ao[L::OFF_NU + OCTO_NU_RV_JITTER] += jit * iv * (resid * resid * iv - 1.0);
+                        ao[L::OFF_NU + OCTO_NU_RV_TREND] = fma(b0, basis, ao[L::OFF_NU + OCTO_NU_RV_TREND]);
+                    }
                 }
             }
             if constexpr (GRAD) *reinterpret_cast<double2*>(&adj[((size_t)r * WAVE + lane) * 2]) = make_double2(b0, b1);
@@ -305,7 +329,11 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
             }
         }
     }
-    if constexpr (NUIS) ao[L::OFF_S] += lp.log_value();                     // Σ log|Σ_row| / Σ log var over the rows this wave owned
+    if constexpr (NUIS) {                                                   // Σ log|Σ_row| / Σ log var (marginalised RV: Σ log 2π var) over the rows this wave owned
+        double lg = lp.log_value();
+        if (L::HAS_MARG && marg) lg = fma((double)n_owned, LOG2PI, lg);
+        ao[L::OFF_S] += lg;
+    }
     // ---- one partial per (tile, task): the planets' sums straight from their waves, the observation's sums added in wave order
     __syncthreads();                                                        // the last chunk's contributions are dead
     if (wv > 0) {
@@ -334,7 +362,7 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
 template <bool GRAD, bool NUIS, int KM>
 static __global__ __launch_bounds__(64 * (1 + OCTO_MAX_PLANETS)) void k_finishp(EvalArgs a) {
     using L = LayoutP<GRAD, NUIS, KM>;
-    static_assert(!(KM & (KM_MARG | KM_ONEIL)), "k_finishp: the kind sets of k_mainp");
+    static_assert(!(KM & KM_ONEIL), "k_finishp: the kind sets of k_mainp");
     extern __shared__ __attribute__((aligned(16))) double lds[];            // (1 + P) rows of 64 validity flags
     const int lane = threadIdx.x & (WAVE - 1);
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -372,6 +400,7 @@ static __global__ __launch_bounds__(64 * (1 + OCTO_MAX_PLANETS)) void k_finishp(
 #pragma unroll
             for (int k = 0; k < NOBS_ACC; ++k) v[k] = 0.0;
             v[0] = vo[L::OFF_S];
+            if constexpr (L::HAS_MARG) { v[1] = vo[L::OFF_MARG + 0]; v[2] = vo[L::OFF_MARG + 1]; v[3] = vo[L::OFF_MARG + 2]; }
             if constexpr (L::N_NU > 0) { v[4] = vo[L::OFF_NU + 0]; v[5] = vo[L::OFF_NU + 1]; v[6] = vo[L::OFF_NU + 2]; }
             ll += obs_finish<2, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, nullptr,
                                                 a.ldw, a.c.k_yr, o, v, a.obs_const[o], dummy_sma, dummy_e, dummy_M, w < a.W, og);

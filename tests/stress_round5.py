@@ -88,6 +88,10 @@ def many_system(rng):
         n = int(rng.integers(1, 150)); ep = np.sort(50000 + rng.uniform(0, 4000, n))
         obs.append(dict(kind=2, planet=-1, epoch=ep, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None,
                         extra=(ep - 52000.0) / 1000.0 if rng.random() < 0.5 else None))
+    if rng.random() < 0.3:      # round 6: marginalised RV on the planet-per-wave kernels (beyond four planets; four planets keep k_main<4> for it)
+        n = int(rng.integers(2, 120)); ep = np.sort(50000 + rng.uniform(0, 4000, n))
+        obs.append(dict(kind=3, planet=-1, epoch=ep, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None,
+                        extra=(ep - 52000.0) / 1000.0 if rng.random() < 0.5 else None))
     nuis = np.zeros((len(obs) * 3, W))
     for io, o in enumerate(obs):
         if o["kind"] in (0, 1):

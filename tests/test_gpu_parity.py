@@ -792,10 +792,12 @@ def test_planet_per_wave_kernels_vs_oracle(oracle, P):
         _cmp_oracle(f"{P} planets astrometry only, W = {W}", ll, g_el, None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
 
 
-def test_more_than_four_planets_refuses_the_other_kinds(pkg):
-    """Beyond OCTO_MAX_PLANETS_ALL_KINDS the library takes relative astrometry and absolute / relative RV only: marginalised RV, the O'Neil
-    prior and HGCA are refused at octo_dataset_create (OCTO_ENOTSUP: valid, not on the device path — the shim then keeps the system on the reference's path), and so are
-    more than OCTO_MAX_PLANETS planets."""
+def test_more_than_four_planets_refuses_the_other_kinds(pkg, oracle):
+    """Beyond OCTO_MAX_PLANETS_ALL_KINDS the library takes relative astrometry and absolute / MARGINALISED (round 6) / relative RV: the O'Neil prior and
+    HGCA are refused at octo_dataset_create (OCTO_ENOTSUP: valid, not on the device path — the shim then keeps the system on the reference's path), and
+    so are more than OCTO_MAX_PLANETS planets. Marginalised RV on the planet-per-wave kernels (rv-absolute-margin.jl:140-185: the
+    usual likelihood of a many-planet RV fit) is a parity case: 5, 6 and 8 planets, a marginalised-RV table with a trend next to relative astrometry and
+    relative RV, with and without per-walker nuisances, forward-only == the value returned with a gradient, against the oracle."""
     gb = _gpu()
     capi = pkg.capi
     ep = np.linspace(50000.0, 50400.0, 12)
@@ -803,9 +805,32 @@ def test_more_than_four_planets_refuses_the_other_kinds(pkg):
     on = dict(kind=5, planet=0, epoch=ep, y1=np.zeros(12), y2=np.zeros(12), s1=np.ones(12), s2=np.ones(12), cor=None)
     ok = dict(kind=0, planet=4, epoch=ep, y1=np.zeros(12), y2=np.zeros(12), s1=np.ones(12), s2=np.ones(12), cor=None)
     pl = lambda n: [dict(orbit_kind=0, has_mass=True) for _ in range(n)]
-    for obs, n in (([rv], 5), ([on], 5), ([ok], capi.MAX_PLANETS + 1)):
+    for obs, n in (([on], 5), ([ok], capi.MAX_PLANETS + 1)):
         with pytest.raises(capi.OctoError) as ei:
             gb.GpuPath(obs, pl(n))
         assert ei.value.status == capi.OCTO_ENOTSUP
     gb.GpuPath([ok], pl(5)).close()
     gb.GpuPath([rv, on], pl(4)).close()
+    import stress_parity as sp
+    rng = np.random.default_rng(88)
+    for P, W in ((5, 70), (6, 257), (8, 3)):
+        elems = np.concatenate([sp.planet_elems(rng, W, 0, 0.05 + 0.4 * i, 0.3 + 0.4 * i) for i in range(P)])      # a compact RV system: periods of days to months
+        n1, n2 = 150, 40
+        t1 = np.sort(50000 + rng.uniform(0, 900, n1)); t2 = np.sort(50000 + rng.uniform(0, 900, n2))
+        obs = [dict(kind=3, planet=-1, epoch=t1, y1=rng.normal(0, 30, n1), y2=None, s1=rng.uniform(1, 8, n1), s2=None, cor=None, extra=(t1 - 50400.0) / 300.0),
+               dict(kind=0, planet=P - 1, epoch=t2, y1=rng.normal(0, 30, n2), y2=rng.normal(0, 30, n2), s1=rng.uniform(3, 12, n2), s2=rng.uniform(3, 12, n2), cor=None),
+               dict(kind=4, planet=1, epoch=t2, y1=rng.normal(0, 500, n2), y2=None, s1=rng.uniform(20, 80, n2), s2=None, cor=None),
+               dict(kind=3, planet=-1, epoch=t2 + 0.5, y1=rng.normal(0, 30, n2), y2=None, s1=rng.uniform(1, 8, n2), s2=None, cor=None)]
+        nuis = np.zeros((len(obs) * 3, W))
+        nuis[0] = rng.normal(0, 10, W); nuis[1] = np.exp(rng.uniform(np.log(0.1), np.log(10), W)); nuis[2] = rng.normal(0, 2, W)
+        nuis[3] = rng.uniform(0, 4, W); nuis[4] = rng.normal(1, 0.01, W); nuis[5] = rng.normal(0, 0.02, W)
+        nuis[6] = rng.normal(0, 10, W); nuis[7] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+        nuis[10] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+        if W >= 7:
+            elems[9 + 1, 2] = 1.3; elems[6, 5] = np.nan
+        for nz in (nuis, None):
+            ll, g, gn = gb.gpu_eval(obs, pl(P), elems, nz, grad=True)
+            llf, _, _ = gb.gpu_eval(obs, pl(P), elems, nz, grad=False)
+            assert np.array_equal(ll, llf), (P, "forward-only and gradient launches disagree")
+            ll_o, g_o, gn_o = oracle.oracle_eval(obs, pl(P), elems, nz, grad=True)
+            _cmp_oracle(f"marginalised RV, {P} planets", ll, g, gn, ll_o, g_o, gn_o, ll_rtol=1e-9, g_rtol=1e-8)

@@ -373,9 +373,10 @@ int tile_prepare(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t
         ds->planets[kp].orbit_kind == OCTO_ORBIT_THIELE_INNES)      // (a ThieleInnesOrbit's period needs its constructor: left as drawn)
         return OCTO_OK;
     bool probe = false, sort_now = ctx->tile_mode == 1;
-    // Two planets: only when forced (mode 1). Their launches are ONE round of blocks (two per CU), which lasts as long as its slowest block: with 5 % of
-    // config 4's lanes unsafe for the always-warm loop, the four tiles that collect them keep the launch at the cold loop's duration whatever the other
-    // sixty gain — measured: 155.2 µs as drawn, 156.8 sorted (the sort's own 3.8 µs included), 145.7 when EVERY tile qualifies (profiles/r6_cfg4_warm_last.txt).
+    // Two planets: only when forced (mode 1). Their launches are ONE round of blocks (two per CU), which lasts as long as its slowest block: the tiles
+    // that collect the severe lanes keep the launch at their duration whatever the others gain (measured with the per-wave criterion the loop started with:
+    // 155.2 µs as drawn, 156.8 sorted, the sort's own 3.8 µs included — profiles/r6_cfg4_warm_last.txt), and with the per-row test the loop has now ~5 % of
+    // config 4's wave-rows are cold as drawn: nothing left for a sort to collect (profiles/r6_cfg4_dyn.txt).
     if (ctx->tile_mode == 2 && ds->n_planets > 1) return OCTO_OK;
     if (ctx->tile_mode == 2) {
         if (ctx->tile_ds != ds->serial || ctx->tile_W != a.W) {      // another dataset or batch size: start over (a pending probe of the old shape is dropped)
@@ -402,7 +403,7 @@ int tile_prepare(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, hipStream_t
     TileArgs ta;
     ta.elems = a.elems; ta.ld = a.ld; ta.W = a.W; ta.perm = ctx->d_perm; ta.stats = probe ? ctx->h_tile_stats : nullptr;
     ta.dm_ref = ds->tile_dm_ref; ta.inv_k_yr = (float)(1.0 / ctx->consts.kepler_year_to_julian_day);
-    ta.planet = kp; ta.strict = ds->n_planets == 2 ? 1 : 0;
+    ta.planet = kp; ta.pad = 0;
     hipLaunchKernelGGL(k_tile_sort, dim3((unsigned)n_seg), dim3(TILE_TPB), 0, st, ta);
     if (probe) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_tile, st));

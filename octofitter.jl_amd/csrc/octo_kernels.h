@@ -482,8 +482,9 @@ __device__ __forceinline__ AstromCoef<P> astrom_coef(const double* __restrict__ 
 template <int P>
 struct WarmState { KWarm st[P]; double thr[P]; uint32_t key_hi; bool row_ok; };
 
-// WLAST (round 6, P >= 2): the LAST planet takes the unconditional warm step (octo_device.h: kepler_warm_step) from ws->st[P − 1], the others the cold solve.
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true, bool WLAST = false>
+// WLAST (round 6, P >= 2): 1 — the LAST planet takes the warm step (octo_device.h: kepler_warm_step) from ws->st[P − 1], the others the cold solve;
+// 2 — the same behind a per-row test (ws->row_ok, wave-uniform): a rejected row re-solves the last planet cold and records that solution.
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true, int WLAST = 0>
 __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                            const AstromCoef<P>& co, double t, double y1, double y2, double c3, double c4, double c5,
                                            const SinCosTab& tab, WarmState<P>* ws = nullptr, double dm = 0.0) {
@@ -502,8 +503,16 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if constexpr (WARM) s[p] = kepler_solve_warm<1>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
-        else if constexpr (WLAST) { if (p == P - 1) s[p] = kepler_warm_step<1>(t, pc[p], ws->st[p], dm); else s[p] = kepler_solve<1, TAB>(t, pc[p], tab); }
+        else if constexpr (WLAST != 0) { if (p == P - 1) s[p] = kepler_warm_step<1>(t, pc[p], ws->st[p], dm); else s[p] = kepler_solve<1, TAB>(t, pc[p], tab); }
         else s[p] = kepler_solve<1, TAB>(t, pc[p], tab);
+        if constexpr (WLAST == 2) {
+            // the rare row the a-priori test rejects (wave-uniform, decided before the row: WarmState::row_ok): the warm step's result is dropped for the
+            // cold solve — a triangle behind the straight-line code both planets share, not two arms
+            if (p == P - 1 && __builtin_expect(!ws->row_ok, 0)) {
+                s[p] = kepler_solve<1, TAB>(t, pc[p], tab);
+                ws->st[p].sE = s[p].sE; ws->st[p].cE = s[p].cE; ws->st[p].invD = s[p].invD;
+            }
+        }
         rap[p] = fma(pc[p].cB, s[p].cE, fma(pc[p].cGb, s[p].sE, -pc[p].cBe));
         dep[p] = fma(pc[p].cA, s[p].cE, fma(pc[p].cFb, s[p].sE, -pc[p].cAe));
     }
@@ -706,7 +715,7 @@ __device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, in
     return rv_coef_vals<P, GRAD, NUIS, KM>(off, jit, trend, margp, ldw, ob_kind, ob_planet, obs_index, pc, wl);
 }
 
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true, bool WLAST = false>
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true, int WLAST = 0>
 __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                        const RvCoef<P>& co, double t, double rv, double c2, double basis, const SinCosTab& tab,
                                        WarmState<P>* ws = nullptr, double dm = 0.0) {
@@ -726,8 +735,14 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if constexpr (WARM) s[p] = kepler_solve_warm<2>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
-        else if constexpr (WLAST) { if (p == P - 1) s[p] = kepler_warm_step<2>(t, pc[p], ws->st[p], dm); else s[p] = kepler_solve<2, TAB>(t, pc[p], tab); }
+        else if constexpr (WLAST != 0) { if (p == P - 1) s[p] = kepler_warm_step<2>(t, pc[p], ws->st[p], dm); else s[p] = kepler_solve<2, TAB>(t, pc[p], tab); }
         else s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
+        if constexpr (WLAST == 2) {
+            if (p == P - 1 && __builtin_expect(!ws->row_ok, 0)) {
+                s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
+                ws->st[p].sE = s[p].sE; ws->st[p].cE = s[p].cE; ws->st[p].invD = s[p].invD;
+            }
+        }
         cnu[p] = (s[p].cE - pc[p].e) * s[p].invD;             // cos ν
         snu[p] = pc[p].beta * s[p].sE * s[p].invD;            // sin ν
         V[p] = fma(cnu[p] + pc[p].e, pc[p].cw, -(snu[p] * pc[p].sw));   // cos(ν+ω) + e cos ω
@@ -953,14 +968,19 @@ constexpr bool main_warm() {
     return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL);
 }
 
-// Two planets (round 6): the LAST planet — the outer one in the usual order — takes the unconditional warm step in waves where it is provably safe on
-// every row (warm_last_init), the other the cold solve, both in one basic block. Config 4's outer planet (a ~ 8-40 AU at a 4-day cadence) qualifies in
-// every tile whose 64 lanes have e < ~0.87 — which is most tiles once the walkers are tiled by that planet's severity (octo_tile.h).
+// Two planets (round 6): the LAST planet — the outer one in the usual order — starts from the previous row's solution. A warm/cold DIAMOND per planet ends the
+// interleaving of the two solves that a kernel at two waves per SIMD lives on (round 5: −3 %, −8 %; and a diamond around the whole row body costs five scalar
+// branches per row: −3 % where every row is warm). So the row body takes the warm step for that planet UNCONDITIONALLY, next to the other planet's cold solve
+// in one basic block, and a rejected row — wave-uniform, decided before the row from the row's own step (slot 7) and every lane's previous 1/D against its
+// bound — solves it again cold in a TRIANGLE behind that block (one branch, not taken on a warm row; the wasted warm step is 35 instructions on the few
+// rows that are rejected). Config 4 as drawn (outer e ~ U(0, 0.95), a ~ 8-40 AU at a 4-day cadence): ~5 % of the wave-rows rejected, 160.9 -> 151.4 µs same
+// box; where no row is rejected 150.3 µs against 149.9 for the loop without the test (profiles/r6_cfg4_dyn.txt).
 template <int P, bool GRAD, bool NUIS, int KM, bool FUSED>
 constexpr bool main_warm_last() { return OCTO_WARM && FUSED && P == 2 && !(KM & (KM_ONEIL | KM_MARG)); }
 
-// the step bound as in warm_init, and the wave qualifies only if every lane's bound on 1/D holds at periastron itself: 1/(1 − e) < thr
-__device__ __forceinline__ float warm_last_init(KWarm& st, const PC& pc, const DevObs& ob, bool enabled) {
+// the step bound as in warm_init; the lane's bound on 1/D of the previous row for the last planet. The chain starts cold (1/D = +Inf).
+template <int P>
+__device__ __forceinline__ float warm_last_init(WarmState<P>& ws, const PC& pc, const DevObs& ob, bool enabled) {
     float bound = 0.0f;
 #pragma unroll
     for (int k = WARM_LADDER - 1; k >= 0; --k) {
@@ -968,12 +988,11 @@ __device__ __forceinline__ float warm_last_init(KWarm& st, const PC& pc, const D
         const bool veto = fabsf(d * (float)pc.invP) > WARM_DM_VETO;
         if (d > 0.0f && __builtin_amdgcn_ballot_w64(veto) == 0) bound = d;
     }
+    ws.key_hi = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint((double)bound));
     const float dmx = fabsf(bound * (1.0f + 0x1p-18f) * (float)pc.invP);
     const float th = __builtin_amdgcn_exp2f(0.2f * (__builtin_amdgcn_logf((float)WARM_TOL) - 3.0f * __builtin_amdgcn_logf(dmx)));
-    const bool unsafe = !(__builtin_amdgcn_rcpf(pc.omef) * 1.0001f < th);      // (a NaN — an invalid walker — counts as safe: its sums are discarded)
-    const bool nanlane = !(pc.e == pc.e) || !(pc.invP == pc.invP);
-    if (__builtin_amdgcn_ballot_w64(unsafe && !nanlane) != 0) bound = 0.0f;
-    st.sE = 0.0; st.cE = 1.0; st.invD = 1.0;
+    ws.thr[P - 1] = (double)th;
+    ws.st[P - 1].sE = 0.0; ws.st[P - 1].cE = 1.0; ws.st[P - 1].invD = __builtin_huge_val();
     return bound;
 }
 
@@ -1164,27 +1183,26 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         }
         bool warm_last = false;
         if constexpr (main_warm_last<P, GRAD, NUIS, KM, FUSED>()) {
-            const float bound = warm_last_init(ws.st[P - 1], pc[P - 1], ob, a.warm != 0);
-            warm_last = bound > 0.0f && tk.key_max <= bound && tk.chunk <= WARM_RESTART && n_rows > 0;
+            const float bound = warm_last_init<P>(ws, pc[P - 1], ob, a.warm != 0);
+            warm_last = bound > 0.0f && n_rows > 0;
         }
         if (main_warm_last<P, GRAD, NUIS, KM, FUSED>() && warm_last) {
             if constexpr (main_warm_last<P, GRAD, NUIS, KM, FUSED>()) {
-                // seed: the last planet's cold solution at the wave's first epoch; the first row then advances by a step of 0
-                {
-                    const KSol s0 = kepler_solve<2, true>(rows[0], pc[P - 1], tab);
-                    ws.st[P - 1].sE = s0.sE; ws.st[P - 1].cE = s0.cE; ws.st[P - 1].invD = s0.invD;
-                }
-                auto lbody = [&](const RowRegs8& r, bool first) {
-                    astrom_row<P, GRAD, NUIS, KM, true, false, true, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4),
-                                                                           row_get(r, 5), tab, &ws, first ? 0.0 : row_get(r, 6));
+                // per row, wave-uniform: the row's own step within the wave's bound (slot 7) and every lane's previous 1/D below its bound — the last planet
+                // starts from the previous row; otherwise (rare) it is solved again cold inside the row body.
+                auto lbody = [&](const RowRegs8& r) {
+                    const uint64_t over = __builtin_amdgcn_ballot_w64(ws.st[P - 1].invD >= ws.thr[P - 1]);
+                    ws.row_ok = ((uint32_t)warm_row_ok<P>(ws, r) & (uint32_t)(over == 0)) != 0;
+                    astrom_row<P, GRAD, NUIS, KM, true, false, true, 2>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4),
+                                                                        row_get(r, 5), tab, &ws, row_get(r, 6));
                 };
                 RowRegs8 A = row_issue8(rows);
                 for (int j = 0; j < n_rows; j += 2) {
                     RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
-                    lbody(A, j == 0);
+                    lbody(A);
                     if (j + 1 >= n_rows) { row_drain(B); break; }
                     A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
-                    lbody(B, false);
+                    lbody(B);
                 }
                 row_drain(A);
             }
@@ -1256,26 +1274,23 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
         }
         bool warm_last = false;
         if constexpr (main_warm_last<P, GRAD, NUIS, KM, FUSED>()) {
-            const float bound = warm_last_init(ws.st[P - 1], pc[P - 1], ob, a.warm != 0);
-            warm_last = bound > 0.0f && tk.key_max <= bound && tk.chunk <= WARM_RESTART && n_rows > 0;
+            const float bound = warm_last_init<P>(ws, pc[P - 1], ob, a.warm != 0);
+            warm_last = bound > 0.0f && n_rows > 0;
         }
         if (main_warm_last<P, GRAD, NUIS, KM, FUSED>() && warm_last) {
             if constexpr (main_warm_last<P, GRAD, NUIS, KM, FUSED>()) {
-                {
-                    const KSol s0 = kepler_solve<2, true>(rows[0], pc[P - 1], tab);
-                    ws.st[P - 1].sE = s0.sE; ws.st[P - 1].cE = s0.cE; ws.st[P - 1].invD = s0.invD;
-                }
-                auto lbody = [&](const RowRegs8& r, bool first) {
-                    rv_row<P, GRAD, NUIS, KM, true, false, true, true>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab, &ws,
-                                                                       first ? 0.0 : row_get(r, 6));
+                auto lbody = [&](const RowRegs8& r) {
+                    const uint64_t over = __builtin_amdgcn_ballot_w64(ws.st[P - 1].invD >= ws.thr[P - 1]);
+                    ws.row_ok = ((uint32_t)warm_row_ok<P>(ws, r) & (uint32_t)(over == 0)) != 0;
+                    rv_row<P, GRAD, NUIS, KM, true, false, true, 2>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab, &ws, row_get(r, 6));
                 };
                 RowRegs8 A = row_issue8(rows);
                 for (int j = 0; j < n_rows; j += 2) {
                     RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
-                    lbody(A, j == 0);
+                    lbody(A);
                     if (j + 1 >= n_rows) { row_drain(B); break; }
                     A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
-                    lbody(B, false);
+                    lbody(B);
                 }
                 row_drain(A);
             }

@@ -39,6 +39,11 @@ namespace octo {
 // much as the rest and the lock-stepped phases run at the pace of the doubly loaded SIMD — 1.05e11 (5 planets) and 1.36e11 (6) Kepler solves per second
 // against 2.1e11 for four planets and 1.6e11 for eight. Blocks of TWO tiles (TPB, a run-time block shape like P: launch_mainp_shape) spread ten or twelve
 // waves over the four SIMDs: 1.55e11 and 2.11e11 (profiles/r5_tpb_ab.txt). Seven planets stay at one tile (fourteen waves were slower: 1.34e11 -> 1.15e11).
+#ifndef OCTO_MP_NOBAR
+#define OCTO_MP_NOBAR 0      // timing diagnostic only (wrong results): 1 drops both barriers of a chunk, 2 the second one
+#endif
+#define MP_BAR1() do { if (OCTO_MP_NOBAR != 1) __syncthreads(); } while (0)
+#define MP_BAR2() do { if (OCTO_MP_NOBAR == 0) __syncthreads(); } while (0)
 constexpr int mp_rows(int P) { return P > 6 ? 2 : 4; }
 constexpr int mp_wpe(int P) { return P > 6 ? 4 : 3; }
 
@@ -173,7 +178,7 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
                 *reinterpret_cast<double2*>(&contrib[((size_t)(r * P + wv) * WAVE + lane) * 2]) = make_double2(c0, 0.0);
             }
         }
-        __syncthreads();
+        MP_BAR1();
         // ---------------- phase 2a: the rows this wave owns — model, residual, density, ∂ll/∂model
 #pragma unroll
         for (int r = 0; r < MP_R; ++r) {
@@ -279,7 +284,7 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
         }
         base += MP_R;
         while (base >= P) base -= P;
-        __syncthreads();
+        MP_BAR2();
         // ---------------- phase 2b: every row's adjoint into this planet's sums (missing rows of a short last chunk carry zero adjoints)
         if constexpr (GRAD) {
             if (is_astrom) {

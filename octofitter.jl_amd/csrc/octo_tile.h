@@ -36,9 +36,8 @@ struct TileArgs {
     float* stats;             // [2·n_segments] mapped pinned: expected cold wave-rows per row, as given | sorted
     float dm_ref;             // the dataset's reference step 2π·Δt [rad·day]: the preferred rung of its main table's ladder
     float inv_k_yr;
-    int32_t planet;           // the planet whose severity is the key (0; two planets: the last one — the two-planet kernels' always-warm planet)
-    int32_t strict;           // 1 (two planets): a tile is warm only if NONE of its lanes can ever fail the a-priori test (main_warm_last): the expected
-                              // cold wave-rows per row of a tile are 0 or 1
+    int32_t planet;           // the planet whose severity is the key (0; two planets: the last one — the planet the two-planet kernels start warm)
+    int32_t pad;
 };
 
 __device__ __forceinline__ float wave_excl_scan(float x, int lane, float& total) {
@@ -166,8 +165,8 @@ static __global__ __launch_bounds__(TILE_TPB) void k_tile_sort(TileArgs a) {
 #pragma unroll
     for (int d = 1; d < LPT; d <<= 1) { s_id += __shfl_xor(s_id, d, WAVE); s_so += __shfl_xor(s_so, d, WAVE); }
     const bool head = (lane & (LPT - 1)) == 0 && TILE_WPT * t < n_seg;
-    float c_id = head ? (a.strict ? (s_id < 0.0f ? 1.0f : 0.0f) : 1.0f - __builtin_amdgcn_exp2f(s_id)) : 0.0f;
-    float c_so = head ? (a.strict ? (s_so < 0.0f ? 1.0f : 0.0f) : 1.0f - __builtin_amdgcn_exp2f(s_so)) : 0.0f;
+    float c_id = head ? 1.0f - __builtin_amdgcn_exp2f(s_id) : 0.0f;
+    float c_so = head ? 1.0f - __builtin_amdgcn_exp2f(s_so) : 0.0f;
 #pragma unroll
     for (int d = LPT; d < WAVE; d <<= 1) { c_id += __shfl_xor(c_id, d, WAVE); c_so += __shfl_xor(c_so, d, WAVE); }
     if (lane == 0) { red[2 * wv] = c_id; red[2 * wv + 1] = c_so; }

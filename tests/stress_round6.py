@@ -76,10 +76,15 @@ def two_system(rng):
     cad = float(rng.choice([0.5, 2.0, 4.0]))
     n = int(rng.integers(60, 500))
     t = 50000.0 + cad * np.arange(n)
+    if rng.random() < 0.3:                        # gaps: rows whose own step exceeds the wave's bound start cold (slot 7 of the record)
+        keep = np.ones(n, bool)
+        for _ in range(int(rng.integers(1, 4))):
+            g0 = int(rng.integers(5, n - 5)); keep[g0:g0 + int(rng.integers(3, 40))] = False
+        t = t[keep]; n = t.size
     e1 = synth.draw_walkers(rng, W, 1.0, 5.0, with_mass=True); e2 = synth.draw_walkers(rng, W, 8.0, 40.0, with_mass=True)
     e2[6] = e1[6]; e2[7] = e1[7]
     if rng.random() < 0.6:
-        e2[1] *= rng.uniform(0.3, 0.9)            # moderate outer eccentricities: waves qualify for the always-warm loop as drawn
+        e2[1] *= rng.uniform(0.3, 0.9)            # moderate outer eccentricities: (nearly) every row of the last planet warm; as drawn (e up to 0.95): cold rows near periastron
     el = np.concatenate([e1, e2])
     if rng.random() < 0.4:
         for w_bad, (row, val) in zip(rng.choice(W, 3, replace=False), ((1, 1.2), (9 + 6, -1.0), (9 + 5, np.nan))):

@@ -223,12 +223,16 @@ def test_two_planets_last_planet_always_warm_and_sorted_tiles(pkg, oracle):
         assert np.array_equal(fwd[0], warm[0])
         ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, el_a[:, idx], None if nz is None else nz[:, idx], grad=True)
         _cmp_oracle("last planet warm vs oracle", warm[0][idx], warm[1][:, idx], None if nz is None else warm[2][:, idx], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)
-        # (b) as drawn + invalid walkers, sort forced on
+        # (b) as drawn + invalid walkers: (b0) unsorted — the per-row test sends the rows after a lane's periastron passage to the cold body —, (b1) sort forced on
         el_b = el.copy(); el_b[1, 7] = 1.1; el_b[9, 500] = np.nan; el_b[9 + 6, 2299] = -2.0
+        drawn = gb.gpu_eval(obs, planets, el_b, nz, grad=True, small_batch=0, options=_opts(capi, 0))
         srt = gb.gpu_eval(obs, planets, el_b, nz, grad=True, small_batch=0, options=_opts(capi, 1))
         uns = gb.gpu_eval(obs, planets, el_b, nz, grad=True, small_batch=0, options={capi.OPT_TILE_SORT: 0, capi.OPT_WARM_START: 0})
-        assert np.isneginf(srt[0][[7, 500, 2299]]).all()
+        assert np.isneginf(srt[0][[7, 500, 2299]]).all() and np.isneginf(drawn[0][[7, 500, 2299]]).all()
         _close("two planets sorted vs as drawn", srt, uns)
+        _close("two planets as drawn, warm vs cold", drawn, uns)
         assert not (np.array_equal(srt[0], uns[0]) and np.array_equal(srt[1], uns[1]))
+        assert not (np.array_equal(drawn[0], uns[0]) and np.array_equal(drawn[1], uns[1])), "as drawn, no row of the last planet started warm"
         ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, el_b[:, idx], None if nz is None else nz[:, idx], grad=True)
         _cmp_oracle("two planets sorted vs oracle", srt[0][idx], srt[1][:, idx], None if nz is None else srt[2][:, idx], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)
+        _cmp_oracle("two planets as drawn vs oracle", drawn[0][idx], drawn[1][:, idx], None if nz is None else drawn[2][:, idx], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)

@@ -418,13 +418,45 @@ __device__ __forceinline__ KSol kepler_warm_step(double t, const PC& pc, KWarm& 
     return s;
 }
 
-template <int INV_NR>
+#ifndef OCTO_WARM_TRI
+#define OCTO_WARM_TRI 1
+#endif
+template <int INV_NR, bool TRI = (OCTO_WARM_TRI != 0)>
 __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const SinCosTab& tab, KWarm& st, double thr, double dm, bool row_ok = true) {
     static_assert(INV_NR >= 0, "the warm start needs 1/(1 − e cos E) of every row");
     KSol s;
     s.dt = t - pc.tp;
     double E1 = 0.0, s1, c1, f0;
     const bool warm_row = row_ok && __builtin_amdgcn_ballot_w64(st.invD >= thr) == 0;      // every lane of the wave passes (a NaN bound — an invalid walker — passes: its sums are discarded)
+    if constexpr (TRI) {
+    // The warm step UNCONDITIONALLY, a rejected row solved again cold behind it — a triangle instead of a diamond (round 6): the straight-line code of a warm
+    // row crosses one branch that is not taken, where the diamond's warm arm ended in a taken one and the scheduler could not move anything across either
+    // arm; a rejected row wastes the ~40 instructions of the step. Same box: config 3 −1.5 to −2.5 %, the nuisance kernels −2.5 to −3 %, rv_gappy −2 %,
+    // wide_prior (20 % of its wave-rows rejected) ±0 (profiles/r6_tri_ab.txt). The first row of a chain enters with 1/D = +Inf: the step's NaNs are dropped.
+    {
+        const double dM = dm * pc.invP;
+        const double x = dM * st.invD;
+        const double z = x * st.invD;
+        const double dE = fma(-((pc.he * st.sE) * z), x, x);
+        const double u = dE * dE;
+        const double sr = dE * fma(u, fma(u, fma(u, OCTO_KT[22], OCTO_KT[17]), OCTO_KT[18]), 1.0);
+        const double cm1 = u * fma(u, fma(u, fma(u, OCTO_KT[23], OCTO_KT[19]), OCTO_KT[20]), -0.5);
+        const double ds = fma(st.sE, cm1, st.cE * sr);
+        s1 = st.sE + ds;
+        c1 = fma(st.cE, cm1, fma(-st.sE, sr, st.cE));
+        f0 = fma(-pc.e, ds, dE - dM);
+        kepler_correct<INV_NR, true>(s, pc, E1, s1, c1, f0);
+    }
+    if (__builtin_expect(!warm_row, 0)) {
+        const double uo = s.dt * pc.invP;
+        const double frac = uo - rint(uo);
+        const float E1f = markley_starter_f32(frac, pc);
+        E1 = (double)E1f;
+        sincos_table(E1f, tab, s1, c1);
+        f0 = fma(-pc.e, s1, fma(-frac, TWO_PI, E1));
+        kepler_correct<INV_NR>(s, pc, E1, s1, c1, f0);
+    }
+    } else {
     if (warm_row) {
         const double dM = dm * pc.invP;
         const double x = dM * st.invD;
@@ -446,6 +478,7 @@ __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const 
         sincos_table(E1f, tab, s1, c1);
         f0 = fma(-pc.e, s1, fma(-frac, TWO_PI, E1));
         kepler_correct<INV_NR>(s, pc, E1, s1, c1, f0);
+    }
     }
     st.sE = s.sE; st.cE = s.cE; st.invD = s.invD;
     return s;

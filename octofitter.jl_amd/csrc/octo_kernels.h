@@ -484,7 +484,7 @@ struct WarmState { KWarm st[P]; double thr[P]; uint32_t key_hi; bool row_ok; };
 
 // WLAST (round 6, P >= 2): 1 — the LAST planet takes the warm step (octo_device.h: kepler_warm_step) from ws->st[P − 1], the others the cold solve;
 // 2 — the same behind a per-row test (ws->row_ok, wave-uniform): a rejected row re-solves the last planet cold and records that solution.
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true, int WLAST = 0>
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, int WARM = 0, bool WCHECK = true, int WLAST = 0>
 __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                            const AstromCoef<P>& co, double t, double y1, double y2, double c3, double c4, double c5,
                                            const SinCosTab& tab, WarmState<P>* ws = nullptr, double dm = 0.0) {
@@ -502,7 +502,7 @@ __device__ __forceinline__ void astrom_row(AccArr<P, GRAD, NUIS, KM>& acc, LogPr
     double ra_m, dec_m;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        if constexpr (WARM) s[p] = kepler_solve_warm<1>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
+        if constexpr (WARM != 0) s[p] = kepler_solve_warm<1, WARM == 1>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
         else if constexpr (WLAST != 0) { if (p == P - 1) s[p] = kepler_warm_step<1>(t, pc[p], ws->st[p], dm); else s[p] = kepler_solve<1, TAB>(t, pc[p], tab); }
         else s[p] = kepler_solve<1, TAB>(t, pc[p], tab);
         if constexpr (WLAST == 2) {
@@ -715,7 +715,7 @@ __device__ __forceinline__ RvCoef<P> rv_coef(const double* __restrict__ nuis, in
     return rv_coef_vals<P, GRAD, NUIS, KM>(off, jit, trend, margp, ldw, ob_kind, ob_planet, obs_index, pc, wl);
 }
 
-template <int P, bool GRAD, bool NUIS, int KM, bool TAB, bool WARM = false, bool WCHECK = true, int WLAST = 0>
+template <int P, bool GRAD, bool NUIS, int KM, bool TAB, int WARM = 0, bool WCHECK = true, int WLAST = 0>
 __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& lp, const PC (&pc)[P],
                                        const RvCoef<P>& co, double t, double rv, double c2, double basis, const SinCosTab& tab,
                                        WarmState<P>* ws = nullptr, double dm = 0.0) {
@@ -734,7 +734,7 @@ __device__ __forceinline__ void rv_row(AccArr<P, GRAD, NUIS, KM>& acc, LogProd& 
     double model = NUIS ? fma(co.trend, basis, co.off) : co.off;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        if constexpr (WARM) s[p] = kepler_solve_warm<2>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
+        if constexpr (WARM != 0) s[p] = kepler_solve_warm<2, WARM == 1>(t, pc[p], tab, ws->st[p], ws->thr[p], dm, WCHECK ? ws->row_ok : true);
         else if constexpr (WLAST != 0) { if (p == P - 1) s[p] = kepler_warm_step<2>(t, pc[p], ws->st[p], dm); else s[p] = kepler_solve<2, TAB>(t, pc[p], tab); }
         else s[p] = kepler_solve<2, TAB>(t, pc[p], tab);
         if constexpr (WLAST == 2) {
@@ -1063,6 +1063,10 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
     // tuple to VGPR lanes WHILE the load was in flight (tools/kernel_resources.py: scalar_load_hazards found it) — they read their rows
     // with plain scalar loads the compiler waits for itself.
     constexpr bool ROW_PREFETCH = FUSED || P == 1;
+    // the warm solve's shape (octo_device.h: kepler_solve_warm): 1 — the warm step unconditionally and a rejected row solved again cold behind it (a triangle);
+    // 2 — warm or cold arm (a diamond): the eight-wave block's kernel, which held to 80 registers parks a double in the triangle's cold block — two scratch
+    // round trips per rejected row, 48.7 -> 50.8 µs per step of the 1 250-walker shard (profiles/r6_tri_ab.txt)
+    constexpr int WMODE = (OCTO_WARM_TRI && NWV == WPB) ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction; make it an SGPR
@@ -1193,14 +1197,14 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 auto lbody = [&](const RowRegs8& r) {
                     const uint64_t over = __builtin_amdgcn_ballot_w64(ws.st[P - 1].invD >= ws.thr[P - 1]);
                     ws.row_ok = ((uint32_t)warm_row_ok<P>(ws, r) & (uint32_t)(over == 0)) != 0;
-                    astrom_row<P, GRAD, NUIS, KM, true, false, true, 2>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4),
+                    astrom_row<P, GRAD, NUIS, KM, true, 0, true, 2>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3), row_get(r, 4),
                                                                         row_get(r, 5), tab, &ws, row_get(r, 6));
                 };
                 RowRegs8 A = row_issue8(rows);
                 for (int j = 0; j < n_rows; j += 2) {
                     RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
                     lbody(A);
-                    if (j + 1 >= n_rows) { row_drain(B); break; }
+                    if (__builtin_expect(j + 1 >= n_rows, 0)) { row_drain(B); break; }
                     A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                     lbody(B);
                 }
@@ -1216,12 +1220,12 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 for (int j = 0; j < n_rows; ++j) {
                     const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
                     ws.row_ok = (uint32_t)__double2hiint(rw[7]) <= ws.key_hi;
-                    astrom_row<P, GRAD, NUIS, KM, true, true, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab, &ws, rw[6]);
+                    astrom_row<P, GRAD, NUIS, KM, true, WMODE, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], tab, &ws, rw[6]);
                 }
             } else if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
                 auto wbody_t = [&](const RowRegs8& r, auto checked) {
                     if constexpr (decltype(checked)::value) ws.row_ok = warm_row_ok<P>(ws, r);
-                    astrom_row<P, GRAD, NUIS, KM, true, true, decltype(checked)::value>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3),
+                    astrom_row<P, GRAD, NUIS, KM, true, WMODE, decltype(checked)::value>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), row_get(r, 3),
                                                                                          row_get(r, 4), row_get(r, 5), tab, &ws, row_get(r, 6));
                 };
                 auto wloop = [&](auto checked) {
@@ -1229,7 +1233,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                     for (int j = 0; j < n_rows; j += 2) {
                         RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
                         wbody_t(A, checked);
-                        if (j + 1 >= n_rows) { row_drain(B); break; }
+                        if (__builtin_expect(j + 1 >= n_rows, 0)) { row_drain(B); break; }
                         A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                         wbody_t(B, checked);
                     }
@@ -1249,7 +1253,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
             for (int j = 0; j < n_rows; j += 2) {
                 RowRegs B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
                 body(A);
-                if (j + 1 >= n_rows) { row_drain(B); break; }
+                if (__builtin_expect(j + 1 >= n_rows, 0)) { row_drain(B); break; }
                 A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                 body(B);
             }
@@ -1282,13 +1286,13 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 auto lbody = [&](const RowRegs8& r) {
                     const uint64_t over = __builtin_amdgcn_ballot_w64(ws.st[P - 1].invD >= ws.thr[P - 1]);
                     ws.row_ok = ((uint32_t)warm_row_ok<P>(ws, r) & (uint32_t)(over == 0)) != 0;
-                    rv_row<P, GRAD, NUIS, KM, true, false, true, 2>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab, &ws, row_get(r, 6));
+                    rv_row<P, GRAD, NUIS, KM, true, 0, true, 2>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab, &ws, row_get(r, 6));
                 };
                 RowRegs8 A = row_issue8(rows);
                 for (int j = 0; j < n_rows; j += 2) {
                     RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
                     lbody(A);
-                    if (j + 1 >= n_rows) { row_drain(B); break; }
+                    if (__builtin_expect(j + 1 >= n_rows, 0)) { row_drain(B); break; }
                     A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                     lbody(B);
                 }
@@ -1304,12 +1308,12 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                 for (int j = 0; j < n_rows; ++j) {
                     const crow_t rw = rows + (int64_t)j * ROW_STRIDE;
                     ws.row_ok = (uint32_t)__double2hiint(rw[7]) <= ws.key_hi;
-                    rv_row<P, GRAD, NUIS, KM, true, true, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], tab, &ws, rw[6]);
+                    rv_row<P, GRAD, NUIS, KM, true, WMODE, true>(acc, lp, pc, co, rw[0], rw[1], rw[2], rw[3], tab, &ws, rw[6]);
                 }
             } else if constexpr (main_warm<P, GRAD, NUIS, KM, FUSED>()) {
                 auto wbody_t = [&](const RowRegs8& r, auto checked) {
                     if constexpr (decltype(checked)::value) ws.row_ok = warm_row_ok<P>(ws, r);
-                    rv_row<P, GRAD, NUIS, KM, true, true, decltype(checked)::value>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab,
+                    rv_row<P, GRAD, NUIS, KM, true, WMODE, decltype(checked)::value>(acc, lp, pc, co, row_get(r, 0), row_get(r, 1), row_get(r, 2), NUIS ? row_get(r, 3) : 0.0, tab,
                                                                                      &ws, row_get(r, 6));
                 };
                 auto wloop = [&](auto checked) {
@@ -1317,7 +1321,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
                     for (int j = 0; j < n_rows; j += 2) {
                         RowRegs8 B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
                         wbody_t(A, checked);
-                        if (j + 1 >= n_rows) { row_drain(B); break; }
+                        if (__builtin_expect(j + 1 >= n_rows, 0)) { row_drain(B); break; }
                         A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                         wbody_t(B, checked);
                     }
@@ -1333,7 +1337,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_main(EvalArgs a) {
             for (int j = 0; j < n_rows; j += 2) {
                 RowRegs B = row_wait_issue(A, rows + (int64_t)(j + 1 < n_rows ? j + 1 : j) * ROW_STRIDE);
                 body(A);
-                if (j + 1 >= n_rows) { row_drain(B); break; }
+                if (__builtin_expect(j + 1 >= n_rows, 0)) { row_drain(B); break; }
                 A = row_wait_issue(B, rows + (int64_t)(j + 2 < n_rows ? j + 2 : j + 1) * ROW_STRIDE);
                 body(B);
             }

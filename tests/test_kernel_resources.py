@@ -69,6 +69,8 @@ def test_throughput_kernels_do_not_spill(rows):
         if n.startswith("k_main<"):
             if SEVEN_WAVES.fullmatch(n):
                 # (round 5: with the warm-started row loop next to the cold one a third dword is parked, still outside both loops: 16 bytes, four instructions)
+                # (round 6: the eight-wave block's kernel, held to 80 registers, keeps the warm solve's DIAMOND: as a triangle it parked a double in each cold
+                # block — two scratch round trips per rejected row, +2 µs per step of the 1 250-walker shard)
                 if r["vgpr_spill_count"] > 3 or r["private_segment_fixed_size"] > 16 or r["scratch_instructions"] > 4:
                     bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"], r["scratch_instructions"]))
             elif FOUR_PLANETS_TWO_WAVES.fullmatch(n):

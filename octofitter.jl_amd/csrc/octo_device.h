@@ -447,6 +447,7 @@ __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const 
         f0 = fma(-pc.e, ds, dE - dM);
         kepler_correct<INV_NR, true>(s, pc, E1, s1, c1, f0);
     }
+#ifndef OCTO_WARM_NOREDO      // (timing diagnostic only, wrong results: no cold re-solve at all — profiles/r6_tri_ab.txt, section E)
     if (__builtin_expect(!warm_row, 0)) {
         const double uo = s.dt * pc.invP;
         const double frac = uo - rint(uo);
@@ -456,6 +457,7 @@ __device__ __forceinline__ KSol kepler_solve_warm(double t, const PC& pc, const 
         f0 = fma(-pc.e, s1, fma(-frac, TWO_PI, E1));
         kepler_correct<INV_NR>(s, pc, E1, s1, c1, f0);
     }
+#endif
     } else {
     if (warm_row) {
         const double dM = dm * pc.invP;

@@ -39,53 +39,55 @@ __device__ __forceinline__ Dual<1> hgca_logpdf2(const Dual<1>& r1, const Dual<1>
     return q * (-0.5) + (-LOG2PI - 0.5 * log(s1 * s1 * s2 * s2 * omr));
 }
 
-// The companions' constants at walker wl with input direction `dir` seeded (one partial, as ForwardDiff would carry it).
+// One companion's constants with input direction `dirl` (0 … 8 = this planet's element rows, anything else: none) seeded — one partial, as ForwardDiff would carry it.
+__device__ __forceinline__ void hgca_setup_one(const double (&elv)[OCTO_N_EL], int orbit_kind, int has_mass, const DevConsts& c, int dirl, HgcaPlanet& h, bool& visual) {
+    using D = Dual<1>;
+    visual = orbit_kind != OCTO_ORBIT_RADVEL && orbit_kind != OCTO_ORBIT_KEP;      // Visual{KepOrbit} or ThieleInnesOrbit (hgca.jl:255-262)
+    const bool ti = orbit_kind == OCTO_ORBIT_THIELE_INNES;
+    D el[OCTO_N_EL];
+#pragma unroll
+    for (int k = 0; k < OCTO_N_EL; ++k) el[k] = (dirl == k) ? dvar<1>(elv[k], 0) : dconst<1>(elv[k]);
+    if (!has_mass) el[OCTO_EL_MASS] = dconst<1>(0.0);
+    const D e = el[OCTO_EL_E], Mt = el[OCTO_EL_M];
+    // The branch below fills LOCALS, and h is written once, outside of it: with `h.T = …` in both arms the optimizer sinks the
+    // two stores into the join block with a phi of the two ADDRESSES (h is still indexed by the caller's loop variable at that point), and
+    // after the loop is unrolled that phi keeps every such field in scratch memory (40 bytes per planet in rounds 2-3: the
+    // `.private_segment_fixed_size` of k_hgca<P >= 2> and of every k_small<P >= 2, NUIS> variant).
+    D sma, T, cA, cB, cF, cG;
+    if (ti) {
+        // constants in mas; a = α/plx   (src/parameterizations.jl:14-19)
+        cA = el[OCTO_EL_TI_A]; cB = el[OCTO_EL_TI_B]; cF = el[OCTO_EL_TI_F]; cG = el[OCTO_EL_TI_G];
+        const D pp = ((cA + cG) * (cA + cG) + (cB - cF) * (cB - cF)) * 0.5;      // u + v, u − v as sums of squares
+        const D mm = ((cA - cG) * (cA - cG) + (cB + cF) * (cB + cF)) * 0.5;      // (see setup_planet_vals)
+        sma = ((dsqrt(pp) + dsqrt(mm)) * 0.70710678118654752440) / el[OCTO_EL_PLX];
+        T = dconst<1>(1.0);
+    } else {
+        D inc = el[OCTO_EL_I], Om = el[OCTO_EL_O];
+        inc.v = inc.v - PI * floor(inc.v / PI);                // KepOrbit ctor invariants, as in k_setup
+        Om.v = Om.v - TWO_PI * floor(Om.v / TWO_PI);
+        sma = el[OCTO_EL_A];
+        T = sma * el[OCTO_EL_PLX] * c.mas_per_au_per_plx;     // parameterizations.jl:215-216
+        const D ci = dcos(inc), sw = dsin(el[OCTO_EL_W]), cw = dcos(el[OCTO_EL_W]), sO = dsin(Om), cO = dcos(Om);
+        cA = cO * cw - sO * sw * ci; cB = sO * cw + cO * sw * ci;
+        cF = -(cO * sw) - sO * cw * ci; cG = -(sO * sw) + cO * cw * ci;
+    }
+    h.T = T; h.cA = cA; h.cB = cB; h.cF = cF; h.cG = cG;
+    const D P_d = dsqrt(sma * sma * sma / Mt) * c.k_yr;   // parameterizations.jl:62
+    h.e = e; h.tp = el[OCTO_EL_TP];
+    h.beta = dsqrt(dconst<1>(1.0) - e * e);
+    h.n_day = dconst<1>(TWO_PI) / P_d;
+    h.fac = -(el[OCTO_EL_MASS] * c.mjup2msol) / Mt;      // q(sol, M_planet) = −M_planet/M_tot · q(sol)
+    h.pc = PC{};
+    h.pc.invP = 1.0 / P_d.v; h.pc.tp = h.tp.v; h.pc.e = e.v;
+    set_starter<false>(h.pc, (float)e.v, (float)(1.0 - e.v), (float)(MK_K1N / (1.0 + e.v)));
+}
+
+// The companions' constants at walker wl with input direction `dir` seeded.
 template <int P>
 __device__ __forceinline__ void hgca_setup(const double (&elv)[P][OCTO_N_EL], const int32_t (&orbit_kind)[MAXP], const int32_t (&has_mass)[MAXP], const DevConsts& c,
                                            int dir, HgcaPlanet (&hp)[P], bool (&visual)[P]) {
-    using D = Dual<1>;
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        visual[p] = orbit_kind[p] != OCTO_ORBIT_RADVEL && orbit_kind[p] != OCTO_ORBIT_KEP;      // Visual{KepOrbit} or ThieleInnesOrbit (hgca.jl:255-262)
-        const bool ti = orbit_kind[p] == OCTO_ORBIT_THIELE_INNES;
-        D el[OCTO_N_EL];
-#pragma unroll
-        for (int k = 0; k < OCTO_N_EL; ++k) el[k] = (dir == p * OCTO_N_EL + k) ? dvar<1>(elv[p][k], 0) : dconst<1>(elv[p][k]);
-        if (!has_mass[p]) el[OCTO_EL_MASS] = dconst<1>(0.0);
-        const D e = el[OCTO_EL_E], Mt = el[OCTO_EL_M];
-        // The branch below fills LOCALS, and hp[p] is written once, outside of it: with `hp[p].T = …` in both arms the optimizer sinks the
-        // two stores into the join block with a phi of the two ADDRESSES (hp is still indexed by the loop variable at that point), and
-        // after the loop is unrolled that phi keeps every such field in scratch memory (40 bytes per planet in rounds 2-3: the
-        // `.private_segment_fixed_size` of k_hgca<P >= 2> and of every k_small<P >= 2, NUIS> variant).
-        D sma, T, cA, cB, cF, cG;
-        if (ti) {
-            // constants in mas; a = α/plx   (src/parameterizations.jl:14-19)
-            cA = el[OCTO_EL_TI_A]; cB = el[OCTO_EL_TI_B]; cF = el[OCTO_EL_TI_F]; cG = el[OCTO_EL_TI_G];
-            const D pp = ((cA + cG) * (cA + cG) + (cB - cF) * (cB - cF)) * 0.5;      // u + v, u − v as sums of squares
-            const D mm = ((cA - cG) * (cA - cG) + (cB + cF) * (cB + cF)) * 0.5;      // (see setup_planet_vals)
-            sma = ((dsqrt(pp) + dsqrt(mm)) * 0.70710678118654752440) / el[OCTO_EL_PLX];
-            T = dconst<1>(1.0);
-        } else {
-            D inc = el[OCTO_EL_I], Om = el[OCTO_EL_O];
-            inc.v = inc.v - PI * floor(inc.v / PI);                // KepOrbit ctor invariants, as in k_setup
-            Om.v = Om.v - TWO_PI * floor(Om.v / TWO_PI);
-            sma = el[OCTO_EL_A];
-            T = sma * el[OCTO_EL_PLX] * c.mas_per_au_per_plx;     // parameterizations.jl:215-216
-            const D ci = dcos(inc), sw = dsin(el[OCTO_EL_W]), cw = dcos(el[OCTO_EL_W]), sO = dsin(Om), cO = dcos(Om);
-            cA = cO * cw - sO * sw * ci; cB = sO * cw + cO * sw * ci;
-            cF = -(cO * sw) - sO * cw * ci; cG = -(sO * sw) + cO * cw * ci;
-        }
-        HgcaPlanet& h = hp[p];
-        h.T = T; h.cA = cA; h.cB = cB; h.cF = cF; h.cG = cG;
-        const D P_d = dsqrt(sma * sma * sma / Mt) * c.k_yr;   // parameterizations.jl:62
-        h.e = e; h.tp = el[OCTO_EL_TP];
-        h.beta = dsqrt(dconst<1>(1.0) - e * e);
-        h.n_day = dconst<1>(TWO_PI) / P_d;
-        h.fac = -(el[OCTO_EL_MASS] * c.mjup2msol) / Mt;      // q(sol, M_planet) = −M_planet/M_tot · q(sol)
-        h.pc = PC{};
-        h.pc.invP = 1.0 / P_d.v; h.pc.tp = h.tp.v; h.pc.e = e.v;
-        set_starter<false>(h.pc, (float)e.v, (float)(1.0 - e.v), (float)(MK_K1N / (1.0 + e.v)));
-    }
+    for (int p = 0; p < P; ++p) hgca_setup_one(elv[p], orbit_kind[p], has_mass[p], c, dir - p * OCTO_N_EL, hp[p], visual[p]);
 }
 
 // The observation's three 2-D Gaussians from the epoch-averaged positions and proper motions (hgca.jl:301-382).
@@ -155,6 +157,61 @@ static __global__ __launch_bounds__(64) void k_hgca(EvalArgs a) {
                 D q, v;
                 hgca_solve(hp[p], t, ax, a.c.yd, q, v);
                 // the counters and epoch sums advance once per (planet, row), as in the reference (:276-278)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa)
+                        if (mm == m && aa == ax) { cnt[mm][aa] += 1; ep[mm][aa] += t; pos[mm][aa] = pos[mm][aa] + q; pm[mm][aa] = pm[mm][aa] + v; }
+            }
+        }
+        ll = ll + hgca_terms(pos, pm, ep, cnt, pm_sys, a.c.yd, ob.pre);
+    }
+    if (w < a.W) {
+        if (dir == 0) a.extra[w] = ll.v;
+        a.extra[(int64_t)(1 + dir) * a.ldw + w] = ll.d[0];
+    }
+}
+
+// The same for a system of more planets than k_hgca<P> is compiled for (round 6: the planet-per-wave kernels' systems, 5 … OCTO_MAX_PLANETS): the number of
+// planets is a run-time loop bound and ONE planet's constants are live at a time — same sums in the same order (planet, then row) as k_hgca<P>.
+static __global__ __launch_bounds__(64) void k_hgcap(EvalArgs a) {
+    using D = Dual<1>;
+    const int64_t w = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    const int64_t wl = w < a.W ? w : a.W - 1;
+    const int dir = blockIdx.y;
+    const int P = a.n_planets;
+    D ll = dconst<1>(0.0);
+    for (int o = 0; o < a.n_obs; ++o) {
+        const DevObs ob = a.obs[o];
+        if (ob.kind != OCTO_HGCA) continue;
+        D pm_sys[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double v = a.nuis[((int64_t)o * OCTO_N_NUIS + k) * a.ld + wl];
+            pm_sys[k] = (dir == P * OCTO_N_EL + o * OCTO_N_NUIS + k) ? dvar<1>(v, 0) : dconst<1>(v);
+        }
+        D pos[2][2], pm[2][2];
+        double ep[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        int cnt[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) { pos[m][ax] = dconst<1>(0.0); pm[m][ax] = dconst<1>(0.0); }
+#pragma unroll 1
+        for (int p = 0; p < P; ++p) {
+            double elv[OCTO_N_EL];
+#pragma unroll
+            for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = a.elems[((int64_t)p * OCTO_N_EL + k) * a.ld + wl];
+            HgcaPlanet hp;
+            bool visual;
+            hgca_setup_one(elv, a.orbit_kind[p], a.has_mass[p], a.c, dir - p * OCTO_N_EL, hp, visual);
+            if (!visual) continue;                              // hgca.jl:255-262 (wave-uniform: a planet's orbit kind)
+            for (int64_t j = 0; j < ob.n; ++j) {
+                const double* rw = ob.raw + j * ROW_STRIDE;     // wave-uniform
+                const double t = rw[0];
+                const int ax = (int)rw[1], m = (int)rw[2];
+                D q, v;
+                hgca_solve(hp, t, ax, a.c.yd, q, v);
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll

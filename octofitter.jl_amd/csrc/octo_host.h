@@ -213,7 +213,8 @@ constexpr int64_t STAGE_DMA_BYTES = 1 << 20;   // host-buffer calls up to this s
 int mainp_occupancy(octo_ctx* ctx, bool nuis, int km_p, int P);
 int launch_mainp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st);
 int launch_finishp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st);
-constexpr int mainp_kind_set(int km) {
+constexpr int mainp_kind_set(int km_all) {
+    const int km = km_all & ~KM_HGCA;      // (an HGCA table has no rows in the epoch loop: k_hgcap -> `extra` -> k_finishp)
     return (km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0 ? (KM_RADEC | KM_SEPPA | KM_COR) : ((km & KM_MARG) ? (KM_ALL & ~KM_ONEIL) : (KM_ALL & ~KM_MARG & ~KM_ONEIL));
 }
 int launch_margp(octo_ctx* ctx, bool nuis, int km_p, const EvalArgs& a, hipStream_t st);      // k_marg for the planet-per-wave kernels' forward partials

@@ -102,7 +102,7 @@ int launch_finishp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, 
 // A dataset of MAXP_T < P <= MAXP planets: always the throughput kernels (no k_small<P> there), k_mainp -> k_finishp on one stream.
 int dispatch_many(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st) {
     if (sm) return fail(ctx, OCTO_EINVAL, "internal: fused model launch requested for a dataset of more than four planets");
-    if (ds->kind_mask & (KM_ONEIL | KM_HGCA)) return fail(ctx, OCTO_EINVAL, "internal: kind set outside the planet-per-wave kernels");
+    if (ds->kind_mask & KM_ONEIL) return fail(ctx, OCTO_EINVAL, "internal: kind set outside the planet-per-wave kernels");
     const int P = ds->n_planets;
     const int km_p = mainp_kind_set(ds->kind_mask);
     const int64_t cols = (a.W + WAVE - 1) / WAVE;
@@ -120,6 +120,14 @@ int dispatch_many(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad,
     if (rc) return rc;
     a.partials = ctx->d_partials;
     a.extra = nullptr; a.marg = nullptr; a.marg_out = nullptr;
+    if (ds->n_hgca > 0) {      // the proper-motion anomaly (no epoch loop): k_hgcap ahead of k_finishp, which adds it (launch_all's hgca_term for these systems)
+        if (!nuis) return fail(ctx, OCTO_EINVAL, "octo_eval: a dataset with an OCTO_HGCA table needs `nuis` (pmra, pmdec)");
+        const int n_dir = grad ? P * OCTO_N_EL + a.n_obs * OCTO_N_NUIS : 1;
+        rc = grow(ctx, ctx->d_extra, ctx->cap_extra, (int64_t)(1 + n_dir) * a.ldw);
+        if (rc) return rc;
+        a.extra = ctx->d_extra;
+        hipLaunchKernelGGL(k_hgcap, dim3((unsigned)cols, (unsigned)n_dir), dim3(WAVE), 0, st, a);
+    }
     if (a.n_tasks > 0) {
         hipEvent_t e1 = nullptr;
         if (ctx->timing_every > 0 && (ctx->timing_seq++ % ctx->timing_every) == 0) {      // HIP events around the epoch-loop kernel, as in launch_all

@@ -1427,7 +1427,7 @@ __device__ __forceinline__ double obs_finish(const DevObs* __restrict__ obs, int
                                              const double* __restrict__ extra_w /* k_hgca's rows at this walker, or null */, int64_t ldw, double k_yr,
                                              int o, const double (&v)[NOBS_ACC],
                                              double cst, const double (&sma_p)[P], const double (&e_p)[P], const double (&M_p)[P], bool write,
-                                             double (&oneil_g)[oneil_slots<P, GRAD, NUIS, KM>()]) {
+                                             double (&oneil_g)[oneil_slots<P, GRAD, NUIS, KM>()], int n_planets_rt = P /* k_finishp: the system's planets (rows of `extra`) */) {
     using L = Layout<P, GRAD, NUIS, KM>;
     const int kind = obs[o].kind;
     double llo;
@@ -1466,7 +1466,7 @@ __device__ __forceinline__ double obs_finish(const DevObs* __restrict__ obs, int
             gn[(int64_t)ld] = v[5];
             gn[(int64_t)2 * ld] = v[6];      // northangle | trend coefficient (zero sums for a table without a basis column)
             if (kind == OCTO_HGCA) {      // ∂/∂(pmra, pmdec) from k_hgca
-                const double* x = extra_w + (int64_t)(1 + P * OCTO_N_EL + o * OCTO_N_NUIS) * ldw;
+                const double* x = extra_w + (int64_t)(1 + n_planets_rt * OCTO_N_EL + o * OCTO_N_NUIS) * ldw;
                 gn[0] = x[0]; gn[(int64_t)ld] = x[ldw]; gn[(int64_t)2 * ld] = 0.0;
             }
         }

@@ -20,7 +20,7 @@
 // buffers suffice. Per row and tile that is P solves + ONE density + P adjoint updates — the instruction count of k_main<P> — spread over P
 // SIMDs at ~100 VGPRs per lane, no scratch, and P is a RUN-TIME block shape: the partials keep k_main's layout (Layout<2>'s offsets hold
 // for every P >= 2), so k_finish<3>, k_finish<4> read them unchanged, and k_finishp below finishes any P up to OCTO_MAX_PLANETS.
-// Kind sets: everything but the O'Neil prior (it keeps k_main<P>, P <= 4). Marginalised RV (round 6, for systems of more than four planets — the usual RV
+// Kind sets: everything but the O'Neil prior (it keeps k_main<P>, P <= 4); an HGCA table reaches k_finishp through `extra` (k_hgcap, octo_hgca.h). Marginalised RV (round 6, for systems of more than four planets — the usual RV
 // likelihood of a many-planet RV fit): the owning wave of a row accumulates the three sums A = Σ 1/var, B = Σ −2 r/var, C = Σ r²/var of
 // rv-absolute-margin.jl:171-180 with the observation's other sums; a gradient takes the two-pass flow of k_main (forward pre-pass over that table's tasks,
 // k_marg for μ̂ = −B/2A and A per walker, then the gradient pass with r̄v = 2 (r − μ̂)/var).
@@ -407,9 +407,10 @@ static __global__ __launch_bounds__(64 * (1 + OCTO_MAX_PLANETS)) void k_finishp(
             v[0] = vo[L::OFF_S];
             if constexpr (L::HAS_MARG) { v[1] = vo[L::OFF_MARG + 0]; v[2] = vo[L::OFF_MARG + 1]; v[3] = vo[L::OFF_MARG + 2]; }
             if constexpr (L::N_NU > 0) { v[4] = vo[L::OFF_NU + 0]; v[5] = vo[L::OFF_NU + 1]; v[6] = vo[L::OFF_NU + 2]; }
-            ll += obs_finish<2, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, nullptr,
-                                                a.ldw, a.c.k_yr, o, v, a.obs_const[o], dummy_sma, dummy_e, dummy_M, w < a.W, og);
+            ll += obs_finish<2, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + wl : nullptr,
+                                                a.ldw, a.c.k_yr, o, v, a.obs_const[o], dummy_sma, dummy_e, dummy_M, w < a.W, og, P);
         }
+        if (a.extra) ll += a.extra[wl];                                     // the proper-motion anomaly (k_hgcap ahead of this launch)
         ok_mine = isfinite(ll);
         if constexpr (!GRAD) {
             for (int p = 0; p < P; ++p) ok_mine = ok_mine && setup_planet<true>(a, p, wl).ok;
@@ -455,7 +456,7 @@ static __global__ __launch_bounds__(64 * (1 + OCTO_MAX_PLANETS)) void k_finishp(
     if constexpr (GRAD) {
         if (grp > 0 && live) {
             const int p = grp - 1;
-            planet_finish<2, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, nullptr, a.ldw, a.c,
+            planet_finish<2, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
                                                             a.orbit_kind[p], a.has_mass[p], p, gp, nullptr, fp, ok);
         }
     }

@@ -92,16 +92,26 @@ def many_system(rng):
         n = int(rng.integers(2, 120)); ep = np.sort(50000 + rng.uniform(0, 4000, n))
         obs.append(dict(kind=3, planet=-1, epoch=ep, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None,
                         extra=(ep - 52000.0) / 1000.0 if rng.random() < 0.5 else None))
+    hgca = rng.random() < 0.3      # round 6, late: an HGCA table beyond four planets (k_hgcap -> k_finishp); four planets: k_hgca<4> -> k_finish<4>
+    if hgca:
+        N = int(rng.integers(1, 4))
+        rows = []
+        for d in np.linspace(-700, 700, N): rows += [(48348.0 + d, 0, 0), (48414.0 + d, 1, 0)]
+        for d in np.linspace(-500, 500, N): rows += [(57408.0 + d, 0, 1), (57470.0 + d, 1, 1)]
+        rows = np.array(rows)
+        obs.append(dict(kind=7, planet=-1, epoch=rows[:, 0], y1=rows[:, 1], y2=rows[:, 2], s1=None, s2=None, cor=None, extra=sp.HG))
     nuis = np.zeros((len(obs) * 3, W))
     for io, o in enumerate(obs):
         if o["kind"] in (0, 1):
             nuis[io * 3] = rng.uniform(0, 4, W); nuis[io * 3 + 1] = rng.normal(1, 0.01, W); nuis[io * 3 + 2] = rng.normal(0, 0.02, W)
+        elif o["kind"] == 7:
+            nuis[io * 3] = rng.normal(4.3, 0.3, W); nuis[io * 3 + 1] = rng.normal(-2.0, 0.3, W)
         else:
             nuis[io * 3] = rng.normal(0, 10, W); nuis[io * 3 + 1] = np.exp(rng.uniform(np.log(0.1), np.log(10), W)); nuis[io * 3 + 2] = rng.normal(0, 2, W)
     if W >= 7 and rng.random() < 0.5:
         for w_bad, (row, val) in zip(rng.choice(W, 3, replace=False), ((1, 1.2), (6, -1.0), (5, np.nan))):
             elems[int(rng.integers(0, P)) * 9 + row, w_bad] = val
-    return obs, planets, elems, (nuis if rng.random() < 0.6 else None)
+    return obs, planets, elems, (nuis if (hgca or rng.random() < 0.6) else None)
 
 
 def main():

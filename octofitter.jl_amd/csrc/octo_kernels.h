@@ -968,15 +968,22 @@ constexpr bool main_warm() {
     return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL);
 }
 
-// Two planets (round 6): the LAST planet — the outer one in the usual order — starts from the previous row's solution. A warm/cold DIAMOND per planet ends the
+// Two and three planets (round 6): the LAST planet — the outer one in the usual order — starts from the previous row's solution. A warm/cold DIAMOND per planet ends the
 // interleaving of the two solves that a kernel at two waves per SIMD lives on (round 5: −3 %, −8 %; and a diamond around the whole row body costs five scalar
 // branches per row: −3 % where every row is warm). So the row body takes the warm step for that planet UNCONDITIONALLY, next to the other planet's cold solve
 // in one basic block, and a rejected row — wave-uniform, decided before the row from the row's own step (slot 7) and every lane's previous 1/D against its
 // bound — solves it again cold in a TRIANGLE behind that block (one branch, not taken on a warm row; the wasted warm step is 35 instructions on the few
 // rows that are rejected). Config 4 as drawn (outer e ~ U(0, 0.95), a ~ 8-40 AU at a 4-day cadence): ~5 % of the wave-rows rejected, 160.9 -> 151.4 µs same
 // box; where no row is rejected 150.3 µs against 149.9 for the loop without the test (profiles/r6_cfg4_dyn.txt).
+#ifndef OCTO_WARM_LAST3
+#define OCTO_WARM_LAST3 1
+#endif
 template <int P, bool GRAD, bool NUIS, int KM, bool FUSED>
-constexpr bool main_warm_last() { return OCTO_WARM && FUSED && P == 2 && !(KM & (KM_ONEIL | KM_MARG)); }
+constexpr bool main_warm_last() {
+    // Three planets (round 6, late): the kind sets without sep/PA rows — RA/Dec [+ cor] [+ absolute | relative RV]: 204-242 VGPRs with the state of the last
+    // planet, no SGPR spills; the sets with sep/PA park ~30 SGPRs with it (and the library has 0.1 MB to spare) — 343.5 -> 319.5 µs per step of the 3-planet probe
+    return OCTO_WARM && FUSED && (P == 2 || (P == 3 && OCTO_WARM_LAST3 && !(KM & KM_SEPPA))) && !(KM & (KM_ONEIL | KM_MARG));
+}
 
 // the step bound as in warm_init; the lane's bound on 1/D of the previous row for the last planet. The chain starts cold (1/D = +Inf).
 template <int P>

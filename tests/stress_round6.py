@@ -4,7 +4,7 @@
          nuisance kernels with RV / sep-PA rows (plain loads); walkers from a WIDE prior (some too fast for every rung, some only for the long steps),
          eccentricities to 0.98, invalid walkers; each system four ways — as drawn, tiles sorted (OCTO_OPT_TILE_SORT = 1), cold (OCTO_OPT_WARM_START = 0)
          and batch-invariant — all against the oracle, warm against cold to 1e-11 / 1e-9, forward-only == the value returned with a gradient;
-  two    two-planet systems (RA/Dec or sep/PA on either planet, absolute / relative RV, nuisances) on dense tables with moderate outer eccentricities
+  two    two- and three-planet systems (RA/Dec or sep/PA on any planet, absolute / relative RV, nuisances) on dense tables with moderate outer eccentricities
          (the last-planet-always-warm loop) and as drawn, sorted and unsorted;
   short  one-table systems of 20-120 rows x 600-3000 walkers: the one-task launch that finishes inside k_main, bit-identical to OCTO_FIN_FUSED=0.
     python tests/stress_round6.py <n_systems> <seed>"""
@@ -81,29 +81,33 @@ def two_system(rng):
         for _ in range(int(rng.integers(1, 4))):
             g0 = int(rng.integers(5, n - 5)); keep[g0:g0 + int(rng.integers(3, 40))] = False
         t = t[keep]; n = t.size
-    e1 = synth.draw_walkers(rng, W, 1.0, 5.0, with_mass=True); e2 = synth.draw_walkers(rng, W, 8.0, 40.0, with_mass=True)
+    P = 3 if rng.random() < 0.4 else 2            # (three planets: the kind sets without sep/PA rows carry the last planet's warm start too)
+    e1 = synth.draw_walkers(rng, W, 1.0, 5.0, with_mass=True); e2 = synth.draw_walkers(rng, W, 15.0 if P == 3 else 8.0, 40.0, with_mass=True)
     e2[6] = e1[6]; e2[7] = e1[7]
+    em = None
+    if P == 3:
+        em = synth.draw_walkers(rng, W, 6.0, 12.0, with_mass=True); em[6] = e1[6]; em[7] = e1[7]
     if rng.random() < 0.6:
         e2[1] *= rng.uniform(0.3, 0.9)            # moderate outer eccentricities: (nearly) every row of the last planet warm; as drawn (e up to 0.95): cold rows near periastron
-    el = np.concatenate([e1, e2])
+    el = np.concatenate([e1, e2] if P == 2 else [e1, em, e2])
     if rng.random() < 0.4:
-        for w_bad, (row, val) in zip(rng.choice(W, 3, replace=False), ((1, 1.2), (9 + 6, -1.0), (9 + 5, np.nan))):
+        for w_bad, (row, val) in zip(rng.choice(W, 3, replace=False), ((1, 1.2), (9 * (P - 1) + 6, -1.0), (9 * (P - 1) + 5, np.nan))):
             el[row, w_bad] = val
-    ip = int(rng.integers(0, 2))
+    ip = int(rng.integers(0, P))
     ra, dec = rng.normal(0, 300, n), rng.normal(0, 300, n)
     obs = [dict(kind=0, planet=ip, epoch=t, y1=ra, y2=dec, s1=rng.uniform(3, 12, n), s2=rng.uniform(3, 12, n), cor=rng.uniform(-0.7, 0.7, n) if rng.random() < 0.3 else None)
            if rng.random() < 0.7 else dict(kind=1, planet=ip, epoch=t, y1=np.arctan2(ra, dec), y2=np.hypot(ra, dec), s1=np.full(n, 0.03), s2=rng.uniform(3, 12, n), cor=None)]
     if rng.random() < 0.7:
         obs.append(dict(kind=2, planet=-1, epoch=t + 0.3, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None))
     if rng.random() < 0.3:
-        obs.append(dict(kind=4, planet=1 - ip, epoch=t[::2], y1=rng.normal(0, 500, t[::2].size), y2=None, s1=rng.uniform(20, 80, t[::2].size), s2=None, cor=None))
+        obs.append(dict(kind=4, planet=(ip + 1) % P, epoch=t[::2], y1=rng.normal(0, 500, t[::2].size), y2=None, s1=rng.uniform(20, 80, t[::2].size), s2=None, cor=None))
     nuis = np.zeros((len(obs) * 3, W))
     for io, o in enumerate(obs):
         if o["kind"] in (0, 1):
             nuis[io * 3] = rng.uniform(0, 4, W); nuis[io * 3 + 1] = rng.normal(1, 0.01, W); nuis[io * 3 + 2] = rng.normal(0, 0.02, W)
         else:
             nuis[io * 3] = rng.normal(0, 10, W); nuis[io * 3 + 1] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
-    return obs, [dict(orbit_kind=0, has_mass=True)] * 2, el, (nuis if rng.random() < 0.6 else None)
+    return obs, [dict(orbit_kind=0, has_mass=True)] * P, el, (nuis if rng.random() < 0.6 else None)
 
 
 def short_system(rng):
@@ -164,7 +168,7 @@ def main():
         bad = (not same) or e_ll > 1e-9 or e_g > 2e-8 or not all((x is None and y is None) or np.array_equal(x, y, equal_nan=True) for x, y in zip(*outs))
         fails += int(bad)
         if bad: print(f"FAIL short system {i}: W = {el.shape[1]}, rows {obs[0]['epoch'].size}, nuis {nz is not None}", flush=True)
-    print(f"{n_sys} gappy single-planet systems (warm loop taken by some wave in {n_warm}) + {n_sys} two-planet systems (always-warm loop in {n_last}) x "
+    print(f"{n_sys} gappy single-planet systems (warm loop taken by some wave in {n_warm}) + {n_sys} two- and three-planet systems (the last planet warm on some row in {n_last}) x "
           f"{{as drawn, sorted, cold, batch-invariant}} (the sort changed some wave in {n_sorted_differs} of {2 * n_sys}) + {n_sys} one-task systems: {fails} failures; worst vs oracle: "
           f"gaps ll {worst['gap_ll']:.2e} grad {worst['gap_g']:.2e} | warm vs cold ll {worst['gc_ll']:.2e} grad {worst['gc_g']:.2e} | two planets ll {worst['two_ll']:.2e} "
           f"grad {worst['two_g']:.2e} | vs cold ll {worst['tc_ll']:.2e} grad {worst['tc_g']:.2e} | one-task ll {worst['short_ll']:.2e} grad {worst['short_g']:.2e}")

@@ -236,3 +236,43 @@ def test_two_planets_last_planet_always_warm_and_sorted_tiles(pkg, oracle):
         ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, el_b[:, idx], None if nz is None else nz[:, idx], grad=True)
         _cmp_oracle("two planets sorted vs oracle", srt[0][idx], srt[1][:, idx], None if nz is None else srt[2][:, idx], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)
         _cmp_oracle("two planets as drawn vs oracle", drawn[0][idx], drawn[1][:, idx], None if nz is None else drawn[2][:, idx], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_three_planets_last_planet_warm(pkg, oracle):
+    """Round 6, late: the three-planet kernels of the kind sets without sep/PA rows carry the last planet's warm start too (octo_kernels.h: main_warm_last) — RA/Dec
+    on the outer planet + absolute RV on a dense cadence, outer eccentricities to 0.95 (rejected rows near periastron re-solve it cold), with and without per-walker
+    nuisances, invalid walkers: against the cold loops (OCTO_OPT_WARM_START = 0; not the same bits: the loop ran) and the oracle; forward-only == the value returned
+    with a gradient. A sep/PA table (a kind set that keeps the cold loop for three planets) gives the cold loop's bits."""
+    gb = _gpu()
+    capi = pkg.capi
+    rng = np.random.default_rng(303)
+    W, n = 700, 260
+    t = 50000.0 + 2.0 * np.arange(n)
+    e1 = synth.draw_walkers(rng, W, 1.0, 5.0, with_mass=True); em = synth.draw_walkers(rng, W, 6.0, 12.0, with_mass=True); e2 = synth.draw_walkers(rng, W, 15.0, 40.0, with_mass=True)
+    for x in (em, e2): x[6] = e1[6]; x[7] = e1[7]
+    el = np.concatenate([e1, em, e2])
+    el[1, 7] = 1.1; el[9, 500] = np.nan; el[18 + 6, 699] = -2.0
+    planets = [dict(orbit_kind=0, has_mass=True)] * 3
+    radec = dict(kind=0, planet=2, epoch=t, y1=rng.normal(0, 300, n), y2=rng.normal(0, 300, n), s1=rng.uniform(3, 12, n), s2=rng.uniform(3, 12, n), cor=None)
+    rv = dict(kind=2, planet=-1, epoch=t + 0.3, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None)
+    obs = [radec, rv]
+    nuis = np.zeros((6, W))
+    nuis[0] = rng.uniform(0, 4, W); nuis[1] = rng.normal(1, 0.01, W); nuis[2] = rng.normal(0, 0.02, W)
+    nuis[3] = rng.normal(0, 10, W); nuis[4] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+    idx = np.arange(0, W, 23)
+    COLD = {capi.OPT_TILE_SORT: 0, capi.OPT_WARM_START: 0}
+    for nz in (nuis, None):
+        warm = gb.gpu_eval(obs, planets, el, nz, grad=True, small_batch=0, options=_opts(capi, 0))
+        cold = gb.gpu_eval(obs, planets, el, nz, grad=True, small_batch=0, options=COLD)
+        assert np.isneginf(warm[0][[7, 500, 699]]).all()
+        assert not (np.array_equal(warm[0], cold[0]) and np.array_equal(warm[1], cold[1], equal_nan=True)), "no row of the last planet started warm"
+        _close("three planets, last planet warm vs cold", warm, cold)
+        fwd = gb.gpu_eval(obs, planets, el, nz, grad=False, small_batch=0, options=_opts(capi, 0))
+        assert np.array_equal(fwd[0], warm[0])
+        ll_o, g_o, gn_o = oracle.oracle_eval(obs, planets, el[:, idx], None if nz is None else nz[:, idx], grad=True)
+        _cmp_oracle("three planets vs oracle", warm[0][idx], warm[1][:, idx], None if nz is None else warm[2][:, idx], ll_o, g_o, gn_o, ll_rtol=1e-10, g_rtol=1e-8)
+    seppa = dict(kind=1, planet=2, epoch=t, y1=np.arctan2(radec["y1"], radec["y2"]), y2=np.hypot(radec["y1"], radec["y2"]), s1=np.full(n, 0.03), s2=rng.uniform(3, 12, n), cor=None)
+    a = gb.gpu_eval([seppa, rv], planets, el, None, grad=True, small_batch=0, options=_opts(capi, 0))
+    b = gb.gpu_eval([seppa, rv], planets, el, None, grad=True, small_batch=0, options=COLD)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True)

@@ -54,8 +54,7 @@ extern "C" {
 #define OCTO_EHIP    2   /* a HIP runtime call failed; see octo_last_error */
 #define OCTO_ENOMEM  3   /* host or device allocation failed */
 #define OCTO_ENODEV  4   /* no usable gfx950 device */
-#define OCTO_ENOTSUP 5   /* a VALID dataset or model that is not on the device path: more planets than OCTO_MAX_PLANETS, the O'Neil
-                          * prior beyond OCTO_MAX_PLANETS_ALL_KINDS planets, an RV table next to a ThieleInnesOrbit planet, a model beyond the size
+#define OCTO_ENOTSUP 5   /* a VALID dataset or model that is not on the device path: more planets than OCTO_MAX_PLANETS, (nothing of the observation kinds since round 6), an RV table next to a ThieleInnesOrbit planet, a model beyond the size
                           * limits of octo_model_create. A host-side binding falls back to the reference's own path on THIS status (and on OCTO_ENODEV) —
                           * not on OCTO_EINVAL (bad input: σ <= 0, non-finite epochs, |cor| >= 1 …), OCTO_EHIP or OCTO_ENOMEM, which are the caller's to see. */
 
@@ -106,8 +105,8 @@ extern "C" {
 #define OCTO_EL_MASS  8   /* companion mass [M_jup]               */
 #define OCTO_N_EL     9
 /* planets per dataset. 1 … OCTO_MAX_PLANETS_ALL_KINDS: every observation kind, both kernel families. Up to OCTO_MAX_PLANETS: the
- * planet-per-wave throughput kernels (one planet per wave of a block, any batch size) for relative astrometry, absolute / marginalised (round 6) /
- * relative RV and HGCA (round 6) — octo_dataset_create refuses the O'Neil prior there, and more planets than that, with OCTO_ENOTSUP. (The
+ * planet-per-wave throughput kernels (one planet per wave of a block, any batch size) — every observation kind since round 6; no small-batch kernels and no
+ * on-device model beyond OCTO_MAX_PLANETS_ALL_KINDS. octo_dataset_create refuses more planets than OCTO_MAX_PLANETS with OCTO_ENOTSUP. (The
  * reference unrolls over any number, src/likelihoods/system.jl:116-118: a host-side binding keeps a refused system on its own path.) */
 #define OCTO_MAX_PLANETS 8
 #define OCTO_MAX_PLANETS_ALL_KINDS 4

@@ -619,11 +619,6 @@ int32_t octo_dataset_create(octo_ctx* ctx, const octo_obs_desc* obs, int32_t n_o
     *out = nullptr;
     if (n_planets < 1) return fail(ctx, OCTO_EINVAL, "octo_dataset_create: a dataset needs at least one planet");
     if (n_planets > MAXP) return fail(ctx, OCTO_ENOTSUP, "octo_dataset_create: 1.." + std::to_string(MAXP) + " planets supported");
-    if (n_planets > MAXP_T)      // beyond the templated kernels: the planet-per-wave kernels' kind sets only (octo_mainp.h)
-        for (int o = 0; o < n_obs; ++o)
-            if (obs[o].kind == OCTO_ONEIL_RADEC || obs[o].kind == OCTO_ONEIL_SEPPA)
-                return fail(ctx, OCTO_ENOTSUP, "octo_dataset_create: with more than " + std::to_string(MAXP_T) + " planets relative astrometry, absolute / marginalised / relative RV and HGCA tables "
-                                              "are supported (no O'Neil prior)");
     for (int p = 0; p < n_planets; ++p)
         if (planets[p].orbit_kind != OCTO_ORBIT_VISUAL_KEP && planets[p].orbit_kind != OCTO_ORBIT_RADVEL &&
             planets[p].orbit_kind != OCTO_ORBIT_THIELE_INNES && planets[p].orbit_kind != OCTO_ORBIT_KEP)

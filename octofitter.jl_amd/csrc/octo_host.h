@@ -215,7 +215,7 @@ int launch_mainp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, co
 int launch_finishp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, const EvalArgs& a, hipStream_t st);
 constexpr int mainp_kind_set(int km_all) {
     const int km = km_all & ~KM_HGCA;      // (an HGCA table has no rows in the epoch loop: k_hgcap -> `extra` -> k_finishp)
-    return (km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0 ? (KM_RADEC | KM_SEPPA | KM_COR) : ((km & KM_MARG) ? (KM_ALL & ~KM_ONEIL) : (KM_ALL & ~KM_MARG & ~KM_ONEIL));
+    return (km & ~(KM_RADEC | KM_SEPPA | KM_COR)) == 0 ? (KM_RADEC | KM_SEPPA | KM_COR) : ((km & (KM_MARG | KM_ONEIL)) ? KM_ALL : (KM_ALL & ~KM_MARG & ~KM_ONEIL));
 }
 int launch_margp(octo_ctx* ctx, bool nuis, int km_p, const EvalArgs& a, hipStream_t st);      // k_marg for the planet-per-wave kernels' forward partials
 // more planets than the templated kernels are compiled for: planner + k_mainp + k_finishp (octo_inst_pn.hip)

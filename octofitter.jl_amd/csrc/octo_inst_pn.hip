@@ -18,7 +18,7 @@ int64_t plan_key_mainp(const octo_ctx* ctx, int64_t W, int64_t n_rows, int block
 }
 
 namespace {
-constexpr int KA = KM_RADEC | KM_SEPPA | KM_COR, KB = KM_ALL & ~KM_MARG & ~KM_ONEIL, KC = KM_ALL & ~KM_ONEIL;      // KC (round 6): + marginalised RV, more than four planets only
+constexpr int KA = KM_RADEC | KM_SEPPA | KM_COR, KB = KM_ALL & ~KM_MARG & ~KM_ONEIL, KC = KM_ALL;      // KC (round 6): + marginalised RV and the O'Neil prior, more than four planets only
 
 // Tiles per block (octo_mainp.h), from the probes of tools/r5_tpb_ab.sh (profiles/r5_tpb_ab.txt): two for 5 and 6 planets — ten waves (3, 3, 2, 2 per SIMD)
 // and twelve (3 each): 1.70 -> 1.15 ms and 1.80 -> 1.16 ms per step of the probe; one for 4 and 8 planets (whole multiples of four waves already) and for
@@ -52,7 +52,8 @@ int launch_mainp_t(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t s
 template <bool GRAD, bool NUIS, int KM>
 int launch_finishp_t(octo_ctx* ctx, int64_t cols, const EvalArgs& a, hipStream_t st) {
     const int waves = GRAD ? 1 + a.n_planets : 1;
-    hipLaunchKernelGGL((k_finishp<GRAD, NUIS, KM>), dim3((unsigned)cols), dim3((unsigned)(WAVE * waves)), sizeof(double) * WAVE * (size_t)(1 + a.n_planets), st, a);
+    const size_t rows = (size_t)(1 + a.n_planets) + ((GRAD && (KM & KM_ONEIL)) ? 6 * (size_t)a.n_planets : 0);      // validity flags [+ the O'Neil terms of each planet's adjoints]
+    hipLaunchKernelGGL((k_finishp<GRAD, NUIS, KM>), dim3((unsigned)cols), dim3((unsigned)(WAVE * waves)), sizeof(double) * WAVE * rows, st, a);
     (void)ctx;
     return OCTO_OK;
 }
@@ -102,7 +103,6 @@ int launch_finishp(octo_ctx* ctx, bool grad, bool nuis, int km_p, int64_t cols, 
 // A dataset of MAXP_T < P <= MAXP planets: always the throughput kernels (no k_small<P> there), k_mainp -> k_finishp on one stream.
 int dispatch_many(octo_ctx* ctx, const octo_dataset* ds, EvalArgs& a, bool grad, bool nuis, const SmallModel* sm, hipStream_t st) {
     if (sm) return fail(ctx, OCTO_EINVAL, "internal: fused model launch requested for a dataset of more than four planets");
-    if (ds->kind_mask & KM_ONEIL) return fail(ctx, OCTO_EINVAL, "internal: kind set outside the planet-per-wave kernels");
     const int P = ds->n_planets;
     const int km_p = mainp_kind_set(ds->kind_mask);
     const int64_t cols = (a.W + WAVE - 1) / WAVE;

@@ -20,7 +20,8 @@
 // buffers suffice. Per row and tile that is P solves + ONE density + P adjoint updates — the instruction count of k_main<P> — spread over P
 // SIMDs at ~100 VGPRs per lane, no scratch, and P is a RUN-TIME block shape: the partials keep k_main's layout (Layout<2>'s offsets hold
 // for every P >= 2), so k_finish<3>, k_finish<4> read them unchanged, and k_finishp below finishes any P up to OCTO_MAX_PLANETS.
-// Kind sets: everything but the O'Neil prior (it keeps k_main<P>, P <= 4); an HGCA table reaches k_finishp through `extra` (k_hgcap, octo_hgca.h). Marginalised RV (round 6, for systems of more than four planets — the usual RV
+// Kind sets: every row kind. An HGCA table reaches k_finishp through `extra` (k_hgcap, octo_hgca.h); the O'Neil prior's term (round 6, more than four planets only: four
+// keep k_main<4> for it) is accumulated by the wave of the planet its table is attached to — it needs that planet's E alone — and closed in k_finishp. Marginalised RV (round 6, for systems of more than four planets — the usual RV
 // likelihood of a many-planet RV fit): the owning wave of a row accumulates the three sums A = Σ 1/var, B = Σ −2 r/var, C = Σ r²/var of
 // rv-absolute-margin.jl:171-180 with the observation's other sums; a gradient takes the two-pass flow of k_main (forward pre-pass over that table's tasks,
 // k_marg for μ̂ = −B/2A and A per walker, then the gradient pass with r̄v = 2 (r − μ̂)/var).
@@ -70,7 +71,6 @@ template <bool GRAD, bool NUIS, int KM, int MP_R, int WPE>
 __attribute__((amdgpu_waves_per_eu(WPE)))
 static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
     using L = LayoutP<GRAD, NUIS, KM>;
-    static_assert(!(KM & KM_ONEIL), "k_mainp: the O'Neil prior stays on k_main<P>");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int P = a.n_planets;                                             // = waves per tile
@@ -113,7 +113,8 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
         const float2 fb = *reinterpret_cast<const float2*>(&v[WC_F32B]);
         set_starter(pc, fa.x, fa.y, fb.x);
     }
-    const bool is_astrom = !L::HAS_RV || ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA;
+    const bool oneil = L::HAS_ONEIL && (ob.kind == OCTO_ONEIL_RADEC || ob.kind == OCTO_ONEIL_SEPPA);      // prior-observable.jl:78-137: the wrapped table's rows + the prior's term
+    const bool is_astrom = !L::HAS_RV || ob.kind == OCTO_ASTROM_RADEC || ob.kind == OCTO_ASTROM_SEPPA || oneil;
     const bool rel = (KM & KM_RVREL) && ob.kind == OCTO_RV_REL;
     const bool marg = (KM & KM_MARG) && ob.kind == OCTO_RV_ABS_MARG;
     // the semi-major axis of the planet the table is attached to, through LDS (relative-astrometry.jl:120-123, rv-relative.jl:148-152: strictly inner)
@@ -134,7 +135,7 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
     double sn = 0.0, cn = 1.0;
     if constexpr (NUIS && (KM & (KM_RADEC | KM_SEPPA)) != 0) { if (is_astrom) sincos_reduced(n2, sn, cn); }
     const double jit = is_astrom ? n0 : n1, j2 = jit * jit;
-    const bool seppa = (KM & KM_SEPPA) && ob.kind == OCTO_ASTROM_SEPPA;
+    const bool seppa = (KM & KM_SEPPA) && (ob.kind == OCTO_ASTROM_SEPPA || (L::HAS_ONEIL && ob.kind == OCTO_ONEIL_SEPPA));
     const double ib2 = GRAD ? 1.0 / (pc.beta * pc.beta) : 0.0;
     double mu_hat = 0.0, iA = 0.0;                                         // marginalised RV, gradient pass: the pre-pass's μ̂ and 1/A of this walker (k_marg)
     if constexpr (GRAD && L::HAS_MARG) {
@@ -164,6 +165,28 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
             for (int r = 0; r < MP_R; ++r) {
                 const KSol s = kepler_solve<1, true>(tr[r], pc, tab);
                 kp[r] = {s.sE, s.cE, s.invD};
+                if constexpr (L::HAS_ONEIL) {
+                    // the O'Neil prior's term of this row, by the wave of the planet the table is attached to (it needs that planet's E alone):
+                    // t = 3M(e + cos E) + 2(−2 + e² + e cos E) sin E, Σ|t| and its adjoints — astrom_row's lines (prior-observable.jl:129-133)
+                    if (oneil && wv == ob.planet && j0 + r < n_rows) {
+                        const double ee = pc.e, sE = s.sE, cE = s.cE;
+                        const double Mm = fma(-ee, sE, s.E);
+                        const double c2 = fma(ee, ee + cE, -2.0);
+                        const double tt = fma(3.0 * Mm, ee + cE, 2.0 * c2 * sE);
+                        ao[L::OFF_ONEIL] += fabs(tt);
+                        if constexpr (GRAD) {
+                            const double sg = tt < 0.0 ? -1.0 : 1.0;
+                            const double D = fma(-ee, cE, 1.0);
+                            const double tM = 3.0 * (ee + cE);
+                            const double tE = fma(-3.0 * Mm, sE, 2.0 * fma(c2, cE, -(ee * sE * sE))) + tM * D;
+                            const double te = fma(2.0 * sE, 2.0 * ee + cE, 3.0 * Mm) - tM * sE;
+                            const double Mb = sg * tE * s.invD;
+                            ao[L::OFF_ONEIL + 1] += sg * te + Mb * sE;
+                            ao[L::OFF_ONEIL + 2] += Mb;
+                            ao[L::OFF_ONEIL + 3] = fma(Mb, tr[r] - pc.tp, ao[L::OFF_ONEIL + 3]);
+                        }
+                    }
+                }
                 const double c0 = coef * fma(pc.cB, s.cE, fma(pc.cGb, s.sE, -pc.cBe));
                 const double c1 = coef * fma(pc.cA, s.cE, fma(pc.cFb, s.sE, -pc.cAe));
                 *reinterpret_cast<double2*>(&contrib[((size_t)(r * P + wv) * WAVE + lane) * 2]) = make_double2(c0, c1);
@@ -367,8 +390,7 @@ static __global__ __launch_bounds__(64 * 4 * WPE) void k_mainp(EvalArgs a) {
 template <bool GRAD, bool NUIS, int KM>
 static __global__ __launch_bounds__(64 * (1 + OCTO_MAX_PLANETS)) void k_finishp(EvalArgs a) {
     using L = LayoutP<GRAD, NUIS, KM>;
-    static_assert(!(KM & KM_ONEIL), "k_finishp: the kind sets of k_mainp");
-    extern __shared__ __attribute__((aligned(16))) double lds[];            // (1 + P) rows of 64 validity flags
+    extern __shared__ __attribute__((aligned(16))) double lds[];            // (1 + P) rows of 64 validity flags [+ P x 6 rows: the O'Neil terms of each planet's adjoints]
     const int lane = threadIdx.x & (WAVE - 1);
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int P = a.n_planets;
@@ -385,8 +407,13 @@ static __global__ __launch_bounds__(64 * (1 + OCTO_MAX_PLANETS)) void k_finishp(
 #pragma unroll
     for (int k = 0; k < OCTO_N_EL; ++k) elv[k] = 0.0;
     bool ok_mine = true;
+    double* const og_lds = lds + (size_t)(1 + P) * WAVE;                    // [P][6][64]: ΔGE, ΔGM, ΔGT, Δā, ΔM̄tot, Δē per planet from its O'Neil tables
+    constexpr int KMF = KM & ~KM_ONEIL;                                     // obs_finish's closed forms without the O'Neil block (its planet arrays are sized by the template's P = 2)
     if (grp == 0) {
-        double dummy_sma[2] = {0.0, 0.0}, dummy_e[2] = {0.0, 0.0}, dummy_M[2] = {1.0, 1.0}, og[1] = {0.0};      // (O'Neil only: not in these kind sets)
+        double dummy_sma[2] = {0.0, 0.0}, dummy_e[2] = {0.0, 0.0}, dummy_M[2] = {1.0, 1.0}, og[1] = {0.0};
+        if constexpr (L::HAS_ONEIL && GRAD) {
+            for (int k = 0; k < P * 6; ++k) og_lds[(size_t)k * WAVE + lane] = 0.0;
+        }
         for (int o = 0; o < a.n_obs; ++o) {
             double vo[NOB];
 #pragma unroll
@@ -407,8 +434,26 @@ static __global__ __launch_bounds__(64 * (1 + OCTO_MAX_PLANETS)) void k_finishp(
             v[0] = vo[L::OFF_S];
             if constexpr (L::HAS_MARG) { v[1] = vo[L::OFF_MARG + 0]; v[2] = vo[L::OFF_MARG + 1]; v[3] = vo[L::OFF_MARG + 2]; }
             if constexpr (L::N_NU > 0) { v[4] = vo[L::OFF_NU + 0]; v[5] = vo[L::OFF_NU + 1]; v[6] = vo[L::OFF_NU + 2]; }
-            ll += obs_finish<2, GRAD, NUIS, KM>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + wl : nullptr,
-                                                a.ldw, a.c.k_yr, o, v, a.obs_const[o], dummy_sma, dummy_e, dummy_M, w < a.W, og, P);
+            ll += obs_finish<2, GRAD, NUIS, KMF>(a.obs, a.ld, L::N_NU > 0 ? a.g_nuis + (int64_t)o * OCTO_N_NUIS * a.ld + w : nullptr, a.extra ? a.extra + wl : nullptr,
+                                                 a.ldw, a.c.k_yr, o, v, a.obs_const[o], dummy_sma, dummy_e, dummy_M, w < a.W, og, P);
+            if constexpr (L::HAS_ONEIL) {
+                // ln_prior = 2 log(Σ|t_j| · ∛P / √(1−e²)), P = period/365.25 (prior-observable.jl:96,136-139) — obs_finish's block for a run-time planet index
+                const int kind = a.obs[o].kind;
+                if ((kind == OCTO_ONEIL_RADEC || kind == OCTO_ONEIL_SEPPA) && a.obs[o].n > 0) {
+                    const int ip = a.obs[o].planet;
+                    const double sma = setup_planet<true>(a, ip, wl).v[WC_A];
+                    const double e = a.elems[((int64_t)ip * OCTO_N_EL + OCTO_EL_E) * a.ld + wl], Mt = a.elems[((int64_t)ip * OCTO_N_EL + OCTO_EL_M) * a.ld + wl];
+                    const double s_abs = vo[L::OFF_ONEIL];
+                    const double Pyr = a.c.k_yr * sqrt(sma * sma * sma / Mt) / 365.25;
+                    ll += 2.0 * log(s_abs * cbrt(Pyr) / sqrt(1.0 - e * e));
+                    if constexpr (GRAD) {
+                        const double f = 2.0 / s_abs;
+                        double* gq = og_lds + (size_t)ip * 6 * WAVE + lane;
+                        gq[0 * WAVE] += f * vo[L::OFF_ONEIL + 1]; gq[1 * WAVE] += f * vo[L::OFF_ONEIL + 2]; gq[2 * WAVE] += f * vo[L::OFF_ONEIL + 3];
+                        gq[3 * WAVE] += 1.0 / sma; gq[4 * WAVE] += -1.0 / (3.0 * Mt); gq[5 * WAVE] += 2.0 * e / (1.0 - e * e);
+                    }
+                }
+            }
         }
         if (a.extra) ll += a.extra[wl];                                     // the proper-motion anomaly (k_hgcap ahead of this launch)
         ok_mine = isfinite(ll);
@@ -456,8 +501,13 @@ static __global__ __launch_bounds__(64 * (1 + OCTO_MAX_PLANETS)) void k_finishp(
     if constexpr (GRAD) {
         if (grp > 0 && live) {
             const int p = grp - 1;
+            double ogp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if constexpr (L::HAS_ONEIL) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ogp[k] = og_lds[((size_t)p * 6 + k) * WAVE + lane];      // (written by wave 0 ahead of the barrier above)
+            }
             planet_finish<2, GRAD, NUIS, KM, OCTO_FIN_FAST>(elv, a.g_elems + (int64_t)p * OCTO_N_EL * a.ld + w, a.ld, a.extra ? a.extra + w : nullptr, a.ldw, a.c,
-                                                            a.orbit_kind[p], a.has_mass[p], p, gp, nullptr, fp, ok);
+                                                            a.orbit_kind[p], a.has_mass[p], p, gp, L::HAS_ONEIL ? ogp : nullptr, fp, ok);
         }
     }
     if (a.mt_lpp) model_tail_n(a, w, grp, GRAD ? 1 + P : 1, P);

@@ -25,7 +25,7 @@ ASTROM_KINDS = (ASTROM_RADEC, ASTROM_SEPPA, ONEIL_RADEC, ONEIL_SEPPA)
 ORBIT_VISUAL_KEP, ORBIT_RADVEL, ORBIT_THIELE_INNES, ORBIT_KEP = 0, 1, 2, 3
 N_EL, N_NUIS = 9, 3
 MAX_PLANETS = 8      # OCTO_MAX_PLANETS
-MAX_PLANETS_ALL_KINDS = 4      # OCTO_MAX_PLANETS_ALL_KINDS: beyond it everything but the O'Neil prior (relative astrometry, absolute / marginalised / relative RV, HGCA)
+MAX_PLANETS_ALL_KINDS = 4      # OCTO_MAX_PLANETS_ALL_KINDS: beyond it the planet-per-wave throughput kernels only (every observation kind since round 6; no small-batch family)
 EL_A, EL_E, EL_I, EL_W, EL_O, EL_TP, EL_M, EL_PLX, EL_MASS = range(9)
 NU_JITTER, NU_PLATESCALE, NU_NORTHANGLE = 0, 1, 2
 NU_RV_OFFSET, NU_RV_JITTER, NU_RV_TREND = 0, 1, 2

@@ -19,7 +19,7 @@ const SRC_FLAG_UNITLEN, SRC_FLAG_TI = Int32(1), Int32(2)
 const STREAM_CTX = Ptr{Cvoid}(typemax(UInt))       # OCTO_STREAM_CTX = (void*)-1: the context's own stream
 const N_EL, N_NUIS = 9, 3
 const OCTO_MAX_PLANETS = 8
-const OCTO_MAX_PLANETS_ALL_KINDS = 4      # beyond it: everything but the O'Neil prior (the library refuses that: OCTO_ENOTSUP)
+const OCTO_MAX_PLANETS_ALL_KINDS = 4      # beyond it: the planet-per-wave throughput kernels only (every observation kind since round 6)
 const EL_KEYS = (:a, :e, :i, :ω, :Ω, :tp, :M, :plx, :mass)
 const EL_KEYS_TI = (:A, :e, :B, :F, :G, :tp, :M, :plx, :mass)     # ThieleInnesOrbit: constants [mas] in the rows of a, i, ω, Ω
 

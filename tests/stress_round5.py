@@ -92,6 +92,12 @@ def many_system(rng):
         n = int(rng.integers(2, 120)); ep = np.sort(50000 + rng.uniform(0, 4000, n))
         obs.append(dict(kind=3, planet=-1, epoch=ep, y1=rng.normal(0, 30, n), y2=None, s1=rng.uniform(1, 8, n), s2=None, cor=None,
                         extra=(ep - 52000.0) / 1000.0 if rng.random() < 0.5 else None))
+    if rng.random() < 0.3:      # round 6, late: the O'Neil prior beyond four planets (four planets: k_main<4>)
+        ip = int(rng.integers(0, P)); n = int(rng.integers(2, 60)); ep = np.sort(50000 + rng.uniform(0, 4000, n))
+        seppa = rng.random() < 0.4
+        ra, dec = rng.normal(0, 300, n), rng.normal(0, 300, n)
+        obs.append(dict(kind=6 if seppa else 5, planet=ip, epoch=ep, y1=np.arctan2(ra, dec) if seppa else ra, y2=np.hypot(ra, dec) if seppa else dec,
+                        s1=np.full(n, 0.03) if seppa else rng.uniform(3, 12, n), s2=rng.uniform(3, 12, n), cor=None))
     hgca = rng.random() < 0.3      # round 6, late: an HGCA table beyond four planets (k_hgcap -> k_finishp); four planets: k_hgca<4> -> k_finish<4>
     if hgca:
         N = int(rng.integers(1, 4))
@@ -102,7 +108,7 @@ def many_system(rng):
         obs.append(dict(kind=7, planet=-1, epoch=rows[:, 0], y1=rows[:, 1], y2=rows[:, 2], s1=None, s2=None, cor=None, extra=sp.HG))
     nuis = np.zeros((len(obs) * 3, W))
     for io, o in enumerate(obs):
-        if o["kind"] in (0, 1):
+        if o["kind"] in (0, 1, 5, 6):
             nuis[io * 3] = rng.uniform(0, 4, W); nuis[io * 3 + 1] = rng.normal(1, 0.01, W); nuis[io * 3 + 2] = rng.normal(0, 0.02, W)
         elif o["kind"] == 7:
             nuis[io * 3] = rng.normal(4.3, 0.3, W); nuis[io * 3 + 1] = rng.normal(-2.0, 0.3, W)

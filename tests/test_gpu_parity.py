@@ -793,9 +793,11 @@ def test_planet_per_wave_kernels_vs_oracle(oracle, P):
 
 
 def test_more_than_four_planets_refuses_the_other_kinds(pkg, oracle):
-    """Beyond OCTO_MAX_PLANETS_ALL_KINDS the library takes relative astrometry, absolute / MARGINALISED (round 6) / relative RV and HGCA (round 6, late): the
-    O'Neil prior is refused at octo_dataset_create (OCTO_ENOTSUP: valid, not on the device path — the shim then keeps the system on the reference's path), and
-    so are more than OCTO_MAX_PLANETS planets. HGCA beyond four planets (k_hgcap -> `extra` -> k_finishp; hgca.jl:155-400): 5, 6 and 8 planets, an HGCA table next
+    """Beyond OCTO_MAX_PLANETS_ALL_KINDS (the limit of the templated kernels and of the small-batch family) the planet-per-wave kernels take every observation
+    kind since round 6 — relative astrometry, absolute / MARGINALISED / relative RV, HGCA, the O'Neil prior; more than OCTO_MAX_PLANETS planets are refused at
+    octo_dataset_create (OCTO_ENOTSUP: valid, not on the device path — the shim then keeps the system on the reference's path). The O'Neil prior beyond four
+    planets (prior-observable.jl:78-137; the term by the wave of the planet the table is attached to, its closed form and adjoints in k_finishp): 5, 6 and 8 planets,
+    RA/Dec and sep/PA wrappers on different planets next to marginalised RV, against the oracle. HGCA beyond four planets (k_hgcap -> `extra` -> k_finishp; hgca.jl:155-400): 5, 6 and 8 planets, an HGCA table next
     to relative astrometry and absolute RV, against the oracle, forward-only == the value returned with a gradient, a RadialVelocityOrbit planet among them (it does
     not contribute: hgca.jl:255-262). Marginalised RV on the planet-per-wave kernels (rv-absolute-margin.jl:140-185: the
     usual likelihood of a many-planet RV fit) is a parity case: 5, 6 and 8 planets, a marginalised-RV table with a trend next to relative astrometry and
@@ -807,11 +809,11 @@ def test_more_than_four_planets_refuses_the_other_kinds(pkg, oracle):
     on = dict(kind=5, planet=0, epoch=ep, y1=np.zeros(12), y2=np.zeros(12), s1=np.ones(12), s2=np.ones(12), cor=None)
     ok = dict(kind=0, planet=4, epoch=ep, y1=np.zeros(12), y2=np.zeros(12), s1=np.ones(12), s2=np.ones(12), cor=None)
     pl = lambda n: [dict(orbit_kind=0, has_mass=True) for _ in range(n)]
-    for obs, n in (([on], 5), ([ok], capi.MAX_PLANETS + 1)):      # (kind 5: the O'Neil prior)
-        with pytest.raises(capi.OctoError) as ei:
-            gb.GpuPath(obs, pl(n))
-        assert ei.value.status == capi.OCTO_ENOTSUP
+    with pytest.raises(capi.OctoError) as ei:      # more planets than OCTO_MAX_PLANETS: valid in the reference, not on the device path
+        gb.GpuPath([ok], pl(capi.MAX_PLANETS + 1))
+    assert ei.value.status == capi.OCTO_ENOTSUP
     gb.GpuPath([ok], pl(5)).close()
+    gb.GpuPath([on], pl(5)).close()
     gb.GpuPath([rv, on], pl(4)).close()
     import stress_parity as sp
     rng = np.random.default_rng(88)
@@ -836,6 +838,28 @@ def test_more_than_four_planets_refuses_the_other_kinds(pkg, oracle):
             assert np.array_equal(ll, llf), (P, "forward-only and gradient launches disagree")
             ll_o, g_o, gn_o = oracle.oracle_eval(obs, pl(P), elems, nz, grad=True)
             _cmp_oracle(f"marginalised RV, {P} planets", ll, g, gn, ll_o, g_o, gn_o, ll_rtol=1e-9, g_rtol=1e-8)
+    # the O'Neil prior beyond four planets
+    for P, W in ((5, 70), (6, 130), (8, 5)):
+        elems = np.concatenate([sp.planet_elems(rng, W, 0, 2 + 5 * i, 5 + 5 * i) for i in range(P)])
+        n1, n2 = 40, 25
+        t1 = np.sort(50000 + rng.uniform(0, 3000, n1)); t2 = np.sort(50000 + rng.uniform(0, 3000, n2))
+        ra, dec = rng.normal(0, 300, n2), rng.normal(0, 300, n2)
+        obs = [dict(kind=5, planet=P - 1, epoch=t1, y1=rng.normal(0, 300, n1), y2=rng.normal(0, 300, n1), s1=rng.uniform(3, 12, n1), s2=rng.uniform(3, 12, n1), cor=rng.uniform(-0.6, 0.6, n1)),
+               dict(kind=6, planet=1, epoch=t2, y1=np.arctan2(ra, dec), y2=np.hypot(ra, dec), s1=np.full(n2, 0.03), s2=rng.uniform(3, 12, n2), cor=None),
+               dict(kind=0, planet=2, epoch=t2 + 1.0, y1=rng.normal(0, 300, n2), y2=rng.normal(0, 300, n2), s1=rng.uniform(3, 12, n2), s2=rng.uniform(3, 12, n2), cor=None),
+               dict(kind=3, planet=-1, epoch=t1 + 0.5, y1=rng.normal(0, 30, n1), y2=None, s1=rng.uniform(1, 8, n1), s2=None, cor=None)]
+        nuis = np.zeros((len(obs) * 3, W))
+        for io in range(3):
+            nuis[io * 3] = rng.uniform(0, 4, W); nuis[io * 3 + 1] = rng.normal(1, 0.01, W); nuis[io * 3 + 2] = rng.normal(0, 0.02, W)
+        nuis[10] = np.exp(rng.uniform(np.log(0.1), np.log(10), W))
+        if W >= 7:
+            elems[9 + 1, 2] = 1.3; elems[6, 5] = np.nan
+        for nz in (nuis, None):
+            ll, g, gn = gb.gpu_eval(obs, pl(P), elems, nz, grad=True)
+            llf, _, _ = gb.gpu_eval(obs, pl(P), elems, nz, grad=False)
+            assert np.array_equal(ll, llf), (P, "forward-only and gradient launches disagree")
+            ll_o, g_o, gn_o = oracle.oracle_eval(obs, pl(P), elems, nz, grad=True)
+            _cmp_oracle(f"O'Neil prior, {P} planets", ll, g, gn, ll_o, g_o, gn_o, ll_rtol=1e-9, g_rtol=1e-8)
     # HGCA beyond four planets
     rows = np.array([(48348.0, 0, 0), (48414.0, 1, 0), (48200.0, 0, 0), (57408.0, 0, 1), (57470.0, 1, 1), (57600.0, 1, 1)])
     hg = np.array([4.71, -1.86, 0.61, 0.49, 0.21, 4.352, -2.013, 0.031, 0.024, -0.12, 4.61, -1.72, 0.052, 0.041, 0.33])

@@ -82,8 +82,9 @@ def test_throughput_kernels_do_not_spill(rows):
             # (the others: up to four dwords parked outside the row loops — the tile-in-block index and its LDS offsets joined the 128-VGPR shape's prologue)
             limit = 48 if ", true, true, " in n[:24] or n.startswith("k_mainp<true, true") else 4
             seg = 128
-            if ", 63, " in n:      # (round 6: the kind set with marginalised RV, more than four planets only — three more sums and μ̂, 1/A per lane in the density phase)
-                limit, seg = (64, 192) if n.startswith("k_mainp<true, true") else (8, 48)
+            if ", 127, " in n:      # (round 6: the kind set with marginalised RV and the O'Neil prior, more than four planets only — three + four more sums, μ̂ and 1/A per lane
+                                    # in the density phase, the prior's term in the solve phase of the attached planet's wave)
+                limit, seg = (80, 200) if n.startswith("k_mainp<true, true") else (16, 64)
             if r["vgpr_spill_count"] > limit or r["private_segment_fixed_size"] > seg:
                 bad.append((n, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
         if n.startswith("k_finishp<") and (r["vgpr_spill_count"] or r["private_segment_fixed_size"]):

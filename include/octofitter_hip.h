@@ -105,8 +105,8 @@ extern "C" {
 #define OCTO_EL_MASS  8   /* companion mass [M_jup]               */
 #define OCTO_N_EL     9
 /* planets per dataset. 1 … OCTO_MAX_PLANETS_ALL_KINDS: every observation kind, both kernel families. Up to OCTO_MAX_PLANETS: the
- * planet-per-wave throughput kernels (one planet per wave of a block, any batch size) — every observation kind since round 6; no small-batch kernels and no
- * on-device model beyond OCTO_MAX_PLANETS_ALL_KINDS. octo_dataset_create refuses more planets than OCTO_MAX_PLANETS with OCTO_ENOTSUP. (The
+ * planet-per-wave throughput kernels (one planet per wave of a block, any batch size) — every observation kind since round 6; no small-batch kernels beyond
+ * OCTO_MAX_PLANETS_ALL_KINDS (a one-θ call takes the throughput launches). octo_dataset_create refuses more planets than OCTO_MAX_PLANETS with OCTO_ENOTSUP. (The
  * reference unrolls over any number, src/likelihoods/system.jl:116-118: a host-side binding keeps a refused system on its own path.) */
 #define OCTO_MAX_PLANETS 8
 #define OCTO_MAX_PLANETS_ALL_KINDS 4

@@ -792,7 +792,7 @@ def test_planet_per_wave_kernels_vs_oracle(oracle, P):
         _cmp_oracle(f"{P} planets astrometry only, W = {W}", ll, g_el, None, ll_o, g_o, None, ll_rtol=1e-10, g_rtol=1e-8)
 
 
-def test_more_than_four_planets_refuses_the_other_kinds(pkg, oracle):
+def test_more_than_four_planets_every_kind(pkg, oracle):
     """Beyond OCTO_MAX_PLANETS_ALL_KINDS (the limit of the templated kernels and of the small-batch family) the planet-per-wave kernels take every observation
     kind since round 6 — relative astrometry, absolute / MARGINALISED / relative RV, HGCA, the O'Neil prior; more than OCTO_MAX_PLANETS planets are refused at
     octo_dataset_create (OCTO_ENOTSUP: valid, not on the device path — the shim then keeps the system on the reference's path). The O'Neil prior beyond four

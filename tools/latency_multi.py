@@ -23,7 +23,8 @@ def time_call(f, n=3000, warm=300):
 
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 Ws = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1]
-for P, W in [(P, W) for P in (1, 2, 3, 4) for W in Ws]:
+PS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 3, 4]
+for P, W in [(P, W) for P in PS for W in Ws]:
     planets = [dict(orbit_kind=0, has_mass=True) for _ in range(P)]
     elems = np.concatenate([sp.planet_elems(rng, W, 0, 2 + 6 * i, 6 + 6 * i) for i in range(P)])
     obs = []

@@ -954,14 +954,19 @@ constexpr unsigned main_min_waves() {
 #ifndef OCTO_WARM
 #define OCTO_WARM 1
 #endif
+#ifndef OCTO_WARM_PLAIN
+#define OCTO_WARM_PLAIN 0
+#endif
 template <int P, bool GRAD, bool NUIS, int KM, bool FUSED>
 constexpr bool main_warm_plain() {
     // The nuisance kernels of the kind sets with sep/PA or RV rows: with the 16-dword row buffers of a second pair of prefetching loops they run out
     // of SGPRs, and the compiler then parks an in-flight prefetch tuple in VGPR lanes (tools/kernel_resources.py: scalar_load_hazards finds it).
     // Their warm loop reads its rows with plain scalar loads the compiler waits for itself (round 5 built that and found no gain on a probe whose
     // random epochs vetoed the warm loop through the table-wide bound; with the per-row test — round 6 — an RV table with offset and jitter,
-    // the usual one, runs warm between its gaps).
-    return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL) && NUIS && (KM & (KM_SEPPA | KM_RV));
+    // the usual one, runs warm between its gaps). Round 6, late: with the uniform regions left unstructured the kind sets WITHOUT sep/PA rows — RA/Dec
+    // [+ cor] + absolute | relative RV — have the SGPRs for the prefetching pair (no hazard: the ISA check passes) and take it: rv_gappy_nuis −2.5 %
+    // (profiles/r6_noplain_ab.txt); the sets with sep/PA keep the plain loads (and the library its last 60 KB).
+    return OCTO_WARM && FUSED && P == 1 && !(KM & KM_ONEIL) && NUIS && ((KM & KM_SEPPA) || ((KM & KM_RV) && OCTO_WARM_PLAIN));
 }
 template <int P, bool GRAD, bool NUIS, int KM, bool FUSED>
 constexpr bool main_warm() {

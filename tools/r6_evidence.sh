@@ -3,7 +3,7 @@
 # (tools/profile_round.sh -> pmc_traffic.json), counter passes of every other kernel incl. the non-uniform workloads (tools/profile_kernels.sh -> kernel
 # table), the -m gpu suite, the driver-comparable bench line, the two-rank gloo dry run, every workload's bench line on this build AND on the round-5
 # library (same box: before / after), the latency family, the strong-scaling shares, and the randomised sweeps.   bash tools/r6_evidence.sh <tag>
-tag=${1:-r6_v6}
+tag=${1:-r6_v7}
 export OCTO_KEEP_DB=1
 bash tools/profile_round.sh $tag > gpurun_out/${tag}_profile.log 2>&1
 cp gpurun_out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
